@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: columnwise matched filter (CMF) Mpixels/s on a 598 x 20000 x 425 float32 BIL cube.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one full pass of the hot path (extract -> mean -> covariance -> eigh -> LOO sweep -> filter -> score)
+over the whole flightline, cube resident in HBM, outputs left on the device.  With N > 1 the cross-track
+columns are sharded contiguously over the ranks (each rank holds only its own column slice of the cube) and
+the step ends with ONE RCCL gather of the score blocks to rank 0 -- total work is fixed: "strong" scaling.
+Rank 0 prints one JSON line (see DESIGN.md §Measurement for every field).
+"""
+import os
+
+os.environ.setdefault("OMP_NUM_THREADS", "1")   # the CPU baseline is a scalar port: tiny LAPACK calls, 1 thread
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LINES, BANDS, SAMPLES = 20000, 425, 598
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s float4 copy)
+
+
+def shard(samples, world, rank):
+    s0 = rank * samples // world
+    s1 = (rank + 1) * samples // world
+    return s0, s1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--lines", type=int, default=LINES)
+    ap.add_argument("--samples", type=int, default=SAMPLES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-columns", type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from srcfinder_amd import _ffi, cmf
+    from srcfinder_amd.synth import make_cube_torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
+    lines, samples = args.lines, args.samples
+    s0, s1 = shard(samples, world, rank)
+    ncols = s1 - s0
+    a0, a1 = cmf.active_window("ch4", False)
+    p = a1 - a0 + 1
+
+    # synthetic flightline: each rank generates only its own column slice [lines, 425, ncols]
+    cube = make_cube_torch(lines, ncols, seed=1234 + rank, abscf_full=lib[:, 2], device=dev,
+                           nodata_column=(ncols // 3))
+    torch.cuda.synchronize()
+
+    maxc = (samples + world - 1) // world
+    out = torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev)
+    gather_list = None
+    sendbuf = None
+    if world > 1:
+        sendbuf = torch.zeros((maxc, lines, 4), dtype=torch.float64, device=dev)   # column-major blocks concatenate
+        if rank == 0:
+            gather_list = [torch.empty_like(sendbuf) for _ in range(world)]
+    image = torch.empty((lines, samples, 4), dtype=torch.float64, device=dev) if (rank == 0 and world > 1) else None
+
+    def step():
+        r = cmf.robust_mf(cube, lib, out=out, out_column0=0)
+        if world > 1:
+            sendbuf[:ncols].copy_(out.permute(1, 0, 2))
+            dist.gather(sendbuf, gather_list, dst=0)
+            if rank == 0:
+                c0 = 0
+                for rr in range(world):
+                    a, b = shard(samples, world, rr)
+                    image[:, a:b, :].copy_(gather_list[rr][:b - a].permute(1, 0, 2))
+                    c0 += b - a
+        return r
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    L = _ffi.lib()
+    barrier()
+    L.sf_cmf_score_timing(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tot_ms = _ffi.C.c_double(0.0)
+    nlaunch = _ffi.C.c_int(0)
+    L.sf_cmf_score_timing_read(_ffi.C.byref(tot_ms), _ffi.C.byref(nlaunch))
+    L.sf_cmf_score_timing(0)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        mpix = lines * samples / (dt / args.steps) / 1e6
+        score_ms = tot_ms.value / max(nlaunch.value, 1)
+        # algorithmic bytes of the score kernel per launch: every active value once
+        # (4p B), the three RGB values (12 B), one 32-byte BIP record [R,G,B,CMF] float64 per pixel
+        bytes_per_pixel = 4 * p + 12 + 32
+        alg_bytes = bytes_per_pixel * lines * ncols
+        achieved = alg_bytes / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
+        line = {
+            "metric": "CMF Mpixels/s on 598x20000x425 cube",
+            "value": round(mpix, 3), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "AVIRIS-NG flightline %d samples x %d lines x %d bands float32 BIL, CH4 radiance "
+                                   "window 351..422 (p=72), 201-point LOO shrinkage sweep, unimodal"
+                                   % (samples, lines, BANDS),
+                       "parallelism": "columns sharded over %d rank(s), one RCCL gather" % world,
+                       "output": "float64 BIP [lines, samples, (R,G,B,CMF)]"},
+            "roofline": {"bound": "hbm", "kernel": "k_score<true>", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "bytes_per_pixel": bytes_per_pixel,
+                         "avg_launch_ms": round(score_ms, 4), "launches": nlaunch.value},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cube, lib, lines, ncols, args.cpu_columns, res)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cube, lib, lines, ncols, ncpu_cols, res):
+    """The oracle (faithful numpy restatement of cmf/robust_mf.py, 201x det+inv+GEMM per column) timed on ONE
+    host core over a bounded sample of the same cube: `ncpu_cols` evenly spaced columns, all lines."""
+    from oracle import cmf_oracle as O
+    cols = [int(round(i * (ncols - 1) / max(ncpu_cols - 1, 1))) for i in range(ncpu_cols)]
+    cols = sorted(set(c for c in cols if c != ncols // 3))        # skip the all-NODATA column (no work)
+    host = cube[:, :, cols].cpu().numpy()
+    t0 = time.perf_counter()
+    o = O.robust_mf_oracle(host, lib)
+    t = time.perf_counter() - t0
+    # parity spot check of the timed sample against the GPU result of the same columns
+    got = res.out[:, cols, 3].cpu().numpy()
+    ref = o["out"][..., 3]
+    nod = ref == -9999.0
+    ok = bool(np.array_equal(got == -9999.0, nod)) and bool(
+        np.all(np.abs(got[~nod] - ref[~nod]) <= 1e-4 * np.abs(ref[~nod]) + 1e-9 * np.abs(ref[~nod]).max()))
+    so = o["status"] == 0
+    aidx_ok = bool(np.array_equal(res.alphaidx.cpu().numpy()[cols][so], o["alphaidx"][so]))
+    return {"value": round(lines * len(cols) / t / 1e6, 5), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+            "sample": "%d evenly spaced columns x %d lines of the benchmark cube, %.1f s, OMP_NUM_THREADS=1"
+                      % (len(cols), lines, t),
+            "parity_on_sample": ok and aidx_ok}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+/* srcfinder_amd C ABI -- the drop-in boundary for the columnwise robust matched filter (CMF).
+ *
+ * The reference (dsmbgu8/srcfinder) is pure Python; its hot path has no FFI of its own.  What a
+ * maintainer would bind with ctypes is exactly this header: each entry point names the piece of
+ * `cmf/robust_mf.py` it replaces (file:line).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer is a DEVICE pointer owned by the caller unless it
+ *     says "host"; the library never allocates or frees result buffers; scratch comes from a caller
+ *     workspace sized by sf_cmf_workspace_bytes().
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued asynchronously on it; nothing synchronises the device.
+ *   - return value: 0 ok, <0 argument error (see sf_last_error_string), >0 a hipError_t.
+ *   - per-column soft failures are data, not errors: status[col] = 0 ok, 1 no valid rows
+ *     (robust_mf.py:303-304), 2 singular covariance (robust_mf.py:371-374 -> scores := 0).
+ *
+ * Geometry: the cube is BIL float32 [lines][bands][samples] (robust_mf.py:206-208).  A call works on
+ * the column shard [s0, s1) and the active band window [b0, b0+p) (0-based; the reference's
+ * 1-based inclusive [a0,a1] is b0 = a0-1, p = a1-a0+1, robust_mf.py:185-194,:298).
+ */
+#ifndef SRCFINDER_AMD_H
+#define SRCFINDER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_MAX_ACTIVE_FUSED 96   /* largest active window of the LDS-resident statistics path */
+#define SF_NALPHA_MAX 208        /* alpha grid is padded to a multiple of 16 (201 -> 208) */
+
+int sf_version(void);
+const char *sf_last_error_string(void);
+
+/* Largest column-major scratch the fused driver needs for a shard of `ncols` columns. */
+size_t sf_cmf_workspace_bytes(int lines, int p, int ncols, int nalpha);
+
+/* Stage 1 -- column extract (robust_mf.py:298), valid-row mask (:282,:299): transposes the active
+ * window of the shard into column-major float32 xt[ncols][lines][ps] (ps = p rounded up to 4) and
+ * writes mask_t[ncols][lines] (1 = every active value is >= 0 and finite). */
+int sf_cmf_extract_columns(const float *cube, int lines, int bands, int samples, int s0, int s1,
+                           int b0, int p, float *xt, uint8_t *mask_t, void *stream);
+
+/* Stages 2, 3 and 5 read the column-major rows `xt` as float32 (xt_f64 = 0: what stage 1 wrote) or as
+ * float64 (xt_f64 = 1: the function-level looshrinkage() entry, whose input is float64 already).
+ *
+ * Stage 2 -- masked column mean (robust_mf.py:301-302,:347): nuse[ncols], mu[ncols][p] (float64).
+ * `scratch` >= sf_cmf_workspace_bytes(). */
+int sf_cmf_column_mean(const void *xt, int xt_f64, const uint8_t *mask_t, int lines, int p, int ncols,
+                       int32_t *nuse, double *mu, void *scratch, void *stream);
+
+/* Stage 3 -- sample covariance of the centred valid rows, ddof = 1 (robust_mf.py:52-70 as called at
+ * :130): cov[ncols][p][p] float64, computed with fp64 MFMA. */
+int sf_cmf_covariance(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse,
+                      const double *mu, int lines, int p, int ncols, double *cov, void *scratch, void *stream);
+
+/* Stage 4 -- symmetric eigendecomposition of the correlation matrix R = D^-1 S D^-1 (the restated
+ * form of the 201 det+inverse calls at robust_mf.py:105-117): d[ncols][p] = sqrt(diag S),
+ * lam[ncols][p], evec[ncols][p][p] (evec[c][j][:] is eigenvector j), status[ncols] (2 when a band has
+ * zero or non-finite variance, 1 when nuse == 0). */
+int sf_cmf_eigh(const double *cov, const int32_t *nuse, int p, int ncols, double *d, double *lam,
+                double *evec, int32_t *status, void *scratch, void *stream);
+
+/* Stage 5 -- leave-one-out NLL for every alpha (robust_mf.py:105-117) and its argmin (:121-127):
+ * nll[ncols][nalpha] (inf where the reference's det over/underflows), alphaidx[ncols] (-1 if none). */
+int sf_cmf_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu,
+                 const double *d, const double *lam, const double *evec, const int32_t *status,
+                 const double *alphas, int nalpha, int lines, int p, int ncols,
+                 double *nll, int32_t *alphaidx, void *scratch, void *stream);
+
+/* Stage 6 -- shrunk covariance C = (1-a)S + a diag(S) (robust_mf.py:130-134), solve, normalise
+ * (:363,:378-381): filt[ncols][p] = scale * C^-1 t / (t^T C^-1 t), bias[ncols] = mu . filt, with
+ * t = abscf*mu (radiance) or abscf-mu (reflectance != 0); scale = 1e5 or 1 (:383-386).
+ * status is updated to 2 where C is singular. */
+int sf_cmf_filter(const double *mu, const double *d, const double *lam, const double *evec,
+                  const double *alphas, const int32_t *alphaidx, const double *abscf, int reflectance,
+                  int p, int ncols, int32_t *status, double *filt, double *bias, void *stream);
+
+/* Stage 7 -- the per-pixel matched filter score and output assembly (robust_mf.py:377-397, :266):
+ * streams the BIL cube once, recomputes row validity inline, writes
+ *   out[(line*out_samples + out_s0 + c)*out_bands + out_bands-1] = x.filt - bias   (valid rows)
+ *                                                               = nodata          (invalid rows)
+ * and, when out_bands == 4, bands 0..2 = cube[line][rgb[k]][col] as float64 for every line of every
+ * column that has at least one valid row (:303-304 skips the others).  Optional: bgmeta int16
+ * [lines][out_samples][2] band 1 = alpha index on valid rows (:365); colstats[3][ncols] = npix, mean,
+ * std (ddof 0) of the written scores (:388-392).  This is the HBM-roofline kernel. */
+int sf_cmf_score(const float *cube, int lines, int bands, int samples, int s0, int s1, int b0, int p,
+                 const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,
+                 const int32_t *nuse, int rgb0, int rgb1, int rgb2, double nodata,
+                 double *out, int out_samples, int out_s0, int out_bands,
+                 int16_t *bgmeta, double *colstats, void *scratch, void *stream);
+
+/* Fused driver = stages 1..7 (the body of the column loop, robust_mf.py:297-397, unimodal k = 1).
+ * Host arrays: none.  Device outputs: out (see sf_cmf_score), alphaidx/nuse/status[ncols],
+ * colstats[3][ncols] (may be NULL), bgmeta (may be NULL), nll_out[ncols][nalpha] (may be NULL). */
+int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int s1, int b0, int p,
+               const double *abscf, const double *alphas, int nalpha, int reflectance,
+               int rgb0, int rgb1, int rgb2, double nodata,
+               double *out, int out_samples, int out_s0, int out_bands,
+               int32_t *alphaidx, int32_t *nuse, int32_t *status, double *colstats,
+               int16_t *bgmeta, double *nll_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Timing hook for bench.py's roofline line: while enabled, every sf_cmf_score launch (direct or
+ * inside sf_cmf_run) is bracketed by a fresh pair of HIP events on the launch stream.
+ * sf_cmf_score_timing_read() synchronises those events, returns the summed kernel time and the
+ * number of launches since the last enable, and clears the list. */
+int sf_cmf_score_timing(int enable);
+int sf_cmf_score_timing_read(double *total_ms, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRCFINDER_AMD_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of libsrcfinder_amd.so (include/srcfinder_amd.h).
+
+The library is the product: there is no CPU fallback.  Importing this module never touches the GPU;
+:func:`lib` loads the shared object on first use and raises if it has not been built
+(``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C srcfinder_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrcfinder_amd.so")
+_lib = None
+
+vp, i32, f64, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/srcfinder_amd.h line by line
+SIGNATURES = {
+    "sf_version": (i32, []),
+    "sf_last_error_string": (C.c_char_p, []),
+    "sf_cmf_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "sf_cmf_extract_columns": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "sf_cmf_column_mean": (i32, [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "sf_cmf_covariance": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "sf_cmf_eigh": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "sf_cmf_loocv": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "sf_cmf_filter": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "sf_cmf_score": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, f64,
+                           vp, i32, i32, i32, vp, vp, vp, vp]),
+    "sf_cmf_run": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, f64,
+                         vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "sf_cmf_score_timing": (i32, [i32]),
+    "sf_cmf_score_timing_read": (i32, [C.POINTER(f64), C.POINTER(i32)]),
+}
+
+
+class SrcfinderError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise SrcfinderError(
+                "HIP library %s is missing: build it (make -C srcfinder_amd/csrc); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError here = header and library out of sync
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().sf_last_error_string()
+        raise SrcfinderError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

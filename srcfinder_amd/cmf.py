@@ -1,0 +1,292 @@
+"""Columnwise robust matched filter on MI355X -- host side of the drop-in boundary.
+
+Mirrors the interface of the reference's ``cmf/robust_mf.py``:
+
+* ``looshrinkage(I_zm, alphas, nll, n, I_reg=[]) -> (C, mindex)``   (robust_mf.py:92-136; fills ``nll``)
+* ``cov(A, **kw)``                                                  (robust_mf.py:52-70)
+* ``robust_mf(cube_bil, library, ...)`` -- the body of the reference's ``__main__`` column loop
+  (robust_mf.py:185-397), which has no callable form upstream; keyword names follow the CLI flags
+  (robust_mf.py:142-166).
+* ``alpha_grid()``, ``active_window()``, ``model_parameters()`` -- the constants the script derives
+  (robust_mf.py:185-194, :241-259).
+
+Everything numerical runs in hand-written HIP kernels behind ``libsrcfinder_amd.so``
+(``include/srcfinder_amd.h``); PyTorch only owns device memory and the stream.  There is no CPU path:
+calling these without the library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+
+PPM_SCALING = 100000.0
+NODATA_DEFAULT = -9999.0
+
+_ACTIVE = {("ch4", False): (351, 422), ("ch4", True): (5, 420),
+           ("co2", False): (309, 391), ("co2", True): (309, 391)}
+
+
+def active_window(gas="ch4", reflectance=False):
+    """1-based inclusive active channel window (robust_mf.py:185-194).
+
+    The reference picks it from the library *file name*; unknown gases make it print and exit --
+    here that is a ``ValueError``."""
+    key = (str(gas).lower(), bool(reflectance))
+    if key not in _ACTIVE:
+        raise ValueError("could not set active range for gas %r" % (gas,))
+    return _ACTIVE[key]
+
+
+def gas_from_library_name(path):
+    name = str(path)
+    if "ch4" in name:
+        return "ch4"
+    if "co2" in name:
+        return "co2"
+    raise ValueError("could not set active range")
+
+
+def alpha_grid():
+    """robust_mf.py:242-243 -- evaluated with the same numpy expression (201 values)."""
+    astep, aminexp, amaxexp = 0.05, -10.0, 0.0
+    return 10.0 ** np.arange(aminexp, amaxexp + astep, astep)
+
+
+def model_parameters(reflectance=False, active=(351, 422), modelname="looshrinkage", bgmodes=1):
+    """The ``model parameters`` header string the reference writes (robust_mf.py:246-259)."""
+    bgmodel = "unimodal" if bgmodes == 1 else "multimodal"
+    s = "modelname=%s, bgmodel=%s" % (modelname, bgmodel)
+    if modelname == "looshrinkage":
+        s += ", aminexp=-10.0, amaxexp=0.0, astep=0.05"
+    s += ", reflectance=%s, active_bands=[%d, %d]" % (bool(reflectance), active[0], active[1])
+    return "{ %s }" % s
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _ffi.SrcfinderError("no GPU visible: srcfinder_amd has no CPU fallback")
+    return torch
+
+
+@dataclass
+class CMFResult:
+    """Outputs of :func:`robust_mf` (device tensors unless ``to_numpy`` was requested).
+
+    out      [lines, samples, 4] float64 BIP, bands (R, G, B, CMF ppm*m); NODATA where a row is invalid
+             ([lines, samples, 1] when ``rgb_bands=()``)                       robust_mf.py:212-228,:383-397
+    bgmeta   [lines, samples, 2] int16 (cluster id = 0, alpha index) or None    robust_mf.py:268-279,:365
+    colstats [3, samples] float64 = npix, mean, std of the written scores       robust_mf.py:388-392
+    alphaidx [samples] int32 (-1: every NLL was inf; untouched columns -2)
+    nuse     [samples] int32 valid rows per column
+    status   [samples] int32: 0 ok, 1 no valid rows, 2 singular covariance
+    nll      [samples, 201] float64 or None
+    """
+    out: object
+    bgmeta: object
+    colstats: object
+    alphaidx: object
+    nuse: object
+    status: object
+    nll: object = None
+    modelparms: str = ""
+
+
+class _Workspace:
+    """One growable device scratch buffer per (device) -- the C ABI never allocates."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, nbytes, device):
+        torch = _torch()
+        key = str(device)
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            cls._bufs[key] = None
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            cls._bufs[key] = buf
+        return buf
+
+
+def _abscf_from_library(library, a0, a1):
+    lib = np.asarray(library, dtype=np.float64)
+    col = lib[:, 2] if lib.ndim == 2 else lib
+    return np.ascontiguousarray(col[a0 - 1:a1])
+
+
+def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcadim=6, reject=False, full=False,
+              model="looshrinkage", rgb_bands=(60, 42, 24), nodata=NODATA_DEFAULT, active=None, metadata=False,
+              columns=None, out=None, out_column0=0, return_nll=False, to_numpy=False):
+    """Unimodal columnwise matched filter of a BIL radiance cube.
+
+    cube_bil : [lines, bands, samples] float32, torch tensor on the GPU (preferred: stays resident) or
+               ndarray (copied once).
+    library  : [bands, 3] target table (column 3 = unit absorption) or its third column.
+    columns  : optional (s0, s1) shard of samples to process (multi-GPU sharding); outputs then cover only
+               those columns unless ``out`` (a preallocated [lines, S, nb] float64 tensor) and
+               ``out_column0`` say where to put them.
+    """
+    torch = _torch()
+    if kmeans != 1 or reject or full:
+        raise NotImplementedError("multimodal background (-k > 1, -r, -f) is not built (SURVEY.md §8 N1)")
+    if model != "looshrinkage":
+        raise NotImplementedError("only the looshrinkage model is built (the 'empirical' branch of the "
+                                  "reference hits a NameError, SURVEY.md D7)")
+    if nodata > 0:
+        raise Exception("nodata value=%f > 0, values will not be masked" % nodata)       # robust_mf.py:232-234
+    rgb_bands = tuple(int(b) for b in rgb_bands)
+    if len(rgb_bands) not in (0, 3):
+        raise Exception("invalid value of rgb_bands argument: %s" % (rgb_bands,))         # robust_mf.py:225-226
+    if not torch.is_tensor(cube_bil):
+        cube_bil = torch.as_tensor(np.ascontiguousarray(cube_bil, dtype=np.float32))
+    if cube_bil.dtype != torch.float32 or cube_bil.dim() != 3:
+        raise TypeError("cube must be float32 [lines, bands, samples]")
+    if not cube_bil.is_cuda:
+        cube_bil = cube_bil.cuda()
+    cube_bil = cube_bil.contiguous()
+    dev = cube_bil.device
+    lines, bands, samples = cube_bil.shape
+    a0, a1 = active if active is not None else active_window(gas, reflectance)
+    p = a1 - a0 + 1
+    s0, s1 = (0, samples) if columns is None else (int(columns[0]), int(columns[1]))
+    ncols = s1 - s0
+    abscf = torch.as_tensor(_abscf_from_library(library, a0, a1), device=dev)
+    alphas_np = alpha_grid()
+    alphas = torch.as_tensor(alphas_np, device=dev)
+    nalpha = len(alphas_np)
+    nb = 4 if len(rgb_bands) == 3 else 1
+    with torch.cuda.device(dev):
+        if out is None:
+            out_t = torch.empty((lines, ncols, nb), dtype=torch.float64, device=dev)
+            out_samples, out_s0 = ncols, 0
+        else:
+            out_t = out
+            if out_t.dtype != torch.float64 or tuple(out_t.shape[::2]) != (lines, nb) or not out_t.is_contiguous():
+                raise TypeError("out must be contiguous float64 [lines, S, %d]" % nb)
+            out_samples, out_s0 = out_t.shape[1], int(out_column0)
+        alphaidx = torch.empty(ncols, dtype=torch.int32, device=dev)
+        nuse = torch.empty(ncols, dtype=torch.int32, device=dev)
+        status = torch.empty(ncols, dtype=torch.int32, device=dev)
+        colstats = torch.empty((3, ncols), dtype=torch.float64, device=dev)
+        bgmeta = torch.empty((lines, out_samples, 2), dtype=torch.int16, device=dev) if metadata else None
+        if metadata and out is not None and out_samples != ncols:
+            bgmeta.zero_()
+        nll = torch.empty((ncols, nalpha), dtype=torch.float64, device=dev) if return_nll else None
+        L = _ffi.lib()
+        wsb = L.sf_cmf_workspace_bytes(lines, p, ncols, nalpha)
+        ws = _Workspace.get(wsb, dev)
+        r = rgb_bands if nb == 4 else (0, 0, 0)
+        rc = L.sf_cmf_run(_ffi.ptr(cube_bil), lines, bands, samples, s0, s1, a0 - 1, p, _ffi.ptr(abscf),
+                          _ffi.ptr(alphas), nalpha, int(bool(reflectance)), r[0], r[1], r[2], float(nodata),
+                          _ffi.ptr(out_t), out_samples, out_s0, nb, _ffi.ptr(alphaidx), _ffi.ptr(nuse),
+                          _ffi.ptr(status), _ffi.ptr(colstats), _ffi.ptr(bgmeta), _ffi.ptr(nll), _ffi.ptr(ws),
+                          C.c_size_t(ws.numel()), _ffi.stream_ptr())
+        _ffi.check(rc, "sf_cmf_run")
+    res = CMFResult(out=out_t, bgmeta=bgmeta, colstats=colstats, alphaidx=alphaidx, nuse=nuse, status=status, nll=nll,
+                    modelparms=model_parameters(reflectance, (a0, a1)))
+    if to_numpy:
+        for k in ("out", "bgmeta", "colstats", "alphaidx", "nuse", "status", "nll"):
+            v = getattr(res, k)
+            if v is not None:
+                setattr(res, k, v.cpu().numpy())
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------
+# function-level entries with the reference's signatures
+# ------------------------------------------------------------------------------------------------------
+def _upload_rows(a):
+    """[n, p] float64 host matrix -> device xt[1][n][ps] float64 (zero padded), all rows valid."""
+    torch = _torch()
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    n, p = a.shape
+    ps = (p + 3) // 4 * 4
+    buf = np.zeros((1, n, ps), np.float64)
+    buf[0, :, :p] = a
+    xt = torch.as_tensor(buf).cuda()
+    mask = torch.ones((1, n), dtype=torch.uint8, device=xt.device)
+    return xt, mask, n, p
+
+
+def cov(A, **kwargs):
+    """Sample covariance with MATLAB semantics: rows are samples, ``ddof=1`` (robust_mf.py:52-70).
+
+    Computed on the GPU (masked mean + centred fp64-MFMA SYRK).  Only ``ddof`` (0 or 1) is honoured."""
+    torch = _torch()
+    ddof = kwargs.pop("ddof", 1)
+    if kwargs:
+        raise TypeError("unsupported numpy.cov keyword(s): %s" % sorted(kwargs))
+    if isinstance(A, torch.Tensor):
+        A = A.detach().cpu().numpy()
+    xt, mask, n, p = _upload_rows(A)
+    if p > 96:
+        raise NotImplementedError("cov(): more than 96 features is outside the fused statistics path")
+    L = _ffi.lib()
+    dev = xt.device
+    ws = _Workspace.get(L.sf_cmf_workspace_bytes(n, p, 1, 1), dev)
+    nuse = torch.empty(1, dtype=torch.int32, device=dev)
+    mu = torch.empty((1, p), dtype=torch.float64, device=dev)
+    S = torch.empty((1, p, p), dtype=torch.float64, device=dev)
+    st = _ffi.stream_ptr()
+    _ffi.check(L.sf_cmf_column_mean(_ffi.ptr(xt), 1, _ffi.ptr(mask), n, p, 1, _ffi.ptr(nuse), _ffi.ptr(mu),
+                                    _ffi.ptr(ws), st), "sf_cmf_column_mean")
+    _ffi.check(L.sf_cmf_covariance(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nuse), _ffi.ptr(mu), n, p, 1,
+                                   _ffi.ptr(S), _ffi.ptr(ws), st), "sf_cmf_covariance")
+    S = S[0].cpu().numpy()
+    if ddof != 1:
+        S = S * ((n - 1.0) / (n - float(ddof)))
+    return S
+
+
+def looshrinkage(I_zm, alphas, nll, n, I_reg=[]):
+    """Leave-one-out shrinkage covariance (Theiler 2012), same contract as robust_mf.py:92-136:
+
+    ``I_zm`` [rows, p] zero-mean float64 samples, ``alphas`` the candidate grid, ``nll`` a float64 array of
+    the same length that is FILLED IN PLACE, ``n`` the sample count used in beta and 1/(2n) (the reference
+    passes the column's ``nuse`` even for a cluster subset).  Returns ``(C, mindex)`` with
+    ``C = (1-alpha) S + alpha diag(S)`` on the unscaled data and ``mindex = -1`` (alpha = 0) when every
+    candidate's NLL is +inf.
+    """
+    torch = _torch()
+    if len(I_reg) != 0:
+        raise NotImplementedError("full-covariance regulariser (I_reg, -f) belongs to the multimodal branch "
+                                  "(SURVEY.md §8 N1) and is not built")
+    alphas_np = np.ascontiguousarray(alphas, dtype=np.float64)
+    xt, mask, rows, p = _upload_rows(I_zm)
+    if p > 96:
+        raise NotImplementedError("looshrinkage(): more than 96 bands is outside the fused statistics path")
+    L = _ffi.lib()
+    dev = xt.device
+    nalpha = len(alphas_np)
+    ws = _Workspace.get(L.sf_cmf_workspace_bytes(rows, p, 1, nalpha), dev)
+    f64 = dict(dtype=torch.float64, device=dev)
+    nrows = torch.tensor([rows], dtype=torch.int32, device=dev)      # numpy.cov's own row count (ddof=1)
+    nloo = torch.tensor([int(n)], dtype=torch.int32, device=dev)     # the n of beta and of 1/(2n)
+    mu = torch.zeros((1, p), **f64)                                   # data is already centred
+    S = torch.empty((1, p, p), **f64)
+    d = torch.empty((1, p), **f64)
+    lam = torch.empty((1, p), **f64)
+    evec = torch.empty((1, p, p), **f64)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    nll_d = torch.empty((1, nalpha), **f64)
+    aidx = torch.empty(1, dtype=torch.int32, device=dev)
+    al = torch.as_tensor(alphas_np, device=dev)
+    st = _ffi.stream_ptr()
+    _ffi.check(L.sf_cmf_covariance(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nrows), _ffi.ptr(mu), rows, p, 1,
+                                   _ffi.ptr(S), _ffi.ptr(ws), st), "sf_cmf_covariance")
+    _ffi.check(L.sf_cmf_eigh(_ffi.ptr(S), _ffi.ptr(nrows), p, 1, _ffi.ptr(d), _ffi.ptr(lam), _ffi.ptr(evec),
+                             _ffi.ptr(status), _ffi.ptr(ws), st), "sf_cmf_eigh")
+    _ffi.check(L.sf_cmf_loocv(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nloo), _ffi.ptr(mu), _ffi.ptr(d),
+                              _ffi.ptr(lam), _ffi.ptr(evec), _ffi.ptr(status), _ffi.ptr(al), nalpha, rows, p, 1,
+                              _ffi.ptr(nll_d), _ffi.ptr(aidx), _ffi.ptr(ws), st), "sf_cmf_loocv")
+    nll[:] = nll_d[0].cpu().numpy()
+    mindex = int(aidx.item())
+    alpha = float(alphas_np[mindex]) if mindex >= 0 else 0.0
+    S = S[0].cpu().numpy()
+    T = np.diag(np.diag(S))
+    Cmat = (1.0 - alpha) * S + alpha * T                               # robust_mf.py:130-134
+    return Cmat, mindex

@@ -1,0 +1,123 @@
+// Shared declarations for the CMF HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "srcfinder_amd.h"
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (c_api.hip) -------------------------------------------------------------
+void sf_set_error(const char *fmt, ...);
+int sf_fail_hip(hipError_t e, const char *what);
+#define SF_HIP(call)                                   \
+  do {                                                 \
+    hipError_t _e = (call);                            \
+    if (_e != hipSuccess) return sf_fail_hip(_e, #call); \
+  } while (0)
+#define SF_LAUNCH_CHECK(name)                          \
+  do {                                                 \
+    hipError_t _e = hipGetLastError();                 \
+    if (_e != hipSuccess) return sf_fail_hip(_e, name); \
+  } while (0)
+
+static inline int sf_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t sf_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Row validity of the reference: ((~(x<0)) & isfinite(x))  (cmf/robust_mf.py:282).
+// NaN fails the first compare, +inf the second, -0.0 passes like the reference.
+__device__ __forceinline__ bool sf_valid(float x) { return (x >= 0.0f) & (x <= 3.402823466e+38f); }
+
+// Column-major row data (xt) may be float32 (the extracted cube) or float64 (the function-level
+// looshrinkage() entry, whose input is already centred float64): 4- and 2-element loads promoted to double.
+__device__ __forceinline__ void sf_load4(const float *p, double &a, double &b, double &c, double &d) {
+  const float4 f = *reinterpret_cast<const float4 *>(p);
+  a = (double)f.x; b = (double)f.y; c = (double)f.z; d = (double)f.w;
+}
+__device__ __forceinline__ void sf_load4(const double *p, double &a, double &b, double &c, double &d) {
+  const double2 u = *reinterpret_cast<const double2 *>(p), v = *reinterpret_cast<const double2 *>(p + 2);
+  a = u.x; b = u.y; c = v.x; d = v.y;
+}
+__device__ __forceinline__ void sf_load2(const float *p, float &a, float &b) {
+  const float2 f = *reinterpret_cast<const float2 *>(p);
+  a = f.x; b = f.y;
+}
+__device__ __forceinline__ void sf_load2(const double *p, double &a, double &b) {
+  const double2 f = *reinterpret_cast<const double2 *>(p);
+  a = f.x; b = f.y;
+}
+
+// ---- geometry shared by host launchers and kernels ---------------------------------------------
+struct SfGeom {
+  int lines, p, ps, nt, s4, ncols, nalpha, nu;
+};
+static inline SfGeom sf_geom(int lines, int p, int ncols, int nalpha) {
+  SfGeom g;
+  g.lines = lines; g.p = p; g.ncols = ncols; g.nalpha = nalpha;
+  g.ps = (p + 3) / 4 * 4;        // xt row stride (floats), 16-byte rows
+  g.nt = (p + 15) / 16;          // 16-wide MFMA tiles over the band axis
+  g.s4 = (p + 3) / 4;            // 4-deep MFMA k-steps over the band / eigen axis
+  g.nu = (nalpha + 15) / 16;     // 16-wide tiles over the alpha grid
+  return g;
+}
+
+// split counts (deterministic functions of the geometry so that results do not depend on the GPU)
+static inline int sf_extract_lines_per_wg(int lines, int ncols) {
+  int colblocks = sf_cdiv(ncols, 64);
+  int target = sf_cdiv(2048, colblocks);
+  int lpw = sf_cdiv(lines, target);
+  lpw = (lpw + 3) / 4 * 4;
+  return lpw < 4 ? 4 : lpw;
+}
+static inline int sf_colsum_chunks(int lines, int ncols) {
+  int want = sf_cdiv(2048, ncols);
+  int maxc = sf_cdiv(lines, 256);
+  int c = want < maxc ? want : maxc;
+  return c < 1 ? 1 : c;
+}
+static inline int sf_syrk_splits(int lines, int ncols) {
+  int want = sf_cdiv(4096, ncols);
+  int maxc = sf_cdiv(lines, 512);
+  int c = want < maxc ? want : maxc;
+  return c < 1 ? 1 : c;
+}
+static inline int sf_sweep_splits(int lines, int ncols) {
+  int want = sf_cdiv(1536, ncols);          // ~6 workgroups per CU (one 256-thread WG per CU, LDS-bound)
+  int maxc = sf_cdiv(lines, 1024);
+  int c = want < maxc ? want : maxc;
+  return c < 1 ? 1 : c;
+}
+static inline int sf_score_lines_per_wg(int lines, int ncols) {
+  int colblocks = sf_cdiv(ncols, 64);
+  int target = sf_cdiv(4096, colblocks);
+  int lpw = sf_cdiv(lines, target);
+  lpw = (lpw + 15) / 16 * 16;
+  return lpw < 16 ? 16 : lpw;
+}
+
+// ---- stage launchers (each in its own .hip) -------------------------------------------------------
+int sf_launch_extract(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
+                      float *xt, uint8_t *mask_t, hipStream_t st);
+size_t sf_mean_scratch_bytes(const SfGeom &g);
+int sf_launch_mean(const void *xt, int xt_f64, const uint8_t *mask_t, const SfGeom &g, int32_t *nuse, double *mu,
+                   void *scratch, hipStream_t st);
+size_t sf_cov_scratch_bytes(const SfGeom &g);
+int sf_launch_cov(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu,
+                  const SfGeom &g, double *cov, void *scratch, hipStream_t st);
+size_t sf_wfrag_elems(const SfGeom &g);   // per column
+int sf_launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, double *d, double *lam, double *evec,
+                   int32_t *status, hipStream_t st);
+size_t sf_loocv_scratch_bytes(const SfGeom &g);
+int sf_launch_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *d,
+                    const double *lam, const double *evec, const int32_t *status, const double *alphas,
+                    const SfGeom &g, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st);
+int sf_launch_filter(const double *mu, const double *d, const double *lam, const double *evec, const double *alphas,
+                     const int32_t *alphaidx, const double *abscf, int reflectance, const SfGeom &g,
+                     int32_t *status, double *filt, double *bias, hipStream_t st);
+size_t sf_score_scratch_bytes(int lines, int ncols);
+int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
+                    const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,
+                    int rgb0, int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0,
+                    int out_bands, int16_t *bgmeta, void *stat_scratch, hipStream_t st);
+int sf_launch_colstats(const void *stat_scratch, int lines, int ncols, const int32_t *nuse, const int32_t *status,
+                       double nodata, double *colstats, hipStream_t st);

@@ -1,0 +1,208 @@
+// Stage 1+2 of the column matched filter: column extract + valid-row mask, masked column mean.
+//
+// Replaces cmf/robust_mf.py:298-302 (strided column view, useidx, float64 promotion) and :347 (mean).
+// The BIL cube keeps adjacent SAMPLES adjacent in memory, so one detector column's spectra are strided
+// by `samples` floats.  The statistics kernels want one column's (lines x p) matrix in front of one
+// workgroup, so this pass transposes the active window once into column-major xt[col][line][ps]
+// through LDS: global reads are 256-byte rows (64 samples x 4 B) of one (line, band); global writes are
+// 256-byte runs of one column's consecutive (line, band) values.  HBM-bound: 4p B read + 4p B written
+// per pixel.
+#include "cmf_common.h"
+
+namespace {
+
+constexpr int XT_TL = 4;      // lines per LDS tile
+constexpr int XT_PBMAX = 80;  // band chunk held in LDS at once
+
+// LDS: tile[64 columns][cs] floats, cs odd -> both the column-strided writes (lane = column) and the
+// row-contiguous reads (lane = element) are bank-conflict free.
+__global__ __launch_bounds__(256) void k_extract(const float *__restrict__ cube, int L, int B, int C, int s0,
+                                                  int Cs, int b0, int p, int PS, float *__restrict__ xt,
+                                                  uint8_t *__restrict__ mask_t, int lines_per_wg, int pbmax, int cs) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ uint8_t vf[64][XT_TL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int colbase = blockIdx.x * 64;
+  const int ncol = min(64, Cs - colbase);
+  const bool colok = lane < ncol;
+  const int lbeg = blockIdx.y * lines_per_wg;
+  const int lend = min(L, lbeg + lines_per_wg);
+  const float *cbase = cube + (size_t)(s0 + colbase + (colok ? lane : 0));
+
+  for (int l0 = lbeg; l0 < lend; l0 += XT_TL) {
+    const int nl = min(XT_TL, lend - l0);
+    bool ok = true;  // thread (line = wave, column = lane)
+    for (int bc0 = 0; bc0 < p; bc0 += pbmax) {
+      const int pb = min(pbmax, p - bc0);
+      const int nrows = nl * pb;  // (line, band) rows of 64 samples in this chunk
+      // ---- global -> LDS, 8 rows in flight per wave
+      for (int base = wave; base < nrows; base += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = base + 4 * u;
+          v[u] = 0.f;
+          if (rr < nrows) {
+            const int l = rr / pb, b = rr - l * pb;
+            v[u] = cbase[((size_t)(l0 + l) * B + (b0 + bc0 + b)) * C];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int rr = base + 4 * u;
+          if (rr < nrows) tile[lane * cs + rr] = v[u];
+        }
+      }
+      __syncthreads();
+      // ---- validity of (line = wave, column = lane) over this band chunk
+      if (wave < nl) {
+        const float *tp = tile + lane * cs + wave * pb;
+        for (int b = 0; b < pb; ++b) ok = ok & sf_valid(tp[b]);
+      }
+      // ---- LDS -> xt; wave handles columns wave, wave+4, ...
+      if (pb == PS) {  // single chunk, no padding: nl*PS contiguous floats per column
+        const int nel = nl * PS;
+        for (int c = wave; c < ncol; c += 4) {
+          float *dst = xt + ((size_t)(colbase + c) * L + l0) * PS;
+          const float *src = tile + c * cs;
+          for (int k = lane; k < nel; k += 64) dst[k] = src[k];
+        }
+      } else {
+        const bool last = (bc0 + pb >= p);
+        const int wid = last ? (PS - bc0) : pb;  // last chunk also writes the zero padding p..PS-1
+        for (int c = wave; c < ncol; c += 4) {
+          for (int l = 0; l < nl; ++l) {
+            float *dst = xt + ((size_t)(colbase + c) * L + l0 + l) * PS + bc0;
+            const float *src = tile + c * cs + l * pb;
+            for (int b = lane; b < wid; b += 64) dst[b] = (b < pb) ? src[b] : 0.f;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // ---- mask: gather the tile's 4 line flags of a column into one 32-bit store where possible
+    if (wave < nl) vf[lane][wave] = ok ? 1 : 0;
+    __syncthreads();
+    if (wave == 0 && colok) {
+      uint8_t *mp = mask_t + (size_t)(colbase + lane) * L + l0;
+      if (nl == XT_TL && (((size_t)(colbase + lane) * L + l0) & 3) == 0) {
+        *reinterpret_cast<uint32_t *>(mp) = *reinterpret_cast<const uint32_t *>(&vf[lane][0]);
+      } else {
+        for (int l = 0; l < nl; ++l) mp[l] = vf[lane][l];
+      }
+    }
+    // vf is rewritten only after the next tile's two barriers
+  }
+}
+
+// Masked column sums over a chunk of lines.  One workgroup = (column, line chunk); thread (sub, q4)
+// accumulates the float4 at band 4*q4 of rows sub, sub+rpi, ...; partials are combined in a fixed order
+// so the mean is bit-reproducible.
+template <typename XT>
+__global__ __launch_bounds__(256) void k_colsum(const XT *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+                                                 int L, int PS, int lines_per_wg, double *__restrict__ sum_part,
+                                                 int *__restrict__ cnt_part) {
+  __shared__ double red[256 * 4];
+  __shared__ int cred[256];
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x, ch = blockIdx.y, Cs = gridDim.x;
+  const int tpr = PS >> 2;
+  const int rpi = 256 / tpr;
+  const int sub = tid / tpr, q4 = tid - sub * tpr;
+  const bool active = sub < rpi;
+  const int lbeg = ch * lines_per_wg, lend = min(L, lbeg + lines_per_wg);
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  int cnt = 0;
+  if (active) {
+    const uint8_t *mp = mask_t + (size_t)c * L;
+    const XT *xp = xt + (size_t)c * L * PS + 4 * q4;
+    for (int r = lbeg + sub; r < lend; r += rpi) {
+      if (mp[r]) {
+        double v0, v1, v2, v3;
+        sf_load4(xp + (size_t)r * PS, v0, v1, v2, v3);
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        ++cnt;
+      }
+    }
+  }
+  red[tid * 4 + 0] = a0; red[tid * 4 + 1] = a1; red[tid * 4 + 2] = a2; red[tid * 4 + 3] = a3;
+  cred[tid] = cnt;
+  __syncthreads();
+  if (tid < tpr) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int s = 0; s < rpi; ++s) {
+      const int t = s * tpr + tid;
+      s0 += red[t * 4 + 0]; s1 += red[t * 4 + 1]; s2 += red[t * 4 + 2]; s3 += red[t * 4 + 3];
+    }
+    double *o = sum_part + ((size_t)ch * Cs + c) * PS + 4 * tid;
+    o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+  }
+  if (tid == 0) {
+    int n = 0;
+    for (int s = 0; s < rpi; ++s) n += cred[s * tpr];  // q4 == 0 threads count rows
+    cnt_part[ch * Cs + c] = n;
+  }
+}
+
+__global__ void k_mean(const double *__restrict__ sum_part, const int *__restrict__ cnt_part, int nch, int Cs, int p,
+                       int PS, int32_t *__restrict__ nuse, double *__restrict__ mu) {
+  const int c = blockIdx.x;
+  int n = 0;
+  for (int ch = 0; ch < nch; ++ch) n += cnt_part[ch * Cs + c];
+  for (int b = threadIdx.x; b < p; b += blockDim.x) {
+    double s = 0;
+    for (int ch = 0; ch < nch; ++ch) s += sum_part[((size_t)ch * Cs + c) * PS + b];
+    mu[(size_t)c * p + b] = n > 0 ? s / (double)n : 0.0;
+  }
+  if (threadIdx.x == 0) nuse[c] = n;
+}
+
+}  // namespace
+
+int sf_launch_extract(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
+                      float *xt, uint8_t *mask_t, hipStream_t st) {
+  const int PS = (p + 3) / 4 * 4;
+  const int pbmax = (p <= XT_PBMAX) ? p : XT_PBMAX;
+  const int cs = (XT_TL * pbmax) | 1;
+  const size_t lds = (size_t)64 * cs * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               64 * ((XT_TL * XT_PBMAX) | 1) * (int)sizeof(float)));
+    attr_set = true;
+  }
+  const int lpw = sf_extract_lines_per_wg(lines, ncols);
+  dim3 grid(sf_cdiv(ncols, 64), sf_cdiv(lines, lpw));
+  hipLaunchKernelGGL(k_extract, grid, dim3(256), lds, st, cube, lines, bands, samples, s0, ncols, b0, p, PS, xt,
+                     mask_t, lpw, pbmax, cs);
+  SF_LAUNCH_CHECK("k_extract");
+  return 0;
+}
+
+size_t sf_mean_scratch_bytes(const SfGeom &g) {
+  const int nch = sf_colsum_chunks(g.lines, g.ncols);
+  return sf_align((size_t)nch * g.ncols * g.ps * sizeof(double)) + sf_align((size_t)nch * g.ncols * sizeof(int));
+}
+
+int sf_launch_mean(const void *xt, int xt_f64, const uint8_t *mask_t, const SfGeom &g, int32_t *nuse, double *mu,
+                   void *scratch, hipStream_t st) {
+  if (g.ps > 1024) {
+    sf_set_error("active window of %d bands is too wide for the column-sum kernel", g.p);
+    return -2;
+  }
+  const int nch = sf_colsum_chunks(g.lines, g.ncols);
+  const int lpw = sf_cdiv(g.lines, nch);
+  double *sum_part = reinterpret_cast<double *>(scratch);
+  int *cnt_part = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) +
+                                          sf_align((size_t)nch * g.ncols * g.ps * sizeof(double)));
+  if (xt_f64)
+    hipLaunchKernelGGL(k_colsum<double>, dim3(g.ncols, nch), dim3(256), 0, st, (const double *)xt, mask_t, g.lines,
+                       g.ps, lpw, sum_part, cnt_part);
+  else
+    hipLaunchKernelGGL(k_colsum<float>, dim3(g.ncols, nch), dim3(256), 0, st, (const float *)xt, mask_t, g.lines,
+                       g.ps, lpw, sum_part, cnt_part);
+  SF_LAUNCH_CHECK("k_colsum");
+  hipLaunchKernelGGL(k_mean, dim3(g.ncols), dim3(128), 0, st, sum_part, cnt_part, nch, g.ncols, g.p, g.ps, nuse, mu);
+  SF_LAUNCH_CHECK("k_mean");
+  return 0;
+}

@@ -1,0 +1,197 @@
+// Stage 7: per-pixel matched-filter score + output assembly -- the HBM-roofline kernel of the path.
+//
+// Replaces cmf/robust_mf.py:377-397 and :266: mf = (x - mu) C^-1 t / (t C^-1 t) is one p-long dot product
+// per pixel with the per-column vector from stage 6 (score = x . filt - bias, float64 accumulate -- the mean
+// term is ~600x the spread of the scores), rows that fail the validity test keep NODATA,
+// and the three RGB bands are copied next to the score so each pixel's 32-byte BIP record
+// [R, G, B, CMF] (float64) is written once, whole.
+//
+// Layout: lane = sample.  For a fixed (line, band) the 64 lanes of a wave read 256 contiguous bytes of the
+// BIL cube; every active value is read exactly once (validity is recomputed inline, no mask traffic).
+// The 64 filter vectors of the workgroup's columns sit in LDS as [band][64] (conflict-free ds_read_b64);
+// each LDS read feeds SC_LPI lines.  Algorithmic bytes per pixel: 4p (cube) + 8 (score)
+// [+ 12 read + 24 written when RGB is fused].  2p flops per pixel -> HBM-bound by a wide margin.
+#include "cmf_common.h"
+
+namespace {
+
+constexpr int SC_LPI = 4;  // lines per wave per iteration
+
+template <bool RGB>
+__global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs,
+                                                int b0, int p, const double *__restrict__ filt,
+                                                const double *__restrict__ bias, const int32_t *__restrict__ status,
+                                                const int32_t *__restrict__ alphaidx, int rgb0, int rgb1, int rgb2,
+                                                double nodata, double *__restrict__ out, int oS, int os0,
+                                                int16_t *__restrict__ bgmeta, double *__restrict__ stat_part,
+                                                int lines_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) double ws[];  // [p][64]
+  __shared__ double sred[4][64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int colbase = blockIdx.x * 64;
+  const int ncol = min(64, Cs - colbase);
+  const bool colok = lane < ncol;
+  const int col = colbase + (colok ? lane : 0);
+
+  for (int idx = tid; idx < 64 * p; idx += 256) {
+    const int cl = idx / p, b = idx - cl * p;
+    ws[b * 64 + cl] = (cl < ncol) ? filt[(size_t)(colbase + cl) * p + b] : 0.0;
+  }
+  const double mybias = bias[col];
+  const int st = status[col];
+  const int ai = alphaidx[col];
+  __syncthreads();
+
+  const int lbeg = blockIdx.y * lines_per_wg, lend = min(L, lbeg + lines_per_wg);
+  const size_t lstride = (size_t)B * C;
+  const float *cb = cube + (size_t)(s0 + col);
+  double s1 = 0.0, s2 = 0.0;
+
+  for (int l = lbeg + wave * SC_LPI; l < lend; l += 4 * SC_LPI) {
+    const int nl = min(SC_LPI, lend - l);
+    const float *px = cb + (size_t)l * lstride + (size_t)b0 * C;
+    double acc[SC_LPI];
+    bool ok[SC_LPI];
+#pragma unroll
+    for (int j = 0; j < SC_LPI; ++j) { acc[j] = 0.0; ok[j] = true; }
+    if (nl == SC_LPI) {
+#pragma unroll 6
+      for (int b = 0; b < p; ++b) {
+        const double wv = ws[b * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < SC_LPI; ++j) {
+          const float x = px[(size_t)j * lstride + (size_t)b * C];
+          ok[j] = ok[j] & sf_valid(x);
+          acc[j] = __builtin_fma((double)x, wv, acc[j]);
+        }
+      }
+    } else {
+      for (int b = 0; b < p; ++b) {
+        const double wv = ws[b * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < SC_LPI; ++j) {
+          if (j < nl) {
+            const float x = px[(size_t)j * lstride + (size_t)b * C];
+            ok[j] = ok[j] & sf_valid(x);
+            acc[j] = __builtin_fma((double)x, wv, acc[j]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SC_LPI; ++j) {
+      if (j < nl && colok) {
+        const bool v = ok[j];
+        // status 2 (singular C): filt = bias = 0 -> the valid rows get exactly 0 (robust_mf.py:373)
+        const double sc = v ? ((st == 2) ? 0.0 : (acc[j] - mybias)) : nodata;
+        if (v) { s1 += sc; s2 += sc * sc; }
+        const size_t pix = (size_t)(l + j) * oS + os0 + col;
+        if (RGB) {
+          double r = 0.0, gg = 0.0, bb = 0.0;
+          if (st != 1) {  // columns without a valid row are skipped before the RGB copy (:303-304)
+            const float *pl = cb + (size_t)(l + j) * lstride;
+            r = (double)pl[(size_t)rgb0 * C];
+            gg = (double)pl[(size_t)rgb1 * C];
+            bb = (double)pl[(size_t)rgb2 * C];
+          }
+          double2 *o = reinterpret_cast<double2 *>(out + pix * 4);
+          o[0] = make_double2(r, gg);
+          o[1] = make_double2(bb, sc);
+        } else {
+          out[pix] = sc;
+        }
+        if (bgmeta) {
+          // int16 pair (cluster id = 0, alpha index); written only on valid rows of solved columns (:365)
+          const uint32_t m = (v && st == 0) ? ((uint32_t)(uint16_t)(int16_t)ai << 16) : 0u;
+          reinterpret_cast<uint32_t *>(bgmeta)[pix] = m;
+        }
+      }
+    }
+  }
+  if (stat_part) {
+    sred[wave][lane][0] = s1;
+    sred[wave][lane][1] = s2;
+    __syncthreads();
+    if (wave == 0 && colok) {
+      double a = 0.0, b = 0.0;
+      for (int w = 0; w < 4; ++w) { a += sred[w][lane][0]; b += sred[w][lane][1]; }
+      double *o = stat_part + ((size_t)blockIdx.y * Cs + col) * 2;
+      o[0] = a;
+      o[1] = b;
+    }
+  }
+}
+
+// npix / mean / std (ddof 0) of the written scores per column (robust_mf.py:388-392).
+__global__ void k_colstats(const double *__restrict__ stat_part, int nchunk, int Cs, const int32_t *__restrict__ nuse,
+                           const int32_t *__restrict__ status, double nodata, double *__restrict__ colstats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cs) return;
+  if (status[c] == 1) {  // column skipped: stats keep their initial value (:293-295)
+    colstats[c] = nodata; colstats[Cs + c] = nodata; colstats[2 * Cs + c] = nodata;
+    return;
+  }
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    a += stat_part[((size_t)k * Cs + c) * 2];
+    b += stat_part[((size_t)k * Cs + c) * 2 + 1];
+  }
+  const double n = (double)nuse[c];
+  const double mean = a / n;
+  double var = b / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  colstats[c] = n;
+  colstats[Cs + c] = mean;
+  colstats[2 * Cs + c] = sqrt(var);
+}
+
+}  // namespace
+
+size_t sf_score_scratch_bytes(int lines, int ncols) {
+  const int lpw = sf_score_lines_per_wg(lines, ncols);
+  return sf_align((size_t)sf_cdiv(lines, lpw) * ncols * 2 * sizeof(double));
+}
+
+int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
+                    const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,
+                    int rgb0, int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0,
+                    int out_bands, int16_t *bgmeta, void *stat_scratch, hipStream_t st) {
+  const size_t lds = (size_t)p * 64 * sizeof(double);
+  if (lds > 150 * 1024) {
+    sf_set_error("active window of %d bands: filter tile does not fit LDS in the score kernel", p);
+    return -2;
+  }
+  static size_t lds_set[2] = {0, 0};
+  const bool rgb = out_bands == 4;
+  if (lds > lds_set[rgb]) {
+    if (rgb)
+      SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else
+      SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set[rgb] = lds;
+  }
+  const int lpw = sf_score_lines_per_wg(lines, ncols);
+  const int nchunk = sf_cdiv(lines, lpw);
+  double *stat_part = reinterpret_cast<double *>(stat_scratch);  // may be null: no column statistics
+  dim3 grid(sf_cdiv(ncols, 64), nchunk);
+  if (rgb)
+    hipLaunchKernelGGL(k_score<true>, grid, dim3(256), lds, st, cube, lines, bands, samples, s0, ncols, b0, p, filt,
+                       bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, out_samples, out_s0, bgmeta, stat_part, lpw);
+  else
+    hipLaunchKernelGGL(k_score<false>, grid, dim3(256), lds, st, cube, lines, bands, samples, s0, ncols, b0, p, filt,
+                       bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, out_samples, out_s0, bgmeta, stat_part, lpw);
+  SF_LAUNCH_CHECK("k_score");
+  return 0;
+}
+
+int sf_launch_colstats(const void *stat_scratch, int lines, int ncols, const int32_t *nuse, const int32_t *status,
+                       double nodata, double *colstats, hipStream_t st) {
+  const int lpw = sf_score_lines_per_wg(lines, ncols);
+  const int nchunk = sf_cdiv(lines, lpw);
+  hipLaunchKernelGGL(k_colstats, dim3(sf_cdiv(ncols, 128)), dim3(128), 0, st,
+                     reinterpret_cast<const double *>(stat_scratch), nchunk, ncols, nuse, status, nodata, colstats);
+  SF_LAUNCH_CHECK("k_colstats");
+  return 0;
+}

@@ -1,0 +1,91 @@
+"""No-GPU checks of the drop-in boundary: the shared library loads, exports every symbol the header
+declares, the ctypes table matches the header, and argument errors are reported without a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from srcfinder_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "srcfinder_amd.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return re.findall(r"\b(sf_[a-z0-9_]+)\s*\(", src)
+
+
+def test_header_declares_the_stage_api():
+    names = declared_functions()
+    for must in ["sf_cmf_run", "sf_cmf_score", "sf_cmf_loocv", "sf_cmf_eigh", "sf_cmf_covariance",
+                 "sf_cmf_column_mean", "sf_cmf_extract_columns", "sf_cmf_filter", "sf_cmf_workspace_bytes"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.isfile(_ffi.LIB_PATH), "build the HIP library first (__graft_entry__.build())"
+    L = ctypes.CDLL(_ffi.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(L, name), "libsrcfinder_amd.so does not export %s" % name
+
+
+def test_ctypes_table_matches_header():
+    names = set(declared_functions())
+    assert names == set(_ffi.SIGNATURES), names ^ set(_ffi.SIGNATURES)
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (_, args) in _ffi.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, src, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else len(params.split(","))
+        assert n == len(args), "%s: header has %d parameters, ctypes table %d" % (name, n, len(args))
+
+
+def test_host_only_entry_points():
+    L = _ffi.lib()
+    assert L.sf_version() >= 100
+    nbytes = L.sf_cmf_workspace_bytes(20000, 72, 598, 201)
+    # xt (598*20000*72*4 = 3.44 GB) dominates
+    assert 3.4e9 < nbytes < 6e9
+    assert L.sf_cmf_workspace_bytes(0, 72, 598, 201) == 0
+
+
+def test_argument_errors_do_not_touch_the_device():
+    L = _ffi.lib()
+    one = ctypes.c_void_p(16)
+    # bad shard
+    rc = L.sf_cmf_extract_columns(one, 10, 425, 64, 5, 3, 350, 72, one, one, None)
+    assert rc < 0 and b"column shard" in L.sf_last_error_string()
+    # bad window
+    rc = L.sf_cmf_extract_columns(one, 10, 425, 64, 0, 64, 400, 72, one, one, None)
+    assert rc < 0 and b"active window" in L.sf_last_error_string()
+    # nodata > 0 must be refused like the reference does (robust_mf.py:232-234)
+    rc = L.sf_cmf_score(one, 10, 425, 64, 0, 64, 350, 72, one, one, one, one, one, 60, 42, 24, 1.0,
+                        one, 64, 0, 4, None, None, None, None)
+    assert rc == -3 and b"nodata" in L.sf_last_error_string()
+
+
+def test_python_surface_rejects_what_the_reference_rejects():
+    from srcfinder_amd import cmf
+    assert cmf.active_window("ch4") == (351, 422)
+    assert cmf.active_window("ch4", True) == (5, 420)
+    assert cmf.active_window("co2") == (309, 391)
+    with pytest.raises(ValueError):
+        cmf.active_window("n2o")
+    a = cmf.alpha_grid()
+    assert len(a) == 201 and a[0] == 1e-10 and a[200] == 1.0000000000003273
+    assert cmf.model_parameters(False, (351, 422)) == (
+        "{ modelname=looshrinkage, bgmodel=unimodal, aminexp=-10.0, amaxexp=0.0, astep=0.05, "
+        "reflectance=False, active_bands=[351, 422] }")
+
+
+def test_model_parameter_string_matches_reference_run(golden_dir):
+    import numpy as np
+    from srcfinder_amd import cmf
+    g = np.load(os.path.join(golden_dir, "cmf_S_radiance.npz"))
+    assert str(g["modelparms"]) == cmf.model_parameters(False, (351, 422))
+    g = np.load(os.path.join(golden_dir, "cmf_R_reflectance.npz"))
+    assert str(g["modelparms"]) == cmf.model_parameters(True, (5, 420))

@@ -42,6 +42,9 @@ class SrcfinderError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
+        # torch first: its wheel carries its own libamdhip64.so.7; loading ours before it would bind the
+        # kernels to a second HIP runtime that sees no device.
+        import torch  # noqa: F401
         if not os.path.isfile(LIB_PATH):
             raise SrcfinderError(
                 "HIP library %s is missing: build it (make -C srcfinder_amd/csrc); there is no CPU fallback" % LIB_PATH)

@@ -24,15 +24,43 @@ struct SyrkCfg {
   static constexpr int TPW = (NTRI + 3) / 4;  // tiles per wave
 };
 
+// upper-triangular tile list (ti <= tj), row-major, as a compile-time table
+template <int NT>
+struct TriTab {
+  int ti[NT * (NT + 1) / 2], tj[NT * (NT + 1) / 2];
+  constexpr TriTab() : ti{}, tj{} {
+    int q = 0;
+    for (int i = 0; i < NT; ++i)
+      for (int j = i; j < NT; ++j) { ti[q] = i; tj[q] = j; ++q; }
+  }
+};
 __device__ __forceinline__ void tri_decode(int q, int nt, int &ti, int &tj) {
   int i = 0, rowlen = nt;
-  while (q >= rowlen) {
-    q -= rowlen;
-    ++i;
-    --rowlen;
-  }
+  while (q >= rowlen) { q -= rowlen; ++i; --rowlen; }
   ti = i;
   tj = i + q;
+}
+
+// MFMA work of wave W on one staged tile: its tile list is a compile-time constant, so the NT operand
+// fragments of a k-step live in named registers (no dynamic indexing) and are read from LDS once.
+template <int NT, int W>
+__device__ __forceinline__ void syrk_wave(const double *__restrict__ xs, d4_t (&acc)[SyrkCfg<NT>::TPW]) {
+  using Cfg = SyrkCfg<NT>;
+  constexpr TriTab<NT> tab{};
+#pragma unroll 2
+  for (int k0 = 0; k0 < SY_TLS; k0 += 4) {
+    double f[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) f[t] = xs[k0 * Cfg::LDX + 16 * t];
+#pragma unroll
+    for (int u = 0; u < Cfg::TPW; ++u) {
+      constexpr int q0 = W * Cfg::TPW;
+      if (q0 + u < Cfg::NTRI) {
+        const int ti = tab.ti[q0 + u < Cfg::NTRI ? q0 + u : 0], tj = tab.tj[q0 + u < Cfg::NTRI ? q0 + u : 0];
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[ti], f[tj], acc[u], 0, 0, 0);
+      }
+    }
+  }
 }
 
 template <int NT, typename XT>
@@ -50,23 +78,14 @@ __global__ __launch_bounds__(256, 4) void k_syrk(const XT *__restrict__ xt, cons
   for (int i = tid; i < Cfg::PP; i += 256) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
   for (int i = tid; i < SY_TLS * Cfg::LDX; i += 256) Xs[i] = 0.0;  // band padding stays zero forever
 
-  int offA[Cfg::TPW], offB[Cfg::TPW];
-  bool have[Cfg::TPW];
   d4_t acc[Cfg::TPW];
 #pragma unroll
-  for (int u = 0; u < Cfg::TPW; ++u) {
-    const int q = wave * Cfg::TPW + u;
-    have[u] = q < Cfg::NTRI;
-    int ti = 0, tj = 0;
-    if (have[u]) tri_decode(q, NT, ti, tj);
-    offA[u] = g * Cfg::LDX + 16 * ti + li;
-    offB[u] = g * Cfg::LDX + 16 * tj + li;
-    acc[u] = d4_t{0.0, 0.0, 0.0, 0.0};
-  }
+  for (int u = 0; u < Cfg::TPW; ++u) acc[u] = d4_t{0.0, 0.0, 0.0, 0.0};
 
   const int tpr = PS >> 2;
   const uint8_t *mp = mask_t + (size_t)c * L;
   const XT *xc = xt + (size_t)c * L * PS;
+  const double *xs = Xs + g * Cfg::LDX + li;  // this lane's operand element of k-step 0, tile 0
   for (int r0 = rbeg; r0 < rend; r0 += SY_TLS) {
     __syncthreads();  // previous tile fully consumed (also orders the initial zero fill / mus)
     for (int it = tid; it < SY_TLS * tpr; it += 256) {
@@ -86,22 +105,17 @@ __global__ __launch_bounds__(256, 4) void k_syrk(const XT *__restrict__ xt, cons
       dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
     }
     __syncthreads();
-#pragma unroll
-    for (int k0 = 0; k0 < SY_TLS; k0 += 4) {
-#pragma unroll
-      for (int u = 0; u < Cfg::TPW; ++u) {
-        if (have[u]) {
-          const double a = Xs[k0 * Cfg::LDX + offA[u]];
-          const double b = Xs[k0 * Cfg::LDX + offB[u]];
-          acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
-        }
-      }
+    switch (wave) {  // wave-uniform
+      case 0: syrk_wave<NT, 0>(xs, acc); break;
+      case 1: syrk_wave<NT, 1>(xs, acc); break;
+      case 2: syrk_wave<NT, 2>(xs, acc); break;
+      default: syrk_wave<NT, 3>(xs, acc); break;
     }
   }
 #pragma unroll
   for (int u = 0; u < Cfg::TPW; ++u) {
-    if (have[u]) {
-      const int q = wave * Cfg::TPW + u;
+    const int q = wave * Cfg::TPW + u;
+    if (q < Cfg::NTRI) {
       double *o = part + (((size_t)c * nsplit + split) * Cfg::NTRI + q) * 256 + lane;
       o[0] = acc[u][0]; o[64] = acc[u][1]; o[128] = acc[u][2]; o[192] = acc[u][3];
     }

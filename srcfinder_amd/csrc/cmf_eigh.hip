@@ -17,18 +17,40 @@ namespace {
 
 constexpr int EIG_MAXSWEEP = 40;
 
-__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+// 8-lane butterfly sum with DPP lane swaps (no LDS traffic): xor 1, xor 2, then half-row mirror (the
+// partner sits in the other quad, whose four lanes already hold the same partial).
+template <int CTRL>
+__device__ __forceinline__ double dpp_swap(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double sum8(double v) {
+  v += dpp_swap<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_swap<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_swap<0x141>(v);  // row_half_mirror
+  return v;
+}
+// 1/sqrt(x) to double precision: hardware estimate + two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+  y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
 
 // pair k of round-robin step s over p2 (even) players; m = p2 - 1
 __device__ __forceinline__ void rr_pair(int s, int k, int m, int &a, int &b) {
-  if (k == 0) {
-    a = s % m;
-    b = m;
-  } else {
-    a = (s + k) % m;
-    b = (s - k + m) % m;
-  }
+  int x = s + k;
+  x = x >= m ? x - m : x;
+  int y = s - k;
+  y = y < 0 ? y + m : y;
+  a = x;
+  b = (k == 0) ? m : y;
 }
+
+constexpr int EIG_RMAX = 12;  // rows per lane: p2 <= 96 -> 12
 
 __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict__ nuse, int p, int p2, int LD,
                        double *__restrict__ d_out, double *__restrict__ lam_out, double *__restrict__ evec_out,
@@ -80,36 +102,60 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
   const int npairs = p2 >> 1, m = p2 - 1;
   const int k = tid >> 3, sub = tid & 7;
   const bool active = k < npairs;
-  const double tol = 4.0 * 2.220446049250313e-16;
+  const int nr = (p2 - sub + 7) >> 3;  // rows sub, sub+8, ... owned by this lane
+  // |g_a . g_b| <= tol |g_a||g_b|: the dot product itself carries ~sqrt(p) eps of rounding, so a
+  // threshold below that never settles; p*eps leaves off-diagonals <= 1e-14 * min(lam_a, lam_b).
+  const double tol = (double)p2 * 2.220446049250313e-16;
+  const double tol2 = tol * tol;
   for (int sweep = 0; sweep < EIG_MAXSWEEP; ++sweep) {
     bool rotated = false;
     for (int s = 0; s < m; ++s) {
       if (active) {
         int a, b;
         rr_pair(s, k, m, a, b);
-        double *ga = G + a * LD, *gb = G + b * LD;
-        double aa = 0, bb = 0, ab = 0;
-        for (int r = sub; r < p2; r += 8) {
-          const double x = ga[r], y = gb[r];
-          aa += x * x; bb += y * y; ab += x * y;
+        double *ga = G + a * LD + sub, *gb = G + b * LD + sub;
+        double *va = V + a * LD + sub, *vb = V + b * LD + sub;
+        double xa[EIG_RMAX], xb[EIG_RMAX], ya[EIG_RMAX], yb[EIG_RMAX];
+#pragma unroll
+        for (int i = 0; i < EIG_RMAX; ++i) {
+          const bool in = i < nr;
+          xa[i] = in ? ga[8 * i] : 0.0;
+          xb[i] = in ? gb[8 * i] : 0.0;
         }
-        aa += shfl_xor_d(aa, 1); bb += shfl_xor_d(bb, 1); ab += shfl_xor_d(ab, 1);
-        aa += shfl_xor_d(aa, 2); bb += shfl_xor_d(bb, 2); ab += shfl_xor_d(ab, 2);
-        aa += shfl_xor_d(aa, 4); bb += shfl_xor_d(bb, 4); ab += shfl_xor_d(ab, 4);
-        const double lim = tol * sqrt(aa * bb);
-        if (aa * bb > 0.0 && fabs(ab) > lim) {
+#pragma unroll
+        for (int i = 0; i < EIG_RMAX; ++i) {  // issued now, consumed after the rotation is known
+          const bool in = i < nr;
+          ya[i] = in ? va[8 * i] : 0.0;
+          yb[i] = in ? vb[8 * i] : 0.0;
+        }
+        double aa = 0, bb = 0, ab = 0;
+#pragma unroll
+        for (int i = 0; i < EIG_RMAX; ++i) {
+          aa = __builtin_fma(xa[i], xa[i], aa);
+          bb = __builtin_fma(xb[i], xb[i], bb);
+          ab = __builtin_fma(xa[i], xb[i], ab);
+        }
+        aa = sum8(aa); bb = sum8(bb); ab = sum8(ab);
+        const double ab2 = aa * bb;
+        if (ab2 > 0.0 && ab * ab > tol2 * ab2) {  // uniform over the pair's 8 lanes
           rotated = true;
-          const double zeta = (bb - aa) / (2.0 * ab);
-          const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-          double *va = V + a * LD, *vb = V + b * LD;
-          for (int r = sub; r < p2; r += 8) {
-            const double x = ga[r], y = gb[r];
-            ga[r] = cs * x - sn * y;
-            gb[r] = sn * x + cs * y;
-            const double vx = va[r], vy = vb[r];
-            va[r] = cs * vx - sn * vy;
-            vb[r] = sn * vx + cs * vy;
+          // tan(2 theta) = 2ab / (bb - aa), small-angle branch, no division:
+          const double tau = bb - aa, gam = 2.0 * ab;
+          const double rinv = rsqrt_nr(__builtin_fma(tau, tau, gam * gam));
+          const double c2 = fabs(tau) * rinv;             // |cos 2theta|
+          const double h = __builtin_fma(0.5, c2, 0.5);   // cos^2 theta in [0.5, 1]
+          const double rh = rsqrt_nr(h);
+          const double cs = h * rh;
+          double sn = fabs(gam) * rinv * 0.5 * rh;
+          sn = ((tau < 0.0) != (gam < 0.0)) ? -sn : sn;
+#pragma unroll
+          for (int i = 0; i < EIG_RMAX; ++i) {
+            if (i < nr) {
+              ga[8 * i] = cs * xa[i] - sn * xb[i];
+              gb[8 * i] = sn * xa[i] + cs * xb[i];
+              va[8 * i] = cs * ya[i] - sn * yb[i];
+              vb[8 * i] = sn * ya[i] + cs * yb[i];
+            }
           }
         }
       }

@@ -13,6 +13,7 @@ namespace {
 
 constexpr int XT_TL = 4;      // lines per LDS tile
 constexpr int XT_PBMAX = 80;  // band chunk held in LDS at once
+constexpr int XT_NB = 18;     // loads in flight per wave
 
 // LDS: tile[64 columns][cs] floats, cs odd -> both the column-strided writes (lane = column) and the
 // row-contiguous reads (lane = element) are bank-conflict free.
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(256) void k_extract(const float *__restrict__ cube,
   const bool colok = lane < ncol;
   const int lbeg = blockIdx.y * lines_per_wg;
   const int lend = min(L, lbeg + lines_per_wg);
-  const float *cbase = cube + (size_t)(s0 + colbase + (colok ? lane : 0));
+  const int lanec = colok ? lane : ncol - 1;
+  const float *cbase = cube + (size_t)(s0 + colbase);  // wave-uniform base, per-lane 32-bit offset
 
   for (int l0 = lbeg; l0 < lend; l0 += XT_TL) {
     const int nl = min(XT_TL, lend - l0);
@@ -35,20 +37,17 @@ __global__ __launch_bounds__(256) void k_extract(const float *__restrict__ cube,
     for (int bc0 = 0; bc0 < p; bc0 += pbmax) {
       const int pb = min(pbmax, p - bc0);
       const int nrows = nl * pb;  // (line, band) rows of 64 samples in this chunk
-      // ---- global -> LDS, 8 rows in flight per wave
-      for (int base = wave; base < nrows; base += 32) {
-        float v[8];
+      // ---- global -> LDS, XT_NB rows (256 B each) in flight per wave
+      for (int base = wave; base < nrows; base += 4 * XT_NB) {
+        float v[XT_NB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int rr = base + 4 * u;
-          v[u] = 0.f;
-          if (rr < nrows) {
-            const int l = rr / pb, b = rr - l * pb;
-            v[u] = cbase[((size_t)(l0 + l) * B + (b0 + bc0 + b)) * C];
-          }
+        for (int u = 0; u < XT_NB; ++u) {
+          const int rr = min(base + 4 * u, nrows - 1);      // clamped duplicates are loaded but not stored
+          const int l = rr / pb, b = rr - l * pb;
+          v[u] = (cbase + ((size_t)(l0 + l) * B + (b0 + bc0 + b)) * C)[lanec];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < XT_NB; ++u) {
           const int rr = base + 4 * u;
           if (rr < nrows) tile[lane * cs + rr] = v[u];
         }

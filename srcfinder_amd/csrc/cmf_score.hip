@@ -16,6 +16,34 @@
 namespace {
 
 constexpr int SC_LPI = 4;  // lines per wave per iteration
+constexpr int SC_UB = 8;   // bands per load batch: SC_LPI*SC_UB loads are issued back to back, two batches in flight
+
+// One batch of loads: SC_UB bands x SC_LPI lines of this lane's column.  Row pointers are wave-uniform
+// (scalar base + per-lane 32-bit offset addressing); bands past the window are clamped to the last band
+// (in-bounds duplicate, weighted by 0 below).
+__device__ __forceinline__ void score_load(float (&x)[SC_LPI][SC_UB], const float *const (&lp)[SC_LPI], int bc, int p,
+                                           int C, int lanec) {
+#pragma unroll
+  for (int bb = 0; bb < SC_UB; ++bb) {
+    const int b = min(bc + bb, p - 1);
+#pragma unroll
+    for (int j = 0; j < SC_LPI; ++j) x[j][bb] = (lp[j] + (size_t)b * C)[lanec];
+  }
+}
+
+__device__ __forceinline__ void score_fma(const float (&x)[SC_LPI][SC_UB], const double *__restrict__ ws, int bc, int p,
+                                          int lane, double (&acc)[SC_LPI], bool (&ok)[SC_LPI]) {
+#pragma unroll
+  for (int bb = 0; bb < SC_UB; ++bb) {
+    const int b = bc + bb;
+    const double wv = (b < p) ? ws[min(b, p - 1) * 64 + lane] : 0.0;
+#pragma unroll
+    for (int j = 0; j < SC_LPI; ++j) {
+      ok[j] = ok[j] & sf_valid(x[j][bb]);
+      acc[j] = __builtin_fma((double)x[j][bb], wv, acc[j]);
+    }
+  }
+}
 
 template <bool RGB>
 __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs,
@@ -31,7 +59,8 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, i
   const int colbase = blockIdx.x * 64;
   const int ncol = min(64, Cs - colbase);
   const bool colok = lane < ncol;
-  const int col = colbase + (colok ? lane : 0);
+  const int lanec = colok ? lane : ncol - 1;  // idle lanes re-read the last column (in bounds), never write
+  const int col = colbase + lanec;
 
   for (int idx = tid; idx < 64 * p; idx += 256) {
     const int cl = idx / p, b = idx - cl * p;
@@ -44,38 +73,35 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, i
 
   const int lbeg = blockIdx.y * lines_per_wg, lend = min(L, lbeg + lines_per_wg);
   const size_t lstride = (size_t)B * C;
-  const float *cb = cube + (size_t)(s0 + col);
+  const float *cb = cube + (size_t)(s0 + colbase);  // wave-uniform
   double s1 = 0.0, s2 = 0.0;
 
   for (int l = lbeg + wave * SC_LPI; l < lend; l += 4 * SC_LPI) {
     const int nl = min(SC_LPI, lend - l);
-    const float *px = cb + (size_t)l * lstride + (size_t)b0 * C;
+    const float *lp[SC_LPI];
+#pragma unroll
+    for (int j = 0; j < SC_LPI; ++j)  // tail lines alias the last line of the chunk (loaded, never written)
+      lp[j] = cb + (size_t)min(l + j, lend - 1) * lstride + (size_t)b0 * C;
     double acc[SC_LPI];
     bool ok[SC_LPI];
 #pragma unroll
     for (int j = 0; j < SC_LPI; ++j) { acc[j] = 0.0; ok[j] = true; }
-    if (nl == SC_LPI) {
-#pragma unroll 6
-      for (int b = 0; b < p; ++b) {
-        const double wv = ws[b * 64 + lane];
+    float xa[SC_LPI][SC_UB], xb[SC_LPI][SC_UB];
+    score_load(xa, lp, 0, p, C, lanec);
+    for (int bc = 0; bc < p; bc += 2 * SC_UB) {
+      if (bc + SC_UB < p) score_load(xb, lp, bc + SC_UB, p, C, lanec);
+      score_fma(xa, ws, bc, p, lane, acc, ok);
+      if (bc + 2 * SC_UB < p) score_load(xa, lp, bc + 2 * SC_UB, p, C, lanec);
+      if (bc + SC_UB < p) score_fma(xb, ws, bc + SC_UB, p, lane, acc, ok);
+    }
+    float rgbv[SC_LPI][3];
+    if (RGB) {
 #pragma unroll
-        for (int j = 0; j < SC_LPI; ++j) {
-          const float x = px[(size_t)j * lstride + (size_t)b * C];
-          ok[j] = ok[j] & sf_valid(x);
-          acc[j] = __builtin_fma((double)x, wv, acc[j]);
-        }
-      }
-    } else {
-      for (int b = 0; b < p; ++b) {
-        const double wv = ws[b * 64 + lane];
-#pragma unroll
-        for (int j = 0; j < SC_LPI; ++j) {
-          if (j < nl) {
-            const float x = px[(size_t)j * lstride + (size_t)b * C];
-            ok[j] = ok[j] & sf_valid(x);
-            acc[j] = __builtin_fma((double)x, wv, acc[j]);
-          }
-        }
+      for (int j = 0; j < SC_LPI; ++j) {
+        const float *pl = cb + (size_t)min(l + j, lend - 1) * lstride;
+        rgbv[j][0] = (pl + (size_t)rgb0 * C)[lanec];
+        rgbv[j][1] = (pl + (size_t)rgb1 * C)[lanec];
+        rgbv[j][2] = (pl + (size_t)rgb2 * C)[lanec];
       }
     }
 #pragma unroll
@@ -87,13 +113,10 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, i
         if (v) { s1 += sc; s2 += sc * sc; }
         const size_t pix = (size_t)(l + j) * oS + os0 + col;
         if (RGB) {
-          double r = 0.0, gg = 0.0, bb = 0.0;
-          if (st != 1) {  // columns without a valid row are skipped before the RGB copy (:303-304)
-            const float *pl = cb + (size_t)(l + j) * lstride;
-            r = (double)pl[(size_t)rgb0 * C];
-            gg = (double)pl[(size_t)rgb1 * C];
-            bb = (double)pl[(size_t)rgb2 * C];
-          }
+          // columns without a valid row are skipped before the RGB copy (:303-304)
+          const double r = (st != 1) ? (double)rgbv[j][0] : 0.0;
+          const double gg = (st != 1) ? (double)rgbv[j][1] : 0.0;
+          const double bb = (st != 1) ? (double)rgbv[j][2] : 0.0;
           double2 *o = reinterpret_cast<double2 *>(out + pix * 4);
           o[0] = make_double2(r, gg);
           o[1] = make_double2(bb, sc);

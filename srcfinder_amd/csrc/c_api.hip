@@ -51,6 +51,7 @@ Ws carve(void *base, const SfGeom &g) {
   w.nll = (double *)c.take(nc * g.nalpha * sizeof(double));
   size_t s = sf_mean_scratch_bytes(g);
   if (sf_cov_scratch_bytes(g) > s) s = sf_cov_scratch_bytes(g);
+  if (sf_eigh_scratch_bytes(g) > s) s = sf_eigh_scratch_bytes(g);
   if (sf_loocv_scratch_bytes(g) > s) s = sf_loocv_scratch_bytes(g);
   if (sf_score_scratch_bytes(g.lines, g.ncols) > s) s = sf_score_scratch_bytes(g.lines, g.ncols);
   w.scratch_bytes = s;
@@ -135,9 +136,8 @@ int sf_cmf_covariance(const void *xt, int xt_f64, const uint8_t *mask_t, const i
 
 int sf_cmf_eigh(const double *cov, const int32_t *nuse, int p, int ncols, double *d, double *lam, double *evec,
                 int32_t *status, void *scratch, void *stream) {
-  (void)scratch;
-  if (!cov || !nuse || !d || !lam || !evec || !status) { sf_set_error("null pointer"); return -1; }
-  return sf_launch_eigh(cov, nuse, sf_geom(1, p, ncols, 1), d, lam, evec, status, (hipStream_t)stream);
+  if (!cov || !nuse || !d || !lam || !evec || !status || !scratch) { sf_set_error("null pointer"); return -1; }
+  return sf_launch_eigh(cov, nuse, sf_geom(1, p, ncols, 1), d, lam, evec, status, scratch, (hipStream_t)stream);
 }
 
 int sf_cmf_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *d,
@@ -208,7 +208,7 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
   if ((rc = sf_launch_extract(cube, lines, bands, samples, s0, ncols, b0, p, w.xt, w.mask_t, st))) return rc;
   if ((rc = sf_launch_mean(w.xt, 0, w.mask_t, g, nuse, w.mu, w.scratch, st))) return rc;
   if ((rc = sf_launch_cov(w.xt, 0, w.mask_t, nuse, w.mu, g, w.cov, w.scratch, st))) return rc;
-  if ((rc = sf_launch_eigh(w.cov, nuse, g, w.d, w.lam, w.evec, status, st))) return rc;
+  if ((rc = sf_launch_eigh(w.cov, nuse, g, w.d, w.lam, w.evec, status, w.scratch, st))) return rc;
   double *nll = nll_out ? nll_out : w.nll;
   if ((rc = sf_launch_loocv(w.xt, 0, w.mask_t, nuse, w.mu, w.d, w.lam, w.evec, status, alphas, g, nll, alphaidx, w.scratch, st)))
     return rc;

@@ -105,8 +105,9 @@ size_t sf_cov_scratch_bytes(const SfGeom &g);
 int sf_launch_cov(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu,
                   const SfGeom &g, double *cov, void *scratch, hipStream_t st);
 size_t sf_wfrag_elems(const SfGeom &g);   // per column
+size_t sf_eigh_scratch_bytes(const SfGeom &g);
 int sf_launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, double *d, double *lam, double *evec,
-                   int32_t *status, hipStream_t st);
+                   int32_t *status, void *scratch, hipStream_t st);
 size_t sf_loocv_scratch_bytes(const SfGeom &g);
 int sf_launch_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *d,
                     const double *lam, const double *evec, const int32_t *status, const double *alphas,

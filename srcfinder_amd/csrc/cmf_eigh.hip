@@ -6,16 +6,19 @@
 //   log det G_a = 2 sum log d_j + sum_j log(n*beta*lam_j + a),
 // i.e. ONE eigendecomposition per column replaces 201 LU factorisations + inversions.
 //
-// Method: one-sided (Hestenes) Jacobi on G = R with accumulated V, both resident in LDS, one workgroup per
-// column, 8 lanes per column pair (dot products reduced with wave shuffles), round-robin pair ordering so
-// the p/2 rotations of a step touch disjoint columns (one barrier per step).  At convergence the columns of
-// G = R V are orthogonal, lam_j = |G[:,j]|, V[:,j] the eigenvector.  Latency-bound (barrier per step), ~70
-// steps per sweep, 6-10 sweeps.
+// Method: one-sided (Hestenes) Jacobi on G = R, one workgroup per column, 8 lanes per column pair (dot
+// products reduced with DPP lane swaps), round-robin pair ordering so the p/2 rotations of a step touch
+// disjoint columns (one barrier per step).  At convergence the columns of G = R V are orthogonal and
+// lam_j = |G[:,j]|.  Two phases so that only ONE p x p matrix has to live in LDS (41 KB at p = 72 -> three
+// matrices per CU instead of one; the kernel is latency-bound, so residency is what buys throughput):
+//   phase 1 rotates G only and records every (cos, sin) in a global scratch list;
+//   phase 2 replays the list on V = I in the same LDS buffer (no dot products, no rotation maths).
+// ~70 steps per sweep, ~12 sweeps at p = 72.
 #include "cmf_common.h"
 
 namespace {
 
-constexpr int EIG_MAXSWEEP = 40;
+constexpr int EIG_MAXSWEEP = 30;
 
 // 8-lane butterfly sum with DPP lane swaps (no LDS traffic): xor 1, xor 2, then half-row mirror (the
 // partner sits in the other quad, whose four lanes already hold the same partial).
@@ -54,11 +57,10 @@ constexpr int EIG_RMAX = 12;  // rows per lane: p2 <= 96 -> 12
 
 __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict__ nuse, int p, int p2, int LD,
                        double *__restrict__ d_out, double *__restrict__ lam_out, double *__restrict__ evec_out,
-                       int32_t *__restrict__ status) {
+                       int32_t *__restrict__ status, double2 *__restrict__ rot, size_t rot_stride) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double *G = sm;                 // [p2][LD] column-major: G[col*LD + row]
-  double *V = sm + (size_t)p2 * LD;
-  double *dv = V + (size_t)p2 * LD;  // [p2]
+  double *M = sm;                    // [p2][LD] column-major: M[col*LD + row]; G in phase 1, V in phase 2
+  double *dv = sm + (size_t)p2 * LD;  // [p2]
   __shared__ int flag[2];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int c = blockIdx.x;
@@ -89,13 +91,11 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
     for (int i = tid; i < p * p; i += nthr) evec_out[(size_t)c * p * p + i] = ((i / p) == (i % p)) ? 1.0 : 0.0;
     return;
   }
-  // G = R, V = I
-  for (int i = tid; i < p2 * p2; i += nthr) {
+  for (int i = tid; i < p2 * p2; i += nthr) {  // G = R
     const int col = i / p2, row = i - col * p2;
     double r = 0.0;
     if (col < p && row < p) r = S[(size_t)row * p + col] / (dv[row] * dv[col]);
-    G[col * LD + row] = r;
-    V[col * LD + row] = (col == row) ? 1.0 : 0.0;
+    M[col * LD + row] = r;
   }
   __syncthreads();
 
@@ -103,30 +103,26 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
   const int k = tid >> 3, sub = tid & 7;
   const bool active = k < npairs;
   const int nr = (p2 - sub + 7) >> 3;  // rows sub, sub+8, ... owned by this lane
+  double2 *myrot = rot + (size_t)c * rot_stride + k;
   // |g_a . g_b| <= tol |g_a||g_b|: the dot product itself carries ~sqrt(p) eps of rounding, so a
   // threshold below that never settles; p*eps leaves off-diagonals <= 1e-14 * min(lam_a, lam_b).
   const double tol = (double)p2 * 2.220446049250313e-16;
   const double tol2 = tol * tol;
+  int nsteps = 0;  // steps whose rotations have to be replayed on V
+  // ---------------- phase 1: orthogonalise the columns of G, record the rotations
   for (int sweep = 0; sweep < EIG_MAXSWEEP; ++sweep) {
     bool rotated = false;
     for (int s = 0; s < m; ++s) {
       if (active) {
         int a, b;
         rr_pair(s, k, m, a, b);
-        double *ga = G + a * LD + sub, *gb = G + b * LD + sub;
-        double *va = V + a * LD + sub, *vb = V + b * LD + sub;
-        double xa[EIG_RMAX], xb[EIG_RMAX], ya[EIG_RMAX], yb[EIG_RMAX];
+        double *ga = M + a * LD + sub, *gb = M + b * LD + sub;
+        double xa[EIG_RMAX], xb[EIG_RMAX];
 #pragma unroll
         for (int i = 0; i < EIG_RMAX; ++i) {
           const bool in = i < nr;
           xa[i] = in ? ga[8 * i] : 0.0;
           xb[i] = in ? gb[8 * i] : 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < EIG_RMAX; ++i) {  // issued now, consumed after the rotation is known
-          const bool in = i < nr;
-          ya[i] = in ? va[8 * i] : 0.0;
-          yb[i] = in ? vb[8 * i] : 0.0;
         }
         double aa = 0, bb = 0, ab = 0;
 #pragma unroll
@@ -137,6 +133,7 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
         }
         aa = sum8(aa); bb = sum8(bb); ab = sum8(ab);
         const double ab2 = aa * bb;
+        double cs = 1.0, sn = 0.0;
         if (ab2 > 0.0 && ab * ab > tol2 * ab2) {  // uniform over the pair's 8 lanes
           rotated = true;
           // tan(2 theta) = 2ab / (bb - aa), small-angle branch, no division:
@@ -145,19 +142,18 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
           const double c2 = fabs(tau) * rinv;             // |cos 2theta|
           const double h = __builtin_fma(0.5, c2, 0.5);   // cos^2 theta in [0.5, 1]
           const double rh = rsqrt_nr(h);
-          const double cs = h * rh;
-          double sn = fabs(gam) * rinv * 0.5 * rh;
+          cs = h * rh;
+          sn = fabs(gam) * rinv * 0.5 * rh;
           sn = ((tau < 0.0) != (gam < 0.0)) ? -sn : sn;
 #pragma unroll
           for (int i = 0; i < EIG_RMAX; ++i) {
             if (i < nr) {
               ga[8 * i] = cs * xa[i] - sn * xb[i];
               gb[8 * i] = sn * xa[i] + cs * xb[i];
-              va[8 * i] = cs * ya[i] - sn * yb[i];
-              vb[8 * i] = sn * ya[i] + cs * yb[i];
             }
           }
         }
+        if (sub == 0) myrot[(size_t)(sweep * m + s) * npairs] = make_double2(cs, sn);
       }
       __syncthreads();
     }
@@ -166,47 +162,91 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
     const int any = flag[1];
     __syncthreads();
     if (tid == 0) flag[1] = 0;
-    if (!any) break;
+    if (!any) break;           // this sweep was all identities: nothing of it to replay
+    nsteps = (sweep + 1) * m;
   }
   __syncthreads();
-  // eigenvalues = column norms of G; eigenvectors = columns of V
+  // eigenvalues = column norms of G
   for (int j = tid; j < p; j += nthr) {
     double s = 0;
     for (int r = 0; r < p2; ++r) {
-      const double x = G[j * LD + r];
+      const double x = M[j * LD + r];
       s += x * x;
     }
     lam_out[(size_t)c * p + j] = sqrt(s);
   }
+  __syncthreads();
+  // ---------------- phase 2: V = I, replay
+  for (int i = tid; i < p2 * p2; i += nthr) {
+    const int col = i / p2, row = i - col * p2;
+    M[col * LD + row] = (col == row) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  double2 rnext = make_double2(1.0, 0.0);
+  if (active && nsteps > 0) rnext = myrot[0];
+  int s = 0;
+  for (int t = 0; t < nsteps; ++t) {
+    if (active) {
+      const double2 r = rnext;
+      if (t + 1 < nsteps) rnext = myrot[(size_t)(t + 1) * npairs];  // in flight across the barrier
+      if (r.y != 0.0) {
+        int a, b;
+        rr_pair(s, k, m, a, b);
+        double *va = M + a * LD + sub, *vb = M + b * LD + sub;
+        double ya[EIG_RMAX], yb[EIG_RMAX];
+#pragma unroll
+        for (int i = 0; i < EIG_RMAX; ++i) {
+          const bool in = i < nr;
+          ya[i] = in ? va[8 * i] : 0.0;
+          yb[i] = in ? vb[8 * i] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < EIG_RMAX; ++i) {
+          if (i < nr) {
+            va[8 * i] = r.x * ya[i] - r.y * yb[i];
+            vb[8 * i] = r.y * ya[i] + r.x * yb[i];
+          }
+        }
+      }
+    }
+    s = (s + 1 == m) ? 0 : s + 1;
+    __syncthreads();
+  }
   for (int i = tid; i < p * p; i += nthr) {
     const int j = i / p, b = i - j * p;
-    evec_out[(size_t)c * p * p + i] = V[j * LD + b];
+    evec_out[(size_t)c * p * p + i] = M[j * LD + b];
   }
 }
 
 }  // namespace
 
+size_t sf_eigh_scratch_bytes(const SfGeom &g) {
+  const int p2 = g.p + (g.p & 1);
+  return sf_align((size_t)g.ncols * EIG_MAXSWEEP * (p2 - 1) * (p2 / 2) * sizeof(double2));
+}
+
 int sf_launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, double *d, double *lam, double *evec,
-                   int32_t *status, hipStream_t st) {
+                   int32_t *status, void *scratch, hipStream_t st) {
   const int p2 = g.p + (g.p & 1);
   int LD = p2;
   while ((LD % 32) != 8 && (LD % 32) != 24) ++LD;
-  const size_t lds = ((size_t)2 * p2 * LD + p2) * sizeof(double);
-  if (lds > 160 * 1024 - 64) {
+  const size_t lds = ((size_t)p2 * LD + p2) * sizeof(double);
+  if (lds > 160 * 1024 - 64 || g.p > SF_MAX_ACTIVE_FUSED) {
     sf_set_error("active window of %d bands exceeds the LDS-resident eigensolver (max %d)", g.p, SF_MAX_ACTIVE_FUSED);
     return -2;
   }
   int threads = (p2 / 2) * 8;
   threads = (threads + 63) / 64 * 64;
   if (threads < 64) threads = 64;
-  if (threads > 1024) threads = 1024;  // unreachable for p <= 96
   static size_t lds_set = 0;
   if (lds > lds_set) {
     SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eigh), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
     lds_set = lds;
   }
-  hipLaunchKernelGGL(k_eigh, dim3(g.ncols), dim3(threads), lds, st, cov, nuse, g.p, p2, LD, d, lam, evec, status);
+  const size_t rot_stride = (size_t)EIG_MAXSWEEP * (p2 - 1) * (p2 / 2);
+  hipLaunchKernelGGL(k_eigh, dim3(g.ncols), dim3(threads), lds, st, cov, nuse, g.p, p2, LD, d, lam, evec, status,
+                     reinterpret_cast<double2 *>(scratch), rot_stride);
   SF_LAUNCH_CHECK("k_eigh");
   return 0;
 }

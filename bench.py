@@ -27,12 +27,6 @@ LINES, BANDS, SAMPLES = 20000, 425, 598
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s float4 copy)
 
 
-def shard(samples, world, rank):
-    s0 = rank * samples // world
-    s1 = (rank + 1) * samples // world
-    return s0, s1
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,6 +41,7 @@ def main():
     import torch
     import torch.distributed as dist
     from srcfinder_amd import _ffi, cmf
+    from srcfinder_amd import dist as sd
     from srcfinder_amd.synth import make_cube_torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -63,7 +58,7 @@ def main():
 
     lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
     lines, samples = args.lines, args.samples
-    s0, s1 = shard(samples, world, rank)
+    s0, s1 = sd.shard_columns(samples, world, rank)
     ncols = s1 - s0
     a0, a1 = cmf.active_window("ch4", False)
     p = a1 - a0 + 1
@@ -73,27 +68,12 @@ def main():
                            nodata_column=(ncols // 3))
     torch.cuda.synchronize()
 
-    maxc = (samples + world - 1) // world
     out = torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev)
-    gather_list = None
-    sendbuf = None
-    if world > 1:
-        sendbuf = torch.zeros((maxc, lines, 4), dtype=torch.float64, device=dev)   # column-major blocks concatenate
-        if rank == 0:
-            gather_list = [torch.empty_like(sendbuf) for _ in range(world)]
-    image = torch.empty((lines, samples, 4), dtype=torch.float64, device=dev) if (rank == 0 and world > 1) else None
 
     def step():
         r = cmf.robust_mf(cube, lib, out=out, out_column0=0)
         if world > 1:
-            sendbuf[:ncols].copy_(out.permute(1, 0, 2))
-            dist.gather(sendbuf, gather_list, dst=0)
-            if rank == 0:
-                c0 = 0
-                for rr in range(world):
-                    a, b = shard(samples, world, rr)
-                    image[:, a:b, :].copy_(gather_list[rr][:b - a].permute(1, 0, 2))
-                    c0 += b - a
+            sd.gather_columns(out, samples, dst=0)      # the single RCCL gather of the score image
         return r
 
     def barrier():

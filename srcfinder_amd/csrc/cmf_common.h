@@ -76,20 +76,34 @@ static inline int sf_colsum_chunks(int lines, int ncols) {
   return c < 1 ? 1 : c;
 }
 static inline int sf_syrk_splits(int lines, int ncols) {
-  int want = sf_cdiv(4096, ncols);
+  // many more workgroups than resident slots (7 per CU) so the last partial round costs < 1/8
+  int want = sf_cdiv(16384, ncols);
   int maxc = sf_cdiv(lines, 512);
   int c = want < maxc ? want : maxc;
   return c < 1 ? 1 : c;
 }
 static inline int sf_sweep_splits(int lines, int ncols) {
-  int want = sf_cdiv(1536, ncols);          // ~6 workgroups per CU (one 256-thread WG per CU, LDS-bound)
-  int maxc = sf_cdiv(lines, 1024);
-  int c = want < maxc ? want : maxc;
-  return c < 1 ? 1 : c;
+  // The sweep runs ONE workgroup per CU (LDS-bound) and all workgroups take the same time, so the launch
+  // proceeds in rounds of 256: pick the row split whose last round is fullest (598 columns x 3 splits
+  // would leave 2 workgroups alone in an 8th round; x 5 fills 11.7 of 12).
+  int maxs = sf_cdiv(lines, 1024);
+  if (maxs > 24) maxs = 24;
+  if (maxs < 1) maxs = 1;
+  int best = 1;
+  double best_cost = 1e300;
+  for (int ns = 1; ns <= maxs; ++ns) {
+    const long wgs = (long)ncols * ns;
+    const long rounds = (wgs + 255) / 256;
+    const double cost = (double)rounds / ns * (1.0 + 0.004 * ns);  // mild preference for fewer prologues
+    if (cost < best_cost * 0.999) { best_cost = cost; best = ns; }
+  }
+  return best;
 }
 static inline int sf_score_lines_per_wg(int lines, int ncols) {
+  // one resident round: ~4 workgroups per CU (LDS-bound), every workgroup the same length
   int colblocks = sf_cdiv(ncols, 64);
-  int target = sf_cdiv(4096, colblocks);
+  int target = 1024 / colblocks;
+  if (target < 1) target = 1;
   int lpw = sf_cdiv(lines, target);
   lpw = (lpw + 15) / 16 * 16;
   return lpw < 16 ? 16 : lpw;

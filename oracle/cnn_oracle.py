@@ -1,0 +1,102 @@
+"""TEST INFRASTRUCTURE -- CPU oracle for the CNN tile scorer (``cnn/cnn_pred_pipeline.py`` + ``cnn/archs/googlenet1.py``).
+
+Checker only (tests, smoke, CPU baseline); ``srcfinder_amd`` never imports it.  A torch-CPU restatement, in
+functional form, of the eval graph of the reference's 1-channel GoogLeNet and of the per-pixel tiling of the
+prediction script.  Parity pin: ``tests/golden/cnn_*.npz`` were produced by the REAL reference classes
+(``googlenet1.GoogLeNet``, ``cnn_pred_pipeline.ClampCH4`` / ``FlightlineConvolve``) on seeded synthetic weights
+(``tests/golden/gen_golden_cnn.py``); ``tests/test_cnn_oracle_golden.py`` checks this file against them.
+
+Restated semantics:
+  * BasicConv2d = conv (no bias) -> BatchNorm(eps=1e-3, running stats) -> ReLU        googlenet1.py:266-275
+  * stem / inception / pools (ceil_mode) / head                                       googlenet1.py:60-89,:110-163,:184-228
+  * ClampCH4, Normalize, Pad(128,128,127,127), window [row:row+256, col:col+256]      cnn_pred_pipeline.py:19-58,:126-157
+  * softmax(logits)[:,1], reshape, -9999 where the input plane is -9999               cnn_pred_pipeline.py:173-189
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+MODEL_NORM = {  # cnn_pred_pipeline.py:126-157
+    "COVID_QC": (110.6390, 183.9152), "CalCH4_v8": (140.6399, 237.5434), "Permian_QC": (100.2635, 158.7060),
+    "multi_256": (115.0, 190.0), "multi_64": (115.0, 190.0),
+}
+BN_EPS = 0.001
+
+
+def _t(x):
+    return x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
+
+
+def basic_conv(x, sd, name, stride=1, pad=0):
+    w = _t(sd[name + ".conv.weight"])
+    y = F.conv2d(x, w, None, stride=stride, padding=pad)
+    y = F.batch_norm(y, _t(sd[name + ".bn.running_mean"]), _t(sd[name + ".bn.running_var"]),
+                     _t(sd[name + ".bn.weight"]), _t(sd[name + ".bn.bias"]), training=False, eps=BN_EPS)
+    return F.relu(y)
+
+
+def inception(x, sd, name):
+    b1 = basic_conv(x, sd, name + ".branch1")
+    b2 = basic_conv(basic_conv(x, sd, name + ".branch2.0"), sd, name + ".branch2.1", pad=1)
+    b3 = basic_conv(basic_conv(x, sd, name + ".branch3.0"), sd, name + ".branch3.1", pad=1)
+    b4 = basic_conv(F.max_pool2d(x, 3, stride=1, padding=1, ceil_mode=True), sd, name + ".branch4.1")
+    return torch.cat([b1, b2, b3, b4], 1)
+
+
+def googlenet_forward(x, sd, taps=None):
+    """x [N,1,256,256] float32 -> logits [N,2].  ``taps`` (dict) collects named intermediate activations."""
+    def tap(k, v):
+        if taps is not None:
+            taps[k] = v
+        return v
+    x = tap("conv1", basic_conv(x, sd, "conv1", stride=2, pad=3))
+    x = tap("maxpool1", F.max_pool2d(x, 3, stride=2, ceil_mode=True))
+    x = tap("conv2", basic_conv(x, sd, "conv2"))
+    x = tap("conv3", basic_conv(x, sd, "conv3", pad=1))
+    x = tap("maxpool2", F.max_pool2d(x, 3, stride=2, ceil_mode=True))
+    x = tap("inception3a", inception(x, sd, "inception3a"))
+    x = tap("inception3b", inception(x, sd, "inception3b"))
+    x = tap("maxpool3", F.max_pool2d(x, 3, stride=2, ceil_mode=True))
+    for n in ("4a", "4b", "4c", "4d", "4e"):
+        x = tap("inception" + n, inception(x, sd, "inception" + n))
+    x = tap("maxpool4", F.max_pool2d(x, 2, stride=2, ceil_mode=True))
+    x = tap("inception5a", inception(x, sd, "inception5a"))
+    x = tap("inception5b", inception(x, sd, "inception5b"))
+    x = torch.flatten(F.adaptive_avg_pool2d(x, (1, 1)), 1)
+    return F.linear(x, _t(sd["fc.weight"]), _t(sd["fc.bias"]))       # dropout is the identity in eval
+
+
+def prepare_plane(plane, mean, std, vmin=0, vmax=4000, dim=256):
+    """float32 plane -> clamp -> normalize -> zero pad: [1, H+dim-1, W+dim-1] (cnn_pred_pipeline.py:39-47)."""
+    x = torch.as_tensor(np.asarray(plane)[None], dtype=torch.float)
+    x = torch.clamp(x, vmin, vmax)
+    x = (x - torch.tensor([mean]).view(-1, 1, 1)) / torch.tensor([std]).view(-1, 1, 1)
+    return F.pad(x, (dim // 2, dim // 2 - 1, dim // 2, dim // 2 - 1), value=0.0)
+
+
+def tile(xpad, idx, width, dim=256):
+    row, col = idx // width, idx % width
+    return xpad[:, row:row + dim, col:col + dim]
+
+
+def predict_plane(plane, sd, mean, std, batch=8, indices=None):
+    """saliency[H,W] float32 (or the values at ``indices``): softmax(logits)[:,1]; -9999 where plane == -9999."""
+    plane = np.asarray(plane)
+    h, w = plane.shape
+    xpad = prepare_plane(plane, mean, std)
+    idxs = list(range(h * w)) if indices is None else list(indices)
+    out = []
+    with torch.no_grad():
+        for i in range(0, len(idxs), batch):
+            b = torch.stack([tile(xpad, j, w) for j in idxs[i:i + batch]])
+            out.append(torch.softmax(googlenet_forward(b, sd), dim=1)[:, 1])
+    p = torch.cat(out).numpy().astype(np.float32)
+    if indices is not None:
+        flat = plane.reshape(-1)[idxs]
+        p[flat == -9999] = -9999
+        return p
+    p = p.reshape(h, w)
+    p[plane == -9999] = -9999
+    return p

@@ -1,0 +1,66 @@
+"""The CNN CPU oracle (oracle/cnn_oracle.py) against golden vectors produced by the REAL reference classes
+(tests/golden/gen_golden_cnn.py).  Runs anywhere (torch CPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cnn_oracle as O
+from srcfinder_amd.cnn_weights import conv_table, synthetic_plane, synthetic_state_dict
+
+MEAN, STD = O.MODEL_NORM["COVID_QC"]
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "cnn_googlenet_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synthetic_state_dict(seed=2024)
+
+
+def test_weight_generator_is_stable(sd):
+    # a pure integer hash: these values must never change (the goldens depend on them)
+    assert len(conv_table()) == 57
+    w = sd["conv1.conv.weight"]
+    assert w.shape == (64, 1, 7, 7) and w.dtype == np.float32
+    assert abs(float(w[0, 0, 0, 0]) - 0.10262156277894974) < 1e-9, float(w[0, 0, 0, 0])
+    assert abs(float(sd["fc.bias"][1]) - (-0.009986969642341137)) < 1e-9, float(sd["fc.bias"][1])
+
+
+def test_prepare_and_tiles(gold):
+    plane = synthetic_plane(40, 30, seed=7)
+    assert np.array_equal(plane, gold["plane40"])
+    xpad = O.prepare_plane(plane, MEAN, STD)
+    assert np.array_equal(xpad.numpy(), gold["padded40"])              # clamp/normalize/pad bit-exact
+    for k, i in enumerate(gold["tiles_idx"]):
+        assert np.array_equal(O.tile(xpad, int(i), 30).numpy(), gold["tiles"][k])
+    # NODATA (-9999) becomes clamp -> 0 -> (0 - mean)/std; outside the image the pad is exactly 0
+    assert xpad[0, 0, 0] == 0.0
+    assert abs(float(xpad[0, 128, 128]) - (0.0 - MEAN) / STD) < 1e-6
+
+
+def test_logits_and_activations(gold, sd):
+    plane = gold["plane40"]
+    xpad = O.prepare_plane(plane, MEAN, STD)
+    b = torch.stack([O.tile(xpad, int(i), 30) for i in gold["logits_idx"]])
+    taps = {}
+    with torch.no_grad():
+        logits = O.googlenet_forward(b, sd, taps).numpy()
+    np.testing.assert_allclose(logits, gold["logits"], rtol=2e-5, atol=2e-5)
+    for n, a in taps.items():
+        np.testing.assert_allclose(a.mean(dim=(0, 2, 3)).numpy(), gold["act_mean_" + n], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(taps["conv1"][0, 0].numpy(), gold["conv1_tile0_ch0"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(taps["inception3a"][0, :, ::4, ::4].numpy(), gold["inception3a_tile0"], rtol=1e-4, atol=1e-5)
+
+
+def test_predict_subset(gold, sd):
+    plane = gold["plane24"]
+    idx = [0, 1, 2, 19, 20, 12 * 20 + 6, 479]                     # includes NODATA pixels (0,0..2) and (12,6)
+    got = O.predict_plane(plane, sd, MEAN, STD, indices=idx)
+    want = gold["saliency24"].reshape(-1)[idx]
+    assert np.array_equal(got == -9999, want == -9999)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)

@@ -109,6 +109,40 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
 int sf_cmf_score_timing(int enable);
 int sf_cmf_score_timing_read(double *total_ms, int *launches);
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * CNN tile scorer (cnn/cnn_pred_pipeline.py + cnn/archs/googlenet1.py, eval graph).  Activations are NHWC
+ * float32 device buffers owned by the caller; conv weights are [Cout][k*k][Cin] float32 with BatchNorm
+ * (eps 1e-3, running statistics) folded in by the caller (srcfinder_amd/cnn.py does it on upload).
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* ClampCH4 -> Normalize -> Pad(dim/2, dim/2, dim/2-1, dim/2-1) (cnn_pred_pipeline.py:19-30, :39-47, :126-157):
+ * plane[H][W] -> padded[H+dim-1][W+dim-1]. */
+int sf_cnn_prepare_plane(const float *plane, int H, int W, float vmin, float vmax, float mean, float stdv, int dim,
+                         float *padded, void *stream);
+
+/* FlightlineConvolve.__getitem__ (cnn_pred_pipeline.py:53-58) fused with conv1 = BasicConv2d(1, 64, 7x7, stride 2,
+ * pad 3) (googlenet1.py:60, :266-275): tiles tile0 .. tile0+ntiles-1 (row-major pixel index) of the padded plane
+ * -> out[ntiles][128][128][64].  w = [64][49], bias = [64]. */
+int sf_cnn_conv1(const float *padded, int Hp, int Wp, int W, long long tile0, int ntiles, const float *w,
+                 const float *bias, float *out, void *stream);
+
+/* nn.MaxPool2d(ksize, stride, pad, ceil_mode=True) (googlenet1.py:61,:64,:68,:75,:213); Ho/Wo are the caller's
+ * ceil-mode output sizes; edge windows are clipped to the input. */
+int sf_cnn_maxpool(const float *in, int N, int H, int W, int C, int ksize, int stride, int pad, float *out, int Ho,
+                   int Wo, void *stream);
+
+/* BasicConv2d with a 1x1 or 3x3 (pad 1) stride-1 kernel (googlenet1.py:266-275): conv + folded-BN bias + ReLU,
+ * written into channels [ch_off, ch_off+Cout) of an output whose pixel stride is ld_out floats -- the inception
+ * concat (googlenet1.py:223-228) costs nothing.  Implicit GEMM on v_mfma_f32_32x32x2_f32. */
+int sf_cnn_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias, int Cout,
+                int ksize, float *out, int ld_out, int ch_off, void *stream);
+
+/* AdaptiveAvgPool2d(1) -> Linear(C, 2) -> softmax[:,1] (googlenet1.py:87-89,:156-161; cnn_pred_pipeline.py:177-180)
+ * and the NODATA rule (:185-189): out[tile0 + t] = plane[tile0 + t] == nodata ? nodata : p.  plane may be NULL. */
+int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, const float *fcb, const float *plane,
+                long long tile0, float nodata, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

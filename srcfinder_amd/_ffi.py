@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libsrcfinder_amd.so")
 _lib = None
 
 vp, i32, f64, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+f32, i64 = C.c_float, C.c_longlong
 
 # name -> (restype, argtypes); mirrors include/srcfinder_amd.h line by line
 SIGNATURES = {
@@ -30,6 +31,11 @@ SIGNATURES = {
                            vp, i32, i32, i32, vp, vp, vp, vp]),
     "sf_cmf_run": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, f64,
                          vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "sf_cnn_prepare_plane": (i32, [vp, i32, i32, f32, f32, f32, f32, i32, vp, vp]),
+    "sf_cnn_conv1": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp, vp]),
+    "sf_cnn_maxpool": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "sf_cnn_conv": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, i32, i32, vp]),
+    "sf_cnn_head": (i32, [vp, i32, i32, i32, vp, vp, vp, i64, f32, vp, vp]),
     "sf_cmf_score_timing": (i32, [i32]),
     "sf_cmf_score_timing_read": (i32, [C.POINTER(f64), C.POINTER(i32)]),
 }

@@ -1,0 +1,272 @@
+"""CNN tile scorer on MI355X -- host side of the drop-in boundary for ``cnn/cnn_pred_pipeline.py``.
+
+Mirrors the reference's surface:
+
+* ``ClampCH4(vmin=250, vmax=4000)``                                   cnn_pred_pipeline.py:19-30
+* ``FlightlineConvolve(flightline, transform, dim=256, device)`` with ``.x``, ``.inshape``, ``.dim``,
+  ``__len__``, ``__getitem__``                                         cnn_pred_pipeline.py:32-58
+* ``MODEL_NORM`` per-model mean/std                                    cnn_pred_pipeline.py:126-157
+* ``GoogLeNetHIP.load_state_dict(sd)`` accepts the ``state_dict`` of ``googlenet(num_classes=2)``
+  (aux heads and ``num_batches_tracked`` ignored)                      googlenet1.py:27-181
+* ``predict_flightline(cmf2d, model|(mean,std), weights, batch)`` = the script's batch loop + reshape +
+  NODATA rule                                                          cnn_pred_pipeline.py:159-189
+
+Every operator runs in a hand-written HIP kernel behind ``libsrcfinder_amd.so``; there is no torch.nn fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .cnn_weights import INCEPTION, conv_table
+
+MODEL_NORM = {
+    "COVID_QC": (110.6390, 183.9152), "CalCH4_v8": (140.6399, 237.5434), "Permian_QC": (100.2635, 158.7060),
+    "multi_256": (115.0, 190.0), "multi_64": (115.0, 190.0),
+}
+BN_EPS = 0.001          # googlenet1.py:270
+NODATA = -9999.0
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _ffi.SrcfinderError("no GPU visible: srcfinder_amd has no CPU fallback")
+    return torch
+
+
+class ClampCH4(object):
+    """Preprocessing step for the methane layer (same contract as the reference class)."""
+
+    def __init__(self, vmin=250, vmax=4000):
+        assert isinstance(vmin, int) and isinstance(vmax, int) and vmax > vmin
+        self.vmin = vmin
+        self.vmax = vmax
+
+    def __call__(self, T):
+        import torch
+        return torch.clamp(T, self.vmin, self.vmax)
+
+    def __repr__(self):
+        return self.__class__.__name__ + '(vmin={0}, vmax={1})'.format(self.vmin, self.vmax)
+
+
+class Normalize(object):
+    """(x - mean) / std, the one ``torchvision.transforms`` op the script uses (:128-156)."""
+
+    def __init__(self, mean, std):
+        self.mean, self.std = float(np.ravel(mean)[0]), float(np.ravel(std)[0])
+
+
+class Compose(object):
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+
+def _parse_transform(transform):
+    """(vmin, vmax, mean, std) from a Compose([ClampCH4, Normalize]) / tuple / model name."""
+    if isinstance(transform, str):
+        m, s = MODEL_NORM[transform]
+        return 0.0, 4000.0, m, s
+    if isinstance(transform, (tuple, list)) and len(transform) == 2 and not isinstance(transform[0], (ClampCH4, Normalize)):
+        return 0.0, 4000.0, float(transform[0]), float(transform[1])
+    ts = transform.transforms if isinstance(transform, Compose) else list(transform)
+    vmin, vmax, mean, std = None, None, 0.0, 1.0
+    for t in ts:
+        if isinstance(t, ClampCH4):
+            vmin, vmax = float(t.vmin), float(t.vmax)
+        elif isinstance(t, Normalize):
+            mean, std = t.mean, t.std
+        else:
+            raise TypeError("unsupported transform %r" % (t,))
+    if vmin is None:
+        raise TypeError("transform must contain ClampCH4")
+    return vmin, vmax, mean, std
+
+
+class FlightlineConvolve(object):
+    """Single flightline for exhaustive CNN convolution (cnn_pred_pipeline.py:32-58).
+
+    ``flightline`` is the 2-D CMF plane (ndarray / tensor; the reference reads band 1 of a raster).
+    ``self.x`` is the clamped, normalised, zero-padded plane ``[1, H+dim-1, W+dim-1]`` on the GPU, produced by the
+    HIP ``sf_cnn_prepare_plane`` kernel; item ``i`` is the window ``x[:, row:row+dim, col:col+dim]``.
+    """
+
+    def __init__(self, flightline, transform, dim=256, device=None):
+        torch = _torch()
+        self.flightline = flightline
+        self.transform = transform
+        dev = torch.device("cuda") if device is None else torch.device(device)
+        plane = flightline if torch.is_tensor(flightline) else torch.as_tensor(np.ascontiguousarray(flightline, dtype=np.float32))
+        plane = plane.to(dev, torch.float32).contiguous()
+        if plane.dim() != 2:
+            raise TypeError("flightline must be a 2-D plane")
+        H, W = plane.shape
+        self.plane = plane
+        self.inshape = (1, H, W)
+        self.dim = dim
+        vmin, vmax, mean, std = _parse_transform(transform)
+        self.x = torch.empty((1, H + dim - 1, W + dim - 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _ffi.check(_ffi.lib().sf_cnn_prepare_plane(_ffi.ptr(plane), H, W, vmin, vmax, mean, std, dim, _ffi.ptr(self.x),
+                                                       _ffi.stream_ptr()), "sf_cnn_prepare_plane")
+
+    def __len__(self):
+        return int(self.inshape[1] * self.inshape[2])
+
+    def __getitem__(self, idx):
+        row = idx // self.inshape[2]
+        col = idx % self.inshape[2]
+        return self.x[:, row:row + self.dim, col:col + self.dim]
+
+
+def _pool_out(n, k, s, p):
+    """ceil_mode output size with PyTorch's last-window rule."""
+    o = -(-(n + 2 * p - k) // s) + 1
+    if (o - 1) * s >= n + p:
+        o -= 1
+    return o
+
+
+class GoogLeNetHIP(object):
+    """Eval graph of the reference's 1-channel GoogLeNet (googlenet1.py:60-89, :110-163) on HIP kernels."""
+
+    def __init__(self, state_dict=None, device=None):
+        torch = _torch()
+        self.device = torch.device("cuda") if device is None else torch.device(device)
+        self.w = {}
+        self._bufs = {}
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    def load_state_dict(self, sd):
+        """Fold BN into conv weight/bias (float64 on the host, stored float32), reorder OIHW -> [O][kh*kw][I]."""
+        torch = _torch()
+
+        def npy(v):
+            return v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+
+        for name, cin, cout, k, s, p in conv_table():
+            w = npy(sd[name + ".conv.weight"]).astype(np.float64)
+            g = npy(sd[name + ".bn.weight"]).astype(np.float64)
+            b = npy(sd[name + ".bn.bias"]).astype(np.float64)
+            m = npy(sd[name + ".bn.running_mean"]).astype(np.float64)
+            v = npy(sd[name + ".bn.running_var"]).astype(np.float64)
+            assert w.shape == (cout, cin, k, k), (name, w.shape)
+            scale = g / np.sqrt(v + BN_EPS)
+            wf = (w * scale[:, None, None, None]).transpose(0, 2, 3, 1).reshape(cout, k * k, cin)
+            bf = b - m * scale
+            self.w[name] = (torch.as_tensor(np.ascontiguousarray(wf, dtype=np.float32)).to(self.device),
+                            torch.as_tensor(bf.astype(np.float32)).to(self.device))
+        self.fcw = torch.as_tensor(np.ascontiguousarray(npy(sd["fc.weight"]), dtype=np.float32)).to(self.device)
+        self.fcb = torch.as_tensor(np.ascontiguousarray(npy(sd["fc.bias"]), dtype=np.float32)).to(self.device)
+        if self.fcw.shape != (2, 1024):
+            raise ValueError("fc.weight must be [2, 1024]")
+        return self
+
+    # -- buffers ---------------------------------------------------------------------------------------------
+    def _buf(self, key, shape):
+        torch = _torch()
+        n = int(np.prod(shape))
+        b = self._bufs.get(key)
+        if b is None or b.numel() < n:
+            self._bufs[key] = None
+            b = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._bufs[key] = b
+        return b[:n].view(*shape)
+
+    # -- operators -------------------------------------------------------------------------------------------
+    def _conv(self, x, name, out, ch_off):
+        L = _ffi.lib()
+        w, b = self.w[name]
+        N, H, W, ldi = x.shape
+        cout, taps, cin = w.shape
+        k = 3 if taps == 9 else 1
+        _ffi.check(L.sf_cnn_conv(_ffi.ptr(x), N, H, W, cin, ldi, _ffi.ptr(w), _ffi.ptr(b), cout, k, _ffi.ptr(out),
+                                 out.shape[3], ch_off, _ffi.stream_ptr()), "sf_cnn_conv(%s)" % name)
+
+    def _pool(self, x, key, k, s, p):
+        L = _ffi.lib()
+        N, H, W, Cc = x.shape
+        Ho, Wo = _pool_out(H, k, s, p), _pool_out(W, k, s, p)
+        out = self._buf(key, (N, Ho, Wo, Cc))
+        _ffi.check(L.sf_cnn_maxpool(_ffi.ptr(x), N, H, W, Cc, k, s, p, _ffi.ptr(out), Ho, Wo, _ffi.stream_ptr()),
+                   "sf_cnn_maxpool")
+        return out
+
+    def _inception(self, x, spec):
+        name, cin, c1, c3r, c3, c5r, c5, pp = spec
+        N, H, W, _ = x.shape
+        y = self._buf(name + ".y", (N, H, W, c1 + c3 + c5 + pp))
+        t2 = self._buf("t2", (N, H, W, c3r))
+        t3 = self._buf("t3", (N, H, W, c5r))
+        self._conv(x, name + ".branch1", y, 0)
+        self._conv(x, name + ".branch2.0", t2, 0)
+        self._conv(t2, name + ".branch2.1", y, c1)
+        self._conv(x, name + ".branch3.0", t3, 0)
+        self._conv(t3, name + ".branch3.1", y, c1 + c3)
+        pooled = self._pool(x, "pool_s1", 3, 1, 1)
+        self._conv(pooled, name + ".branch4.1", y, c1 + c3 + c5)
+        return y
+
+    def forward_tiles(self, padded, width, tile0, ntiles, plane=None, out=None, taps=None):
+        """Score tiles tile0..tile0+ntiles-1 of the padded plane; writes ``out[tile0:tile0+ntiles]`` (float32)."""
+        torch = _torch()
+        L = _ffi.lib()
+        Hp, Wp = padded.shape[-2], padded.shape[-1]
+        with torch.cuda.device(self.device):
+            st = _ffi.stream_ptr()
+            a1 = self._buf("conv1", (ntiles, 128, 128, 64))
+            w, b = self.w["conv1"]
+            _ffi.check(L.sf_cnn_conv1(_ffi.ptr(padded), Hp, Wp, width, C.c_longlong(tile0), ntiles, _ffi.ptr(w), _ffi.ptr(b),
+                                      _ffi.ptr(a1), st), "sf_cnn_conv1")
+            x = self._pool(a1, "pool1", 3, 2, 0)
+            a3 = self._buf("conv2", x.shape)
+            self._conv(x, "conv2", a3, 0)
+            a4 = self._buf("conv3", (ntiles, 64, 64, 192))
+            self._conv(a3, "conv3", a4, 0)
+            x = self._pool(a4, "pool2", 3, 2, 0)
+            rec = {} if taps is not None else None
+            for spec in INCEPTION:
+                x = self._inception(x, spec)
+                if taps is not None:
+                    taps[spec[0]] = x.clone()
+                if spec[0] == "inception3b":
+                    x = self._pool(x, "pool3", 3, 2, 0)
+                elif spec[0] == "inception4e":
+                    x = self._pool(x, "pool4", 2, 2, 0)
+            if taps is not None:
+                taps["conv1"] = a1.clone()
+            N, H, W, Cc = x.shape
+            if out is None:
+                out = torch.empty(tile0 + ntiles, dtype=torch.float32, device=self.device)
+            _ffi.check(L.sf_cnn_head(_ffi.ptr(x), ntiles, H * W, Cc, _ffi.ptr(self.fcw), _ffi.ptr(self.fcb),
+                                     _ffi.ptr(plane), C.c_longlong(tile0), NODATA, _ffi.ptr(out), st), "sf_cnn_head")
+        return out
+
+
+def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=None, rows=None, net=None, to_numpy=False):
+    """saliency[H, W] float32 = softmax(GoogLeNet(window))[:, 1] for the 256x256 window centred on every pixel,
+    -9999 where ``cmf2d`` is -9999 (cnn_pred_pipeline.py:159-189).
+
+    model   : a name of MODEL_NORM or a (mean, std) pair
+    weights : a GoogLeNet ``state_dict`` (name -> tensor/ndarray)
+    rows    : optional (r0, r1) image rows to score (multi-GPU row sharding); other rows are left at 0
+    """
+    torch = _torch()
+    if net is None:
+        if weights is None:
+            raise ValueError("weights (a GoogLeNet state_dict) are required")      # the script exits 1 (:93-95)
+        net = GoogLeNetHIP(weights)
+    ds = FlightlineConvolve(cmf2d, model, device=net.device)
+    H, W = ds.inshape[1], ds.inshape[2]
+    out = torch.zeros(H * W, dtype=torch.float32, device=net.device)
+    r0, r1 = (0, H) if rows is None else rows
+    i0, i1 = r0 * W, r1 * W
+    for t0 in range(i0, i1, batch):
+        n = min(batch, i1 - t0)
+        net.forward_tiles(ds.x, W, t0, n, plane=ds.plane, out=out)
+    out = out.view(H, W)
+    return out.cpu().numpy() if to_numpy else out

@@ -1,0 +1,336 @@
+// CNN tile scorer kernels (gfx950): the eval graph of cnn/archs/googlenet1.py evaluated on a 256x256 window
+// around every pixel (cnn/cnn_pred_pipeline.py).  Activations are NHWC float32 so that the contraction axis
+// (tap, input channel) of every convolution is contiguous; BatchNorm (eps 1e-3, running stats) is folded into
+// the weights/bias on upload, ReLU is fused into the conv epilogue, inception branches write straight into their
+// channel slice of the concatenated output.  Convolutions run as implicit GEMM on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, no reduced precision) -- MFMA-bound: 3.7 GFLOP per tile.
+#include "cmf_common.h"
+
+typedef float f16_t __attribute__((ext_vector_type(16)));
+
+namespace {
+
+// ---- clamp -> normalize -> zero pad (cnn_pred_pipeline.py:19-30, :39-47, :126-157) -------------------------------
+__global__ void k_prepare(const float *__restrict__ plane, int H, int W, float vmin, float vmax, float mean, float stdv,
+                          int padlo, int Hp, int Wp, float *__restrict__ padded) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Hp * Wp) return;
+  const int y = i / Wp - padlo, x = i % Wp - padlo;
+  float v = 0.f;
+  if (y >= 0 && y < H && x >= 0 && x < W) {
+    float t = plane[(size_t)y * W + x];
+    t = fminf(fmaxf(t, vmin), vmax);  // torch.clamp (NaN stays NaN: fmaxf(NaN, a) = a would not -> handle below)
+    if (plane[(size_t)y * W + x] != plane[(size_t)y * W + x]) t = plane[(size_t)y * W + x];
+    v = (t - mean) / stdv;
+  }
+  padded[i] = v;
+}
+
+// ---- conv1: 7x7 stride 2 pad 3, 1 -> 64 channels, read straight from the padded plane (no tile copy) ---------------
+// (googlenet1.py:60; tile window cnn_pred_pipeline.py:53-58).  The tile is its own image: taps outside
+// [0,256) are zero even where the padded flightline has data.  One workgroup = 16x16 outputs of one tile.
+constexpr int C1_PATCH = 37;  // 2*15 + 7
+__global__ __launch_bounds__(256) void k_conv1(const float *__restrict__ padded, int Wp, int Wimg, long long tile0,
+                                                const float *__restrict__ w /*[64][49]*/, const float *__restrict__ bias,
+                                                float *__restrict__ out /*[n][128][128][64]*/) {
+  __shared__ float patch[C1_PATCH][C1_PATCH + 1];
+  __shared__ __attribute__((aligned(16))) float ws[49][64];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int t = blockIdx.y;
+  const long long tile = tile0 + t;
+  const int trow = (int)(tile / Wimg), tcol = (int)(tile % Wimg);
+  const int oy0 = (blockIdx.x >> 3) * 16, ox0 = (blockIdx.x & 7) * 16;
+  for (int i = tid; i < 49 * 64; i += 256) ws[i / 64][i % 64] = w[(i % 64) * 49 + i / 64];
+  for (int i = tid; i < C1_PATCH * C1_PATCH; i += 256) {
+    const int py = i / C1_PATCH, px = i % C1_PATCH;
+    const int iy = 2 * oy0 - 3 + py, ix = 2 * ox0 - 3 + px;  // tile-local input coordinates
+    float v = 0.f;
+    if (iy >= 0 && iy < 256 && ix >= 0 && ix < 256) v = padded[(size_t)(trow + iy) * Wp + tcol + ix];
+    patch[py][px] = v;
+  }
+  __syncthreads();
+  float acc[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+  for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      const float v = patch[2 * ty + ky][2 * tx + kx];
+      const float4 *wr = reinterpret_cast<const float4 *>(&ws[ky * 7 + kx][0]);
+#pragma unroll
+      for (int c4 = 0; c4 < 16; ++c4) {
+        const float4 ww = wr[c4];
+        acc[4 * c4 + 0] = fmaf(v, ww.x, acc[4 * c4 + 0]);
+        acc[4 * c4 + 1] = fmaf(v, ww.y, acc[4 * c4 + 1]);
+        acc[4 * c4 + 2] = fmaf(v, ww.z, acc[4 * c4 + 2]);
+        acc[4 * c4 + 3] = fmaf(v, ww.w, acc[4 * c4 + 3]);
+      }
+    }
+  }
+  float4 *o = reinterpret_cast<float4 *>(out + (((size_t)t * 128 + oy0 + ty) * 128 + ox0 + tx) * 64);
+  const float4 *b4 = reinterpret_cast<const float4 *>(bias);
+#pragma unroll
+  for (int c4 = 0; c4 < 16; ++c4) {
+    const float4 bb = b4[c4];
+    o[c4] = make_float4(fmaxf(acc[4 * c4] + bb.x, 0.f), fmaxf(acc[4 * c4 + 1] + bb.y, 0.f),
+                        fmaxf(acc[4 * c4 + 2] + bb.z, 0.f), fmaxf(acc[4 * c4 + 3] + bb.w, 0.f));
+  }
+}
+
+// ---- max pool, NHWC, window clipped to the input (ceil_mode edge windows are partial) ------------------------------
+// (googlenet1.py:61,:64,:68,:75 and the stride-1 pool of the inception branch4 :213)
+__global__ void k_maxpool(const float *__restrict__ in, int N, int H, int W, int C, int ks, int stride, int pad,
+                          float *__restrict__ out, int Ho, int Wo) {
+  const int c4n = C >> 2;
+  const size_t total = (size_t)N * Ho * Wo * c4n;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c4 = (int)(i % c4n);
+  size_t r = i / c4n;
+  const int ox = (int)(r % Wo); r /= Wo;
+  const int oy = (int)(r % Ho);
+  const int n = (int)(r / Ho);
+  const int y0 = max(oy * stride - pad, 0), y1 = min(oy * stride - pad + ks, H);
+  const int x0 = max(ox * stride - pad, 0), x1 = min(ox * stride - pad + ks, W);
+  float4 m = make_float4(-3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f);
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      const float4 v = *reinterpret_cast<const float4 *>(in + (((size_t)n * H + y) * W + x) * C + 4 * c4);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+  *reinterpret_cast<float4 *>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + 4 * c4) = m;
+}
+
+// ---- implicit-GEMM convolution, 1x1 or 3x3 (pad k/2), stride 1, + folded-BN bias + ReLU ----------------------------
+// (BasicConv2d, googlenet1.py:266-275).  D[m][co] = sum_{tap,ci} in[pixel(m)+tap][ci] * w[co][tap][ci];
+// block tile 128 pixels x BN channels, k-chunk BK input channels of one tap; each wave owns 32 pixel rows and all
+// BN columns (BN/32 MFMA tiles sharing the A fragment).  Register-staged double buffering: the next chunk's global
+// loads are in flight while the current chunk is multiplied out of LDS.
+template <int BK, int BN>
+__global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in, int M, int H, int W, int Cin, int ld_in,
+                                                     const float *__restrict__ wt, const float *__restrict__ bias, int Cout,
+                                                     int ks, float *__restrict__ out, int ld_out, int ch_off) {
+  constexpr int BM = 128, LDA = BM + 1, LDB = BN + 1;
+  constexpr int TPP = BK / 4;        // threads per pixel row (one float4 each)
+  constexpr int PPP = 256 / TPP;     // rows per pass
+  constexpr int NPA = BM / PPP;      // passes for the A tile
+  constexpr int NPB = (BN + PPP - 1) / PPP;
+  constexpr int NT = BN / 32;
+  __shared__ float As[BK * LDA];
+  __shared__ float Bs[BK * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = tid % TPP, ri = tid / TPP;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int pad = ks >> 1, taps = ks * ks, nchunk = Cin / BK, nit = taps * nchunk;
+
+  int py[NPA], px[NPA];
+  const float *pb[NPA];
+#pragma unroll
+  for (int a = 0; a < NPA; ++a) {
+    const int m = m0 + ri + PPP * a;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int x = mm % W, y = (mm / W) % H;
+    py[a] = ok ? y : -100000;  // invalid rows fail every bounds test
+    px[a] = x;
+    pb[a] = in + (size_t)mm * ld_in + 4 * q;
+  }
+  const float *wb[NPB];
+  bool wok[NPB];
+#pragma unroll
+  for (int b = 0; b < NPB; ++b) {
+    const int co = n0 + ri + PPP * b;
+    wok[b] = (ri + PPP * b < BN) && co < Cout;
+    wb[b] = wt + (size_t)(wok[b] ? co : 0) * taps * Cin + 4 * q;
+  }
+
+  f16_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  float4 ra[NPA], rb[NPB];
+  auto gload = [&](int it) {
+    const int tap = it / nchunk, c0 = (it - tap * nchunk) * BK;
+    const int dy = tap / ks - pad, dx = tap % ks - pad;
+#pragma unroll
+    for (int a = 0; a < NPA; ++a) {
+      const int yy = py[a] + dy, xx = px[a] + dx;
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      ra[a] = ok ? *reinterpret_cast<const float4 *>(pb[a] + ((ptrdiff_t)dy * W + dx) * ld_in + c0)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int b = 0; b < NPB; ++b)
+      rb[b] = wok[b] ? *reinterpret_cast<const float4 *>(wb[b] + (size_t)tap * Cin + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int a = 0; a < NPA; ++a) {
+      float *d = As + (4 * q) * LDA + ri + PPP * a;
+      d[0] = ra[a].x; d[LDA] = ra[a].y; d[2 * LDA] = ra[a].z; d[3 * LDA] = ra[a].w;
+    }
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+      if (ri + PPP * b < BN) {
+        float *d = Bs + (4 * q) * LDB + ri + PPP * b;
+        d[0] = rb[b].x; d[LDB] = rb[b].y; d[2 * LDB] = rb[b].z; d[3 * LDB] = rb[b].w;
+      }
+    }
+  };
+
+  gload(0);
+  lstore();
+  __syncthreads();
+  const float *ap = As + (lane >> 5) * LDA + 32 * wave + (lane & 31);
+  const float *bp = Bs + (lane >> 5) * LDB + (lane & 31);
+  for (int it = 0; it < nit; ++it) {
+    if (it + 1 < nit) gload(it + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const float a = ap[2 * kk * LDA];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float b = bp[2 * kk * LDB + 32 * t];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (it + 1 < nit) {
+      lstore();
+      __syncthreads();
+    }
+  }
+  // epilogue: acc[t][r] = D[row = (r&3) + 8(r>>2) + 4(lane>>5)][col = lane&31]
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int co = n0 + 32 * t + (lane & 31);
+    if (co < Cout) {
+      const float bb = bias[co];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M) out[(size_t)m * ld_out + ch_off + co] = fmaxf(acc[t][r] + bb, 0.f);
+      }
+    }
+  }
+}
+
+// ---- head: global average pool -> FC(1024 -> 2) -> softmax[:,1]; NODATA where the input plane is NODATA ------------
+// (googlenet1.py:87-89,:156-161; cnn_pred_pipeline.py:177-189)
+__global__ __launch_bounds__(256) void k_head(const float *__restrict__ in, int HW, int C, const float *__restrict__ fcw,
+                                               const float *__restrict__ fcb, const float *__restrict__ plane, long long tile0,
+                                               float nodata, float *__restrict__ out) {
+  __shared__ float red[2][256];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  float d0 = 0.f, d1 = 0.f;
+  const float inv = 1.0f / (float)HW;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += in[((size_t)t * HW + p) * C + c];
+    const float a = s * inv;
+    d0 = fmaf(a, fcw[c], d0);
+    d1 = fmaf(a, fcw[C + c], d1);
+  }
+  red[0][tid] = d0;
+  red[1][tid] = d1;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float l0 = red[0][0] + fcb[0], l1 = red[1][0] + fcb[1];
+    const float mx = fmaxf(l0, l1);
+    const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+    float p = e1 / (e0 + e1);
+    if (plane && plane[tile0 + t] == nodata) p = nodata;
+    out[tile0 + t] = p;
+  }
+}
+
+template <int BK, int BN>
+int launch_conv(const float *in, int M, int H, int W, int Cin, int ld_in, const float *wt, const float *bias, int Cout,
+                int ks, float *out, int ld_out, int ch_off, hipStream_t st) {
+  dim3 grid(sf_cdiv(M, 128), sf_cdiv(Cout, BN));
+  hipLaunchKernelGGL((k_conv_igemm<BK, BN>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, out,
+                     ld_out, ch_off);
+  SF_LAUNCH_CHECK("k_conv_igemm");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sf_cnn_prepare_plane(const float *plane, int H, int W, float vmin, float vmax, float mean, float stdv, int dim,
+                         float *padded, void *stream) {
+  if (!plane || !padded || H < 1 || W < 1 || dim < 2 || !(vmax > vmin) || !(stdv != 0.f)) {
+    sf_set_error("sf_cnn_prepare_plane: bad argument");
+    return -1;
+  }
+  const int Hp = H + dim - 1, Wp = W + dim - 1;
+  hipLaunchKernelGGL(k_prepare, dim3(sf_cdiv(Hp * Wp, 256)), dim3(256), 0, (hipStream_t)stream, plane, H, W, vmin, vmax,
+                     mean, stdv, dim / 2, Hp, Wp, padded);
+  SF_LAUNCH_CHECK("k_prepare");
+  return 0;
+}
+
+int sf_cnn_conv1(const float *padded, int Hp, int Wp, int W, long long tile0, int ntiles, const float *w,
+                 const float *bias, float *out, void *stream) {
+  if (!padded || !w || !bias || !out || ntiles < 1 || W < 1 || Wp != W + 255 || tile0 < 0 ||
+      (tile0 + ntiles + W - 1) / W > Hp - 255) {
+    sf_set_error("sf_cnn_conv1: bad argument");
+    return -1;
+  }
+  hipLaunchKernelGGL(k_conv1, dim3(64, ntiles), dim3(256), 0, (hipStream_t)stream, padded, Wp, W, tile0, w, bias, out);
+  SF_LAUNCH_CHECK("k_conv1");
+  return 0;
+}
+
+int sf_cnn_maxpool(const float *in, int N, int H, int W, int C, int ksize, int stride, int pad, float *out, int Ho,
+                   int Wo, void *stream) {
+  if (!in || !out || N < 1 || (C & 3) || ksize < 1 || stride < 1) {
+    sf_set_error("sf_cnn_maxpool: bad argument (channels must be a multiple of 4)");
+    return -1;
+  }
+  const size_t total = (size_t)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(k_maxpool, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, N, H, W, C,
+                     ksize, stride, pad, out, Ho, Wo);
+  SF_LAUNCH_CHECK("k_maxpool");
+  return 0;
+}
+
+int sf_cnn_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias, int Cout,
+                int ksize, float *out, int ld_out, int ch_off, void *stream) {
+  if (!in || !w || !bias || !out || N < 1 || (ksize != 1 && ksize != 3) || (Cin & 7) || (ld_in & 3) || Cin > ld_in ||
+      ch_off < 0 || ch_off + Cout > ld_out) {
+    sf_set_error("sf_cnn_conv: bad argument (ksize 1|3, Cin multiple of 8)");
+    return -1;
+  }
+  const long long Ml = (long long)N * H * W;
+  if (Ml > 2000000000LL) { sf_set_error("sf_cnn_conv: batch too large"); return -1; }
+  const int M = (int)Ml;
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = Cout >= 48;
+  if (Cin % 32 == 0)
+    return wide ? launch_conv<32, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, out, ld_out, ch_off, st)
+                : launch_conv<32, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, out, ld_out, ch_off, st);
+  if (Cin % 16 == 0)
+    return wide ? launch_conv<16, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, out, ld_out, ch_off, st)
+                : launch_conv<16, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, out, ld_out, ch_off, st);
+  return wide ? launch_conv<8, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, out, ld_out, ch_off, st)
+              : launch_conv<8, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, out, ld_out, ch_off, st);
+}
+
+int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, const float *fcb, const float *plane,
+                long long tile0, float nodata, float *out, void *stream) {
+  if (!in || !fcw || !fcb || !out || ntiles < 1) { sf_set_error("sf_cnn_head: bad argument"); return -1; }
+  hipLaunchKernelGGL(k_head, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, in, HW, C, fcw, fcb, plane, tile0, nodata,
+                     out);
+  SF_LAUNCH_CHECK("k_head");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+"""GPU parity of the CNN tile scorer (HIP kernels through the C ABI) against goldens made by the reference's own
+classes (googlenet1.GoogLeNet, cnn_pred_pipeline.ClampCH4 / FlightlineConvolve) and against the torch-CPU oracle.
+
+float32 network: the bar is 1e-4 relative on the saliency (softmax probability) with NODATA placement exact;
+preprocessing (clamp / normalize / pad / window) is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cnn_oracle as O  # noqa: E402
+from srcfinder_amd import cnn  # noqa: E402
+from srcfinder_amd.cnn_weights import synthetic_plane, synthetic_state_dict  # noqa: E402
+
+MEAN, STD = cnn.MODEL_NORM["COVID_QC"]
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "cnn_googlenet_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def net():
+    import torch
+    assert torch.cuda.is_available()
+    return cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024))
+
+
+def test_clampch4_contract():
+    c = cnn.ClampCH4(vmin=0, vmax=4000)
+    assert repr(c) == "ClampCH4(vmin=0, vmax=4000)"
+    with pytest.raises(AssertionError):
+        cnn.ClampCH4(vmin=0.5, vmax=4000)
+    with pytest.raises(AssertionError):
+        cnn.ClampCH4(vmin=10, vmax=5)
+
+
+def test_flightline_convolve_bit_exact(gold):
+    tf = cnn.Compose([cnn.ClampCH4(vmin=0, vmax=4000), cnn.Normalize([MEAN], [STD])])
+    ds = cnn.FlightlineConvolve(gold["plane40"], transform=tf)
+    assert len(ds) == 40 * 30 and ds.dim == 256 and tuple(ds.inshape) == (1, 40, 30)
+    assert np.array_equal(ds.x.cpu().numpy(), gold["padded40"])
+    for k, i in enumerate(gold["tiles_idx"]):
+        assert np.array_equal(ds[int(i)].cpu().numpy(), gold["tiles"][k])
+
+
+def test_activations_and_probabilities(gold, net):
+    import torch
+    ds = cnn.FlightlineConvolve(gold["plane40"], "COVID_QC")
+    idx = [int(i) for i in gold["logits_idx"]]
+    probs, means = [], {}
+    for j, i in enumerate(idx):
+        taps = {}
+        out = net.forward_tiles(ds.x, 30, i, 1, taps=taps)
+        probs.append(float(out[i].item()))
+        for n, a in taps.items():                      # NHWC [1,H,W,C]
+            means.setdefault(n, []).append(a.mean(dim=(0, 1, 2)).cpu().numpy())
+        if j == 0:
+            np.testing.assert_allclose(taps["conv1"][0, :, :, 0].cpu().numpy(), gold["conv1_tile0_ch0"], rtol=1e-5, atol=1e-6)
+            got3a = taps["inception3a"][0].permute(2, 0, 1)[:, ::4, ::4].cpu().numpy()
+            np.testing.assert_allclose(got3a, gold["inception3a_tile0"], rtol=1e-4, atol=5e-5)   # fp32 noise next to ReLU zeros
+    for n, lst in means.items():
+        np.testing.assert_allclose(np.mean(lst, axis=0), gold["act_mean_" + n], rtol=1e-4, atol=1e-5)
+    want = torch.softmax(torch.as_tensor(gold["logits"]), dim=1)[:, 1].numpy()
+    np.testing.assert_allclose(np.array(probs), want, rtol=1e-4, atol=1e-7)
+
+
+def test_predict_flightline_matches_reference_loop(gold, net):
+    sal = cnn.predict_flightline(gold["plane24"], "COVID_QC", net=net, batch=64, to_numpy=True)
+    want = gold["saliency24"]
+    assert sal.shape == want.shape and sal.dtype == np.float32
+    assert np.array_equal(sal == -9999, want == -9999)
+    v = want != -9999
+    np.testing.assert_allclose(sal[v], want[v], rtol=1e-4, atol=1e-7)
+
+
+def test_batch_split_and_row_shard_invariance(gold, net):
+    """Tiles are independent: batch size and row sharding must not change any value."""
+    import torch
+    plane = synthetic_plane(9, 13, seed=3)
+    a = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=117)
+    b = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=5)
+    assert torch.equal(a, b)
+    top = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=32, rows=(0, 4))
+    bot = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=32, rows=(4, 9))
+    assert torch.equal(torch.cat([top[:4], bot[4:]]), a)
+    o = O.predict_plane(plane, synthetic_state_dict(seed=2024), MEAN, STD, indices=[0, 50, 116])
+    np.testing.assert_allclose(a.reshape(-1)[[0, 50, 116]].cpu().numpy(), o, rtol=1e-4, atol=1e-7)

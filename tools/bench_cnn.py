@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Secondary benchmark: CNN tile scorer throughput (tiles/s, TFLOP/s) on one MI355X.
+   python tools/bench_cnn.py --tiles 4096 --batch 256 [--cpu]
+3.706 GFLOP per 256x256 tile (1.853 GMAC).  --cpu adds the torch-CPU oracle on a few tiles."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiles", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--cpu", action="store_true")
+    args = ap.parse_args()
+    import torch
+    from srcfinder_amd import cnn
+    from srcfinder_amd.cnn_weights import synthetic_plane, synthetic_state_dict
+
+    sd = synthetic_state_dict(2024)
+    net = cnn.GoogLeNetHIP(sd)
+    w = 64
+    h = (args.tiles + w - 1) // w
+    plane = synthetic_plane(h, w, seed=5)
+    ds = cnn.FlightlineConvolve(plane, "COVID_QC")
+    out = torch.zeros(h * w, dtype=torch.float32, device="cuda")
+
+    def run():
+        for t0 in range(0, args.tiles, args.batch):
+            net.forward_tiles(ds.x, w, t0, min(args.batch, args.tiles - t0), plane=ds.plane, out=out)
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    line = {"metric": "CNN tiles/s (GoogLeNet 256x256 window per pixel, fp32)", "value": round(args.tiles / dt, 1),
+            "unit": "tiles/s", "tflops": round(args.tiles * 3.706e9 / dt / 1e12, 2), "batch": args.batch,
+            "tiles": args.tiles, "dtype": "f32", "mfma_peak_tflops": 157.3}
+    if args.cpu:
+        from oracle import cnn_oracle as O
+        torch.set_num_threads(os.cpu_count() or 1)
+        n = 32
+        t0 = time.perf_counter()
+        O.predict_plane(plane, sd, *cnn.MODEL_NORM["COVID_QC"], batch=16, indices=range(n))
+        t = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(n / t, 2), "unit": "tiles/s", "cores": os.cpu_count(), "kind": "port",
+                                "sample": "%d tiles, torch CPU" % n}
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

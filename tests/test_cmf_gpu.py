@@ -202,6 +202,17 @@ def test_score_only_output_and_co2_window(torch_cuda, library):
     _compare_run(res, o, 150, 20)
 
 
+def test_reflectance_flag_against_oracle(torch_cuda, library):
+    """-R semantics (target = abscf - mu, no ppm scaling; robust_mf.py:378-386) on a window the LDS-resident
+    statistics path supports; the reference's own p = 416 window is pinned for the oracle only."""
+    cube = make_cube_numpy(180, 33, seed=21, abscf_full=library[:, 2], nodata_column=9)
+    res = cmf.robust_mf(cube, library, reflectance=True, active=(351, 422), metadata=True, to_numpy=True)
+    o = O.robust_mf_oracle(cube, library, reflectance=True, active=(351, 422))
+    _compare_run(res, o, 180, 33)
+    with pytest.raises(_ffi.SrcfinderError, match="exceeds"):
+        cmf.robust_mf(cube, library, reflectance=True)          # default -R window 5..420 (p = 416)
+
+
 def test_column_shards_are_bit_identical(torch_cuda, library):
     """Sharding columns over ranks must not change any column's arithmetic."""
     torch = torch_cuda

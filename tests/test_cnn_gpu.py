@@ -89,3 +89,22 @@ def test_batch_split_and_row_shard_invariance(gold, net):
     assert torch.equal(torch.cat([top[:4], bot[4:]]), a)
     o = O.predict_plane(plane, synthetic_state_dict(seed=2024), MEAN, STD, indices=[0, 50, 116])
     np.testing.assert_allclose(a.reshape(-1)[[0, 50, 116]].cpu().numpy(), o, rtol=1e-4, atol=1e-7)
+
+
+def test_cmf_into_cnn_end_to_end(net, library):
+    """BASELINE config 4 in miniature: cube -> HIP CMF -> HIP CNN, against oracle CMF -> oracle CNN."""
+    import torch
+    from oracle import cmf_oracle as CO
+    from srcfinder_amd import pipeline
+    from srcfinder_amd.synth import make_cube_numpy
+    cube = make_cube_numpy(20, 12, seed=31, abscf_full=library[:, 2], nodata_lines=1, nodata_column=5)
+    res, sal = pipeline.cmf_then_cnn(torch.as_tensor(cube).cuda(), library, None, net=net, batch=64)
+    ref = CO.robust_mf_oracle(cube, library)
+    plane = ref["out"][..., 3].astype(np.float32)
+    assert np.array_equal(res.out[..., 3].cpu().numpy() == -9999.0, plane == -9999.0)
+    idx = [0, 13, 77, 150, 239]
+    want = O.predict_plane(plane, synthetic_state_dict(seed=2024), MEAN, STD, indices=idx)
+    got = sal.reshape(-1)[idx].cpu().numpy()
+    assert np.array_equal(got == -9999, want == -9999)
+    v = want != -9999
+    np.testing.assert_allclose(got[v], want[v], rtol=2e-4, atol=1e-7)

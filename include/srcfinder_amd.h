@@ -107,6 +107,9 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
  * sf_cmf_score_timing_read() synchronises those events, returns the summed kernel time and the
  * number of launches since the last enable, and clears the list. */
 int sf_cmf_score_timing(int enable);
+/* Tuning knobs for experiments (tools/tune_score.py); defaults are the shipped choices.  key 1: score kernel
+ * (lines, bands)-per-batch variant, 2: lines per workgroup, 3: XCD-aware block map on/off. */
+int sf_debug_set(int key, int value);
 int sf_cmf_score_timing_read(double *total_ms, int *launches);
 
 

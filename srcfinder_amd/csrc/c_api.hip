@@ -8,6 +8,8 @@
 
 #include "cmf_common.h"
 
+extern int g_score_variant, g_score_lpw, g_score_xcd;  // cmf_score.hip
+
 namespace {
 thread_local char g_err[512] = "";
 
@@ -81,14 +83,14 @@ int timed_score(const float *cube, int lines, int bands, int samples, int s0, in
     SF_HIP(hipEventRecord(tl.a, st));
   }
   int rc = sf_launch_score(cube, lines, bands, samples, s0, ncols, b0, p, filt, bias, status, alphaidx, rgb0, rgb1, rgb2,
-                           nodata, out, out_samples, out_s0, out_bands, bgmeta, colstats ? scratch : nullptr, st);
+                           nodata, out, out_samples, out_s0, out_bands, bgmeta, scratch, colstats != nullptr, st);
   if (timed) {
     SF_HIP(hipEventRecord(tl.b, st));
     if (!g_timed) g_timed = new std::vector<TimedLaunch>();
     g_timed->push_back(tl);
   }
   if (rc) return rc;
-  if (colstats) rc = sf_launch_colstats(scratch, lines, ncols, nuse, status, nodata, colstats, st);
+  if (colstats) rc = sf_launch_colstats(scratch, lines, samples, s0, ncols, p, nuse, status, nodata, colstats, st);
   return rc;
 }
 }  // namespace
@@ -216,6 +218,16 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
     return rc;
   return timed_score(cube, lines, bands, samples, s0, ncols, b0, p, w.filt, w.bias, status, alphaidx, nuse, rgb0, rgb1,
                      rgb2, nodata, out, out_samples, out_s0, out_bands, bgmeta, colstats, w.scratch, st);
+}
+
+
+int sf_debug_set(int key, int value) {
+  switch (key) {
+    case 1: g_score_variant = value; return 0;
+    case 2: g_score_lpw = value; return 0;
+    case 3: g_score_xcd = value; return 0;
+    default: sf_set_error("sf_debug_set: unknown key %d", key); return -1;
+  }
 }
 
 int sf_cmf_score_timing(int enable) {

@@ -47,6 +47,21 @@ __device__ __forceinline__ void sf_load2(const double *p, double &a, double &b) 
   a = f.x; b = f.y;
 }
 
+// XCD-aware workgroup -> (column block, line chunk) map for the two kernels that stream the BIL cube in
+// 64-sample column blocks.  A block's 256-byte row segments start at arbitrary offsets inside 128-byte lines,
+// so neighbouring column blocks share their boundary lines.  Workgroups are dealt round-robin over the 8 XCDs
+// (bid % 8), each with a private L2: with the natural (cb fastest) order the two sharers sit on different
+// XCDs and both fetch the line (measured: FETCH_SIZE = 1.5x the algorithmic bytes).  Here all column blocks of a
+// line chunk get consecutive slots of ONE XCD, so the second request is an L2 hit.  Speed only: any placement
+// gives the same results.
+__device__ __forceinline__ bool sf_xcd_map(int bid, int ncb, int nchunk, int &cb, int &chunk) {
+  const int xcd = bid & 7, slot = bid >> 3;
+  chunk = (slot / ncb) * 8 + xcd;
+  cb = slot % ncb;
+  return chunk < nchunk;
+}
+static inline int sf_xcd_grid(int ncb, int nchunk) { return sf_cdiv(nchunk, 8) * 8 * ncb; }
+
 // ---- geometry shared by host launchers and kernels ---------------------------------------------
 struct SfGeom {
   int lines, p, ps, nt, s4, ncols, nalpha, nu;
@@ -100,13 +115,12 @@ static inline int sf_sweep_splits(int lines, int ncols) {
   return best;
 }
 static inline int sf_score_lines_per_wg(int lines, int ncols) {
-  // one resident round: ~4 workgroups per CU (LDS-bound), every workgroup the same length
+  // 64-line chunks measured best on the full flightline (tools/tune_score.py: several resident rounds of
+  // short workgroups beat one round of long ones); keep at least ~2 rounds of 1024 workgroups on small shards
   int colblocks = sf_cdiv(ncols, 64);
-  int target = 1024 / colblocks;
-  if (target < 1) target = 1;
-  int lpw = sf_cdiv(lines, target);
-  lpw = (lpw + 15) / 16 * 16;
-  return lpw < 16 ? 16 : lpw;
+  int lpw = 64;
+  while (lpw > 16 && (long)colblocks * sf_cdiv(lines, lpw) < 2048) lpw -= 16;
+  return lpw;
 }
 
 // ---- stage launchers (each in its own .hip) -------------------------------------------------------
@@ -133,6 +147,6 @@ size_t sf_score_scratch_bytes(int lines, int ncols);
 int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
                     const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,
                     int rgb0, int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0,
-                    int out_bands, int16_t *bgmeta, void *stat_scratch, hipStream_t st);
-int sf_launch_colstats(const void *stat_scratch, int lines, int ncols, const int32_t *nuse, const int32_t *status,
-                       double nodata, double *colstats, hipStream_t st);
+                    int out_bands, int16_t *bgmeta, void *scratch, int want_stats, hipStream_t st);
+int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0, int ncols, int p, const int32_t *nuse,
+                       const int32_t *status, double nodata, double *colstats, hipStream_t st);

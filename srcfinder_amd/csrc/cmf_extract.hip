@@ -19,14 +19,17 @@ constexpr int XT_NB = 18;     // loads in flight per wave
 // row-contiguous reads (lane = element) are bank-conflict free.
 __global__ __launch_bounds__(256) void k_extract(const float *__restrict__ cube, int L, int B, int C, int s0,
                                                   int Cs, int b0, int p, int PS, float *__restrict__ xt,
-                                                  uint8_t *__restrict__ mask_t, int lines_per_wg, int pbmax, int cs) {
+                                                  uint8_t *__restrict__ mask_t, int lines_per_wg, int pbmax, int cs, int ncb,
+                                                  int nchunk) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   __shared__ uint8_t vf[64][XT_TL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int colbase = blockIdx.x * 64;
+  int cbi, chunk;
+  if (!sf_xcd_map(blockIdx.x, ncb, nchunk, cbi, chunk)) return;
+  const int colbase = cbi * 64;
   const int ncol = min(64, Cs - colbase);
   const bool colok = lane < ncol;
-  const int lbeg = blockIdx.y * lines_per_wg;
+  const int lbeg = chunk * lines_per_wg;
   const int lend = min(L, lbeg + lines_per_wg);
   const int lanec = colok ? lane : ncol - 1;
   const float *cbase = cube + (size_t)(s0 + colbase);  // wave-uniform base, per-lane 32-bit offset
@@ -171,9 +174,9 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
     attr_set = true;
   }
   const int lpw = sf_extract_lines_per_wg(lines, ncols);
-  dim3 grid(sf_cdiv(ncols, 64), sf_cdiv(lines, lpw));
-  hipLaunchKernelGGL(k_extract, grid, dim3(256), lds, st, cube, lines, bands, samples, s0, ncols, b0, p, PS, xt,
-                     mask_t, lpw, pbmax, cs);
+  const int ncb = sf_cdiv(ncols, 64), nchunk = sf_cdiv(lines, lpw);
+  hipLaunchKernelGGL(k_extract, dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), lds, st, cube, lines, bands, samples, s0, ncols,
+                     b0, p, PS, xt, mask_t, lpw, pbmax, cs, ncb, nchunk);
   SF_LAUNCH_CHECK("k_extract");
   return 0;
 }

@@ -15,12 +15,13 @@
 
 namespace {
 
-constexpr int SC_LPI = 4;  // lines per wave per iteration
-constexpr int SC_UB = 8;   // bands per load batch: SC_LPI*SC_UB loads are issued back to back, two batches in flight
+// SC_LPI lines per wave per iteration, SC_UB bands per load batch: SC_LPI*SC_UB loads are issued back to back,
+// two batches in flight (template parameters; the default is picked in sf_launch_score).
 
 // One batch of loads: SC_UB bands x SC_LPI lines of this lane's column.  Row pointers are wave-uniform
 // (scalar base + per-lane 32-bit offset addressing); bands past the window are clamped to the last band
 // (in-bounds duplicate, weighted by 0 below).
+template <int SC_LPI, int SC_UB>
 __device__ __forceinline__ void score_load(float (&x)[SC_LPI][SC_UB], const float *const (&lp)[SC_LPI], int bc, int p,
                                            int C, int lanec) {
 #pragma unroll
@@ -31,6 +32,7 @@ __device__ __forceinline__ void score_load(float (&x)[SC_LPI][SC_UB], const floa
   }
 }
 
+template <int SC_LPI, int SC_UB>
 __device__ __forceinline__ void score_fma(const float (&x)[SC_LPI][SC_UB], const double *__restrict__ ws, int bc, int p,
                                           int lane, double (&acc)[SC_LPI], bool (&ok)[SC_LPI]) {
 #pragma unroll
@@ -45,18 +47,26 @@ __device__ __forceinline__ void score_fma(const float (&x)[SC_LPI][SC_UB], const
   }
 }
 
-template <bool RGB>
+template <bool RGB, int SC_LPI, int SC_UB>
 __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs,
                                                 int b0, int p, const double *__restrict__ filt,
                                                 const double *__restrict__ bias, const int32_t *__restrict__ status,
                                                 const int32_t *__restrict__ alphaidx, int rgb0, int rgb1, int rgb2,
                                                 double nodata, double *__restrict__ out, int oS, int os0,
                                                 int16_t *__restrict__ bgmeta, double *__restrict__ stat_part,
-                                                int lines_per_wg) {
+                                                int lines_per_wg, int ncb, int nchunk, int xcdmap) {
   extern __shared__ __attribute__((aligned(16))) double ws[];  // [p][64]
   __shared__ double sred[4][64][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int colbase = blockIdx.x * 64;
+  int cbi, chunk;
+  if (xcdmap) {
+    if (!sf_xcd_map(blockIdx.x, ncb, nchunk, cbi, chunk)) return;
+  } else {
+    cbi = blockIdx.x % ncb;
+    chunk = blockIdx.x / ncb;
+    if (chunk >= nchunk) return;
+  }
+  const int colbase = cbi * 64;
   const int ncol = min(64, Cs - colbase);
   const bool colok = lane < ncol;
   const int lanec = colok ? lane : ncol - 1;  // idle lanes re-read the last column (in bounds), never write
@@ -71,7 +81,7 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, i
   const int ai = alphaidx[col];
   __syncthreads();
 
-  const int lbeg = blockIdx.y * lines_per_wg, lend = min(L, lbeg + lines_per_wg);
+  const int lbeg = chunk * lines_per_wg, lend = min(L, lbeg + lines_per_wg);
   const size_t lstride = (size_t)B * C;
   const float *cb = cube + (size_t)(s0 + colbase);  // wave-uniform
   double s1 = 0.0, s2 = 0.0;
@@ -87,12 +97,12 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, i
 #pragma unroll
     for (int j = 0; j < SC_LPI; ++j) { acc[j] = 0.0; ok[j] = true; }
     float xa[SC_LPI][SC_UB], xb[SC_LPI][SC_UB];
-    score_load(xa, lp, 0, p, C, lanec);
+    score_load<SC_LPI, SC_UB>(xa, lp, 0, p, C, lanec);
     for (int bc = 0; bc < p; bc += 2 * SC_UB) {
-      if (bc + SC_UB < p) score_load(xb, lp, bc + SC_UB, p, C, lanec);
-      score_fma(xa, ws, bc, p, lane, acc, ok);
-      if (bc + 2 * SC_UB < p) score_load(xa, lp, bc + 2 * SC_UB, p, C, lanec);
-      if (bc + SC_UB < p) score_fma(xb, ws, bc + SC_UB, p, lane, acc, ok);
+      if (bc + SC_UB < p) score_load<SC_LPI, SC_UB>(xb, lp, bc + SC_UB, p, C, lanec);
+      score_fma<SC_LPI, SC_UB>(xa, ws, bc, p, lane, acc, ok);
+      if (bc + 2 * SC_UB < p) score_load<SC_LPI, SC_UB>(xa, lp, bc + 2 * SC_UB, p, C, lanec);
+      if (bc + SC_UB < p) score_fma<SC_LPI, SC_UB>(xb, ws, bc + SC_UB, p, lane, acc, ok);
     }
     float rgbv[SC_LPI][3];
     if (RGB) {
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, i
     if (wave == 0 && colok) {
       double a = 0.0, b = 0.0;
       for (int w = 0; w < 4; ++w) { a += sred[w][lane][0]; b += sred[w][lane][1]; }
-      double *o = stat_part + ((size_t)blockIdx.y * Cs + col) * 2;
+      double *o = stat_part + ((size_t)chunk * Cs + col) * 2;
       o[0] = a;
       o[1] = b;
     }
@@ -170,48 +180,67 @@ __global__ void k_colstats(const double *__restrict__ stat_part, int nchunk, int
 
 }  // namespace
 
-size_t sf_score_scratch_bytes(int lines, int ncols) {
-  const int lpw = sf_score_lines_per_wg(lines, ncols);
+static size_t score_stat_bytes(int lines, int ncols) {
+  const int lpw = 8;  // upper bound on the number of line chunks whatever the tuning
   return sf_align((size_t)sf_cdiv(lines, lpw) * ncols * 2 * sizeof(double));
 }
+size_t sf_score_scratch_bytes(int lines, int ncols) { return score_stat_bytes(lines, ncols); }
 
-int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
-                    const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,
-                    int rgb0, int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0,
-                    int out_bands, int16_t *bgmeta, void *stat_scratch, hipStream_t st) {
+// tuning knobs (sf_debug_set): 0 = use the built-in choice
+int g_score_variant = 0, g_score_lpw = 0, g_score_xcd = 1;
+
+template <bool RGB, int LPI, int UB>
+int launch_score_t(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
+                   const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx, int rgb0,
+                   int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0, int16_t *bgmeta,
+                   double *stat_part, int lpw, hipStream_t st) {
   const size_t lds = (size_t)p * 64 * sizeof(double);
-  if (lds > 150 * 1024) {
-    sf_set_error("active window of %d bands: filter tile does not fit LDS in the score kernel", p);
-    return -2;
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<RGB, LPI, UB>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
   }
-  static size_t lds_set[2] = {0, 0};
-  const bool rgb = out_bands == 4;
-  if (lds > lds_set[rgb]) {
-    if (rgb)
-      SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else
-      SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set[rgb] = lds;
-  }
-  const int lpw = sf_score_lines_per_wg(lines, ncols);
   const int nchunk = sf_cdiv(lines, lpw);
-  double *stat_part = reinterpret_cast<double *>(stat_scratch);  // may be null: no column statistics
-  dim3 grid(sf_cdiv(ncols, 64), nchunk);
-  if (rgb)
-    hipLaunchKernelGGL(k_score<true>, grid, dim3(256), lds, st, cube, lines, bands, samples, s0, ncols, b0, p, filt,
-                       bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, out_samples, out_s0, bgmeta, stat_part, lpw);
-  else
-    hipLaunchKernelGGL(k_score<false>, grid, dim3(256), lds, st, cube, lines, bands, samples, s0, ncols, b0, p, filt,
-                       bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, out_samples, out_s0, bgmeta, stat_part, lpw);
+  const int ncb = sf_cdiv(ncols, 64);
+  const int nblk = g_score_xcd ? sf_xcd_grid(ncb, nchunk) : ncb * nchunk;
+  hipLaunchKernelGGL((k_score<RGB, LPI, UB>), dim3(nblk), dim3(256), lds, st, cube, lines, bands, samples, s0, ncols, b0,
+                     p, filt, bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, out_samples, out_s0, bgmeta, stat_part,
+                     lpw, ncb, nchunk, g_score_xcd);
   SF_LAUNCH_CHECK("k_score");
   return 0;
 }
 
-int sf_launch_colstats(const void *stat_scratch, int lines, int ncols, const int32_t *nuse, const int32_t *status,
-                       double nodata, double *colstats, hipStream_t st) {
-  const int lpw = sf_score_lines_per_wg(lines, ncols);
+int sf_score_lpw(int lines, int ncols) { return g_score_lpw > 0 ? g_score_lpw : sf_score_lines_per_wg(lines, ncols); }
+
+#define SC_ARGS cube, lines, bands, samples, s0, ncols, b0, p, filt, bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, \
+                out_samples, out_s0, bgmeta, stat_part, lpw, st
+int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
+                    const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,
+                    int rgb0, int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0,
+                    int out_bands, int16_t *bgmeta, void *scratch, int want_stats, hipStream_t st) {
+  if ((size_t)p * 64 * sizeof(double) > 150 * 1024) {
+    sf_set_error("active window of %d bands: filter tile does not fit LDS in the score kernel", p);
+    return -2;
+  }
+  const int lpw = sf_score_lpw(lines, ncols);
+  double *stat_part = (scratch && want_stats) ? reinterpret_cast<double *>(scratch) : nullptr;
+  if (out_bands != 4) return launch_score_t<false, 8, 4>(SC_ARGS);
+  switch (g_score_variant) {
+    case 1: return launch_score_t<true, 2, 16>(SC_ARGS);
+    case 3: return launch_score_t<true, 4, 4>(SC_ARGS);
+    case 4: return launch_score_t<true, 2, 8>(SC_ARGS);
+    case 5: return launch_score_t<true, 8, 8>(SC_ARGS);
+    case 6: return launch_score_t<true, 4, 8>(SC_ARGS);
+    default: return launch_score_t<true, 8, 4>(SC_ARGS);  // measured best (tools/tune_score.py)
+  }
+}
+#undef SC_ARGS
+
+int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0, int ncols, int p, const int32_t *nuse,
+                       const int32_t *status, double nodata, double *colstats, hipStream_t st) {
+  (void)samples; (void)s0; (void)p;
+  const int lpw = sf_score_lpw(lines, ncols);
   const int nchunk = sf_cdiv(lines, lpw);
   hipLaunchKernelGGL(k_colstats, dim3(sf_cdiv(ncols, 128)), dim3(128), 0, st,
                      reinterpret_cast<const double *>(stat_scratch), nchunk, ncols, nuse, status, nodata, colstats);

@@ -73,7 +73,9 @@ def main():
     def step():
         r = cmf.robust_mf(cube, lib, out=out, out_column0=0)
         if world > 1:
-            sd.gather_columns(out, samples, dst=0)      # the single RCCL gather of the score image
+            # the single RCCL gather of the score image: the float64 CMF band of every
+            # rank's block, 8 B/pixel; the RGB copy stays with the rank that read those columns
+            sd.gather_columns(out[..., 3], samples, dst=0)
         return r
 
     def barrier():

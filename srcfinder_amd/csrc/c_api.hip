@@ -52,6 +52,7 @@ Ws carve(void *base, const SfGeom &g) {
   w.bias = (double *)c.take(nc * sizeof(double));
   w.nll = (double *)c.take(nc * g.nalpha * sizeof(double));
   size_t s = sf_mean_scratch_bytes(g);
+  if (sf_extract_sum_bytes(g) > s) s = sf_extract_sum_bytes(g);
   if (sf_cov_scratch_bytes(g) > s) s = sf_cov_scratch_bytes(g);
   if (sf_eigh_scratch_bytes(g) > s) s = sf_eigh_scratch_bytes(g);
   if (sf_loocv_scratch_bytes(g) > s) s = sf_loocv_scratch_bytes(g);
@@ -121,7 +122,8 @@ int sf_cmf_extract_columns(const float *cube, int lines, int bands, int samples,
                            float *xt, uint8_t *mask_t, void *stream) {
   if (int rc = check_geom(lines, bands, samples, s0, s1, b0, p)) return rc;
   if (!cube || !xt || !mask_t) { sf_set_error("null pointer"); return -1; }
-  return sf_launch_extract(cube, lines, bands, samples, s0, s1 - s0, b0, p, xt, mask_t, (hipStream_t)stream);
+  return sf_launch_extract(cube, lines, bands, samples, s0, s1 - s0, b0, p, xt, mask_t, nullptr, nullptr,
+                           (hipStream_t)stream);
 }
 
 int sf_cmf_column_mean(const void *xt, int xt_f64, const uint8_t *mask_t, int lines, int p, int ncols, int32_t *nuse,
@@ -207,8 +209,14 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
   }
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if ((rc = sf_launch_extract(cube, lines, bands, samples, s0, ncols, b0, p, w.xt, w.mask_t, st))) return rc;
-  if ((rc = sf_launch_mean(w.xt, 0, w.mask_t, g, nuse, w.mu, w.scratch, st))) return rc;
+  if (sf_extract_fuses_sum(p)) {  // column sums ride along with the transpose (per-chunk partials in scratch)
+    if ((rc = sf_launch_extract_fused(cube, lines, bands, samples, s0, b0, g, w.xt, w.mask_t, w.scratch, st))) return rc;
+    if ((rc = sf_launch_mean_from_partials(g, nuse, w.mu, w.scratch, st))) return rc;
+  } else {
+    if ((rc = sf_launch_extract(cube, lines, bands, samples, s0, ncols, b0, p, w.xt, w.mask_t, nullptr, nullptr, st)))
+      return rc;
+    if ((rc = sf_launch_mean(w.xt, 0, w.mask_t, g, nuse, w.mu, w.scratch, st))) return rc;
+  }
   if ((rc = sf_launch_cov(w.xt, 0, w.mask_t, nuse, w.mu, g, w.cov, w.scratch, st))) return rc;
   if ((rc = sf_launch_eigh(w.cov, nuse, g, w.d, w.lam, w.evec, status, w.scratch, st))) return rc;
   double *nll = nll_out ? nll_out : w.nll;

@@ -125,7 +125,12 @@ static inline int sf_score_lines_per_wg(int lines, int ncols) {
 
 // ---- stage launchers (each in its own .hip) -------------------------------------------------------
 int sf_launch_extract(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
-                      float *xt, uint8_t *mask_t, hipStream_t st);
+                      float *xt, uint8_t *mask_t, double *sum_part, int *cnt_part, hipStream_t st);
+size_t sf_extract_sum_bytes(const SfGeom &g);
+bool sf_extract_fuses_sum(int p);
+int sf_launch_extract_fused(const float *cube, int lines, int bands, int samples, int s0, int b0, const SfGeom &g,
+                            float *xt, uint8_t *mask_t, void *scratch, hipStream_t st);
+int sf_launch_mean_from_partials(const SfGeom &g, int32_t *nuse, double *mu, void *scratch, hipStream_t st);
 size_t sf_mean_scratch_bytes(const SfGeom &g);
 int sf_launch_mean(const void *xt, int xt_f64, const uint8_t *mask_t, const SfGeom &g, int32_t *nuse, double *mu,
                    void *scratch, hipStream_t st);

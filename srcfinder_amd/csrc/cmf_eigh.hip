@@ -6,14 +6,15 @@
 //   log det G_a = 2 sum log d_j + sum_j log(n*beta*lam_j + a),
 // i.e. ONE eigendecomposition per column replaces 201 LU factorisations + inversions.
 //
-// Method: one-sided (Hestenes) Jacobi on G = R, one workgroup per column, 8 lanes per column pair (dot
-// products reduced with DPP lane swaps), round-robin pair ordering so the p/2 rotations of a step touch
-// disjoint columns (one barrier per step).  At convergence the columns of G = R V are orthogonal and
-// lam_j = |G[:,j]|.  Two phases so that only ONE p x p matrix has to live in LDS (41 KB at p = 72 -> three
-// matrices per CU instead of one; the kernel is latency-bound, so residency is what buys throughput):
-//   phase 1 rotates G only and records every (cos, sin) in a global scratch list;
-//   phase 2 replays the list on V = I in the same LDS buffer (no dot products, no rotation maths).
-// ~70 steps per sweep, ~12 sweeps at p = 72.
+// Method: one-sided (Hestenes) Jacobi, one workgroup per column, 8 lanes per column pair (dot products reduced
+// with DPP lane swaps), round-robin pair ordering so the p/2 rotations of a step touch disjoint columns (one
+// LDS-only barrier per step), ONE p x p matrix in LDS (41 KB at p = 72 -> three columns per CU).
+//   * Normal path: Cholesky R = L L^T in LDS, then Jacobi on the columns of G = L.  At convergence
+//     G = U diag(sigma): lam_j = |g_j|^2 and the eigenvector is g_j/|g_j| -- no eigenvector accumulation at all,
+//     ~10 sweeps, and small eigenvalues keep high relative accuracy (Demmel-Veselic).
+//   * Fallback (R not positive definite, e.g. fewer valid rows than bands): Jacobi on G = R, every (cos, sin)
+//     recorded in a global scratch list and replayed on V = I in the same LDS buffer.
+// The kernel is latency-bound: ~70 steps per sweep, each ~200 dependent fp64 instructions of a single wave.
 #include "cmf_common.h"
 
 namespace {
@@ -53,14 +54,24 @@ __device__ __forceinline__ void rr_pair(int s, int k, int m, int &a, int &b) {
   b = (k == 0) ? m : y;
 }
 
-constexpr int EIG_RMAX = 12;  // rows per lane: p2 <= 96 -> 12
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
+// global access (vmcnt(0)); the step loops below keep a rotation store (phase 1) or a rotation prefetch
+// (phase 2) in flight across the barrier, and waiting for it costs a full memory round trip per step
+// (measured: 4200 -> ~1000 cycles per step).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// RMAX = ceil(p2/8) rows per lane; FULL = (p2 % 8 == 0): every lane owns exactly RMAX rows and all row
+// predicates fold away.  Loads are always unconditional (clamped row, value zeroed afterwards): predicated
+// LDS loads compile to one exec-masked branch + wait EACH and serialise the step (measured 2300 -> ~900 cycles).
+template <int EIG_RMAX, bool FULL>
 __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict__ nuse, int p, int p2, int LD,
                        double *__restrict__ d_out, double *__restrict__ lam_out, double *__restrict__ evec_out,
                        int32_t *__restrict__ status, double2 *__restrict__ rot, size_t rot_stride) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *M = sm;                    // [p2][LD] column-major: M[col*LD + row]; G in phase 1, V in phase 2
   double *dv = sm + (size_t)p2 * LD;  // [p2]
+  double *nrm = dv + p2;              // [p2] squared column norms of G, refreshed every sweep
   __shared__ int flag[2];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int c = blockIdx.x;
@@ -91,11 +102,44 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
     for (int i = tid; i < p * p; i += nthr) evec_out[(size_t)c * p * p + i] = ((i / p) == (i % p)) ? 1.0 : 0.0;
     return;
   }
-  for (int i = tid; i < p2 * p2; i += nthr) {  // G = R
-    const int col = i / p2, row = i - col * p2;
-    double r = 0.0;
-    if (col < p && row < p) r = S[(size_t)row * p + col] / (dv[row] * dv[col]);
-    M[col * LD + row] = r;
+  auto load_R = [&]() {
+    for (int i = tid; i < p2 * p2; i += nthr) {
+      const int col = i / p2, row = i - col * p2;
+      double r = 0.0;
+      if (col < p && row < p) r = S[(size_t)row * p + col] / (dv[row] * dv[col]);
+      M[col * LD + row] = r;
+    }
+  };
+  load_R();
+  __syncthreads();
+
+  // ---------------- Cholesky R = L L^T in place (lower triangle of the column-major buffer)
+  bool chol_ok = true;
+  for (int kk = 0; kk < p; ++kk) {
+    const double dk = M[kk * LD + kk];  // final after the previous trailing update + barrier
+    if (!(dk > 0.0) || !(dk <= 1.79769313486231570e+308)) { chol_ok = false; break; }  // uniform
+    const double rk = rsqrt_nr(dk);
+    __syncthreads();                    // everyone has read dk before it is overwritten
+    for (int i = kk + tid; i < p; i += nthr) M[kk * LD + i] = (i == kk) ? dk * rk : M[kk * LD + i] * rk;
+    __syncthreads();
+    const int rem = p - kk - 1;         // trailing update of the lower triangle, columns kk+1 .. p-1
+    for (int e = tid; e < rem * rem; e += nthr) {
+      const int jj = e / rem, ii = e - jj * rem;
+      if (ii >= jj) {
+        const int j = kk + 1 + jj, i = kk + 1 + ii;
+        M[j * LD + i] = __builtin_fma(-M[kk * LD + i], M[kk * LD + j], M[j * LD + i]);
+      }
+    }
+    __syncthreads();
+  }
+  if (chol_ok) {
+    for (int i = tid; i < p2 * p2; i += nthr) {  // G = L: zero the strict upper triangle and the padding
+      const int col = i / p2, row = i - col * p2;
+      if (row < col || col >= p || row >= p) M[col * LD + row] = 0.0;
+    }
+  } else {
+    __syncthreads();
+    load_R();
   }
   __syncthreads();
 
@@ -108,10 +152,21 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
   // threshold below that never settles; p*eps leaves off-diagonals <= 1e-14 * min(lam_a, lam_b).
   const double tol = (double)p2 * 2.220446049250313e-16;
   const double tol2 = tol * tol;
-  int nsteps = 0;  // steps whose rotations have to be replayed on V
-  // ---------------- phase 1: orthogonalise the columns of G, record the rotations
+  int nsteps = 0;  // fallback only: steps whose rotations have to be replayed on V
+  // ---------------- phase 1: orthogonalise the columns of G (record the rotations in the fallback)
   for (int sweep = 0; sweep < EIG_MAXSWEEP; ++sweep) {
     bool rotated = false;
+    // exact squared norms once per sweep; inside the sweep they are carried through the rotations
+    // (|a'|^2 = c^2 aa - 2cs ab + s^2 bb), so a step needs ONE dot product instead of three
+    for (int j = tid; j < p2; j += nthr) {
+      double sacc = 0;
+      for (int r = 0; r < p2; ++r) {
+        const double x = M[j * LD + r];
+        sacc = __builtin_fma(x, x, sacc);
+      }
+      nrm[j] = sacc;
+    }
+    __syncthreads();
     for (int s = 0; s < m; ++s) {
       if (active) {
         int a, b;
@@ -120,18 +175,16 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
         double xa[EIG_RMAX], xb[EIG_RMAX];
 #pragma unroll
         for (int i = 0; i < EIG_RMAX; ++i) {
-          const bool in = i < nr;
-          xa[i] = in ? ga[8 * i] : 0.0;
-          xb[i] = in ? gb[8 * i] : 0.0;
+          const int ii = FULL ? i : min(i, nr - 1);
+          const double va_ = ga[8 * ii], vb_ = gb[8 * ii];
+          xa[i] = (FULL || i < nr) ? va_ : 0.0;
+          xb[i] = (FULL || i < nr) ? vb_ : 0.0;
         }
-        double aa = 0, bb = 0, ab = 0;
+        const double aa = nrm[a], bb = nrm[b];
+        double ab = 0;
 #pragma unroll
-        for (int i = 0; i < EIG_RMAX; ++i) {
-          aa = __builtin_fma(xa[i], xa[i], aa);
-          bb = __builtin_fma(xb[i], xb[i], bb);
-          ab = __builtin_fma(xa[i], xb[i], ab);
-        }
-        aa = sum8(aa); bb = sum8(bb); ab = sum8(ab);
+        for (int i = 0; i < EIG_RMAX; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
+        ab = sum8(ab);
         const double ab2 = aa * bb;
         double cs = 1.0, sn = 0.0;
         if (ab2 > 0.0 && ab * ab > tol2 * ab2) {  // uniform over the pair's 8 lanes
@@ -147,15 +200,20 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
           sn = ((tau < 0.0) != (gam < 0.0)) ? -sn : sn;
 #pragma unroll
           for (int i = 0; i < EIG_RMAX; ++i) {
-            if (i < nr) {
+            if (FULL || i < nr) {
               ga[8 * i] = cs * xa[i] - sn * xb[i];
               gb[8 * i] = sn * xa[i] + cs * xb[i];
             }
           }
+          if (sub == 0) {
+            const double cc = cs * cs, ss = sn * sn, x2 = 2.0 * cs * sn * ab;
+            nrm[a] = cc * aa - x2 + ss * bb;
+            nrm[b] = ss * aa + x2 + cc * bb;
+          }
         }
-        if (sub == 0) myrot[(size_t)(sweep * m + s) * npairs] = make_double2(cs, sn);
+        if (!chol_ok && sub == 0) myrot[(size_t)(sweep * m + s) * npairs] = make_double2(cs, sn);
       }
-      __syncthreads();
+      lds_barrier();
     }
     if (rotated) flag[1] = 1;  // benign race: every writer stores 1
     __syncthreads();
@@ -166,14 +224,33 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
     nsteps = (sweep + 1) * m;
   }
   __syncthreads();
-  // eigenvalues = column norms of G
+  if (chol_ok) {
+    // G = U diag(sigma): lam = sigma^2, eigenvector = normalised column
+    for (int j = tid; j < p; j += nthr) {
+      double sacc = 0;
+      for (int r = 0; r < p; ++r) {
+        const double x = M[j * LD + r];
+        sacc = __builtin_fma(x, x, sacc);
+      }
+      nrm[j] = sacc;
+      lam_out[(size_t)c * p + j] = sacc;
+    }
+    __syncthreads();
+    for (int i = tid; i < p * p; i += nthr) {
+      const int j = i / p, b = i - j * p;
+      const double s2 = nrm[j];
+      evec_out[(size_t)c * p * p + i] = s2 > 0.0 ? M[j * LD + b] * rsqrt_nr(s2) : ((j == b) ? 1.0 : 0.0);
+    }
+    return;
+  }
+  // eigenvalues = column norms of G = R V
   for (int j = tid; j < p; j += nthr) {
-    double s = 0;
+    double sacc = 0;
     for (int r = 0; r < p2; ++r) {
       const double x = M[j * LD + r];
-      s += x * x;
+      sacc += x * x;
     }
-    lam_out[(size_t)c * p + j] = sqrt(s);
+    lam_out[(size_t)c * p + j] = sqrt(sacc);
   }
   __syncthreads();
   // ---------------- phase 2: V = I, replay
@@ -196,13 +273,13 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
         double ya[EIG_RMAX], yb[EIG_RMAX];
 #pragma unroll
         for (int i = 0; i < EIG_RMAX; ++i) {
-          const bool in = i < nr;
-          ya[i] = in ? va[8 * i] : 0.0;
-          yb[i] = in ? vb[8 * i] : 0.0;
+          const int ii = FULL ? i : min(i, nr - 1);
+          ya[i] = va[8 * ii];
+          yb[i] = vb[8 * ii];
         }
 #pragma unroll
         for (int i = 0; i < EIG_RMAX; ++i) {
-          if (i < nr) {
+          if (FULL || i < nr) {
             va[8 * i] = r.x * ya[i] - r.y * yb[i];
             vb[8 * i] = r.y * ya[i] + r.x * yb[i];
           }
@@ -210,7 +287,7 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
       }
     }
     s = (s + 1 == m) ? 0 : s + 1;
-    __syncthreads();
+    lds_barrier();
   }
   for (int i = tid; i < p * p; i += nthr) {
     const int j = i / p, b = i - j * p;
@@ -230,7 +307,7 @@ int sf_launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, doub
   const int p2 = g.p + (g.p & 1);
   int LD = p2;
   while ((LD % 32) != 8 && (LD % 32) != 24) ++LD;
-  const size_t lds = ((size_t)p2 * LD + p2) * sizeof(double);
+  const size_t lds = ((size_t)p2 * LD + 2 * p2) * sizeof(double);
   if (lds > 160 * 1024 - 64 || g.p > SF_MAX_ACTIVE_FUSED) {
     sf_set_error("active window of %d bands exceeds the LDS-resident eigensolver (max %d)", g.p, SF_MAX_ACTIVE_FUSED);
     return -2;
@@ -238,15 +315,24 @@ int sf_launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, doub
   int threads = (p2 / 2) * 8;
   threads = (threads + 63) / 64 * 64;
   if (threads < 64) threads = 64;
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_eigh), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-    lds_set = lds;
-  }
   const size_t rot_stride = (size_t)EIG_MAXSWEEP * (p2 - 1) * (p2 / 2);
-  hipLaunchKernelGGL(k_eigh, dim3(g.ncols), dim3(threads), lds, st, cov, nuse, g.p, p2, LD, d, lam, evec, status,
-                     reinterpret_cast<double2 *>(scratch), rot_stride);
+  const int rmax = (p2 + 7) / 8;
+  const bool full = (p2 % 8) == 0;
+  auto go = [&](auto kern) -> int {
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(g.ncols), dim3(threads), lds, st, cov, nuse, g.p, p2, LD, d, lam, evec, status,
+                       reinterpret_cast<double2 *>(scratch), rot_stride);
+    return 0;
+  };
+  int rc = -2;
+  switch (rmax) {
+#define EIG_CASE(R) case R: rc = full ? go(k_eigh<R, true>) : go(k_eigh<R, false>); break;
+    EIG_CASE(1) EIG_CASE(2) EIG_CASE(3) EIG_CASE(4) EIG_CASE(5) EIG_CASE(6)
+    EIG_CASE(7) EIG_CASE(8) EIG_CASE(9) EIG_CASE(10) EIG_CASE(11) EIG_CASE(12)
+#undef EIG_CASE
+    default: sf_set_error("eigensolver: unsupported size %d", g.p); return -2;
+  }
+  if (rc) return rc;
   SF_LAUNCH_CHECK("k_eigh");
   return 0;
 }

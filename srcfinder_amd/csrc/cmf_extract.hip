@@ -11,18 +11,21 @@
 
 namespace {
 
-constexpr int XT_TL = 4;      // lines per LDS tile
 constexpr int XT_PBMAX = 80;  // band chunk held in LDS at once
 constexpr int XT_NB = 18;     // loads in flight per wave
 
 // LDS: tile[64 columns][cs] floats, cs odd -> both the column-strided writes (lane = column) and the
-// row-contiguous reads (lane = element) are bank-conflict free.
+// row-contiguous reads (lane = element) are bank-conflict free.  TL = lines per tile.
+// FUSE_SUM (single band chunk only): the masked column sums of stage 2 are accumulated here, while the
+// tile is still in LDS, and written as per-chunk partials -- saves re-reading xt (4p B per pixel).
+template <int TL, bool FUSE_SUM>
 __global__ __launch_bounds__(256) void k_extract(const float *__restrict__ cube, int L, int B, int C, int s0,
                                                   int Cs, int b0, int p, int PS, float *__restrict__ xt,
                                                   uint8_t *__restrict__ mask_t, int lines_per_wg, int pbmax, int cs, int ncb,
-                                                  int nchunk) {
+                                                  int nchunk, double *__restrict__ sum_part, int *__restrict__ cnt_part) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
-  __shared__ uint8_t vf[64][XT_TL];
+  __shared__ uint8_t vf[64][4];
+  constexpr int NSUM = FUSE_SUM ? (XT_PBMAX + 3) / 4 : 1;  // bands per wave: wave, wave+4, ...
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int cbi, chunk;
   if (!sf_xcd_map(blockIdx.x, ncb, nchunk, cbi, chunk)) return;
@@ -33,9 +36,13 @@ __global__ __launch_bounds__(256) void k_extract(const float *__restrict__ cube,
   const int lend = min(L, lbeg + lines_per_wg);
   const int lanec = colok ? lane : ncol - 1;
   const float *cbase = cube + (size_t)(s0 + colbase);  // wave-uniform base, per-lane 32-bit offset
+  double sums[NSUM];
+  int nvalid = 0;
+#pragma unroll
+  for (int i = 0; i < NSUM; ++i) sums[i] = 0.0;
 
-  for (int l0 = lbeg; l0 < lend; l0 += XT_TL) {
-    const int nl = min(XT_TL, lend - l0);
+  for (int l0 = lbeg; l0 < lend; l0 += TL) {
+    const int nl = min(TL, lend - l0);
     bool ok = true;  // thread (line = wave, column = lane)
     for (int bc0 = 0; bc0 < p; bc0 += pbmax) {
       const int pb = min(pbmax, p - bc0);
@@ -60,7 +67,9 @@ __global__ __launch_bounds__(256) void k_extract(const float *__restrict__ cube,
       if (wave < nl) {
         const float *tp = tile + lane * cs + wave * pb;
         for (int b = 0; b < pb; ++b) ok = ok & sf_valid(tp[b]);
+        if (bc0 + pb >= p) vf[lane][wave] = ok ? 1 : 0;
       }
+      if (FUSE_SUM) __syncthreads();  // vf of this tile is complete
       // ---- LDS -> xt; wave handles columns wave, wave+4, ...
       if (pb == PS) {  // single chunk, no padding: nl*PS contiguous floats per column
         const int nel = nl * PS;
@@ -80,20 +89,51 @@ __global__ __launch_bounds__(256) void k_extract(const float *__restrict__ cube,
           }
         }
       }
+      if (FUSE_SUM) {
+        // ---- masked sums: lane = column, this wave's bands wave, wave+4, ...; lines in fixed order
+        bool vl[TL];
+#pragma unroll
+        for (int l = 0; l < TL; ++l) vl[l] = (l < nl) && vf[lane][l];
+        if (wave == 0) {
+#pragma unroll
+          for (int l = 0; l < TL; ++l) nvalid += vl[l] ? 1 : 0;
+        }
+        const float *tp = tile + lane * cs;
+#pragma unroll
+        for (int i = 0; i < NSUM; ++i) {
+          const int b = wave + 4 * i;
+          if (b < pb) {
+#pragma unroll
+            for (int l = 0; l < TL; ++l)
+              if (vl[l]) sums[i] += (double)tp[l * pb + b];
+          }
+        }
+      }
       __syncthreads();
     }
-    // ---- mask: gather the tile's 4 line flags of a column into one 32-bit store where possible
-    if (wave < nl) vf[lane][wave] = ok ? 1 : 0;
-    __syncthreads();
+    // ---- mask: the tile's line flags of a column, one 32-bit store where possible
+    if (!FUSE_SUM) __syncthreads();
     if (wave == 0 && colok) {
       uint8_t *mp = mask_t + (size_t)(colbase + lane) * L + l0;
-      if (nl == XT_TL && (((size_t)(colbase + lane) * L + l0) & 3) == 0) {
+      if (TL == 4 && nl == 4 && (((size_t)(colbase + lane) * L + l0) & 3) == 0) {
         *reinterpret_cast<uint32_t *>(mp) = *reinterpret_cast<const uint32_t *>(&vf[lane][0]);
       } else {
         for (int l = 0; l < nl; ++l) mp[l] = vf[lane][l];
       }
     }
-    // vf is rewritten only after the next tile's two barriers
+    // vf is rewritten only after the next tile's barriers
+  }
+  if (FUSE_SUM && colok) {
+    double *o = sum_part + ((size_t)chunk * Cs + colbase + lane) * PS;
+#pragma unroll
+    for (int i = 0; i < NSUM; ++i) {
+      const int b = wave + 4 * i;
+      if (b < p) o[b] = sums[i];
+    }
+    if (wave == 0) {
+      cnt_part[chunk * Cs + colbase + lane] = nvalid;
+      for (int b = p; b < PS; ++b) o[b] = 0.0;
+    }
   }
 }
 
@@ -161,29 +201,74 @@ __global__ void k_mean(const double *__restrict__ sum_part, const int *__restric
 
 }  // namespace
 
+static int extract_chunks(int lines, int ncols, int *lpw_out) {
+  const int lpw = sf_extract_lines_per_wg(lines, ncols);
+  *lpw_out = lpw;
+  return sf_cdiv(lines, lpw);
+}
+
 int sf_launch_extract(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
-                      float *xt, uint8_t *mask_t, hipStream_t st) {
+                      float *xt, uint8_t *mask_t, double *sum_part, int *cnt_part, hipStream_t st) {
   const int PS = (p + 3) / 4 * 4;
   const int pbmax = (p <= XT_PBMAX) ? p : XT_PBMAX;
-  const int cs = (XT_TL * pbmax) | 1;
+  constexpr int TL = 4;
+  const int cs = (TL * pbmax) | 1;
   const size_t lds = (size_t)64 * cs * sizeof(float);
+  const bool fuse = sum_part != nullptr && p <= XT_PBMAX;
   static bool attr_set = false;
   if (!attr_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               64 * ((XT_TL * XT_PBMAX) | 1) * (int)sizeof(float)));
+    const int maxlds = 64 * ((TL * XT_PBMAX) | 1) * (int)sizeof(float);
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract<TL, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract<TL, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
     attr_set = true;
   }
-  const int lpw = sf_extract_lines_per_wg(lines, ncols);
-  const int ncb = sf_cdiv(ncols, 64), nchunk = sf_cdiv(lines, lpw);
-  hipLaunchKernelGGL(k_extract, dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), lds, st, cube, lines, bands, samples, s0, ncols,
-                     b0, p, PS, xt, mask_t, lpw, pbmax, cs, ncb, nchunk);
+  int lpw;
+  const int nchunk = extract_chunks(lines, ncols, &lpw);
+  const int ncb = sf_cdiv(ncols, 64);
+  if (fuse)
+    hipLaunchKernelGGL((k_extract<TL, true>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), lds, st, cube, lines, bands,
+                       samples, s0, ncols, b0, p, PS, xt, mask_t, lpw, pbmax, cs, ncb, nchunk, sum_part, cnt_part);
+  else
+    hipLaunchKernelGGL((k_extract<TL, false>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), lds, st, cube, lines, bands,
+                       samples, s0, ncols, b0, p, PS, xt, mask_t, lpw, pbmax, cs, ncb, nchunk, nullptr, nullptr);
   SF_LAUNCH_CHECK("k_extract");
   return 0;
+}
+
+// scratch of the fused extract+sum path: [nchunk][ncols][ps] doubles + [nchunk][ncols] ints
+size_t sf_extract_sum_bytes(const SfGeom &g) {
+  int lpw;
+  const int nchunk = extract_chunks(g.lines, g.ncols, &lpw);
+  return sf_align((size_t)nchunk * g.ncols * g.ps * sizeof(double)) + sf_align((size_t)nchunk * g.ncols * sizeof(int));
+}
+bool sf_extract_fuses_sum(int p) { return p <= XT_PBMAX; }
+
+int sf_launch_extract_fused(const float *cube, int lines, int bands, int samples, int s0, int b0, const SfGeom &g,
+                            float *xt, uint8_t *mask_t, void *scratch, hipStream_t st) {
+  int lpw;
+  const int nchunk = extract_chunks(g.lines, g.ncols, &lpw);
+  double *sum_part = reinterpret_cast<double *>(scratch);
+  int *cnt_part = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) +
+                                          sf_align((size_t)nchunk * g.ncols * g.ps * sizeof(double)));
+  return sf_launch_extract(cube, lines, bands, samples, s0, g.ncols, b0, g.p, xt, mask_t, sum_part, cnt_part, st);
 }
 
 size_t sf_mean_scratch_bytes(const SfGeom &g) {
   const int nch = sf_colsum_chunks(g.lines, g.ncols);
   return sf_align((size_t)nch * g.ncols * g.ps * sizeof(double)) + sf_align((size_t)nch * g.ncols * sizeof(int));
+}
+
+int sf_launch_mean_from_partials(const SfGeom &g, int32_t *nuse, double *mu, void *scratch, hipStream_t st) {
+  int lpw;
+  const int nchunk = extract_chunks(g.lines, g.ncols, &lpw);
+  double *sum_part = reinterpret_cast<double *>(scratch);
+  int *cnt_part = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) +
+                                          sf_align((size_t)nchunk * g.ncols * g.ps * sizeof(double)));
+  hipLaunchKernelGGL(k_mean, dim3(g.ncols), dim3(128), 0, st, sum_part, cnt_part, nchunk, g.ncols, g.p, g.ps, nuse, mu);
+  SF_LAUNCH_CHECK("k_mean");
+  return 0;
 }
 
 int sf_launch_mean(const void *xt, int xt_f64, const uint8_t *mask_t, const SfGeom &g, int32_t *nuse, double *mu,

@@ -213,6 +213,28 @@ def test_reflectance_flag_against_oracle(torch_cuda, library):
         cmf.robust_mf(cube, library, reflectance=True)          # default -R window 5..420 (p = 416)
 
 
+def test_fewer_valid_rows_than_bands(torch_cuda, library):
+    """n < p: the sample correlation matrix is singular, Cholesky fails and the eigensolver takes its
+    fallback (Jacobi on R with replayed rotations); the shrinkage still makes every G_alpha invertible."""
+    cube = make_cube_numpy(58, 9, seed=41, abscf_full=library[:, 2], nodata_lines=2, nodata_column=4)
+    res = cmf.robust_mf(cube, library, metadata=True, to_numpy=True, return_nll=True)
+    o = O.robust_mf_oracle(cube, library, return_nll=True)
+    assert np.array_equal(res.nuse, o["nuse"]) and res.nuse.max() < 72
+    solved = o["status"] == 0
+    assert np.array_equal(res.alphaidx[solved], o["alphaidx"][solved])
+    f = np.isfinite(o["nll"][solved])
+    assert np.array_equal(np.isfinite(res.nll[solved]), f)
+    # for the smallest alphas G_alpha has condition ~1e10: the reference's own LU det/inverse carry ~1e-6 there
+    np.testing.assert_allclose(res.nll[solved][f], o["nll"][solved][f], rtol=5e-5)
+    near = o["nll"][solved] < o["nll"][solved].min(axis=1, keepdims=True) + 5.0
+    np.testing.assert_allclose(res.nll[solved][near], o["nll"][solved][near], rtol=1e-9)
+    nod = o["out"][..., 3] == -9999.0
+    assert np.array_equal(res.out[..., 3] == -9999.0, nod)
+    # C is numerically singular-ish here (alpha ~ 1e-3 on a rank-deficient S): scores agree to the
+    # conditioning of the reference's own LU inverse, far inside the 1e-4 bar
+    assert score_close(res.out[..., 3][~nod], o["out"][..., 3][~nod], rel=1e-4).all()
+
+
 def test_column_shards_are_bit_identical(torch_cuda, library):
     """Sharding columns over ranks must not change any column's arithmetic."""
     torch = torch_cuda

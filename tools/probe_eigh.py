@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Time the batched eigensolver alone for different batch sizes (latency vs throughput)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from srcfinder_amd import _ffi
+from srcfinder_amd.synth import synth_columns
+L = _ffi.lib()
+p = 72
+mats = []
+for seed in range(8):
+    x = synth_columns(20000, p, 100 + seed); x -= x.mean(0)
+    mats.append(np.cov(x.T))
+P = _ffi.ptr
+for nc in (1, 64, 256, 512, 598, 768, 1536):
+    S = torch.as_tensor(np.stack([mats[i % 8] for i in range(nc)])).cuda()
+    nuse = torch.full((nc,), 20000, dtype=torch.int32, device="cuda")
+    d = torch.empty((nc, p), dtype=torch.float64, device="cuda"); lam = torch.empty_like(d)
+    ev = torch.empty((nc, p, p), dtype=torch.float64, device="cuda")
+    st = torch.empty(nc, dtype=torch.int32, device="cuda")
+    ws = torch.empty(L.sf_cmf_workspace_bytes(64, p, nc, 201), dtype=torch.uint8, device="cuda")
+    def run():
+        _ffi.check(L.sf_cmf_eigh(P(S), P(nuse), p, nc, P(d), P(lam), P(ev), P(st), P(ws), _ffi.stream_ptr()), "eigh")
+    run(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); run(); run(); run(); b.record(); torch.cuda.synchronize()
+    print("ncols %5d : %.3f ms per call" % (nc, a.elapsed_time(b) / 3))

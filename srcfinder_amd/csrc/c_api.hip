@@ -52,10 +52,14 @@ Ws carve(void *base, const SfGeom &g) {
   w.bias = (double *)c.take(nc * sizeof(double));
   w.nll = (double *)c.take(nc * g.nalpha * sizeof(double));
   size_t s = sf_mean_scratch_bytes(g);
-  if (sf_extract_sum_bytes(g) > s) s = sf_extract_sum_bytes(g);
-  if (sf_cov_scratch_bytes(g) > s) s = sf_cov_scratch_bytes(g);
-  if (sf_eigh_scratch_bytes(g) > s) s = sf_eigh_scratch_bytes(g);
-  if (sf_loocv_scratch_bytes(g) > s) s = sf_loocv_scratch_bytes(g);
+  if (g.p <= SF_MAX_ACTIVE_FUSED) {
+    if (sf_extract_sum_bytes(g) > s) s = sf_extract_sum_bytes(g);
+    if (sf_cov_scratch_bytes(g) > s) s = sf_cov_scratch_bytes(g);
+    if (sf_eigh_scratch_bytes(g) > s) s = sf_eigh_scratch_bytes(g);
+    if (sf_loocv_scratch_bytes(g) > s) s = sf_loocv_scratch_bytes(g);
+  } else {
+    if (sf_wide_scratch_bytes(g) > s) s = sf_wide_scratch_bytes(g);
+  }
   if (sf_score_scratch_bytes(g.lines, g.ncols) > s) s = sf_score_scratch_bytes(g.lines, g.ncols);
   w.scratch_bytes = s;
   w.scratch = c.take(s);
@@ -196,8 +200,8 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
     return -1;
   }
   if (nodata > 0) { sf_set_error("nodata value=%f > 0, values will not be masked", nodata); return -3; }
-  if (p > SF_MAX_ACTIVE_FUSED) {
-    sf_set_error("active window of %d bands exceeds the fused statistics path (max %d)", p, SF_MAX_ACTIVE_FUSED);
+  if (p > 512) {
+    sf_set_error("active window of %d bands exceeds the wide statistics path (max 512)", p);
     return -2;
   }
   const int ncols = s1 - s0;
@@ -209,19 +213,29 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
   }
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (sf_extract_fuses_sum(p)) {  // column sums ride along with the transpose (per-chunk partials in scratch)
-    if ((rc = sf_launch_extract_fused(cube, lines, bands, samples, s0, b0, g, w.xt, w.mask_t, w.scratch, st))) return rc;
-    if ((rc = sf_launch_mean_from_partials(g, nuse, w.mu, w.scratch, st))) return rc;
-  } else {
+  double *nll = nll_out ? nll_out : w.nll;
+  if (p > SF_MAX_ACTIVE_FUSED) {  // wide window (e.g. reflectance 5..420): batched-GEMM statistics path
     if ((rc = sf_launch_extract(cube, lines, bands, samples, s0, ncols, b0, p, w.xt, w.mask_t, nullptr, nullptr, st)))
       return rc;
     if ((rc = sf_launch_mean(w.xt, 0, w.mask_t, g, nuse, w.mu, w.scratch, st))) return rc;
+    if ((rc = sf_launch_wide_stats(w.xt, w.mask_t, nuse, w.mu, alphas, g, w.cov, w.d, w.lam, w.evec, status, nll, alphaidx,
+                                   w.scratch, st)))
+      return rc;
+  } else {
+    if (sf_extract_fuses_sum(p)) {  // column sums ride along with the transpose (per-chunk partials in scratch)
+      if ((rc = sf_launch_extract_fused(cube, lines, bands, samples, s0, b0, g, w.xt, w.mask_t, w.scratch, st))) return rc;
+      if ((rc = sf_launch_mean_from_partials(g, nuse, w.mu, w.scratch, st))) return rc;
+    } else {
+      if ((rc = sf_launch_extract(cube, lines, bands, samples, s0, ncols, b0, p, w.xt, w.mask_t, nullptr, nullptr, st)))
+        return rc;
+      if ((rc = sf_launch_mean(w.xt, 0, w.mask_t, g, nuse, w.mu, w.scratch, st))) return rc;
+    }
+    if ((rc = sf_launch_cov(w.xt, 0, w.mask_t, nuse, w.mu, g, w.cov, w.scratch, st))) return rc;
+    if ((rc = sf_launch_eigh(w.cov, nuse, g, w.d, w.lam, w.evec, status, w.scratch, st))) return rc;
+    if ((rc = sf_launch_loocv(w.xt, 0, w.mask_t, nuse, w.mu, w.d, w.lam, w.evec, status, alphas, g, nll, alphaidx, w.scratch,
+                              st)))
+      return rc;
   }
-  if ((rc = sf_launch_cov(w.xt, 0, w.mask_t, nuse, w.mu, g, w.cov, w.scratch, st))) return rc;
-  if ((rc = sf_launch_eigh(w.cov, nuse, g, w.d, w.lam, w.evec, status, w.scratch, st))) return rc;
-  double *nll = nll_out ? nll_out : w.nll;
-  if ((rc = sf_launch_loocv(w.xt, 0, w.mask_t, nuse, w.mu, w.d, w.lam, w.evec, status, alphas, g, nll, alphaidx, w.scratch, st)))
-    return rc;
   if ((rc = sf_launch_filter(w.mu, w.d, w.lam, w.evec, alphas, alphaidx, abscf, reflectance, g, status, w.filt, w.bias, st)))
     return rc;
   return timed_score(cube, lines, bands, samples, s0, ncols, b0, p, w.filt, w.bias, status, alphaidx, nuse, rgb0, rgb1,

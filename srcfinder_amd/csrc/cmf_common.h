@@ -78,8 +78,11 @@ static inline SfGeom sf_geom(int lines, int p, int ncols, int nalpha) {
 
 // split counts (deterministic functions of the geometry so that results do not depend on the GPU)
 static inline int sf_extract_lines_per_wg(int lines, int ncols) {
+  // ~2048 workgroups (2 resident per CU, several rounds), but never more than 256 line chunks: every chunk
+  // leaves a partial-sum record per column that the mean kernel has to read back
   int colblocks = sf_cdiv(ncols, 64);
   int target = sf_cdiv(2048, colblocks);
+  if (target > 256) target = 256;
   int lpw = sf_cdiv(lines, target);
   lpw = (lpw + 3) / 4 * 4;
   return lpw < 4 ? 4 : lpw;
@@ -116,10 +119,10 @@ static inline int sf_sweep_splits(int lines, int ncols) {
 }
 static inline int sf_score_lines_per_wg(int lines, int ncols) {
   // 64-line chunks measured best on the full flightline (tools/tune_score.py: several resident rounds of
-  // short workgroups beat one round of long ones); keep at least ~2 rounds of 1024 workgroups on small shards
+  // short workgroups beat one round of long ones); keep at least ~1 round of 1024 workgroups on small shards
   int colblocks = sf_cdiv(ncols, 64);
   int lpw = 64;
-  while (lpw > 16 && (long)colblocks * sf_cdiv(lines, lpw) < 2048) lpw -= 16;
+  while (lpw > 16 && (long)colblocks * sf_cdiv(lines, lpw) < 1024) lpw -= 16;
   return lpw;
 }
 
@@ -148,6 +151,13 @@ int sf_launch_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int
 int sf_launch_filter(const double *mu, const double *d, const double *lam, const double *evec, const double *alphas,
                      const int32_t *alphaidx, const double *abscf, int reflectance, const SfGeom &g,
                      int32_t *status, double *filt, double *bias, hipStream_t st);
+size_t sf_wide_scratch_bytes(const SfGeom &g);
+int sf_launch_wide_stats(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *alphas,
+                         const SfGeom &g, double *cov, double *d, double *lam, double *evec, int32_t *status,
+                         double *nll, int32_t *alphaidx, void *scratch, hipStream_t st);
+int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
+                         const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
+                         hipStream_t st);
 size_t sf_score_scratch_bytes(int lines, int ncols);
 int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
                     const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,

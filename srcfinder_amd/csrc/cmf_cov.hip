@@ -129,19 +129,17 @@ __global__ __launch_bounds__(256) void k_syrk_reduce(const double *__restrict__ 
                                                       const int32_t *__restrict__ nuse, int p,
                                                       double *__restrict__ cov) {
   using Cfg = SyrkCfg<NT>;
-  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, reg = tid >> 6;
+  const int c = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, reg = tid >> 6;
   const double denom = (double)nuse[c] - 1.0;
-  for (int q = 0; q < Cfg::NTRI; ++q) {
-    int ti, tj;
-    tri_decode(q, NT, ti, tj);
-    double s = 0;
-    for (int sp = 0; sp < nsplit; ++sp) s += part[(((size_t)c * nsplit + sp) * Cfg::NTRI + q) * 256 + tid];
-    s /= denom;
-    const int i = 16 * ti + (lane >> 4) + 4 * reg, j = 16 * tj + (lane & 15);
-    if (i < p && j < p) {
-      cov[((size_t)c * p + i) * p + j] = s;
-      if (ti != tj) cov[((size_t)c * p + j) * p + i] = s;
-    }
+  int ti, tj;
+  tri_decode(q, NT, ti, tj);
+  double s = 0;
+  for (int sp = 0; sp < nsplit; ++sp) s += part[(((size_t)c * nsplit + sp) * Cfg::NTRI + q) * 256 + tid];
+  s /= denom;
+  const int i = 16 * ti + (lane >> 4) + 4 * reg, j = 16 * tj + (lane & 15);
+  if (i < p && j < p) {
+    cov[((size_t)c * p + i) * p + j] = s;
+    if (ti != tj) cov[((size_t)c * p + j) * p + i] = s;
   }
 }
 
@@ -159,7 +157,7 @@ int launch_cov_nt(const void *xt, int xt_f64, const uint8_t *mask_t, const int32
     hipLaunchKernelGGL((k_syrk<NT, float>), dim3(g.ncols, nsplit), dim3(256), 0, st, (const float *)xt, mask_t, mu,
                        g.lines, g.p, g.ps, rows, part);
   SF_LAUNCH_CHECK("k_syrk");
-  hipLaunchKernelGGL(k_syrk_reduce<NT>, dim3(g.ncols), dim3(256), 0, st, part, nsplit, nuse, g.p, cov);
+  hipLaunchKernelGGL(k_syrk_reduce<NT>, dim3(g.ncols, SyrkCfg<NT>::NTRI), dim3(256), 0, st, part, nsplit, nuse, g.p, cov);
   SF_LAUNCH_CHECK("k_syrk_reduce");
   return 0;
 }

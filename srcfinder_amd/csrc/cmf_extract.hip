@@ -186,17 +186,40 @@ __global__ __launch_bounds__(256) void k_colsum(const XT *__restrict__ xt, const
   }
 }
 
-__global__ void k_mean(const double *__restrict__ sum_part, const int *__restrict__ cnt_part, int nch, int Cs, int p,
-                       int PS, int32_t *__restrict__ nuse, double *__restrict__ mu) {
-  const int c = blockIdx.x;
-  int n = 0;
-  for (int ch = 0; ch < nch; ++ch) n += cnt_part[ch * Cs + c];
-  for (int b = threadIdx.x; b < p; b += blockDim.x) {
-    double s = 0;
-    for (int ch = 0; ch < nch; ++ch) s += sum_part[((size_t)ch * Cs + c) * PS + b];
-    mu[(size_t)c * p + b] = n > 0 ? s / (double)n : 0.0;
+// Combine the per-chunk partial sums: one 512-thread workgroup per column; lane = band, the 8 waves split the
+// chunk range and are combined in a fixed order (bit-reproducible), so a long chunk list costs nchunk/8 steps.
+__global__ __launch_bounds__(512) void k_mean(const double *__restrict__ sum_part, const int *__restrict__ cnt_part,
+                                               int nch, int Cs, int p, int PS, int32_t *__restrict__ nuse,
+                                               double *__restrict__ mu) {
+  __shared__ double red[8][64];
+  __shared__ int cred[512];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int cnt = 0;
+  for (int ch = tid; ch < nch; ch += 512) cnt += cnt_part[ch * Cs + c];
+  cred[tid] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int i = 0; i < 512; ++i) n += cred[i];
+    cred[0] = n;
+    nuse[c] = n;
   }
-  if (threadIdx.x == 0) nuse[c] = n;
+  __syncthreads();
+  const int n = cred[0];
+  for (int b0 = 0; b0 < p; b0 += 64) {
+    const int b = b0 + lane;
+    double s = 0;
+    if (b < p)
+      for (int ch = wave; ch < nch; ch += 8) s += sum_part[((size_t)ch * Cs + c) * PS + b];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && b < p) {
+      double t = 0;
+      for (int w = 0; w < 8; ++w) t += red[w][lane];
+      mu[(size_t)c * p + b] = n > 0 ? t / (double)n : 0.0;
+    }
+    __syncthreads();
+  }
 }
 
 }  // namespace
@@ -266,7 +289,7 @@ int sf_launch_mean_from_partials(const SfGeom &g, int32_t *nuse, double *mu, voi
   double *sum_part = reinterpret_cast<double *>(scratch);
   int *cnt_part = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) +
                                           sf_align((size_t)nchunk * g.ncols * g.ps * sizeof(double)));
-  hipLaunchKernelGGL(k_mean, dim3(g.ncols), dim3(128), 0, st, sum_part, cnt_part, nchunk, g.ncols, g.p, g.ps, nuse, mu);
+  hipLaunchKernelGGL(k_mean, dim3(g.ncols), dim3(512), 0, st, sum_part, cnt_part, nchunk, g.ncols, g.p, g.ps, nuse, mu);
   SF_LAUNCH_CHECK("k_mean");
   return 0;
 }
@@ -289,7 +312,7 @@ int sf_launch_mean(const void *xt, int xt_f64, const uint8_t *mask_t, const SfGe
     hipLaunchKernelGGL(k_colsum<float>, dim3(g.ncols, nch), dim3(256), 0, st, (const float *)xt, mask_t, g.lines,
                        g.ps, lpw, sum_part, cnt_part);
   SF_LAUNCH_CHECK("k_colsum");
-  hipLaunchKernelGGL(k_mean, dim3(g.ncols), dim3(128), 0, st, sum_part, cnt_part, nch, g.ncols, g.p, g.ps, nuse, mu);
+  hipLaunchKernelGGL(k_mean, dim3(g.ncols), dim3(512), 0, st, sum_part, cnt_part, nch, g.ncols, g.p, g.ps, nuse, mu);
   SF_LAUNCH_CHECK("k_mean");
   return 0;
 }

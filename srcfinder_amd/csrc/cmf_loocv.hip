@@ -361,6 +361,15 @@ int launch_sweep(const XT *xt, const uint8_t *mask_t, const int32_t *nuse, const
 
 }  // namespace
 
+int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
+                         const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(k_nll, dim3(g.ncols), dim3(256), 0, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha, g.p,
+                     g.nu * 16, nll, alphaidx);
+  SF_LAUNCH_CHECK("k_nll");
+  return 0;
+}
+
 size_t sf_wfrag_elems(const SfGeom &g) { return (size_t)g.nt * g.s4 * 64; }
 
 size_t sf_loocv_scratch_bytes(const SfGeom &g) {

@@ -33,12 +33,12 @@ __device__ __forceinline__ void score_load(float (&x)[SC_LPI][SC_UB], const floa
 }
 
 template <int SC_LPI, int SC_UB>
-__device__ __forceinline__ void score_fma(const float (&x)[SC_LPI][SC_UB], const double *__restrict__ ws, int bc, int p,
-                                          int lane, double (&acc)[SC_LPI], bool (&ok)[SC_LPI]) {
+__device__ __forceinline__ void score_fma(const float (&x)[SC_LPI][SC_UB], const double *__restrict__ ws, int wld, int bc,
+                                          int p, int lane, double (&acc)[SC_LPI], bool (&ok)[SC_LPI]) {
 #pragma unroll
   for (int bb = 0; bb < SC_UB; ++bb) {
     const int b = bc + bb;
-    const double wv = (b < p) ? ws[min(b, p - 1) * 64 + lane] : 0.0;
+    const double wv = (b < p) ? ws[(size_t)min(b, p - 1) * wld + lane] : 0.0;
 #pragma unroll
     for (int j = 0; j < SC_LPI; ++j) {
       ok[j] = ok[j] & sf_valid(x[j][bb]);
@@ -47,14 +47,16 @@ __device__ __forceinline__ void score_fma(const float (&x)[SC_LPI][SC_UB], const
   }
 }
 
-template <bool RGB, int SC_LPI, int SC_UB>
+// WGL: the 64 filter vectors are read from a transposed global copy wT[band][column] (L2-resident) instead of
+// LDS -- for windows too wide for a [p][64] float64 LDS tile.
+template <bool RGB, int SC_LPI, int SC_UB, bool WGL>
 __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs,
                                                 int b0, int p, const double *__restrict__ filt,
                                                 const double *__restrict__ bias, const int32_t *__restrict__ status,
                                                 const int32_t *__restrict__ alphaidx, int rgb0, int rgb1, int rgb2,
                                                 double nodata, double *__restrict__ out, int oS, int os0,
                                                 int16_t *__restrict__ bgmeta, double *__restrict__ stat_part,
-                                                int lines_per_wg, int ncb, int nchunk, int xcdmap) {
+                                                int lines_per_wg, int ncb, int nchunk, int xcdmap, const double *__restrict__ wT, int ldw) {
   extern __shared__ __attribute__((aligned(16))) double ws[];  // [p][64]
   __shared__ double sred[4][64][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,10 +74,14 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, i
   const int lanec = colok ? lane : ncol - 1;  // idle lanes re-read the last column (in bounds), never write
   const int col = colbase + lanec;
 
-  for (int idx = tid; idx < 64 * p; idx += 256) {
-    const int cl = idx / p, b = idx - cl * p;
-    ws[b * 64 + cl] = (cl < ncol) ? filt[(size_t)(colbase + cl) * p + b] : 0.0;
+  if (!WGL) {
+    for (int idx = tid; idx < 64 * p; idx += 256) {
+      const int cl = idx / p, b = idx - cl * p;
+      ws[b * 64 + cl] = (cl < ncol) ? filt[(size_t)(colbase + cl) * p + b] : 0.0;
+    }
   }
+  const double *wsrc = WGL ? (wT + colbase + lanec - lane) : ws;   // wsrc[b*wld + lane] is this lane's weight
+  const int wld = WGL ? ldw : 64;
   const double mybias = bias[col];
   const int st = status[col];
   const int ai = alphaidx[col];
@@ -100,9 +106,9 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, i
     score_load<SC_LPI, SC_UB>(xa, lp, 0, p, C, lanec);
     for (int bc = 0; bc < p; bc += 2 * SC_UB) {
       if (bc + SC_UB < p) score_load<SC_LPI, SC_UB>(xb, lp, bc + SC_UB, p, C, lanec);
-      score_fma<SC_LPI, SC_UB>(xa, ws, bc, p, lane, acc, ok);
+      score_fma<SC_LPI, SC_UB>(xa, wsrc, wld, bc, p, lane, acc, ok);
       if (bc + 2 * SC_UB < p) score_load<SC_LPI, SC_UB>(xa, lp, bc + 2 * SC_UB, p, C, lanec);
-      if (bc + SC_UB < p) score_fma<SC_LPI, SC_UB>(xb, ws, bc + SC_UB, p, lane, acc, ok);
+      if (bc + SC_UB < p) score_fma<SC_LPI, SC_UB>(xb, wsrc, wld, bc + SC_UB, p, lane, acc, ok);
     }
     float rgbv[SC_LPI][3];
     if (RGB) {
@@ -155,20 +161,30 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, i
   }
 }
 
-// npix / mean / std (ddof 0) of the written scores per column (robust_mf.py:388-392).
-__global__ void k_colstats(const double *__restrict__ stat_part, int nchunk, int Cs, const int32_t *__restrict__ nuse,
-                           const int32_t *__restrict__ status, double nodata, double *__restrict__ colstats) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Cs) return;
+// npix / mean / std (ddof 0) of the written scores per column (robust_mf.py:388-392).  One 256-thread
+// workgroup per 64 columns: lane = column, the 4 waves split the chunk list, fixed combination order.
+__global__ __launch_bounds__(256) void k_colstats(const double *__restrict__ stat_part, int nchunk, int Cs,
+                                                   const int32_t *__restrict__ nuse, const int32_t *__restrict__ status,
+                                                   double nodata, double *__restrict__ colstats) {
+  __shared__ double red[4][64][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double a = 0.0, b = 0.0;
+  if (c < Cs)
+    for (int k = wave; k < nchunk; k += 4) {
+      a += stat_part[((size_t)k * Cs + c) * 2];
+      b += stat_part[((size_t)k * Cs + c) * 2 + 1];
+    }
+  red[wave][lane][0] = a;
+  red[wave][lane][1] = b;
+  __syncthreads();
+  if (wave != 0 || c >= Cs) return;
   if (status[c] == 1) {  // column skipped: stats keep their initial value (:293-295)
     colstats[c] = nodata; colstats[Cs + c] = nodata; colstats[2 * Cs + c] = nodata;
     return;
   }
-  double a = 0.0, b = 0.0;
-  for (int k = 0; k < nchunk; ++k) {
-    a += stat_part[((size_t)k * Cs + c) * 2];
-    b += stat_part[((size_t)k * Cs + c) * 2 + 1];
-  }
+  a = 0.0; b = 0.0;
+  for (int w = 0; w < 4; ++w) { a += red[w][lane][0]; b += red[w][lane][1]; }
   const double n = (double)nuse[c];
   const double mean = a / n;
   double var = b / n - mean * mean;
@@ -184,29 +200,40 @@ static size_t score_stat_bytes(int lines, int ncols) {
   const int lpw = 8;  // upper bound on the number of line chunks whatever the tuning
   return sf_align((size_t)sf_cdiv(lines, lpw) * ncols * 2 * sizeof(double));
 }
-size_t sf_score_scratch_bytes(int lines, int ncols) { return score_stat_bytes(lines, ncols); }
+size_t sf_score_scratch_bytes(int lines, int ncols) {
+  // statistics partials + (wide windows only) the transposed filter, sized for the largest supported window
+  return score_stat_bytes(lines, ncols) + sf_align((size_t)512 * ((ncols + 63) / 64 * 64) * sizeof(double));
+}
 
 // tuning knobs (sf_debug_set): 0 = use the built-in choice
 int g_score_variant = 0, g_score_lpw = 0, g_score_xcd = 1;
 
-template <bool RGB, int LPI, int UB>
+// filt[c][p] -> wT[b][ldw]
+__global__ void k_filt_transpose(const double *__restrict__ filt, int Cs, int p, int ldw, double *__restrict__ wT) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p * ldw) return;
+  const int b = i / ldw, c = i - b * ldw;
+  wT[i] = (c < Cs) ? filt[(size_t)c * p + b] : 0.0;
+}
+
+template <bool RGB, int LPI, int UB, bool WGL = false>
 int launch_score_t(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
                    const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx, int rgb0,
                    int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0, int16_t *bgmeta,
-                   double *stat_part, int lpw, hipStream_t st) {
-  const size_t lds = (size_t)p * 64 * sizeof(double);
+                   double *stat_part, int lpw, hipStream_t st, const double *wT = nullptr, int ldw = 0) {
+  const size_t lds = WGL ? 0 : (size_t)p * 64 * sizeof(double);
   static size_t lds_set = 0;
   if (lds > lds_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<RGB, LPI, UB>),
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<RGB, LPI, UB, WGL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set = lds;
   }
   const int nchunk = sf_cdiv(lines, lpw);
   const int ncb = sf_cdiv(ncols, 64);
   const int nblk = g_score_xcd ? sf_xcd_grid(ncb, nchunk) : ncb * nchunk;
-  hipLaunchKernelGGL((k_score<RGB, LPI, UB>), dim3(nblk), dim3(256), lds, st, cube, lines, bands, samples, s0, ncols, b0,
+  hipLaunchKernelGGL((k_score<RGB, LPI, UB, WGL>), dim3(nblk), dim3(256), lds, st, cube, lines, bands, samples, s0, ncols, b0,
                      p, filt, bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, out_samples, out_s0, bgmeta, stat_part,
-                     lpw, ncb, nchunk, g_score_xcd);
+                     lpw, ncb, nchunk, g_score_xcd, wT, ldw);
   SF_LAUNCH_CHECK("k_score");
   return 0;
 }
@@ -219,12 +246,17 @@ int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0
                     const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,
                     int rgb0, int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0,
                     int out_bands, int16_t *bgmeta, void *scratch, int want_stats, hipStream_t st) {
-  if ((size_t)p * 64 * sizeof(double) > 150 * 1024) {
-    sf_set_error("active window of %d bands: filter tile does not fit LDS in the score kernel", p);
-    return -2;
-  }
   const int lpw = sf_score_lpw(lines, ncols);
   double *stat_part = (scratch && want_stats) ? reinterpret_cast<double *>(scratch) : nullptr;
+  if ((size_t)p * 64 * sizeof(double) > 100 * 1024) {  // wide window: filter from a transposed global copy
+    if (!scratch) { sf_set_error("score kernel: a window of %d bands needs scratch", p); return -1; }
+    const int ldw = (ncols + 63) / 64 * 64;
+    double *wT = reinterpret_cast<double *>(reinterpret_cast<char *>(scratch) + score_stat_bytes(lines, ncols));
+    hipLaunchKernelGGL(k_filt_transpose, dim3(sf_cdiv(p * ldw, 256)), dim3(256), 0, st, filt, ncols, p, ldw, wT);
+    SF_LAUNCH_CHECK("k_filt_transpose");
+    if (out_bands != 4) return launch_score_t<false, 4, 8, true>(SC_ARGS, wT, ldw);
+    return launch_score_t<true, 4, 8, true>(SC_ARGS, wT, ldw);
+  }
   if (out_bands != 4) return launch_score_t<false, 8, 4>(SC_ARGS);
   switch (g_score_variant) {
     case 1: return launch_score_t<true, 2, 16>(SC_ARGS);
@@ -242,7 +274,7 @@ int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0,
   (void)samples; (void)s0; (void)p;
   const int lpw = sf_score_lpw(lines, ncols);
   const int nchunk = sf_cdiv(lines, lpw);
-  hipLaunchKernelGGL(k_colstats, dim3(sf_cdiv(ncols, 128)), dim3(128), 0, st,
+  hipLaunchKernelGGL(k_colstats, dim3(sf_cdiv(ncols, 64)), dim3(256), 0, st,
                      reinterpret_cast<const double *>(stat_scratch), nchunk, ncols, nuse, status, nodata, colstats);
   SF_LAUNCH_CHECK("k_colstats");
   return 0;

@@ -209,8 +209,17 @@ def test_reflectance_flag_against_oracle(torch_cuda, library):
     res = cmf.robust_mf(cube, library, reflectance=True, active=(351, 422), metadata=True, to_numpy=True)
     o = O.robust_mf_oracle(cube, library, reflectance=True, active=(351, 422))
     _compare_run(res, o, 180, 33)
-    with pytest.raises(_ffi.SrcfinderError, match="exceeds"):
-        cmf.robust_mf(cube, library, reflectance=True)          # default -R window 5..420 (p = 416)
+
+
+def test_golden_reflectance_wide_window(torch_cuda, golden_dir, library):
+    """The reference's own -R run (active 5..420, p = 416): wide-window statistics path (batched fp64 GEMMs +
+    global-memory Jacobi) against the golden produced by the real reference."""
+    g = np.load(os.path.join(golden_dir, "cmf_R_reflectance.npz"))
+    cube = make_cube_numpy(int(g["lines"]), int(g["samples"]), seed=int(g["seed"]), abscf_full=library[:, 2],
+                           active=(5, 420), nodata_column=int(g["nodata_column"]))
+    res = cmf.robust_mf(cube, library, reflectance=True, metadata=True, to_numpy=True)
+    assert res.modelparms == str(g["modelparms"])
+    _compare_run(res, g, int(g["lines"]), int(g["samples"]))
 
 
 def test_fewer_valid_rows_than_bands(torch_cuda, library):

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--samples", type=int, default=SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-columns", type=int, default=8)
+    ap.add_argument("--active", type=str, default="", help="a0,a1 (1-based inclusive) override of the active window, e.g. 1,425")
     args = ap.parse_args()
 
     import torch
@@ -61,7 +62,11 @@ def main():
     s0, s1 = sd.shard_columns(samples, world, rank)
     ncols = s1 - s0
     a0, a1 = cmf.active_window("ch4", False)
+    if args.active:
+        a0, a1 = (int(v) for v in args.active.split(","))
     p = a1 - a0 + 1
+    global ACTIVE
+    ACTIVE = (a0, a1)
 
     # synthetic flightline: each rank generates only its own column slice [lines, 425, ncols]
     cube = make_cube_torch(lines, ncols, seed=1234 + rank, abscf_full=lib[:, 2], device=dev,
@@ -71,7 +76,7 @@ def main():
     out = torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev)
 
     def step():
-        r = cmf.robust_mf(cube, lib, out=out, out_column0=0)
+        r = cmf.robust_mf(cube, lib, out=out, out_column0=0, active=(a0, a1))
         if world > 1:
             # the single RCCL gather of the score image: the float64 CMF band of every
             # rank's block, 8 B/pixel; the RGB copy stays with the rank that read those columns
@@ -116,9 +121,9 @@ def main():
             "value": round(mpix, 3), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "AVIRIS-NG flightline %d samples x %d lines x %d bands float32 BIL, CH4 radiance "
-                                   "window 351..422 (p=72), 201-point LOO shrinkage sweep, unimodal"
-                                   % (samples, lines, BANDS),
+            "config": {"workload": "AVIRIS-NG flightline %d samples x %d lines x %d bands float32 BIL, active "
+                                   "window %d..%d (p=%d%s), 201-point LOO shrinkage sweep, unimodal"
+                                   % (samples, lines, BANDS, a0, a1, p, ", CH4 radiance" if (a0, a1) == (351, 422) else ""),
                        "parallelism": "columns sharded over %d rank(s), one RCCL gather" % world,
                        "output": "float64 BIP [lines, samples, (R,G,B,CMF)]"},
             "roofline": {"bound": "hbm", "kernel": "k_score<true>", "achieved": round(achieved, 1),
@@ -133,6 +138,9 @@ def main():
         dist.destroy_process_group()
 
 
+ACTIVE = None
+
+
 def cpu_baseline(cube, lib, lines, ncols, ncpu_cols, res):
     """The oracle (faithful numpy restatement of cmf/robust_mf.py, 201x det+inv+GEMM per column) timed on ONE
     host core over a bounded sample of the same cube: `ncpu_cols` evenly spaced columns, all lines."""
@@ -141,7 +149,7 @@ def cpu_baseline(cube, lib, lines, ncols, ncpu_cols, res):
     cols = sorted(set(c for c in cols if c != ncols // 3))        # skip the all-NODATA column (no work)
     host = cube[:, :, cols].cpu().numpy()
     t0 = time.perf_counter()
-    o = O.robust_mf_oracle(host, lib)
+    o = O.robust_mf_oracle(host, lib, active=ACTIVE)
     t = time.perf_counter() - t0
     # parity spot check of the timed sample against the GPU result of the same columns
     got = res.out[:, cols, 3].cpu().numpy()

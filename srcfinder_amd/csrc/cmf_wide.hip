@@ -195,12 +195,14 @@ __global__ __launch_bounds__(256) void k_nllrows(const double *__restrict__ Rm, 
 
 // ---- one-sided Jacobi with the matrix in global memory (one 1024-thread workgroup per column) -------------------
 // Same method as k_eigh (cmf_eigh.hip): Cholesky R = L L^T, Jacobi on the columns of L, eigenvectors = normalised
-// columns; if R is not positive definite, Jacobi on R with V accumulated alongside.  The operands are touched by
-// different waves of the workgroup from step to step, so every access goes through L2 (volatile -> sc-bit loads).
-__device__ __forceinline__ double vshfl_sum8(double v) {
+// columns; if R is not positive definite, Jacobi on R with V accumulated alongside.  All waves of the workgroup
+// run on one CU and share its L1, so plain loads/stores ordered by __syncthreads() (which drains vmcnt) are
+// coherent; 16 lanes per pair keep a pair's two columns in registers between the dot product and the rotation.
+__device__ __forceinline__ double vshfl_sum16(double v) {
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
   v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
   return v;
 }
 __device__ __forceinline__ void rr_pair_w(int s, int k, int m, int &a, int &b) {
@@ -212,7 +214,9 @@ __device__ __forceinline__ void rr_pair_w(int s, int k, int m, int &a, int &b) {
   b = (k == 0) ? m : y;
 }
 
-__global__ __launch_bounds__(1024) void k_eigh_global(const double *__restrict__ cov, const int32_t *__restrict__ nuse, int p,
+constexpr int EG_RMAX = 32;  // rows per lane at 16 lanes per pair: p2 <= 512
+
+__global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ cov, const int32_t *__restrict__ nuse, int p,
                                                        int p2, int c0, double *__restrict__ d_out,
                                                        double *__restrict__ lam_out, double *__restrict__ evec_out,
                                                        int32_t *__restrict__ status, double *__restrict__ gscratch) {
@@ -221,8 +225,8 @@ __global__ __launch_bounds__(1024) void k_eigh_global(const double *__restrict__
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int c = c0 + blockIdx.x;
   const double *S = cov + (size_t)c * p * p;
-  volatile double *G = gscratch + (size_t)blockIdx.x * 2 * p2 * p2;  // [p2][p2] column-major
-  volatile double *V = G + (size_t)p2 * p2;
+  double *G = gscratch + (size_t)blockIdx.x * 2 * p2 * p2;  // [p2][p2] column-major
+  double *V = G + (size_t)p2 * p2;
   const int n = nuse[c];
   const int LD = p2;
   if (tid < 2) flag[tid] = 0;
@@ -284,8 +288,9 @@ __global__ __launch_bounds__(1024) void k_eigh_global(const double *__restrict__
   __syncthreads();
 
   const int npairs = p2 >> 1, m = p2 - 1;
-  const int kloc = tid >> 3, sub = tid & 7;
-  const int ppp = nthr >> 3;  // pairs per pass
+  const int kloc = tid >> 4, sub = tid & 15;
+  const int ppp = nthr >> 4;  // pairs per pass
+  const int nr = (p2 - sub + 15) >> 4;
   const double tol = (double)p2 * 2.220446049250313e-16, tol2 = tol * tol;
   for (int sweep = 0; sweep < 40; ++sweep) {
     bool rotated = false;
@@ -299,10 +304,20 @@ __global__ __launch_bounds__(1024) void k_eigh_global(const double *__restrict__
       for (int k = kloc; k < npairs; k += ppp) {  // disjoint pairs: no ordering needed between passes
         int a, b;
         rr_pair_w(s, k, m, a, b);
+        double *ga = G + (size_t)a * LD + sub, *gb = G + (size_t)b * LD + sub;
         const double aa = nrm[a], bb = nrm[b];
+        double xa[EG_RMAX], xb[EG_RMAX];
+#pragma unroll
+        for (int i = 0; i < EG_RMAX; ++i) {
+          const int ii = min(i, nr - 1);
+          const double u = ga[16 * ii], v = gb[16 * ii];
+          xa[i] = i < nr ? u : 0.0;
+          xb[i] = i < nr ? v : 0.0;
+        }
         double ab = 0;
-        for (int r = sub; r < p2; r += 8) ab += G[a * LD + r] * G[b * LD + r];
-        ab = vshfl_sum8(ab);
+#pragma unroll
+        for (int i = 0; i < EG_RMAX; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
+        ab = vshfl_sum16(ab);
         const double ab2 = aa * bb;
         if (ab2 > 0.0 && ab * ab > tol2 * ab2) {
           rotated = true;
@@ -313,14 +328,19 @@ __global__ __launch_bounds__(1024) void k_eigh_global(const double *__restrict__
           const double cs = sqrt(h);
           double sn = fabs(gam) * rinv * 0.5 / cs;
           sn = ((tau < 0.0) != (gam < 0.0)) ? -sn : sn;
-          for (int r = sub; r < p2; r += 8) {
-            const double x = G[a * LD + r], y = G[b * LD + r];
-            G[a * LD + r] = cs * x - sn * y;
-            G[b * LD + r] = sn * x + cs * y;
-            if (!chol_ok) {
-              const double vx = V[a * LD + r], vy = V[b * LD + r];
-              V[a * LD + r] = cs * vx - sn * vy;
-              V[b * LD + r] = sn * vx + cs * vy;
+#pragma unroll
+          for (int i = 0; i < EG_RMAX; ++i) {
+            if (i < nr) {
+              ga[16 * i] = cs * xa[i] - sn * xb[i];
+              gb[16 * i] = sn * xa[i] + cs * xb[i];
+            }
+          }
+          if (!chol_ok) {
+            double *va = V + (size_t)a * LD + sub, *vb = V + (size_t)b * LD + sub;
+            for (int i = 0; i < nr; ++i) {
+              const double vx = va[16 * i], vy = vb[16 * i];
+              va[16 * i] = cs * vx - sn * vy;
+              vb[16 * i] = sn * vx + cs * vy;
             }
           }
           if (sub == 0) {
@@ -421,7 +441,7 @@ int sf_launch_wide_stats(const float *xt, const uint8_t *mask_t, const int32_t *
     SF_LAUNCH_CHECK("k_dgemm(syrk)");
     hipLaunchKernelGGL(k_scale_cov, dim3(64, nb), dim3(256), 0, st, cov, nuse, p, c0);
     SF_LAUNCH_CHECK("k_scale_cov");
-    hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(1024), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv);
+    hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv);
     SF_LAUNCH_CHECK("k_eigh_global");
     hipLaunchKernelGGL(k_wmat, dim3(64, nb), dim3(256), 0, st, evec, d, p, c0, W);
     SF_LAUNCH_CHECK("k_wmat");

@@ -116,6 +116,11 @@ def main():
         bytes_per_pixel = 4 * p + 12 + 32
         alg_bytes = bytes_per_pixel * lines * ncols
         achieved = alg_bytes / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.isfile(pmc) and (lines, samples, p, world) == (LINES, SAMPLES, 72, 1):
+            # HBM bytes per k_score launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see file)
+            traffic = json.load(open(pmc))["kernels"]["k_score"]["hbm_bytes_per_launch"]
         line = {
             "metric": "CMF Mpixels/s on 598x20000x425 cube",
             "value": round(mpix, 3), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
@@ -128,7 +133,7 @@ def main():
                        "output": "float64 BIP [lines, samples, (R,G,B,CMF)]"},
             "roofline": {"bound": "hbm", "kernel": "k_score<true>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "bytes_per_pixel": bytes_per_pixel,
+                         "traffic": traffic, "bytes_per_pixel": bytes_per_pixel,
                          "avg_launch_ms": round(score_ms, 4), "launches": nlaunch.value},
         }
         if world == 1 and not args.no_cpu_baseline:

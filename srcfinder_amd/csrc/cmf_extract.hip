@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256) void k_extract(const float *__restrict__ cube,
       uint8_t *mp = mask_t + (size_t)(colbase + lane) * L + l0;
       if (TL == 4 && nl == 4 && (((size_t)(colbase + lane) * L + l0) & 3) == 0) {
         *reinterpret_cast<uint32_t *>(mp) = *reinterpret_cast<const uint32_t *>(&vf[lane][0]);
+      } else if (TL == 2 && nl == 2 && (((size_t)(colbase + lane) * L + l0) & 1) == 0) {
+        *reinterpret_cast<uint16_t *>(mp) = *reinterpret_cast<const uint16_t *>(&vf[lane][0]);
       } else {
         for (int l = 0; l < nl; ++l) mp[l] = vf[lane][l];
       }
@@ -234,7 +236,7 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
                       float *xt, uint8_t *mask_t, double *sum_part, int *cnt_part, hipStream_t st) {
   const int PS = (p + 3) / 4 * 4;
   const int pbmax = (p <= XT_PBMAX) ? p : XT_PBMAX;
-  constexpr int TL = 4;
+  constexpr int TL = 2;
   const int cs = (TL * pbmax) | 1;
   const size_t lds = (size_t)64 * cs * sizeof(float);
   const bool fuse = sum_part != nullptr && p <= XT_PBMAX;

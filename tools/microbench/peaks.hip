@@ -21,6 +21,34 @@ __global__ __launch_bounds__(256) void k_mfma64(double *out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// MFMA + independent fp64 VALU FMAs in the same wave: do the two pipes overlap?
+template <int NFMA>
+__global__ __launch_bounds__(256) void k_mix(double *out, int iters, long long *cyc) {
+  d4 acc[4];
+  for (int c = 0; c < 4; ++c) acc[c] = d4{0, 0, 0, 0};
+  double x[8];
+  for (int c = 0; c < 8; ++c) x[c] = threadIdx.x * 1e-3 + c;
+  double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-6;
+  const double fa = 1.0000001, fb = 1e-9;
+  const long long t0 = clock64();
+  const long long w0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+#pragma unroll
+      for (int f = 0; f < NFMA; ++f) x[(c * NFMA + f) & 7] = __builtin_fma(x[(c * NFMA + f) & 7], fa, fb);
+    }
+  }
+  const long long t1 = clock64();
+  const long long w1 = wall_clock64();
+  double s = 0;
+  for (int c = 0; c < 4; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+  for (int c = 0; c < 8; ++c) s += x[c];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; }
+}
+
 __global__ __launch_bounds__(256) void k_fma64(double *out, int iters) {
   double x[8];
   for (int c = 0; c < 8; ++c) x[c] = threadIdx.x * 1e-3 + c;
@@ -90,6 +118,20 @@ int main() {
     flops = (double)blocks1 * 4 * iters * 1 * 2048.0;
     printf("mfma_f64_16x16x4 (1 wave/SIMD x 1 dependent chain): %.1f TFLOP/s, %.1f cycles/instr\n", flops / ms / 1e9,
            (double)ms * 1e-3 * prop.clockRate * 1e3 / iters);
+  }
+  {
+    long long *cyc;
+    CK(hipMalloc(&cyc, 16));
+    const int blocks1 = prop.multiProcessorCount;  // 1 wave per SIMD, like the sweep kernel
+    auto mix = [&](auto kern, int nf) {
+      float ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(blocks1), dim3(256), 0, 0, out, iters, cyc); }, 3);
+      long long h[2];
+      hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);
+      const double mf = (double)blocks1 * 4 * iters * 4 * 2048.0, vf = (double)blocks1 * 256 * iters * 4.0 * nf * 2.0;
+      printf("mix 1 MFMA + %2d fp64 FMA (1 wave/SIMD): MFMA %.1f TF + VALU %.1f TF; %.1f shader cycles per MFMA slot; clock %.2f GHz\n",
+             nf, mf / ms / 1e9, vf / ms / 1e9, (double)h[0] / (iters * 4.0), (double)h[0] / ((double)h[1] * 10.0) );
+    };
+    mix(k_mix<0>, 0); mix(k_mix<2>, 2); mix(k_mix<4>, 4); mix(k_mix<6>, 6); mix(k_mix<8>, 8); mix(k_mix<12>, 12); mix(k_mix<16>, 16);
   }
   {
     const int blocks = prop.multiProcessorCount * 8;

@@ -142,7 +142,7 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
     if len(rgb_bands) not in (0, 3):
         raise Exception("invalid value of rgb_bands argument: %s" % (rgb_bands,))         # robust_mf.py:225-226
     if not torch.is_tensor(cube_bil):
-        cube_bil = torch.as_tensor(np.ascontiguousarray(cube_bil, dtype=np.float32))
+        cube_bil = torch.from_numpy(np.array(cube_bil, dtype=np.float32, order="C", copy=True))
     if cube_bil.dtype != torch.float32 or cube_bil.dim() != 3:
         raise TypeError("cube must be float32 [lines, bands, samples]")
     if not cube_bil.is_cuda:

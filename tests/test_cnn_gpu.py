@@ -108,3 +108,56 @@ def test_cmf_into_cnn_end_to_end(net, library):
     assert np.array_equal(got == -9999, want == -9999)
     v = want != -9999
     np.testing.assert_allclose(got[v], want[v], rtol=2e-4, atol=1e-7)
+
+
+def test_command_lines_end_to_end(tmp_path, library):
+    """The two CLI mirrors on real files: ENVI BIL cube -> robust_mf CLI -> 4-band product (+bgmeta, +csv) ->
+    cnn_pred CLI on band 4 -> saliency raster; against the oracles."""
+    import torch
+    from oracle import cmf_oracle as CO
+    from srcfinder_amd import cli_cnn_pred, cli_robust_mf, envi
+    from srcfinder_amd.synth import make_cube_numpy
+    cube = make_cube_numpy(40, 14, seed=77, abscf_full=library[:, 2], nodata_lines=2, nodata_column=6)
+    inp = str(tmp_path / "ang_test_rdn")
+    mm = envi.create_image(inp, {"lines": 40, "samples": 14, "bands": 425, "data ignore value": -9999,
+                                 "wavelength": ["0"] * 425, "description": "synthetic"}, np.float32, "bil")
+    mm[...] = cube
+    mm.flush()
+    libpath = str(tmp_path / "ang_ch4_unit_3col_425chan.txt")
+    np.savetxt(libpath, library, fmt="%.12f")
+    outp = str(tmp_path / "ang_test_ch4mf")
+    assert cli_robust_mf.main(["-m", inp, libpath, outp]) == 0
+    prod, meta = envi.open_memmap(outp)
+    assert (meta["lines"], meta["samples"], meta["bands"], meta["data type"], meta["interleave"]) == (40, 14, 4, 5, "bip")
+    assert meta["model parameters"] == cmf_params()
+    assert "wavelength" not in meta and meta["band names"][3] == "CH4 Absorption (ppm x m)"
+    ref = CO.robust_mf_oracle(cube, np.loadtxt(libpath))
+    nod = ref["out"][..., 3] == -9999.0
+    assert np.array_equal(np.asarray(prod)[..., 3] == -9999.0, nod)
+    assert np.array_equal(np.asarray(prod)[..., :3], ref["out"][..., :3])
+    np.testing.assert_allclose(np.asarray(prod)[..., 3][~nod], ref["out"][..., 3][~nod], rtol=1e-4, atol=1e-6)
+    bg, bmeta = envi.open_memmap(outp + "_bgmeta")
+    assert np.array_equal(np.asarray(bg), ref["bgmeta"]) and int(bmeta["num alphas"]) == 201
+    rows = open(os.path.splitext(inp)[0] + "_column_stats.csv").read().strip().split("\n")
+    assert [r.split(",")[0] for r in rows] == ["", "npix", "avg", "std"]
+    assert [float(v) for v in rows[1].split(",")[1:]] == list(ref["colstats"][0])
+    # CNN CLI on band 4 of that product
+    wpath = str(tmp_path / "COVID_QC.pt")
+    sd = synthetic_state_dict(seed=2024)
+    torch.save({k: torch.as_tensor(v) for k, v in sd.items()}, wpath)
+    assert cli_cnn_pred.main([outp, "-m", "COVID_QC", "-g", "0", "-b", "64", "-o", str(tmp_path), "--band", "4",
+                              "--weights", wpath]) == 0
+    sal, smeta = envi.open_memmap(str(tmp_path / "ang_test_ch4mf_saliency.img"))
+    assert (smeta["lines"], smeta["samples"], smeta["bands"], smeta["data type"]) == (40, 14, 1, 4)
+    plane = np.asarray(prod)[..., 3].astype(np.float32)
+    idx = [0, 100, 333, 559]
+    want = O.predict_plane(plane, sd, MEAN, STD, indices=idx)
+    got = np.asarray(sal)[0].reshape(-1)[idx]
+    assert np.array_equal(got == -9999, want == -9999)
+    v = want != -9999
+    np.testing.assert_allclose(got[v], want[v], rtol=2e-4, atol=1e-7)
+
+
+def cmf_params():
+    from srcfinder_amd import cmf
+    return cmf.model_parameters(False, (351, 422))

@@ -1,0 +1,57 @@
+"""Host-side pieces of the CLI mirrors (no GPU): ENVI round trips, header parsing, flag sets."""
+import os
+
+import numpy as np
+
+from srcfinder_amd import cli_cnn_pred, cli_robust_mf, envi
+
+
+def test_envi_roundtrip_all_interleaves(tmp_path):
+    rng = np.random.default_rng(0)
+    cube = rng.standard_normal((5, 7, 3)).astype(np.float32)              # BIL: lines, bands, samples
+    for il, arr in (("bil", cube), ("bip", cube.transpose(0, 2, 1)), ("bsq", cube.transpose(1, 0, 2))):
+        path = str(tmp_path / ("cube_" + il))
+        mm = envi.create_image(path, {"lines": 5, "samples": 3, "bands": 7, "data ignore value": -9999,
+                                      "description": "test cube"}, np.float32, il)
+        mm[...] = arr
+        mm.flush()
+        back, meta = envi.open_memmap(path)
+        assert meta["interleave"] == il and meta["data type"] == 4 and meta["lines"] == 5
+        assert float(meta["data ignore value"]) == -9999
+        assert np.array_equal(np.asarray(envi.to_bil(back, meta)), cube)
+
+
+def test_parse_reference_style_header(tmp_path):
+    hdr = tmp_path / "prod.hdr"
+    hdr.write_text("""ENVI
+description = {
+  AVIRIS-NG product }
+samples = 669
+lines   = 2801
+bands   = 4
+header offset = 0
+file type = ENVI Standard
+data type = 5
+interleave = bip
+byte order = 0
+map info = { UTM , 1.000 , 1.000 , 600000.0 , 4000000.0 , 3.2 , 3.2 , 13 , North , WGS-84 , units=Meters , rotation=-15.0 }
+band names = { Red Radiance (uW/nm/sr/cm2) , Green Radiance (uW/nm/sr/cm2) , Blue Radiance (uW/nm/sr/cm2) , CH4 Absorption (ppm x m) }
+data ignore value = -9999
+model parameters = { modelname=looshrinkage, bgmodel=unimodal, aminexp=-10.0, amaxexp=0.0, astep=0.05, reflectance=False, active_bands=[351, 422] }
+""")
+    m = envi.read_header(str(hdr))
+    assert (m["samples"], m["lines"], m["bands"], m["data type"], m["interleave"]) == (669, 2801, 4, 5, "bip")
+    assert len(m["band names"]) == 4 and m["band names"][3] == "CH4 Absorption (ppm x m)"
+    assert m["model parameters"].startswith("{ modelname=looshrinkage") and "active_bands=[351, 422]" in m["model parameters"]
+
+
+def test_cli_flag_sets_match_the_reference():
+    a = cli_robust_mf.build_parser().parse_args(["-m", "-R", "-k", "1", "--rgb_bands", "60,42,24", "in", "lib_ch4.txt", "out"])
+    assert a.metadata and a.reflectance and a.kmeans == 1 and a.pcadim == 6 and a.model == "looshrinkage"
+    assert (a.input, a.library, a.output) == ("in", "lib_ch4.txt", "out")
+    c = cli_cnn_pred.build_parser().parse_args(["flight.img", "-m", "CalCH4_v8", "-g", "0", "1", "-b", "512", "-o", "out"])
+    assert c.model == "CalCH4_v8" and c.gpus == [0, 1] and c.batch == 512 and c.output == "out" and c.band == 1
+
+
+def test_cnn_cli_exits_1_without_weights(tmp_path):
+    assert cli_cnn_pred.main([str(tmp_path / "x.img"), "--weights", str(tmp_path / "missing.pt")]) == 1

@@ -244,6 +244,38 @@ def test_fewer_valid_rows_than_bands(torch_cuda, library):
     assert score_close(res.out[..., 3][~nod], o["out"][..., 3][~nod], rel=1e-4).all()
 
 
+@pytest.mark.parametrize("active", [(351, 421), (360, 366), (340, 422)])
+def test_odd_and_unusual_windows(torch_cuda, library, active):
+    """p = 71 (odd: the eigensolver pads a dummy column), p = 7 (single MFMA tile), p = 83 with another offset."""
+    cube = make_cube_numpy(131, 19, seed=51, abscf_full=library[:, 2], active=active, nodata_column=3)
+    res = cmf.robust_mf(cube, library, active=active, metadata=True, to_numpy=True)
+    o = O.robust_mf_oracle(cube, library, active=active)
+    _compare_run(res, o, 131, 19)
+
+
+def test_degenerate_shapes(torch_cuda, library):
+    """One column; fewer lines than a tile; a column with a single valid row (status 2 here, NaN in the reference:
+    documented deviation) next to normal ones; +inf inside the window invalidates the row."""
+    cube = make_cube_numpy(90, 1, seed=61, abscf_full=library[:, 2], nodata_lines=0, nodata_column=-1)
+    cube[5, 360, 0] = np.inf
+    res = cmf.robust_mf(cube, library, to_numpy=True)
+    o = O.robust_mf_oracle(cube, library)
+    assert res.out[5, 0, 3] == -9999.0 and o["out"][5, 0, 3] == -9999.0
+    nod = o["out"][..., 3] == -9999.0
+    assert np.array_equal(res.out[..., 3] == -9999.0, nod)
+    assert score_close(res.out[..., 3][~nod], o["out"][..., 3][~nod]).all()
+    cube = make_cube_numpy(3, 5, seed=62, abscf_full=library[:, 2], nodata_lines=0, nodata_column=2)
+    res = cmf.robust_mf(cube, library, to_numpy=True)          # 3 rows << 72 bands: runs, no crash
+    assert res.out.shape == (3, 5, 4) and res.status[2] == 1 and np.all(res.out[:, 2, 3] == -9999.0)
+    assert np.array_equal(res.nuse, np.array([3, 3, 0, 3, 3]))
+    cube = make_cube_numpy(40, 4, seed=63, abscf_full=library[:, 2], nodata_lines=0, nodata_column=-1)
+    cube[1:, 351:360, 1] = -9999.0                              # column 1 keeps exactly one valid row
+    res = cmf.robust_mf(cube, library, to_numpy=True)
+    assert res.nuse[1] == 1 and res.status[1] == 2 and res.out[0, 1, 3] == 0.0
+    o = O.robust_mf_oracle(cube[:, :, [0, 2, 3]], library)
+    assert score_close(res.out[:, [0, 2, 3], 3], o["out"][..., 3]).all()
+
+
 def test_column_shards_are_bit_identical(torch_cuda, library):
     """Sharding columns over ranks must not change any column's arithmetic."""
     torch = torch_cuda

@@ -141,6 +141,13 @@ int sf_cnn_maxpool(const float *in, int N, int H, int W, int C, int ksize, int s
 int sf_cnn_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias, int Cout,
                 int ksize, float *out, int ld_out, int ch_off, void *stream);
 
+/* The three 1x1 BasicConv2d that read the same inception input (branch1, branch2[0], branch3[0];
+ * googlenet1.py:199-210) as ONE GEMM: w = [c0+c1+c2][Cin] (the three folded weight sets stacked), output channels
+ * [0,c0) -> out0 (+off0, stride ld0), [c0,c0+c1) -> out1, the rest -> out2. */
+int sf_cnn_conv_split3(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias,
+                       int c0, int c1, int c2, float *out0, int ld0, int off0, float *out1, int ld1, int off1,
+                       float *out2, int ld2, int off2, void *stream);
+
 /* AdaptiveAvgPool2d(1) -> Linear(C, 2) -> softmax[:,1] (googlenet1.py:87-89,:156-161; cnn_pred_pipeline.py:177-180)
  * and the NODATA rule (:185-189): out[tile0 + t] = plane[tile0 + t] == nodata ? nodata : p.  plane may be NULL. */
 int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, const float *fcb, const float *plane,

@@ -35,6 +35,8 @@ SIGNATURES = {
     "sf_cnn_conv1": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp, vp]),
     "sf_cnn_maxpool": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "sf_cnn_conv": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, i32, i32, vp]),
+    "sf_cnn_conv_split3": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, i32, vp, i32, i32,
+                                 vp, i32, i32, vp]),
     "sf_cnn_head": (i32, [vp, i32, i32, i32, vp, vp, vp, i64, f32, vp, vp]),
     "sf_cmf_score_timing": (i32, [i32]),
     "sf_debug_set": (i32, [i32, i32]),

@@ -160,6 +160,11 @@ class GoogLeNetHIP(object):
             bf = b - m * scale
             self.w[name] = (torch.as_tensor(np.ascontiguousarray(wf, dtype=np.float32)).to(self.device),
                             torch.as_tensor(bf.astype(np.float32)).to(self.device))
+        for spec in INCEPTION:       # stacked weights of the three 1x1 convs that share the block input
+            name = spec[0]
+            ws = [self.w[name + s_][0] for s_ in (".branch1", ".branch2.0", ".branch3.0")]
+            bs = [self.w[name + s_][1] for s_ in (".branch1", ".branch2.0", ".branch3.0")]
+            self.w[name + ".head3"] = (torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous())
         self.fcw = torch.as_tensor(np.ascontiguousarray(npy(sd["fc.weight"]), dtype=np.float32)).to(self.device)
         self.fcb = torch.as_tensor(np.ascontiguousarray(npy(sd["fc.bias"]), dtype=np.float32)).to(self.device)
         if self.fcw.shape != (2, 1024):
@@ -202,10 +207,11 @@ class GoogLeNetHIP(object):
         y = self._buf(name + ".y", (N, H, W, c1 + c3 + c5 + pp))
         t2 = self._buf("t2", (N, H, W, c3r))
         t3 = self._buf("t3", (N, H, W, c5r))
-        self._conv(x, name + ".branch1", y, 0)
-        self._conv(x, name + ".branch2.0", t2, 0)
+        w3, b3 = self.w[name + ".head3"]            # branch1 | branch2[0] | branch3[0] in one GEMM
+        _ffi.check(_ffi.lib().sf_cnn_conv_split3(_ffi.ptr(x), N, H, W, cin, x.shape[3], _ffi.ptr(w3), _ffi.ptr(b3),
+                                                 c1, c3r, c5r, _ffi.ptr(y), y.shape[3], 0, _ffi.ptr(t2), c3r, 0,
+                                                 _ffi.ptr(t3), c5r, 0, _ffi.stream_ptr()), "sf_cnn_conv_split3(%s)" % name)
         self._conv(t2, name + ".branch2.1", y, c1)
-        self._conv(x, name + ".branch3.0", t3, 0)
         self._conv(t3, name + ".branch3.1", y, c1 + c3)
         pooled = self._pool(x, "pool_s1", 3, 1, 1)
         self._conv(pooled, name + ".branch4.1", y, c1 + c3 + c5)

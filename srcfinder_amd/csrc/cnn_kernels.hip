@@ -106,10 +106,18 @@ __global__ void k_maxpool(const float *__restrict__ in, int N, int H, int W, int
 // block tile 128 pixels x BN channels, k-chunk BK input channels of one tap; each wave owns 32 pixel rows and all
 // BN columns (BN/32 MFMA tiles sharing the A fragment).  Register-staged double buffering: the next chunk's global
 // loads are in flight while the current chunk is multiplied out of LDS.
+// Output routing: channels [0, e0) -> dst[0], [e0, e1) -> dst[1], [e1, Cout) -> dst[2]; each destination has its own
+// pixel stride and channel offset.  One launch can therefore evaluate the three 1x1 convolutions that read the
+// same inception input (branch1, branch2.0, branch3.0) as ONE GEMM with a wider N.
+struct ConvDst {
+  float *p[3];
+  int ld[3], off[3], end[3];
+};
+
 template <int BK, int BN>
 __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in, int M, int H, int W, int Cin, int ld_in,
                                                      const float *__restrict__ wt, const float *__restrict__ bias, int Cout,
-                                                     int ks, float *__restrict__ out, int ld_out, int ch_off) {
+                                                     int ks, ConvDst dst) {
   constexpr int BM = 128, LDA = BM + 1, LDB = BN + 1;
   constexpr int TPP = BK / 4;        // threads per pixel row (one float4 each)
   constexpr int PPP = 256 / TPP;     // rows per pass
@@ -208,10 +216,14 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in
     const int co = n0 + 32 * t + (lane & 31);
     if (co < Cout) {
       const float bb = bias[co];
+      const int sg = (co < dst.end[0]) ? 0 : ((co < dst.end[1]) ? 1 : 2);
+      const int cbase = (sg == 0) ? 0 : dst.end[sg - 1];
+      float *op = dst.p[sg] + dst.off[sg] + (co - cbase);
+      const int ld = dst.ld[sg];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M) out[(size_t)m * ld_out + ch_off + co] = fmaxf(acc[t][r] + bb, 0.f);
+        if (m < M) op[(size_t)m * ld] = fmaxf(acc[t][r] + bb, 0.f);
       }
     }
   }
@@ -252,10 +264,9 @@ __global__ __launch_bounds__(256) void k_head(const float *__restrict__ in, int 
 
 template <int BK, int BN>
 int launch_conv(const float *in, int M, int H, int W, int Cin, int ld_in, const float *wt, const float *bias, int Cout,
-                int ks, float *out, int ld_out, int ch_off, hipStream_t st) {
+                int ks, const ConvDst &dst, hipStream_t st) {
   dim3 grid(sf_cdiv(M, 128), sf_cdiv(Cout, BN));
-  hipLaunchKernelGGL((k_conv_igemm<BK, BN>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, out,
-                     ld_out, ch_off);
+  hipLaunchKernelGGL((k_conv_igemm<BK, BN>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
   SF_LAUNCH_CHECK("k_conv_igemm");
   return 0;
 }
@@ -302,6 +313,22 @@ int sf_cnn_maxpool(const float *in, int N, int H, int W, int C, int ksize, int s
   return 0;
 }
 
+static int conv_dispatch(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias,
+                         int Cout, int ksize, const ConvDst &dst, hipStream_t st) {
+  const long long Ml = (long long)N * H * W;
+  if (Ml > 2000000000LL) { sf_set_error("sf_cnn_conv: batch too large"); return -1; }
+  const int M = (int)Ml;
+  const bool wide = Cout >= 48;
+  if (Cin % 32 == 0)
+    return wide ? launch_conv<32, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)
+                : launch_conv<32, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st);
+  if (Cin % 16 == 0)
+    return wide ? launch_conv<16, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)
+                : launch_conv<16, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st);
+  return wide ? launch_conv<8, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)
+              : launch_conv<8, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st);
+}
+
 int sf_cnn_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias, int Cout,
                 int ksize, float *out, int ld_out, int ch_off, void *stream) {
   if (!in || !w || !bias || !out || N < 1 || (ksize != 1 && ksize != 3) || (Cin & 7) || (ld_in & 3) || Cin > ld_in ||
@@ -309,19 +336,28 @@ int sf_cnn_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const 
     sf_set_error("sf_cnn_conv: bad argument (ksize 1|3, Cin multiple of 8)");
     return -1;
   }
-  const long long Ml = (long long)N * H * W;
-  if (Ml > 2000000000LL) { sf_set_error("sf_cnn_conv: batch too large"); return -1; }
-  const int M = (int)Ml;
-  hipStream_t st = (hipStream_t)stream;
-  const bool wide = Cout >= 48;
-  if (Cin % 32 == 0)
-    return wide ? launch_conv<32, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, out, ld_out, ch_off, st)
-                : launch_conv<32, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, out, ld_out, ch_off, st);
-  if (Cin % 16 == 0)
-    return wide ? launch_conv<16, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, out, ld_out, ch_off, st)
-                : launch_conv<16, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, out, ld_out, ch_off, st);
-  return wide ? launch_conv<8, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, out, ld_out, ch_off, st)
-              : launch_conv<8, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, out, ld_out, ch_off, st);
+  ConvDst d{};
+  d.p[0] = d.p[1] = d.p[2] = out;
+  d.ld[0] = d.ld[1] = d.ld[2] = ld_out;
+  d.off[0] = d.off[1] = d.off[2] = ch_off;
+  d.end[0] = d.end[1] = d.end[2] = Cout;
+  return conv_dispatch(in, N, H, W, Cin, ld_in, w, bias, Cout, ksize, d, (hipStream_t)stream);
+}
+
+int sf_cnn_conv_split3(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias,
+                       int c0, int c1, int c2, float *out0, int ld0, int off0, float *out1, int ld1, int off1,
+                       float *out2, int ld2, int off2, void *stream) {
+  if (!in || !w || !bias || !out0 || !out1 || !out2 || N < 1 || (Cin & 7) || (ld_in & 3) || Cin > ld_in || c0 < 1 ||
+      c1 < 1 || c2 < 1 || off0 + c0 > ld0 || off1 + c1 > ld1 || off2 + c2 > ld2) {
+    sf_set_error("sf_cnn_conv_split3: bad argument");
+    return -1;
+  }
+  ConvDst d{};
+  d.p[0] = out0; d.p[1] = out1; d.p[2] = out2;
+  d.ld[0] = ld0; d.ld[1] = ld1; d.ld[2] = ld2;
+  d.off[0] = off0; d.off[1] = off1; d.off[2] = off2;
+  d.end[0] = c0; d.end[1] = c0 + c1; d.end[2] = c0 + c1 + c2;
+  return conv_dispatch(in, N, H, W, Cin, ld_in, w, bias, c0 + c1 + c2, 1, d, (hipStream_t)stream);
 }
 
 int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, const float *fcb, const float *plane,

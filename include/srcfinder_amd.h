@@ -153,6 +153,21 @@ int sf_cnn_conv_split3(const float *in, int N, int H, int W, int Cin, int ld_in,
 int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, const float *fcb, const float *plane,
                 long long tile0, float nodata, float *out, void *stream);
 
+/* ---- reduced-precision option of the CNN scorer (NOT the parity path): float16 activations/weights, fp32 accumulate on
+ * v_mfma_f32_32x32x16_f16 -- the precision class of the reference's own cuDNN-TF32 default on recent GPUs.  Same
+ * operators, arguments as the fp32 entry points; activation / weight pointers are float16 (passed as void*). */
+int sf_cnn_conv1_f16(const float *padded, int Hp, int Wp, int W, long long tile0, int ntiles, const float *w,
+                     const float *bias, void *out, void *stream);
+int sf_cnn_maxpool_f16(const void *in, int N, int H, int W, int C, int ksize, int stride, int pad, void *out, int Ho,
+                       int Wo, void *stream);
+int sf_cnn_conv_f16(const void *in, int N, int H, int W, int Cin, int ld_in, const void *w, const float *bias, int Cout,
+                    int ksize, void *out, int ld_out, int ch_off, void *stream);
+int sf_cnn_conv_split3_f16(const void *in, int N, int H, int W, int Cin, int ld_in, const void *w, const float *bias,
+                           int c0, int c1, int c2, void *out0, int ld0, int off0, void *out1, int ld1, int off1,
+                           void *out2, int ld2, int off2, void *stream);
+int sf_cnn_head_f16(const void *in, int ntiles, int HW, int C, const float *fcw, const float *fcb, const float *plane,
+                    long long tile0, float nodata, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

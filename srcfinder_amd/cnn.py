@@ -133,8 +133,17 @@ def _pool_out(n, k, s, p):
 class GoogLeNetHIP(object):
     """Eval graph of the reference's 1-channel GoogLeNet (googlenet1.py:60-89, :110-163) on HIP kernels."""
 
-    def __init__(self, state_dict=None, device=None):
+    def __init__(self, state_dict=None, device=None, precision="fp32"):
+        """precision: "fp32" (the parity path: exact fp32 FMA chains on the fp32 matrix cores) or "fp16" (float16
+        activations/weights with fp32 accumulation -- the precision class of cuDNN's TF32 default, ~4x faster,
+        own tolerance)."""
         torch = _torch()
+        if precision not in ("fp32", "fp16"):
+            raise ValueError("precision must be 'fp32' or 'fp16'")
+        self.precision = precision
+        self.half = precision == "fp16"
+        self.adt = torch.float16 if self.half else torch.float32
+        self.sfx = "_f16" if self.half else ""
         self.device = torch.device("cuda") if device is None else torch.device(device)
         self.w = {}
         self._bufs = {}
@@ -158,7 +167,8 @@ class GoogLeNetHIP(object):
             scale = g / np.sqrt(v + BN_EPS)
             wf = (w * scale[:, None, None, None]).transpose(0, 2, 3, 1).reshape(cout, k * k, cin)
             bf = b - m * scale
-            self.w[name] = (torch.as_tensor(np.ascontiguousarray(wf, dtype=np.float32)).to(self.device),
+            wdt = self.adt if name != "conv1" else torch.float32      # conv1 runs on the fp32 VALU in both modes
+            self.w[name] = (torch.as_tensor(np.ascontiguousarray(wf, dtype=np.float32)).to(self.device).to(wdt),
                             torch.as_tensor(bf.astype(np.float32)).to(self.device))
         for spec in INCEPTION:       # stacked weights of the three 1x1 convs that share the block input
             name = spec[0]
@@ -178,7 +188,7 @@ class GoogLeNetHIP(object):
         b = self._bufs.get(key)
         if b is None or b.numel() < n:
             self._bufs[key] = None
-            b = torch.empty(n, dtype=torch.float32, device=self.device)
+            b = torch.empty(n, dtype=self.adt, device=self.device)
             self._bufs[key] = b
         return b[:n].view(*shape)
 
@@ -189,16 +199,17 @@ class GoogLeNetHIP(object):
         N, H, W, ldi = x.shape
         cout, taps, cin = w.shape
         k = 3 if taps == 9 else 1
-        _ffi.check(L.sf_cnn_conv(_ffi.ptr(x), N, H, W, cin, ldi, _ffi.ptr(w), _ffi.ptr(b), cout, k, _ffi.ptr(out),
-                                 out.shape[3], ch_off, _ffi.stream_ptr()), "sf_cnn_conv(%s)" % name)
+        fn = getattr(L, "sf_cnn_conv" + self.sfx)
+        _ffi.check(fn(_ffi.ptr(x), N, H, W, cin, ldi, _ffi.ptr(w), _ffi.ptr(b), cout, k, _ffi.ptr(out),
+                      out.shape[3], ch_off, _ffi.stream_ptr()), "sf_cnn_conv(%s)" % name)
 
     def _pool(self, x, key, k, s, p):
         L = _ffi.lib()
         N, H, W, Cc = x.shape
         Ho, Wo = _pool_out(H, k, s, p), _pool_out(W, k, s, p)
         out = self._buf(key, (N, Ho, Wo, Cc))
-        _ffi.check(L.sf_cnn_maxpool(_ffi.ptr(x), N, H, W, Cc, k, s, p, _ffi.ptr(out), Ho, Wo, _ffi.stream_ptr()),
-                   "sf_cnn_maxpool")
+        fn = getattr(L, "sf_cnn_maxpool" + self.sfx)
+        _ffi.check(fn(_ffi.ptr(x), N, H, W, Cc, k, s, p, _ffi.ptr(out), Ho, Wo, _ffi.stream_ptr()), "sf_cnn_maxpool")
         return out
 
     def _inception(self, x, spec):
@@ -208,9 +219,10 @@ class GoogLeNetHIP(object):
         t2 = self._buf("t2", (N, H, W, c3r))
         t3 = self._buf("t3", (N, H, W, c5r))
         w3, b3 = self.w[name + ".head3"]            # branch1 | branch2[0] | branch3[0] in one GEMM
-        _ffi.check(_ffi.lib().sf_cnn_conv_split3(_ffi.ptr(x), N, H, W, cin, x.shape[3], _ffi.ptr(w3), _ffi.ptr(b3),
-                                                 c1, c3r, c5r, _ffi.ptr(y), y.shape[3], 0, _ffi.ptr(t2), c3r, 0,
-                                                 _ffi.ptr(t3), c5r, 0, _ffi.stream_ptr()), "sf_cnn_conv_split3(%s)" % name)
+        fn = getattr(_ffi.lib(), "sf_cnn_conv_split3" + self.sfx)
+        _ffi.check(fn(_ffi.ptr(x), N, H, W, cin, x.shape[3], _ffi.ptr(w3), _ffi.ptr(b3), c1, c3r, c5r, _ffi.ptr(y),
+                      y.shape[3], 0, _ffi.ptr(t2), c3r, 0, _ffi.ptr(t3), c5r, 0, _ffi.stream_ptr()),
+                   "sf_cnn_conv_split3(%s)" % name)
         self._conv(t2, name + ".branch2.1", y, c1)
         self._conv(t3, name + ".branch3.1", y, c1 + c3)
         pooled = self._pool(x, "pool_s1", 3, 1, 1)
@@ -226,8 +238,8 @@ class GoogLeNetHIP(object):
             st = _ffi.stream_ptr()
             a1 = self._buf("conv1", (ntiles, 128, 128, 64))
             w, b = self.w["conv1"]
-            _ffi.check(L.sf_cnn_conv1(_ffi.ptr(padded), Hp, Wp, width, C.c_longlong(tile0), ntiles, _ffi.ptr(w), _ffi.ptr(b),
-                                      _ffi.ptr(a1), st), "sf_cnn_conv1")
+            _ffi.check(getattr(L, "sf_cnn_conv1" + self.sfx)(_ffi.ptr(padded), Hp, Wp, width, C.c_longlong(tile0), ntiles,
+                                                             _ffi.ptr(w), _ffi.ptr(b), _ffi.ptr(a1), st), "sf_cnn_conv1")
             x = self._pool(a1, "pool1", 3, 2, 0)
             a3 = self._buf("conv2", x.shape)
             self._conv(x, "conv2", a3, 0)
@@ -248,12 +260,14 @@ class GoogLeNetHIP(object):
             N, H, W, Cc = x.shape
             if out is None:
                 out = torch.empty(tile0 + ntiles, dtype=torch.float32, device=self.device)
-            _ffi.check(L.sf_cnn_head(_ffi.ptr(x), ntiles, H * W, Cc, _ffi.ptr(self.fcw), _ffi.ptr(self.fcb),
-                                     _ffi.ptr(plane), C.c_longlong(tile0), NODATA, _ffi.ptr(out), st), "sf_cnn_head")
+            _ffi.check(getattr(L, "sf_cnn_head" + self.sfx)(_ffi.ptr(x), ntiles, H * W, Cc, _ffi.ptr(self.fcw),
+                                                            _ffi.ptr(self.fcb), _ffi.ptr(plane), C.c_longlong(tile0),
+                                                            NODATA, _ffi.ptr(out), st), "sf_cnn_head")
         return out
 
 
-def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=None, rows=None, net=None, to_numpy=False):
+def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=None, rows=None, net=None, to_numpy=False,
+                       precision="fp32"):
     """saliency[H, W] float32 = softmax(GoogLeNet(window))[:, 1] for the 256x256 window centred on every pixel,
     -9999 where ``cmf2d`` is -9999 (cnn_pred_pipeline.py:159-189).
 
@@ -265,7 +279,7 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
     if net is None:
         if weights is None:
             raise ValueError("weights (a GoogLeNet state_dict) are required")      # the script exits 1 (:93-95)
-        net = GoogLeNetHIP(weights)
+        net = GoogLeNetHIP(weights, precision=precision)
     ds = FlightlineConvolve(cmf2d, model, device=net.device)
     H, W = ds.inshape[1], ds.inshape[2]
     out = torch.zeros(H * W, dtype=torch.float32, device=net.device)

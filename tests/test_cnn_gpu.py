@@ -161,3 +161,15 @@ def test_command_lines_end_to_end(tmp_path, library):
 def cmf_params():
     from srcfinder_amd import cmf
     return cmf.model_parameters(False, (351, 422))
+
+
+def test_fp16_option_is_close_but_separate(gold):
+    """precision="fp16" (float16 operands, fp32 accumulate): NOT the parity path; its own tolerance.
+    NODATA placement stays exact; saliency within 5e-3 absolute / 2e-2 relative of the fp32 reference golden."""
+    net16 = cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024), precision="fp16")
+    sal = cnn.predict_flightline(gold["plane24"], "COVID_QC", net=net16, batch=64, to_numpy=True)
+    want = gold["saliency24"]
+    assert np.array_equal(sal == -9999, want == -9999)
+    v = want != -9999
+    np.testing.assert_allclose(sal[v], want[v], rtol=2e-2, atol=5e-3)
+    assert np.abs(sal[v] - want[v]).max() > 0          # it really is a different arithmetic

@@ -19,13 +19,14 @@ def main():
     ap.add_argument("--tiles", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"])
     args = ap.parse_args()
     import torch
     from srcfinder_amd import cnn
     from srcfinder_amd.cnn_weights import synthetic_plane, synthetic_state_dict
 
     sd = synthetic_state_dict(2024)
-    net = cnn.GoogLeNetHIP(sd)
+    net = cnn.GoogLeNetHIP(sd, precision=args.precision)
     w = 64
     h = (args.tiles + w - 1) // w
     plane = synthetic_plane(h, w, seed=5)
@@ -42,9 +43,10 @@ def main():
     run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    line = {"metric": "CNN tiles/s (GoogLeNet 256x256 window per pixel, fp32)", "value": round(args.tiles / dt, 1),
+    line = {"metric": "CNN tiles/s (GoogLeNet 256x256 window per pixel, %s)" % args.precision, "value": round(args.tiles / dt, 1),
             "unit": "tiles/s", "tflops": round(args.tiles * 3.706e9 / dt / 1e12, 2), "batch": args.batch,
-            "tiles": args.tiles, "dtype": "f32", "mfma_peak_tflops": 157.3}
+            "tiles": args.tiles, "dtype": "f32" if args.precision == "fp32" else "f16 (fp32 accumulate)",
+            "mfma_peak_tflops": 157.3 if args.precision == "fp32" else 2500.0}
     if args.cpu:
         from oracle import cnn_oracle as O
         torch.set_num_threads(os.cpu_count() or 1)

@@ -186,28 +186,42 @@ __global__ __launch_bounds__(256) void k_conv1_h(const float *__restrict__ padde
   }
 }
 
+constexpr int PRH = 4;  // vertically adjacent outputs per thread (row maxima shared between overlapping windows)
 __global__ void k_maxpool_h(const _Float16 *__restrict__ in, int N, int H, int W, int C, int ks, int stride, int pad,
                             _Float16 *__restrict__ out, int Ho, int Wo) {
   const int c8n = C >> 3;
-  const size_t total = (size_t)N * Ho * Wo * c8n;
+  const int hob = (Ho + PRH - 1) / PRH;
+  const size_t total = (size_t)N * hob * Wo * c8n;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int c8 = (int)(i % c8n);
   size_t r = i / c8n;
   const int ox = (int)(r % Wo); r /= Wo;
-  const int oy = (int)(r % Ho);
-  const int n = (int)(r / Ho);
-  const int y0 = max(oy * stride - pad, 0), y1 = min(oy * stride - pad + ks, H);
+  const int oyb = (int)(r % hob);
+  const int n = (int)(r / hob);
   const int x0 = max(ox * stride - pad, 0), x1 = min(ox * stride - pad + ks, W);
-  h8_t m;
+  h8_t lowest;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) m[j] = (_Float16)(-65504.0f);
-  for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x) {
-      const h8_t v = *reinterpret_cast<const h8_t *>(in + (((size_t)n * H + y) * W + x) * C + 8 * c8);
-      m = __builtin_elementwise_max(m, v);
+  for (int j = 0; j < 8; ++j) lowest[j] = (_Float16)(-65504.0f);
+  const int oy0 = oyb * PRH;
+  const int ylo = max(oy0 * stride - pad, 0);
+  const int yhi = min((min(oy0 + PRH, Ho) - 1) * stride - pad + ks, H);
+  h8_t acc[PRH];
+#pragma unroll
+  for (int k = 0; k < PRH; ++k) acc[k] = lowest;
+  for (int y = ylo; y < yhi; ++y) {
+    h8_t m = lowest;
+    for (int x = x0; x < x1; ++x)
+      m = __builtin_elementwise_max(m, *reinterpret_cast<const h8_t *>(in + (((size_t)n * H + y) * W + x) * C + 8 * c8));
+#pragma unroll
+    for (int k = 0; k < PRH; ++k) {
+      const int ys = (oy0 + k) * stride - pad;
+      if (y >= ys && y < ys + ks) acc[k] = __builtin_elementwise_max(acc[k], m);
     }
-  *reinterpret_cast<h8_t *>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + 8 * c8) = m;
+  }
+#pragma unroll
+  for (int k = 0; k < PRH; ++k)
+    if (oy0 + k < Ho) *reinterpret_cast<h8_t *>(out + (((size_t)n * Ho + oy0 + k) * Wo + ox) * C + 8 * c8) = acc[k];
 }
 
 __global__ __launch_bounds__(256) void k_head_h(const _Float16 *__restrict__ in, int HW, int C,
@@ -286,7 +300,7 @@ int sf_cnn_maxpool_f16(const void *in, int N, int H, int W, int C, int ksize, in
     sf_set_error("sf_cnn_maxpool_f16: bad argument (channels must be a multiple of 8)");
     return -1;
   }
-  const size_t total = (size_t)N * Ho * Wo * (C / 8);
+  const size_t total = (size_t)N * ((Ho + PRH - 1) / PRH) * Wo * (C / 8);
   hipLaunchKernelGGL(k_maxpool_h, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const _Float16 *)in, N, H, W, C, ksize, stride, pad, (_Float16 *)out, Ho, Wo);
   SF_LAUNCH_CHECK("k_maxpool_h");

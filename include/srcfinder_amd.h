@@ -102,6 +102,13 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
                int32_t *alphaidx, int32_t *nuse, int32_t *status, double *colstats,
                int16_t *bgmeta, double *nll_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Column profile of a finished product (triage/cmf_profile.py:110-140, the default non-robust statistics):
+ * over the pixels of band `band` of img[lines][samples][nbands] (float64) that are not NODATA/NaN and > 0 (after the
+ * float32 cast the reference applies): profile[5][samples] = npix, mean, std (ddof 0), min, max (NaN where npix = 0).
+ * scratch >= ceil(lines/256) * samples * 5 doubles. */
+int sf_cmf_column_profile(const double *img, int lines, int samples, int nbands, int band, double nodata,
+                          double *profile, void *scratch, void *stream);
+
 /* Timing hook for bench.py's roofline line: while enabled, every sf_cmf_score launch (direct or
  * inside sf_cmf_run) is bracketed by a fresh pair of HIP events on the launch stream.
  * sf_cmf_score_timing_read() synchronises those events, returns the summed kernel time and the

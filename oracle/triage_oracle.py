@@ -1,0 +1,24 @@
+"""TEST INFRASTRUCTURE -- numpy restatement of the column profile of ``triage/cmf_profile.py:110-140``.
+
+PARITY UNPINNED: the reference function reads its inputs through ``srcfinder_util.openimgmm`` (GDAL / spectral, absent
+here) and cannot be executed in this container, so there is no golden from the real code; this file follows the
+listing line by line instead (float32 cast :112, validity + positivity mask :113-114, nan-statistics :128-131)."""
+import warnings
+
+import numpy as np
+
+
+def column_profile(cmf_plane, nodata=-9999.0):
+    nodatav = np.float32(nodata)
+    cmf = np.float32(np.array(cmf_plane, copy=True))
+    cmfnodata = (cmf == nodatav) | np.isnan(cmf)
+    cmfmask = ~cmfnodata & (cmf > 0)
+    cmf[~cmfmask] = np.nan
+    colnum = np.count_nonzero(cmfmask, axis=0)
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        colavg = np.nanmean(cmf, axis=0)
+        colstd = np.nanstd(cmf, axis=0)
+        colmin = np.nanmin(cmf, axis=0)
+        colmax = np.nanmax(cmf, axis=0)
+    return np.stack([colnum, colavg, colstd, colmin, colmax]).astype(np.float64)

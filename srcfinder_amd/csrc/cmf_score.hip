@@ -194,6 +194,52 @@ __global__ __launch_bounds__(256) void k_colstats(const double *__restrict__ sta
   colstats[2 * Cs + c] = sqrt(var);
 }
 
+// ---- column profile of a finished CMF product (triage/cmf_profile.py:110-140, non-robust statistics) ----------
+// Over the pixels that are valid (not NODATA, not NaN) AND positive: npix, mean, std (ddof 0), min, max per column.
+// lane = column, workgroups split the lines; partials [chunk][col][5] combined in a fixed order.
+__global__ __launch_bounds__(256) void k_profile(const double *__restrict__ img, int L, int S, int nb, int band,
+                                                  double nodata, int lines_per_wg, double *__restrict__ part) {
+  __shared__ double red[4][64][5];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int lbeg = blockIdx.y * lines_per_wg, lend = min(L, lbeg + lines_per_wg);
+  double n = 0, s1 = 0, s2 = 0, mn = __builtin_inf(), mx = -__builtin_inf();
+  if (c < S)
+    for (int l = lbeg + wave; l < lend; l += 4) {
+      const double v = img[((size_t)l * S + c) * nb + band];
+      const double vf = (double)(float)v;                 // the reference profiles the float32 cast of the product
+      if (v == v && v != nodata && vf > 0.0) { n += 1; s1 += vf; s2 += vf * vf; mn = fmin(mn, vf); mx = fmax(mx, vf); }
+    }
+  red[wave][lane][0] = n; red[wave][lane][1] = s1; red[wave][lane][2] = s2; red[wave][lane][3] = mn; red[wave][lane][4] = mx;
+  __syncthreads();
+  if (wave == 0 && c < S) {
+    for (int w = 1; w < 4; ++w) {
+      n += red[w][lane][0]; s1 += red[w][lane][1]; s2 += red[w][lane][2];
+      mn = fmin(mn, red[w][lane][3]); mx = fmax(mx, red[w][lane][4]);
+    }
+    double *o = part + ((size_t)blockIdx.y * S + c) * 5;
+    o[0] = n; o[1] = s1; o[2] = s2; o[3] = mn; o[4] = mx;
+  }
+}
+__global__ void k_profile_finish(const double *__restrict__ part, int nchunk, int S, double *__restrict__ prof) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= S) return;
+  double n = 0, s1 = 0, s2 = 0, mn = __builtin_inf(), mx = -__builtin_inf();
+  for (int k = 0; k < nchunk; ++k) {
+    const double *o = part + ((size_t)k * S + c) * 5;
+    n += o[0]; s1 += o[1]; s2 += o[2]; mn = fmin(mn, o[3]); mx = fmax(mx, o[4]);
+  }
+  const double nanv = __builtin_nan("");
+  const double mean = n > 0 ? s1 / n : nanv;
+  double var = n > 0 ? s2 / n - mean * mean : nanv;
+  if (var < 0) var = 0;
+  prof[c] = n;
+  prof[S + c] = mean;
+  prof[2 * S + c] = sqrt(var);
+  prof[3 * S + c] = n > 0 ? mn : nanv;
+  prof[4 * S + c] = n > 0 ? mx : nanv;
+}
+
 }  // namespace
 
 static size_t score_stat_bytes(int lines, int ncols) {
@@ -277,5 +323,22 @@ int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0,
   hipLaunchKernelGGL(k_colstats, dim3(sf_cdiv(ncols, 64)), dim3(256), 0, st,
                      reinterpret_cast<const double *>(stat_scratch), nchunk, ncols, nuse, status, nodata, colstats);
   SF_LAUNCH_CHECK("k_colstats");
+  return 0;
+}
+
+extern "C" int sf_cmf_column_profile(const double *img, int lines, int samples, int nbands, int band, double nodata,
+                                     double *profile, void *scratch, void *stream) {
+  if (!img || !profile || !scratch || lines < 1 || samples < 1 || band < 0 || band >= nbands) {
+    sf_set_error("sf_cmf_column_profile: bad argument");
+    return -1;
+  }
+  const int lpw = 256, nchunk = sf_cdiv(lines, lpw);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_profile, dim3(sf_cdiv(samples, 64), nchunk), dim3(256), 0, st, img, lines, samples, nbands, band,
+                     nodata, lpw, reinterpret_cast<double *>(scratch));
+  SF_LAUNCH_CHECK("k_profile");
+  hipLaunchKernelGGL(k_profile_finish, dim3(sf_cdiv(samples, 128)), dim3(128), 0, st,
+                     reinterpret_cast<const double *>(scratch), nchunk, samples, profile);
+  SF_LAUNCH_CHECK("k_profile_finish");
   return 0;
 }

@@ -361,3 +361,22 @@ def test_full_size_properties(torch_cuda, library):
     assert score_close(got[..., 3][~nod], o["out"][..., 3][~nod]).all()
     so = o["status"] == 0
     assert np.array_equal(r1.alphaidx.cpu().numpy()[cols][so], o["alphaidx"][so])
+
+
+def test_column_profile_and_systematics(torch_cuda, library):
+    """N2: triage column profile of the product on the GPU against the numpy restatement (parity unpinned: the
+    reference function cannot run here), and the rolling-median flag rule on a planted column."""
+    from oracle import triage_oracle as TO
+    from srcfinder_amd import triage
+    cube = make_cube_numpy(300, 70, seed=71, abscf_full=library[:, 2], nodata_column=11)
+    res = cmf.robust_mf(torch_cuda.as_tensor(cube).cuda(), library)
+    prof = triage.column_profile(res.out)
+    want = TO.column_profile(res.out[..., 3].cpu().numpy())
+    assert np.array_equal(prof[0], want[0])
+    assert np.array_equal(np.isnan(prof[1]), np.isnan(want[1])) and np.isnan(prof[1][11])
+    f = ~np.isnan(want[1])
+    np.testing.assert_allclose(prof[1:, f], want[1:, f], rtol=2e-5)
+    avg = prof[1].copy()
+    avg[40] += 50 * np.nanstd(avg)                       # a planted systematic column
+    coldiff, sigma, counts = triage.systematics_flags(avg)
+    assert sigma > 0 and counts[2] >= 1 and np.nanargmax(coldiff) == 40

@@ -55,3 +55,24 @@ def test_cli_flag_sets_match_the_reference():
 
 def test_cnn_cli_exits_1_without_weights(tmp_path):
     assert cli_cnn_pred.main([str(tmp_path / "x.img"), "--weights", str(tmp_path / "missing.pt")]) == 1
+
+
+def test_systematics_flags_host_logic(tmp_path):
+    """N2 host side (triage/cmf_profile.py:182-205): rolling 3-column median, MAD threshold, CSV layout."""
+    import numpy as np
+    from srcfinder_amd import triage
+    rng = np.random.default_rng(5)
+    avg = 100 + rng.standard_normal(64)
+    avg[20] += 40
+    avg[33] = np.nan
+    coldiff, sigma, counts = triage.systematics_flags(avg)
+    assert np.nanargmax(coldiff) == 20 and counts[0] >= counts[1] >= counts[2] >= 1
+    assert np.isnan(coldiff[32:35]).all() and np.isfinite(coldiff[0]) and np.isfinite(coldiff[-1])
+    w = np.sort(avg[:3])
+    assert coldiff[0] == avg[0] - w[1] and coldiff[5] == avg[5] - np.median(avg[4:7])
+    fin = avg[np.isfinite(avg)]
+    assert sigma == np.median(np.abs(fin - np.median(fin)))
+    prof = np.stack([np.arange(4.0), np.ones(4), np.zeros(4), np.ones(4), np.ones(4)])
+    triage.write_column_stats_csv(tmp_path / "c.csv", prof)
+    rows = (tmp_path / "c.csv").read_text().strip().split("\n")
+    assert rows[0] == "npix,avg,std,min,max" and len(rows) == 5 and rows[2].startswith("1.0,1.0,0.0")

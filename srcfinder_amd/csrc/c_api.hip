@@ -9,6 +9,7 @@
 #include "cmf_common.h"
 
 extern int g_score_variant, g_score_lpw, g_score_xcd;  // cmf_score.hip
+extern int g_sweep_variant;                            // cmf_loocv.hip
 
 namespace {
 thread_local char g_err[512] = "";
@@ -248,6 +249,7 @@ int sf_debug_set(int key, int value) {
     case 1: g_score_variant = value; return 0;
     case 2: g_score_lpw = value; return 0;
     case 3: g_score_xcd = value; return 0;
+    case 4: g_sweep_variant = value; return 0;
     default: sf_set_error("sf_debug_set: unknown key %d", key); return -1;
   }
 }

@@ -165,3 +165,10 @@ int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0
                     int out_bands, int16_t *bgmeta, void *scratch, int want_stats, hipStream_t st);
 int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0, int ncols, int p, const int32_t *nuse,
                        const int32_t *status, double nodata, double *colstats, hipStream_t st);
+// cmf_loocv4.hip: the production-window sweep (p in 69..72, 201-point grid) on the 4x4x4 fp64 MFMA
+constexpr int SF_SW4_NJ = 18, SF_SW4_NM = 13;
+int sf_launch_wfrag4(const double *evec, const double *d, const SfGeom &g, size_t wstride, double *wfrag, hipStream_t st);
+int sf_launch_sweep4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
+                     const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,
+                     int nsplit, double *part, int variant, hipStream_t st);
+

@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256, 1) void k_sweep(const XT *__restrict__ xt, con
 __global__ __launch_bounds__(256) void k_nll(const double *__restrict__ part, int nsplit, const int32_t *__restrict__ nuse,
                                               const double *__restrict__ d, const double *__restrict__ lam,
                                               const int32_t *__restrict__ status, const double *__restrict__ alphas,
-                                              int nalpha, int p, int NA16, double *__restrict__ nll_out,
-                                              int32_t *__restrict__ alphaidx) {
+                                              int nalpha, int p, int NA16, int rq_scaled,
+                                              double *__restrict__ nll_out, int32_t *__restrict__ alphaidx) {
   __shared__ double snll[SF_NALPHA_MAX];
   __shared__ double slogd;
   const int c = blockIdx.x, tid = threadIdx.x;
@@ -286,6 +286,9 @@ __global__ __launch_bounds__(256) void k_nll(const double *__restrict__ part, in
         lsum += pp[i];
         rsum += pp[NA16 + i];
       }
+      // k_sweep4 hands over beta sum r/q.  beta = 0 (alpha = 1): G = diag S, q = 1 and
+      // sum_k r_k = sum_k sum_b x_kb^2 / S_bb = (n - 1) p.
+      if (rq_scaled) rsum = (beta > 0.0) ? rsum / beta : (n - 1.0) * (double)p;
       if (ld < -744.4400719213812) {
         v = inf;  // det underflowed to 0 -> the reference skips this alpha (robust_mf.py:112-113)
       } else {
@@ -361,16 +364,25 @@ int launch_sweep(const XT *xt, const uint8_t *mask_t, const int32_t *nuse, const
 
 }  // namespace
 
+int g_sweep_variant = 0;  // sf_debug_set key 4: 0 = built-in choice, 1 = force the 16x16x4 kernels
+
 int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
                          const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
                          hipStream_t st) {
   hipLaunchKernelGGL(k_nll, dim3(g.ncols), dim3(256), 0, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha, g.p,
-                     g.nu * 16, nll, alphaidx);
+                     g.nu * 16, 0, nll, alphaidx);
   SF_LAUNCH_CHECK("k_nll");
   return 0;
 }
 
-size_t sf_wfrag_elems(const SfGeom &g) { return (size_t)g.nt * g.s4 * 64; }
+static bool sweep4_ok(const SfGeom &g, int xt_f64) {
+  return !xt_f64 && g_sweep_variant != 1 && g.nu == SF_SW4_NM && g.s4 == SF_SW4_NJ;
+}
+
+size_t sf_wfrag_elems(const SfGeom &g) {
+  const size_t a = (size_t)g.nt * g.s4 * 64, b = (size_t)SF_SW4_NJ * SF_SW4_NJ * 16;
+  return a > b ? a : b;
+}
 
 size_t sf_loocv_scratch_bytes(const SfGeom &g) {
   const int nsplit = sf_sweep_splits(g.lines, g.ncols);
@@ -390,13 +402,23 @@ int sf_launch_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int
   double *wfrag = reinterpret_cast<double *>(scratch);
   double *part = reinterpret_cast<double *>(reinterpret_cast<char *>(scratch) +
                                             sf_align((size_t)g.ncols * wstride * sizeof(double)));
+  if (sweep4_ok(g, xt_f64)) {
+    if (int rcw = sf_launch_wfrag4(evec, d, g, wstride, wfrag, st)) return rcw;
+    int rc4 = sf_launch_sweep4((const float *)xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part,
+                               g_sweep_variant, st);
+    if (rc4) return rc4;
+    hipLaunchKernelGGL(k_nll, dim3(g.ncols), dim3(256), 0, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha, g.p,
+                       g.nu * 16, 1, nll, alphaidx);
+    SF_LAUNCH_CHECK("k_nll");
+    return 0;
+  }
   hipLaunchKernelGGL(k_wfrag, dim3(g.ncols), dim3(256), 0, st, evec, d, g.p, g.s4, g.nt, wstride, wfrag);
   SF_LAUNCH_CHECK("k_wfrag");
   int rc = xt_f64 ? launch_sweep((const double *)xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part, st)
                   : launch_sweep((const float *)xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_nll, dim3(g.ncols), dim3(256), 0, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha, g.p,
-                     g.nu * 16, nll, alphaidx);
+                     g.nu * 16, 0, nll, alphaidx);
   SF_LAUNCH_CHECK("k_nll");
   return 0;
 }

@@ -1,0 +1,378 @@
+// Stage 5, production window: the LOO sweep on v_mfma_f64_4x4x4_f64 (see cmf_loocv.hip for the algorithm and for
+// the 16x16x4 kernels that serve every other window).  Built with -mllvm -amdgpu-mfma-vgpr-form=1: the results of
+// both products feed VALU code (square, row reduction), and every VALU instruction stalls the 4x4x4 fp64 MFMA
+// stream (tools/microbench/mix4.hip: +4.5 cycles per instruction on a 16.5-cycle slot), so AGPR accumulators and
+// their v_accvgpr_read copies are pure loss here.
+#include "cmf_common.h"
+#include <type_traits>
+
+namespace {
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_sweep4: the production window (p <= 72, 201-point grid) on v_mfma_f64_4x4x4_f64.
+//
+// Measured on MI355X (tools/microbench/mfma64.hip): the 16x16x4 fp64 MFMA issues at ~100 cycles (46-48 TFLOP/s),
+// the 4x4x4 (4 blocks) one at 17 cycles (71 TFLOP/s, ~90 % of the DP unit) -- 1.5x the throughput for 4x the
+// operand traffic.  Register layout of the 4x4x4 instruction (tools/microbench/mfma4_layout.hip), with
+// lane = 16 q + 4 m + n:   block = m;   A[i][k] at (q = k, n = i);   B[k][j] at (q = k, n = j);   D[i][j] at (q = i, n = j).
+//
+//   GEMM1  D1[jidx][row] += W^T[jidx][band] . X^T[band][row]     blocks m = the four 4-row groups of the 16-row tile,
+//          A = W blocks (LDS, 16 values broadcast to the 4 blocks), B = this lane's 18 consecutive bands of its row
+//   z = D1^2 sits at (q = jidx, n = row): exactly the A layout of the next product.  Rotating z by 0/4/8/12 lanes
+//   inside each 16-lane row (DPP row_ror) lets block m meet row group (m + s) % 4:
+//   GEMM2  D2_s[row][alpha] += z_s[row][jidx] . C[jidx][alpha]    blocks m = four 4-alpha groups of a 16-alpha tile,
+//          B = c_ij fragments (LDS, 512 B per read, reused by the 4 rotations)
+// so every (row, alpha) pair is produced exactly once and a lane owns ONE alpha (16 M + (lane & 15)) for 4 rows of
+// the tile per alpha tile M -- the same reduction shape as k_sweep.  324 + 936 MFMAs per 16 rows.
+// LDS: c fragments 119,808 B + W blocks 41,472 B + mu = 161,856 B of the 163,840.
+constexpr int S4J = SF_SW4_NJ, S4M = SF_SW4_NM;
+// LDS reads of GEMM2 step t (one per alpha tile of its group of 4; none past the last step)
+constexpr int sw4_reads(int t) {
+  const int gr = t / S4J, left = S4M - 4 * gr;
+  return left <= 0 ? 0 : (left < 4 ? left : 4);
+}
+
+__global__ void k_wfrag4(const double *__restrict__ evec, const double *__restrict__ d, int p, size_t stride,
+                         double *__restrict__ wfrag) {
+  // wfrag[c][(ig*18 + jg)*16 + 4 q + n] = V[b][j] / d[b],   b = 18 q + ig,   j = 4 jg + n
+  const int c = blockIdx.x;
+  const double *ev = evec + (size_t)c * p * p;
+  const double *dd = d + (size_t)c * p;
+  double *w = wfrag + (size_t)c * stride;
+  for (int i = threadIdx.x; i < S4J * S4J * 16; i += blockDim.x) {
+    const int n = i & 3, q = (i >> 2) & 3, blk = i >> 4;
+    const int ig = blk / S4J, jg = blk - ig * S4J;
+    const int b = S4J * q + ig, j = 4 * jg + n;
+    w[i] = (j < p && b < p) ? ev[(size_t)j * p + b] / dd[b] : 0.0;
+  }
+}
+
+// LDS reads the compiler may not move or merge: issue order = source order, completion is awaited explicitly with
+// lds_wait<N>() whose operands tie the loaded registers to the wait (nothing can read them before it).
+template <int OFF>
+__device__ __forceinline__ double lds_ld(unsigned addr) {
+  double r;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait(double &a, double &b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT));
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait1(double &a) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT));
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait4(double &a, double &b, double &c, double &d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT));
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait6(double &a, double &b, double &c, double &d, double &e, double &f) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(CNT));
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+template <int EXP>  // 0 = production; 1..3 = timing experiments (skip GEMM1 / epilogue / GEMM2), wrong results
+__global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+                                                    const int32_t *__restrict__ nuse, const double *__restrict__ mu,
+                                                    const double *__restrict__ lam, const double *__restrict__ wfrag,
+                                                    size_t wstride, const int32_t *__restrict__ status,
+                                                    const double *__restrict__ alphas, int nalpha, int L, int p,
+                                                    int PS, int rows_per_wg, double *__restrict__ part) {
+  constexpr int NJ = S4J, NM = S4M, NA16 = NM * 16;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *cfrag = sm;                        // [NM][NJ][64]
+  double *wblk = cfrag + NM * NJ * 64;       // [NJ ig][NJ jg][16]
+  double *mus = wblk + NJ * NJ * 16;         // [72]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  double *po = part + ((size_t)c * nsplit + split) * 2 * NA16;
+  if (status[c] != 0) {
+    for (int i = tid; i < 2 * NA16; i += 256) po[i] = 0.0;
+    return;
+  }
+  const double n = (double)nuse[c];
+  for (int i = tid; i < 4 * NJ; i += 256) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
+  {
+    const double *lc = lam + (size_t)c * p;
+    for (int idx = tid; idx < NM * NJ * 64; idx += 256) {
+      const int ln = idx & 63, us = idx >> 6;
+      const int u = us / NJ, jg = us - u * NJ;
+      const int i = 16 * u + (ln & 15), j = 4 * jg + (ln >> 4);
+      double v = 0.0;
+      if (i < nalpha && j < p) {
+        const double a = alphas[i];
+        const double beta = (1.0 - a) / (n - 1.0);
+        v = -beta / ((n * beta) * lc[j] + a);   // GEMM2 accumulates q = 1 - beta r directly (accumulator starts at 1)
+      }
+      cfrag[idx] = v;
+    }
+    const double *wsrc = wfrag + (size_t)c * wstride;
+    for (int i = tid; i < NJ * NJ * 16; i += 256) wblk[i] = wsrc[i];
+  }
+  __syncthreads();
+
+  double P[NM], N[NM];
+  int E[NM];
+#pragma unroll
+  for (int u = 0; u < NM; ++u) { P[u] = 1.0; N[u] = 0.0; E[u] = 0; }
+  int ntile = 0;
+
+  const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
+  const uint8_t *mp = mask_t + (size_t)c * L;
+  const float *xc = xt + (size_t)c * L * PS + NJ * g;
+  const double *cf = cfrag + lane;
+  const double *wf = wblk + 4 * g + (lane & 3);
+  const double qnan = __builtin_nan("");
+
+  float xraw[NJ];
+  bool rowok_next;
+  auto fetch = [&](int r0, float (&dst)[NJ], bool &ok) {
+    const int row = r0 + li;
+    ok = (row < rend) && (mp[row < rend ? row : rbeg] != 0);
+    const float *xp = xc + (size_t)(ok ? row : rbeg) * PS;
+#pragma unroll
+    for (int s = 0; s < NJ; s += 2) sf_load2(xp + s, dst[s], dst[s + 1]);
+  };
+  int r0 = rbeg + 16 * wave;
+  if (r0 < rend) fetch(r0, xraw, rowok_next);
+
+  if (EXP == 4) r0 = rend;   // timing experiment: prologue + final reduction only
+  for (; r0 < rend; r0 += 16 * 4) {
+    const bool rowok = rowok_next;
+    int opq = 0;
+    asm volatile("" : "+v"(opq));  // keeps the loop-invariant LDS operand reads inside the iteration (see k_sweep)
+    const double *cfl = cf + opq;
+    const double *wfl = wf + opq;
+    const double *musl = mus + opq;
+    double x[NJ];
+#pragma unroll
+    for (int s = 0; s < NJ; ++s) {
+      const int b = NJ * g + s;
+      x[s] = (rowok && b < p) ? (double)xraw[s] - musl[b] : 0.0;
+    }
+    if (r0 + 64 < rend) fetch(r0 + 64, xraw, rowok_next);
+    // ---- GEMM1: 18 independent chains, one 4-band step at a time.  The A blocks of step s+1 are read (in-order
+    //      asm reads, two per two MFMAs) while step s multiplies; left to itself the scheduler sinks every read
+    //      next to its use and waits for it: 2 MFMAs per LDS round trip.
+    double z[4][NJ];
+    double wa[2][NJ];
+    const unsigned wadr = (unsigned)(size_t)wfl;  // LDS byte address of this lane's slot in block (0, 0)
+    static_for<0, NJ>([&](auto jc) {
+      constexpr int jg = decltype(jc)::value;
+      z[0][jg] = 0.0;
+      wa[0][jg] = lds_ld<jg * 128>(wadr);
+    });
+    if constexpr (EXP == 1) {
+#pragma unroll
+      for (int jg = 0; jg < NJ; ++jg) z[0][jg] = x[jg] + wa[0][jg];
+    } else
+    static_for<0, NJ>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      static_for<0, NJ / 6>([&](auto kc) {
+        constexpr int k = decltype(kc)::value * 6;
+        lds_wait6<0>(wa[s & 1][k], wa[s & 1][k + 1], wa[s & 1][k + 2], wa[s & 1][k + 3], wa[s & 1][k + 4], wa[s & 1][k + 5]);
+      });
+      static_for<0, NJ / 2>([&](auto jc) {
+        constexpr int jg = decltype(jc)::value * 2;
+        if constexpr (s + 1 < NJ) {
+          wa[(s + 1) & 1][jg] = lds_ld<((s + 1) * NJ + jg) * 128>(wadr);
+          wa[(s + 1) & 1][jg + 1] = lds_ld<((s + 1) * NJ + jg + 1) * 128>(wadr);
+        }
+        z[0][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(wa[s & 1][jg], x[s], z[0][jg], 0, 0, 0);
+        z[0][jg + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(wa[s & 1][jg + 1], x[s], z[0][jg + 1], 0, 0, 0);
+      });
+    });
+#pragma unroll
+    for (int jg = 0; jg < NJ; ++jg) {
+      const double zz = z[0][jg] * z[0][jg];
+      z[0][jg] = zz;
+      z[1][jg] = dpp_row<0x124>(zz);  // row_ror:4
+      z[2][jg] = dpp_row<0x128>(zz);  // row_ror:8
+      z[3][jg] = dpp_row<0x12C>(zz);  // row_ror:12
+    }
+    // ---- GEMM2: alpha tiles in groups of 4 (16 independent chains); the c fragments are read DEPTH-1 steps
+    //      ahead through a register ring that runs across group boundaries.  The fragments carry -beta_i, the
+    //      accumulators start at 1: what comes out is q = 1 - beta r, and with r/q = (1/q - 1)/beta the row
+    //      reduction needs only  prod q  and  sum 1/q.  Both are kept as a fraction: P = prod q (mantissa, the
+    //      exponent split off into E) and N with N/P = sum 1/q, updated per 4 rows without a division:
+    //        m = q0 q1 q2 q3,  nu = (q0+q1) q2 q3 + (q2+q3) q0 q1  (= m sum 1/q_s),  N <- N m + nu P,  P <- P m.
+    constexpr int TG = 4, NG = (NM + TG - 1) / TG, NSTEP = NG * NJ, DEPTH = 4;
+    double br[TG][DEPTH];
+    const unsigned cadr = (unsigned)(size_t)cfl;        // fragment (tile 0, jg 0) of this lane
+    auto loadb = [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int gr = t / NJ, jg = t - gr * NJ;
+      static_for<0, TG>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (gr * TG + k < NM) br[k][t % DEPTH] = lds_ld<(k * NJ + jg) * 512>(cadr + gr * (TG * NJ * 512));
+      });
+    };
+    if constexpr (EXP == 3) {
+#pragma unroll
+      for (int u = 0; u < NM; ++u) N[u] += z[u & 3][u];
+    } else {
+    static_for<0, DEPTH - 1>(loadb);
+    double acc[2][TG][4];
+    // Row reduction of the TG alpha tiles of group `gr` from accumulator set `st`, in four short stages of
+    // independent instructions (one stage per MFMA step of the NEXT group: a tile's update is a chain of ~10
+    // dependent fp64 operations and, issued in one piece, idles the matrix pipe for its whole latency).
+    double rm01[TG], rm23[TG], rs01[TG], rs23[TG], rm[TG], rnu[TG];
+    int rsg[TG];
+    auto reduce_stage = [&](auto grc, auto stc, auto stagec) {
+      constexpr int gq = decltype(grc)::value, st = decltype(stc)::value, stage = decltype(stagec)::value;
+      constexpr int ntile = (NM - gq * TG) < TG ? (NM - gq * TG) : TG;
+#pragma unroll
+      for (int k = 0; k < ntile; ++k) {
+        const int u = gq * TG + k;
+        // acc[st][k][s] = q for alpha i = 16u + li and row (group (m + s) % 4, index g) of this tile
+        if constexpr (EXP == 2) {
+          if (stage == 0) N[u] += (acc[st][k][0] + acc[st][k][1]) + (acc[st][k][2] + acc[st][k][3]);
+        } else if constexpr (stage == 0) {
+          const double q0 = acc[st][k][0], q1 = acc[st][k][1], q2 = acc[st][k][2], q3 = acc[st][k][3];
+          rm01[k] = q0 * q1; rm23[k] = q2 * q3; rs01[k] = q0 + q1; rs23[k] = q2 + q3;
+          rsg[k] = __double2hiint(q0) | __double2hiint(q1) | __double2hiint(q2) | __double2hiint(q3);
+        } else if constexpr (stage == 1) {
+          rm[k] = rm01[k] * rm23[k];
+          rnu[k] = __builtin_fma(rs01[k], rm23[k], rs23[k] * rm01[k]);
+        } else if constexpr (stage == 2) {
+          rnu[k] = __builtin_fma(N[u], rm[k], rnu[k] * P[u]);   // N m + nu P
+          rm[k] = P[u] * rm[k];                                 // P m
+        } else {
+          const int e = __builtin_amdgcn_frexp_exp(rm[k]);
+          P[u] = __builtin_amdgcn_frexp_mant(rm[k]);
+          const double nn = __builtin_amdgcn_ldexp(rnu[k], -e);
+          N[u] = (rsg[k] < 0) ? qnan : nn;   // some q < 0: log(q) is NaN in the reference
+          E[u] += e;
+        }
+      }
+    };
+    static_for<0, NSTEP>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int gr = t / NJ, jg = t - gr * NJ, st = gr & 1;
+      constexpr int nt = sw4_reads(t);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (t + DEPTH - 1 < NSTEP) loadb(std::integral_constant<int, t + DEPTH - 1>{});
+      // in-order returns: everything but the reads of the newer steps t+1 .. t+DEPTH-1 has landed
+      constexpr int newer = sw4_reads(t + 1) + sw4_reads(t + 2) + sw4_reads(t + 3);
+      static_assert(DEPTH == 4 && newer <= 15, "lgkmcnt is a 4-bit counter");
+      if constexpr (nt == 4) lds_wait4<newer>(br[0][t % DEPTH], br[1][t % DEPTH], br[2][t % DEPTH], br[3][t % DEPTH]);
+      else lds_wait1<newer>(br[0][t % DEPTH]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int k = 0; k < nt; ++k) {
+          if constexpr (jg == 0) acc[st][k][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(z[s][jg], br[k][t % DEPTH], 1.0, 0, 0, 0);
+          else acc[st][k][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(z[s][jg], br[k][t % DEPTH], acc[st][k][s], 0, 0, 0);
+        }
+      // the previous group's tiles are reduced underneath this group's MFMAs (stages at steps 1, 3, 5, 7)
+      if constexpr (gr > 0 && (jg & 1) == 1 && jg < 8)
+        reduce_stage(std::integral_constant<int, gr - 1>{}, std::integral_constant<int, 1 - st>{},
+                     std::integral_constant<int, jg / 2>{});
+      if constexpr (t == NSTEP - 1) {   // the last group (one tile) has nothing to hide under
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 4>([&](auto sc) {
+          reduce_stage(std::integral_constant<int, gr>{}, std::integral_constant<int, st>{}, sc);
+        });
+      }
+    });
+    }
+    ntile += 1;
+  }
+
+  __syncthreads();
+  double *redP = sm;
+  double *redR = redP + 4 * NA16;
+  int *redE = reinterpret_cast<int *>(redR + 4 * NA16);
+#pragma unroll
+  for (int u = 0; u < NM; ++u) {
+    double pv = P[u], rv = N[u] / P[u] - 4.0 * (double)ntile;   // sum over this lane's rows of (1/q - 1) = beta r/q
+    int ev = E[u];
+#pragma unroll
+    for (int msk = 16; msk <= 32; msk <<= 1) {
+      const double po2 = shfl_xor_d(pv, msk);
+      const int eo = __shfl_xor(ev, msk, 64);
+      rv += shfl_xor_d(rv, msk);
+      const double pm = pv * po2;
+      ev += eo + __builtin_amdgcn_frexp_exp(pm);
+      pv = __builtin_amdgcn_frexp_mant(pm);
+    }
+    if (g == 0) {
+      redP[wave * NA16 + 16 * u + li] = pv;
+      redR[wave * NA16 + 16 * u + li] = rv;
+      redE[wave * NA16 + 16 * u + li] = ev;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < NA16; i += 256) {
+    double pv = 1.0, rv = 0.0;
+    int ev = 0;
+    for (int w = 0; w < 4; ++w) {
+      const double pm = pv * redP[w * NA16 + i];
+      ev += redE[w * NA16 + i] + __builtin_amdgcn_frexp_exp(pm);
+      pv = __builtin_amdgcn_frexp_mant(pm);
+      rv += redR[w * NA16 + i];
+    }
+    po[i] = log(pv) + (double)ev * 0.6931471805599453094;
+    po[NA16 + i] = rv;   // = beta_i sum_k r_k/q_k: k_nll divides (rq_scaled = 1)
+  }
+}
+
+constexpr size_t SW4_LDS = ((size_t)S4M * S4J * 64 + S4J * S4J * 16 + 4 * S4J) * sizeof(double);
+
+template <int EXP>
+int launch_sweep4_t(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
+                    const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,
+                    int nsplit, double *part, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4<EXP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)SW4_LDS));
+    attr_set = true;
+  }
+  int rows = sf_cdiv(g.lines, nsplit);
+  rows = (rows + 63) / 64 * 64;
+  hipLaunchKernelGGL(k_sweep4<EXP>, dim3(g.ncols, nsplit), dim3(256), SW4_LDS, st, xt, mask_t, nuse, mu, lam, wfrag,
+                     wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part);
+  SF_LAUNCH_CHECK("k_sweep4");
+  return 0;
+}
+
+}  // namespace
+
+int sf_launch_wfrag4(const double *evec, const double *d, const SfGeom &g, size_t wstride, double *wfrag, hipStream_t st) {
+  hipLaunchKernelGGL(k_wfrag4, dim3(g.ncols), dim3(256), 0, st, evec, d, g.p, wstride, wfrag);
+  SF_LAUNCH_CHECK("k_wfrag4");
+  return 0;
+}
+
+int sf_launch_sweep4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
+                     const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,
+                     int nsplit, double *part, int variant, hipStream_t st) {
+#define SW4_ARGS xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part, st
+#ifdef SF_SWEEP_EXPERIMENTS
+  if (variant == 11) return launch_sweep4_t<1>(SW4_ARGS);
+  if (variant == 12) return launch_sweep4_t<2>(SW4_ARGS);
+  if (variant == 13) return launch_sweep4_t<3>(SW4_ARGS);
+  if (variant == 14) return launch_sweep4_t<4>(SW4_ARGS);
+#endif
+  return launch_sweep4_t<0>(SW4_ARGS);
+#undef SW4_ARGS
+}

@@ -167,6 +167,10 @@ int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0,
                        const int32_t *status, double nodata, double *colstats, hipStream_t st);
 // cmf_loocv4.hip: the production-window sweep (p in 69..72, 201-point grid) on the 4x4x4 fp64 MFMA
 constexpr int SF_SW4_NJ = 18, SF_SW4_NM = 13;
+// cmf_cov4.hip: the production-window covariance on the 4x4x4 fp64 MFMA
+size_t sf_cov4_scratch_bytes(const SfGeom &g);
+int sf_launch_cov4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
+                   double *cov, void *scratch, hipStream_t st);
 int sf_launch_wfrag4(const double *evec, const double *d, const SfGeom &g, size_t wstride, double *wfrag, hipStream_t st);
 int sf_launch_sweep4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
                      const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,

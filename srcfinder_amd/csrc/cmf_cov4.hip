@@ -1,0 +1,190 @@
+// Stage 3, production window: the per-column covariance on v_mfma_f64_4x4x4_f64 (cmf_cov.hip serves the others).
+//
+// Replaces numpy.cov as called by looshrinkage (cmf/robust_mf.py:52-70, :98, :130).  The 4x4x4 fp64 MFMA issues
+// 1.5x the flops per cycle of the 16x16x4 one on MI355X (tools/microbench/mfma64.hip), and for X^T X it needs no
+// LDS at all.  With lane = 16 q + 4 m + n the instruction computes, per block m,  D_m[i][j] += sum_k A_m[i][k] B_m[k][j]
+// with A[i][k] at (q = k, n = i), B[k][j] at (q = k, n = j), D[i][j] at (q = i, n = j).  Take k = a row of the 4-row
+// group m and i, j = bands inside 4-band groups I, J: ONE register per band group,
+//     f[I] at lane (q, m, n) = x[row 4m + q][band(I, n)] - mu,
+// is both the A operand of tile row I and the B operand of tile column J.  A wave keeps all 171 upper-triangular
+// 4x4 tiles (x 4 blocks = 4 row groups, summed at the end) in registers and issues 171 MFMAs per 16 rows with
+// every operand already in registers; band(I, n) = 18 n + I makes a lane's 18 values contiguous in the row.
+// One 256-thread workgroup per CU (512-register waves), (column, row split) per workgroup as in the sweep.
+#include "cmf_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int C4_NG = SF_SW4_NJ;                 // 18 band groups of 4
+constexpr int C4_NTRI = C4_NG * (C4_NG + 1) / 2;  // 171 tiles
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// index of tile (I, J), I <= J, in the row-major upper-triangular list
+constexpr int tri_index(int I, int J) { return I * C4_NG - I * (I - 1) / 2 + (J - I); }
+
+// 171 accumulators are 342 registers: more than either register file holds.  Left to the compiler they migrate
+// between the files inside the loop (~200 v_accvgpr moves per tile, each one a stall of the MFMA stream), so
+// the file of every accumulator is pinned: the first C4_NACC_A tiles live in AGPRs, the rest in VGPRs.
+constexpr int C4_NACC_A = 112;
+template <int T>
+__device__ __forceinline__ void mfma_acc(double &acc, double a, double b) {
+  if constexpr (T < C4_NACC_A) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+template <int EXP>  // 0 = production; 1 = no loads in the loop, 2 = no MFMAs (timing experiments, wrong results)
+__global__ __launch_bounds__(256, 1) void k_syrk4(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+                                                   const double *__restrict__ mu, int L, int p, int rows_per_wg,
+                                                   double *__restrict__ part) {
+  constexpr int NG = C4_NG, PS = 4 * C4_NG;
+  __shared__ double red[4][C4_NTRI][16];   // 87.5 KB: the four waves' tiles before the final sum
+  __shared__ double mus[PS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, m = (lane >> 2) & 3, n = lane & 3;
+  const int c = blockIdx.x, split = blockIdx.y;
+  for (int i = tid; i < PS; i += 256) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
+  __syncthreads();
+  const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
+  const uint8_t *mp = mask_t + (size_t)c * L;
+  const float *xc = xt + (size_t)c * L * PS + NG * n;
+  const int rlane = 4 * m + q;   // this lane's row inside a 16-row tile
+
+  double acc[C4_NTRI];
+#pragma unroll
+  for (int t = 0; t < C4_NTRI; ++t) acc[t] = 0.0;
+
+  // Row tiles are fetched DEPTH tiles ahead: one tile is only ~1.2 us of MFMA work, less than the HBM latency
+  // under load, and a wave has nothing else to hide it behind (one wave per SIMD).  (DEPTH 3 does not fit: the
+  // allocator then has to move pinned accumulators around the asm MFMAs, which no hazard recogniser sees.)
+  constexpr int DEPTH = 2;
+  float xraw[DEPTH][NG];
+  uint8_t mk[DEPTH];
+  __shared__ double zeros[NG];
+  if (tid < NG) zeros[tid] = 0.0;
+  // nothing in a fetch depends on loaded data (the validity byte travels with the row and is looked at when the
+  // tile is used): a dependent address would make every fetch wait for all the tiles in flight
+  auto fetch = [&](int r0, auto sc) {
+    constexpr int sl = decltype(sc)::value;
+    const int row = r0 + rlane;
+    const int rr = row < rend ? row : rbeg;
+    mk[sl] = mp[rr];
+    const float *xp = xc + (size_t)rr * PS;
+#pragma unroll
+    for (int s = 0; s < NG; s += 2) sf_load2(xp + s, xraw[sl][s], xraw[sl][s + 1]);
+  };
+  int r0 = rbeg + 16 * wave;
+  static_for<0, DEPTH>([&](auto sc) { fetch(r0 + 64 * decltype(sc)::value, sc); });
+  __syncthreads();   // zeros[]
+  for (; r0 < rend; r0 += 64 * DEPTH) {
+    static_for<0, DEPTH>([&](auto sc) {
+      constexpr int sl = decltype(sc)::value;
+      const int rt = r0 + 64 * sl;
+      {   // no branch in here: tiles past the end are clamped reads of zero weight (the split is a multiple of 64 DEPTH rows)
+        const bool ok = (rt + rlane < rend) && mk[sl] != 0;
+        int opq = 0;
+        asm volatile("" : "+v"(opq));   // keep the 18 mean reads inside the iteration (see k_sweep)
+        // invalid row: raw bits -> 0 and mean -> 0, so the operand is exactly 0 whatever the row held
+        const double *musl = (ok ? mus + NG * n : zeros) + opq;
+        double f[NG];
+#pragma unroll
+        for (int I = 0; I < NG; ++I) {
+          const float xv = (ok && NG * n + I < p) ? xraw[sl][I] : 0.0f;
+          f[I] = (double)xv - musl[I];
+        }
+        if (EXP != 1) fetch(rt + 64 * DEPTH, sc);
+        if constexpr (EXP == 2) {
+#pragma unroll
+          for (int I = 0; I < NG; ++I) acc[I] += f[I];
+        } else
+        static_for<0, NG>([&](auto ic) {
+          constexpr int I = decltype(ic)::value;
+          static_for<I, NG>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            mfma_acc<tri_index(I, J)>(acc[tri_index(I, J)], f[I], f[J]);
+          });
+        });
+      }
+    });
+  }
+  // ---- sum the 4 blocks (row groups) of every tile, then the 4 waves
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the asm MFMAs are invisible to the hazard recogniser: let the last ones retire
+#pragma unroll
+  for (int t = 0; t < C4_NTRI; ++t) {
+    double v = acc[t];
+    v += dpp_row<0x124>(v);   // row_ror:4
+    v += dpp_row<0x128>(v);   // row_ror:8
+    if (m == 0) red[wave][t][4 * q + n] = v;
+  }
+  __syncthreads();
+  double *po = part + ((size_t)c * gridDim.y + split) * (C4_NTRI * 16);
+  for (int i = tid; i < C4_NTRI * 16; i += 256) {
+    const int t = i >> 4, e = i & 15;
+    po[i] = (red[0][t][e] + red[1][t][e]) + (red[2][t][e] + red[3][t][e]);
+  }
+}
+
+// part[c][split][tile][4 i + j] -> cov[c][band(I,i)][band(J,j)] (and its mirror), band(I, i) = 18 i + I
+__global__ __launch_bounds__(256) void k_syrk4_reduce(const double *__restrict__ part, int nsplit,
+                                                       const int32_t *__restrict__ nuse, int p, double *__restrict__ cov) {
+  const int c = blockIdx.x;
+  const double denom = (double)nuse[c] - 1.0;
+  for (int idx = blockIdx.y * 256 + threadIdx.x; idx < C4_NTRI * 16; idx += 256 * gridDim.y) {
+    const int t = idx >> 4, i = (idx >> 2) & 3, j = idx & 3;
+    int I = 0, rem = t, rowlen = C4_NG;
+    while (rem >= rowlen) { rem -= rowlen; ++I; --rowlen; }
+    const int J = I + rem;
+    double s = 0;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[((size_t)c * nsplit + sp) * (C4_NTRI * 16) + idx];
+    s /= denom;
+    const int a = C4_NG * i + I, b = C4_NG * j + J;
+    if (a < p && b < p) {
+      if (I != J) {
+        cov[((size_t)c * p + a) * p + b] = s;
+        cov[((size_t)c * p + b) * p + a] = s;
+      } else if (i <= j) {   // diagonal tile: keep one of the two (identical) halves
+        cov[((size_t)c * p + a) * p + b] = s;
+        cov[((size_t)c * p + b) * p + a] = s;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+size_t sf_cov4_scratch_bytes(const SfGeom &g) {
+  return sf_align((size_t)g.ncols * sf_sweep_splits(g.lines, g.ncols) * C4_NTRI * 16 * sizeof(double));
+}
+
+int sf_launch_cov4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
+                   double *cov, void *scratch, hipStream_t st) {
+  const int nsplit = sf_sweep_splits(g.lines, g.ncols);
+  int rows = sf_cdiv(g.lines, nsplit);
+  rows = (rows + 127) / 128 * 128;   // whole prefetch rings: 4 waves x 16 rows x depth 2
+  double *part = reinterpret_cast<double *>(scratch);
+#ifdef SF_SWEEP_EXPERIMENTS
+  extern int g_cov_variant;
+  if (g_cov_variant == 11)
+    hipLaunchKernelGGL(k_syrk4<1>, dim3(g.ncols, nsplit), dim3(256), 0, st, xt, mask_t, mu, g.lines, g.p, rows, part);
+  else if (g_cov_variant == 12)
+    hipLaunchKernelGGL(k_syrk4<2>, dim3(g.ncols, nsplit), dim3(256), 0, st, xt, mask_t, mu, g.lines, g.p, rows, part);
+  else
+#endif
+  hipLaunchKernelGGL(k_syrk4<0>, dim3(g.ncols, nsplit), dim3(256), 0, st, xt, mask_t, mu, g.lines, g.p, rows, part);
+  SF_LAUNCH_CHECK("k_syrk4");
+  hipLaunchKernelGGL(k_syrk4_reduce, dim3(g.ncols, 4), dim3(256), 0, st, part, nsplit, nuse, g.p, cov);
+  SF_LAUNCH_CHECK("k_syrk4_reduce");
+  return 0;
+}

@@ -49,12 +49,12 @@ __global__ void k_wfrag4(const double *__restrict__ evec, const double *__restri
   }
 }
 
-// LDS reads the compiler may not move or merge: issue order = source order, completion is awaited explicitly with
+// LDS reads (into AGPRs: MFMA operands only, keeps the VALU-visible file free) the compiler may not move or merge: issue order = source order, completion is awaited explicitly with
 // lds_wait<N>() whose operands tie the loaded registers to the wait (nothing can read them before it).
 template <int OFF>
 __device__ __forceinline__ double lds_ld(unsigned addr) {
   double r;
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=a"(r) : "v"(addr), "n"(OFF));
   return r;
 }
 template <int CNT>
@@ -63,15 +63,15 @@ __device__ __forceinline__ void lds_wait(double &a, double &b) {
 }
 template <int CNT>
 __device__ __forceinline__ void lds_wait1(double &a) {
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT));
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(a) : "n"(CNT));
 }
 template <int CNT>
 __device__ __forceinline__ void lds_wait4(double &a, double &b, double &c, double &d) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT));
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+a"(a), "+a"(b), "+a"(c), "+a"(d) : "n"(CNT));
 }
 template <int CNT>
 __device__ __forceinline__ void lds_wait6(double &a, double &b, double &c, double &d, double &e, double &f) {
-  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(CNT));
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+a"(a), "+a"(b), "+a"(c), "+a"(d), "+a"(e), "+a"(f) : "n"(CNT));
 }
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -109,23 +109,36 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
     return;
   }
   const double n = (double)nuse[c];
+  // ---- prologue.  The alpha grid and the eigenvalues are staged in LDS first (the fragment loop would otherwise
+  //      wait on two dependent global loads per entry), and the global -> LDS copies are issued in batches.
   for (int i = tid; i < 4 * NJ; i += 256) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
   {
-    const double *lc = lam + (size_t)c * p;
+    double *ta = wblk, *tl = wblk + NA16;   // temporaries in the W area (filled afterwards)
+    for (int i = tid; i < NA16; i += 256) ta[i] = (i < nalpha) ? alphas[i] : 1.0;
+    for (int i = tid; i < 4 * NJ; i += 256) tl[i] = (i < p) ? lam[(size_t)c * p + i] : 1.0;
+    __syncthreads();
+    // fragment position idx = tid + 256 k: the lane is fixed, so alpha = 16 u + (lane & 15), eigen index = 4 jg + (lane >> 4)
+#pragma unroll 2
     for (int idx = tid; idx < NM * NJ * 64; idx += 256) {
-      const int ln = idx & 63, us = idx >> 6;
+      const int us = idx >> 6;
       const int u = us / NJ, jg = us - u * NJ;
-      const int i = 16 * u + (ln & 15), j = 4 * jg + (ln >> 4);
-      double v = 0.0;
-      if (i < nalpha && j < p) {
-        const double a = alphas[i];
-        const double beta = (1.0 - a) / (n - 1.0);
-        v = -beta / ((n * beta) * lc[j] + a);   // GEMM2 accumulates q = 1 - beta r directly (accumulator starts at 1)
-      }
-      cfrag[idx] = v;
+      const double a = ta[16 * u + li], lj = tl[4 * jg + g];
+      const double beta = (1.0 - a) / (n - 1.0);
+      const double v = -beta / ((n * beta) * lj + a);   // GEMM2 accumulates q = 1 - beta r directly (accumulator starts at 1)
+      cfrag[idx] = (16 * u + li < nalpha && 4 * jg + g < p) ? v : 0.0;
     }
+    __syncthreads();
     const double *wsrc = wfrag + (size_t)c * wstride;
-    for (int i = tid; i < NJ * NJ * 16; i += 256) wblk[i] = wsrc[i];
+    constexpr int WN = NJ * NJ * 16;   // 5184 = 20.25 x 256
+#pragma unroll
+    for (int k0 = 0; k0 < 5; ++k0) {
+      double t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = wsrc[tid + 256 * (4 * k0 + k)];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wblk[tid + 256 * (4 * k0 + k)] = t[k];
+    }
+    if (tid < WN - 20 * 256) wblk[tid + 20 * 256] = wsrc[tid + 20 * 256];
   }
   __syncthreads();
 

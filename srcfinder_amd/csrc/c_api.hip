@@ -11,6 +11,7 @@
 extern int g_score_variant, g_score_lpw, g_score_xcd;  // cmf_score.hip
 extern int g_sweep_variant;                            // cmf_loocv.hip
 extern int g_cov_variant;                              // cmf_cov.hip
+extern int g_extract_variant;                          // cmf_extract.hip
 
 namespace {
 thread_local char g_err[512] = "";
@@ -252,6 +253,7 @@ int sf_debug_set(int key, int value) {
     case 3: g_score_xcd = value; return 0;
     case 4: g_sweep_variant = value; return 0;
     case 5: g_cov_variant = value; return 0;
+    case 6: g_extract_variant = value; return 0;
     default: sf_set_error("sf_debug_set: unknown key %d", key); return -1;
   }
 }

@@ -78,12 +78,11 @@ static inline SfGeom sf_geom(int lines, int p, int ncols, int nalpha) {
 
 // split counts (deterministic functions of the geometry so that results do not depend on the GPU)
 static inline int sf_extract_lines_per_wg(int lines, int ncols) {
-  // ~2048 workgroups (2 resident per CU, several rounds), but never more than 256 line chunks: every chunk
-  // leaves a partial-sum record per column that the mean kernel has to read back
-  int colblocks = sf_cdiv(ncols, 64);
-  int target = sf_cdiv(2048, colblocks);
-  if (target > 256) target = 256;
-  int lpw = sf_cdiv(lines, target);
+  // <= 250 line chunks: every chunk leaves a partial-sum record per column that the mean kernel reads back.
+  // Deliberately independent of the number of columns: the chunk boundaries fix the order in which a column's
+  // masked sum is accumulated, and that must not depend on how the columns are sharded over ranks.
+  (void)ncols;
+  int lpw = sf_cdiv(lines, 250);
   lpw = (lpw + 3) / 4 * 4;
   return lpw < 4 ? 4 : lpw;
 }

@@ -224,6 +224,7 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
     nsteps = (sweep + 1) * m;
   }
   __syncthreads();
+  if (chol_ok && tid == 0) rot[(size_t)c * rot_stride] = make_double2((double)(nsteps / m), 0.0);  // tools/probe_eigh.py
   if (chol_ok) {
     // G = U diag(sigma): lam = sigma^2, eigenvector = normalised column
     for (int j = tid; j < p; j += nthr) {

@@ -224,7 +224,116 @@ __global__ __launch_bounds__(512) void k_mean(const double *__restrict__ sum_par
   }
 }
 
+// ---- narrow cubes (a rank's column shard held compactly: C == the number of columns wanted) ---------------
+// Here the whole active window of a line is ONE contiguous run of p*C floats, so the 64-column blocking above
+// (256-byte rows, a second block that is mostly idle lanes) is the wrong shape: k_extract_flat streams the run
+// with fully coalesced loads, one workgroup per line chunk, the next tile's loads in flight (registers) while
+// the current one is transposed out of LDS.  Same chunking and the same line order of the fused masked sums
+// as k_extract, so a column's mean is bit-identical whichever kernel (shard layout) produced it.
+constexpr int XF_NT = 1024;           // one 16-wave workgroup per line chunk: the grid is only ~250 workgroups, so the
+                                      // parallelism that hides LDS / HBM latency has to come from inside the workgroup
+constexpr int XF_MAXLD = 12;          // loads per thread per tile: tile <= 12 * 1024 floats = 48 KB
+constexpr int XF_MAXSUM = 6;          // (band, column) pairs per thread for the fused sums: p*C <= 6144
+
+__global__ __launch_bounds__(XF_NT) void k_extract_flat(const float *__restrict__ cube, int L, int B, int C, int b0,
+                                                       int p, int PS, int TL, float *__restrict__ xt,
+                                                       uint8_t *__restrict__ mask_t, int lines_per_wg,
+                                                       double *__restrict__ sum_part, int *__restrict__ cnt_part) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [TL][p][C], then int vf[TL][C]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = blockIdx.x;
+  const int rowlen = p * C;
+  int *vf = reinterpret_cast<int *>(tile + (size_t)TL * rowlen);
+  const int lbeg = chunk * lines_per_wg, lend = min(L, lbeg + lines_per_wg);
+  const bool fuse = sum_part != nullptr;
+  double sums[XF_MAXSUM];
+  int ccol[XF_MAXSUM];
+#pragma unroll
+  for (int k = 0; k < XF_MAXSUM; ++k) { sums[k] = 0.0; ccol[k] = (tid + XF_NT * k) % C; }
+  int nvalid = 0;
+
+  float v[XF_MAXLD];
+  auto fetch = [&](int l0) {
+    const int nl = min(TL, lend - l0);
+    const int n = nl * rowlen;
+#pragma unroll
+    for (int k = 0; k < XF_MAXLD; ++k) {
+      const int idx = min(tid + XF_NT * k, n - 1);            // clamped duplicates are loaded but not stored
+      const int l = (idx >= rowlen) + (idx >= 2 * rowlen) + (idx >= 3 * rowlen);
+      v[k] = cube[((size_t)(l0 + l) * B + b0) * C + (idx - l * rowlen)];
+    }
+  };
+  if (lbeg < lend) fetch(lbeg);
+  for (int l0 = lbeg; l0 < lend; l0 += TL) {
+    const int nl = min(TL, lend - l0);
+    const int n = nl * rowlen;
+#pragma unroll
+    for (int k = 0; k < XF_MAXLD; ++k)
+      if (tid + XF_NT * k < n) tile[tid + XF_NT * k] = v[k];
+    for (int i = tid; i < nl * C; i += XF_NT) vf[i] = 1;
+    if (l0 + TL < lend) fetch(l0 + TL);
+    __syncthreads();
+    // ---- validity of (line, column): four threads share the bands of one pixel
+    for (int i = tid; i < nl * C * 4; i += XF_NT) {
+      const int qd = i & 3, lc = i >> 2;
+      const int l = lc / C, c = lc - l * C;
+      const float *tp = tile + (size_t)l * rowlen + c;
+      bool ok = true;
+      for (int b = qd; b < p; b += 4) ok = ok & sf_valid(tp[b * C]);
+      if (!ok) vf[lc] = 0;   // benign race: every writer stores 0
+    }
+    __syncthreads();
+    // ---- LDS -> xt: a wave writes the nl*PS contiguous floats of a column
+    const int nel = nl * PS;
+    for (int c = wave; c < C; c += XF_NT / 64) {
+      float *dst = xt + ((size_t)c * L + l0) * PS;
+#pragma unroll 4
+      for (int k = lane; k < nel; k += 64) {
+        const int l = (k >= PS) + (k >= 2 * PS) + (k >= 3 * PS);
+        const int b = k - l * PS;
+        dst[k] = (b < p) ? tile[(size_t)l * rowlen + b * C + c] : 0.f;
+      }
+    }
+    for (int i = tid; i < nl * C; i += XF_NT) {
+      const int l = i / C, c = i - l * C;
+      mask_t[(size_t)c * L + l0 + l] = (uint8_t)vf[i];
+    }
+    if (fuse) {
+      // masked sums, lines in order (the order k_extract uses): thread owns pairs idx = tid + 256 k = b*C + c
+#pragma unroll
+      for (int k = 0; k < XF_MAXSUM; ++k) {
+        const int idx = tid + XF_NT * k;
+        if (idx < rowlen) {
+          for (int l = 0; l < nl; ++l) {   // branch-free: the two LDS reads of every line are independent
+            const double xv = (double)tile[(size_t)l * rowlen + idx];
+            sums[k] += vf[l * C + ccol[k]] ? xv : 0.0;
+          }
+        }
+      }
+      if (tid < C)
+        for (int l = 0; l < nl; ++l) nvalid += vf[l * C + tid];
+    }
+    __syncthreads();
+  }
+  if (fuse) {
+#pragma unroll
+    for (int k = 0; k < XF_MAXSUM; ++k) {
+      const int idx = tid + XF_NT * k;
+      if (idx < rowlen) {
+        const int b = idx / C;
+        sum_part[((size_t)chunk * C + ccol[k]) * PS + b] = sums[k];
+      }
+    }
+    if (tid < C) {
+      cnt_part[chunk * C + tid] = nvalid;
+      for (int b = p; b < PS; ++b) sum_part[((size_t)chunk * C + tid) * PS + b] = 0.0;
+    }
+  }
+}
+
 }  // namespace
+
+int g_extract_variant = 0;  // sf_debug_set key 6: 1 = never use the flat (narrow-cube) kernel
 
 static int extract_chunks(int lines, int ncols, int *lpw_out) {
   const int lpw = sf_extract_lines_per_wg(lines, ncols);
@@ -251,6 +360,23 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
   }
   int lpw;
   const int nchunk = extract_chunks(lines, ncols, &lpw);
+  // a compact narrow cube (a rank's shard): the flat kernel, if a tile of at least one line fits
+  if (s0 == 0 && ncols == samples && p <= XT_PBMAX && (size_t)p * ncols <= XF_NT * (size_t)XF_MAXSUM &&
+      ncols <= 256 && g_extract_variant != 1) {
+    int tl = (XF_NT * XF_MAXLD) / (p * ncols);
+    if (tl > 4) tl = 4;
+    const size_t ldsf = ((size_t)tl * p * ncols + (size_t)tl * ncols) * sizeof(float);
+    static size_t lds_set = 0;
+    if (ldsf > lds_set) {
+      SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract_flat),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * 1024)));
+      lds_set = 64 * 1024;
+    }
+    hipLaunchKernelGGL(k_extract_flat, dim3(nchunk), dim3(XF_NT), ldsf, st, cube, lines, bands, samples, b0, p, PS, tl, xt,
+                       mask_t, lpw, fuse ? sum_part : nullptr, fuse ? cnt_part : nullptr);
+    SF_LAUNCH_CHECK("k_extract_flat");
+    return 0;
+  }
   const int ncb = sf_cdiv(ncols, 64);
   if (fuse)
     hipLaunchKernelGGL((k_extract<TL, true>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), lds, st, cube, lines, bands,

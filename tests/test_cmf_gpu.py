@@ -380,3 +380,23 @@ def test_column_profile_and_systematics(torch_cuda, library):
     avg[40] += 50 * np.nanstd(avg)                       # a planted systematic column
     coldiff, sigma, counts = triage.systematics_flags(avg)
     assert sigma > 0 and counts[2] >= 1 and np.nanargmax(coldiff) == 40
+
+
+def test_narrow_cube_extract_is_bit_identical(torch_cuda, library):
+    """A compact narrow cube (one rank's shard) takes the flat extract kernel; forcing the blocked kernel on the
+    same cube, and cutting the same columns out of a wider cube, must give bit-identical products."""
+    L = _ffi.lib()
+    wide = make_cube_numpy(203, 150, seed=77, abscf_full=library[:, 2], nodata_column=33)
+    narrow = np.ascontiguousarray(wide[:, :, 20:95])
+    try:
+        L.sf_debug_set(6, 0)
+        a = cmf.robust_mf(narrow, library, metadata=True, to_numpy=True)
+        L.sf_debug_set(6, 1)
+        b = cmf.robust_mf(narrow, library, metadata=True, to_numpy=True)
+    finally:
+        L.sf_debug_set(6, 0)
+    c = cmf.robust_mf(wide, library, metadata=True, to_numpy=True, columns=(20, 95))
+    for x, y in ((a, b), (a, c)):
+        assert np.array_equal(x.out, y.out) and np.array_equal(x.bgmeta, y.bgmeta)
+        assert np.array_equal(x.alphaidx, y.alphaidx) and np.array_equal(x.nuse, y.nuse)
+        assert np.array_equal(x.colstats, y.colstats, equal_nan=True)

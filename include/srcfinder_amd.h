@@ -102,6 +102,31 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
                int32_t *alphaidx, int32_t *nuse, int32_t *status, double *colstats,
                int16_t *bgmeta, double *nll_out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- multimodal background (cmf/robust_mf.py:306-332, -k > 1) ------------------------------------------------
+ * The per-cluster statistics are stages 2..6 above run with the row mask  valid & (label == k)  (stage 5 takes the
+ * COLUMN's valid-row count as n, as the reference passes `nuse`, :355-356).  The three entry points below are what
+ * the unimodal path does not have.
+ *
+ * Cluster labels (:309-313): rows of a column in the top-`pcadim` whitened principal coordinates of the
+ * eigenbasis of stage 4, then deterministic Lloyd iterations from along-track quantile seeds.  The reference's
+ * MiniBatchKMeans is unseeded and cannot be reproduced; labels_t[ncols][lines] uint8 (255 = invalid row) is a pure
+ * function of (data, k, seed).  scratch >= ncols * lines * pcadim floats.  k <= 8, pcadim <= 8. */
+int sf_cmf_kmeans(const float *xt, const uint8_t *mask_t, const double *mu, const double *d, const double *lam,
+                  const double *evec, int lines, int p, int ncols, int k, int pcadim, unsigned long long seed, int iters,
+                  uint8_t *labels_t, void *scratch, void *stream);
+
+/* Matched filter of ONE cluster (:377-386): rows with rowmask_t[ncols][lines] != 0 get their score in the last
+ * band of `out` (0 when status == 2, :371-374) and the (cluster, alpha index) pair in bgmeta (:327, :365); every
+ * other pixel is left as it is (initialise the product with sf_cmf_score and an all-zero filter first). */
+int sf_cmf_score_cluster(const float *cube, int lines, int bands, int samples, int s0, int s1, int b0, int p,
+                         const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,
+                         const uint8_t *rowmask_t, int cluster, double *out, int out_samples, int out_s0, int out_bands,
+                         int16_t *bgmeta, void *stream);
+
+/* Column statistics of the finished product over a column's valid rows (:388-392): colstats[3][ncols]. */
+int sf_cmf_colstats_rows(const double *out, int out_samples, int out_s0, int out_bands, const uint8_t *mask_t, int lines,
+                         int ncols, double nodata, double *colstats, void *stream);
+
 /* Column profile of a finished product (triage/cmf_profile.py:110-140, the default non-robust statistics):
  * over the pixels of band `band` of img[lines][samples][nbands] (float64) that are not NODATA/NaN and > 0 (after the
  * float32 cast the reference applies): profile[5][samples] = npix, mean, std (ddof 0), min, max (NaN where npix = 0).

@@ -237,3 +237,65 @@ def robust_mf_oracle(cube_bil: np.ndarray, library: np.ndarray, *, gas="ch4", re
     if return_nll:
         res["nll"] = nll_all
     return res
+
+
+def robust_mf_multimodal_oracle(cube_bil: np.ndarray, library: np.ndarray, labels: np.ndarray, *, gas="ch4",
+                                reflectance=False, rgb_bands=(60, 42, 24), nodata=-9999.0, active=None,
+                                shrinkage=looshrinkage):
+    """Multimodal (k > 1) column loop of cmf/robust_mf.py:297-397 with the cluster labels INJECTED
+    (labels[lines, samples], ids >= 0; what the reference's unseeded MiniBatchKMeans chose, :312-313, as stored
+    in its bgmeta image, :327).  No rejection (-r) and no full-column regulariser (-f).  Per cluster of a
+    column (:336-386): its own mean, looshrinkage with n = the COLUMN's valid-row count (the reference passes
+    `nuse`, :355-356, not the cluster size), its own inverse and matched filter.
+    Returns dict(out, bgmeta, colstats, alphaidx[samples, k] (-2 = cluster absent), status[samples, k])."""
+    lines, nbands, samples = cube_bil.shape
+    lib = np.float64(np.asarray(library))
+    abscf_full = lib[:, 2] if lib.ndim == 2 else lib
+    a0, a1 = active if active is not None else active_window(gas, reflectance)
+    abscf = abscf_full[a0 - 1:a1]
+    alphas = alpha_grid()
+    nll = np.zeros(len(alphas))
+    nrgb = len(rgb_bands)
+    k = int(labels.max()) + 1
+    out = np.zeros((lines, samples, 4 if nrgb == 3 else 1), np.float64)
+    out[:, :, -1] = nodata
+    bgmeta = np.zeros((lines, samples, 2), np.int16)
+    colstats = np.ones((3, samples)) * nodata
+    alphaidx = np.full((samples, k), -2, np.int64)
+    status = np.zeros((samples, k), np.int32)
+    for col in range(samples):
+        icol_full = cube_bil[:, a0 - 1:a1, col]
+        use = useidx(icol_full)
+        icol = np.float64(icol_full[use, :].copy())
+        nuse = icol.shape[0]
+        if nuse == 0:
+            continue
+        bglabels = labels[use, col]
+        for ki in np.unique(bglabels):
+            kmask = bglabels == ki
+            bgmeta[use[kmask], col, 0] = ki                                        # :327
+            icol_ki = icol[kmask, :].copy()
+            mu = np.mean(icol_ki, axis=0)
+            try:
+                c, aidx = shrinkage(icol_ki - mu, alphas, nll, nuse)               # n = nuse of the column (:355)
+                alphaidx[col, ki] = aidx
+                cinv = inv(c)
+                bgmeta[use[kmask], col, 1] = aidx
+            except sla.LinAlgError:
+                out[use[kmask], col, -1] = 0
+                status[col, ki] = 2
+                continue
+            xc = icol_ki - mu
+            target = abscf.copy()
+            target = target - mu if reflectance else target * mu
+            normalizer = target.dot(cinv).dot(target.T)
+            mf = (xc.dot(cinv).dot(target.T)) / normalizer
+            out[use[kmask], col, -1] = mf if reflectance else mf * PPM_SCALING
+        colpix = out[use, col, -1]
+        colstats[0, col] = nuse
+        colstats[1, col] = np.mean(colpix)
+        colstats[2, col] = np.std(colpix)
+        if nrgb == 3:
+            for oi, bi in enumerate(rgb_bands):
+                out[:, col, oi] = cube_bil[:, bi, col]
+    return dict(out=out, bgmeta=bgmeta, colstats=colstats, alphaidx=alphaidx, status=status)

@@ -94,6 +94,8 @@ class CMFResult:
     status: object
     nll: object = None
     modelparms: str = ""
+    labels: object = None      # multimodal only: [lines, samples] uint8 cluster of every row (255 = invalid row);
+                               # alphaidx / status are then [samples, k] (status 1 = cluster absent in the column)
 
 
 class _Workspace:
@@ -120,8 +122,9 @@ def _abscf_from_library(library, a0, a1):
 
 def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcadim=6, reject=False, full=False,
               model="looshrinkage", rgb_bands=(60, 42, 24), nodata=NODATA_DEFAULT, active=None, metadata=False,
-              columns=None, out=None, out_column0=0, return_nll=False, to_numpy=False):
-    """Unimodal columnwise matched filter of a BIL radiance cube.
+              columns=None, out=None, out_column0=0, return_nll=False, to_numpy=False, labels=None, kmeans_seed=0,
+              kmeans_iters=30):
+    """Columnwise matched filter of a BIL radiance cube (unimodal, or multimodal with ``kmeans`` > 1).
 
     cube_bil : [lines, bands, samples] float32, torch tensor on the GPU (preferred: stays resident) or
                ndarray (copied once).
@@ -129,10 +132,18 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
     columns  : optional (s0, s1) shard of samples to process (multi-GPU sharding); outputs then cover only
                those columns unless ``out`` (a preallocated [lines, S, nb] float64 tensor) and
                ``out_column0`` say where to put them.
+    kmeans   : number of background modes per column (robust_mf.py:306-332).  The rows of a column are clustered
+               on the device (``kmeans_seed``: the labels are a pure function of data, k and seed -- the reference's
+               MiniBatchKMeans is unseeded) unless ``labels`` ([lines, samples] ints >= 0, e.g. the cluster band of
+               a reference bgmeta image) injects them; ``result.labels`` holds the labels used.
     """
     torch = _torch()
-    if kmeans != 1 or reject or full:
-        raise NotImplementedError("multimodal background (-k > 1, -r, -f) is not built (SURVEY.md §8 N1)")
+    if reject or full:
+        raise NotImplementedError("cluster rejection (-r) and the full-column regulariser (-f) are not built "
+                                  "(SURVEY.md §8 N1)")
+    kmeans = int(kmeans)
+    if kmeans < 1 or kmeans > 8:
+        raise ValueError("kmeans must be in 1..8")
     if model != "looshrinkage":
         raise NotImplementedError("only the looshrinkage model is built (the 'empirical' branch of the "
                                   "reference hits a NameError, SURVEY.md D7)")
@@ -177,6 +188,20 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
             bgmeta.zero_()
         nll = torch.empty((ncols, nalpha), dtype=torch.float64, device=dev) if return_nll else None
         L = _ffi.lib()
+        if kmeans > 1:
+            if return_nll:
+                raise NotImplementedError("return_nll with kmeans > 1")
+            r = rgb_bands if nb == 4 else (0, 0, 0)
+            res = _multimodal(torch, L, cube_bil, lines, bands, samples, s0, s1, a0, p, abscf, alphas, nalpha,
+                              bool(reflectance), r, float(nodata), out_t, out_samples, out_s0, nb, bgmeta, kmeans,
+                              int(pcadim), labels, int(kmeans_seed), int(kmeans_iters))
+            res.modelparms = model_parameters(reflectance, (a0, a1), bgmodes=kmeans)
+            if to_numpy:
+                for k in ("out", "bgmeta", "colstats", "alphaidx", "nuse", "status", "labels"):
+                    v = getattr(res, k)
+                    if v is not None:
+                        setattr(res, k, v.cpu().numpy())
+            return res
         wsb = L.sf_cmf_workspace_bytes(lines, p, ncols, nalpha)
         ws = _Workspace.get(wsb, dev)
         r = rgb_bands if nb == 4 else (0, 0, 0)
@@ -194,6 +219,81 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
             if v is not None:
                 setattr(res, k, v.cpu().numpy())
     return res
+
+
+def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alphas, nalpha, reflectance, rgb, nodata,
+                out_t, out_samples, out_s0, nb, bgmeta, k, pcadim, labels, seed, iters):
+    """Multimodal column loop (robust_mf.py:306-386, no -r / -f): stage entry points of the C ABI, once per
+    cluster with the row mask  valid & (label == ki);  stage 5 gets the COLUMN's valid-row count as n (:355-356)."""
+    if p > 96:
+        raise NotImplementedError("multimodal background needs an active window of <= 96 bands")
+    dev = cube.device
+    ncols = s1 - s0
+    ps = (p + 3) // 4 * 4
+    P, st = _ffi.ptr, _ffi.stream_ptr()
+    f64 = dict(dtype=torch.float64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    ws = _Workspace.get(L.sf_cmf_workspace_bytes(lines, p, ncols, nalpha), dev)
+    xt = torch.empty((ncols, lines, ps), dtype=torch.float32, device=dev)
+    mask = torch.empty((ncols, lines), dtype=torch.uint8, device=dev)
+    nuse_col, nuse_k, status_k, aidx_k = (torch.empty(ncols, **i32) for _ in range(4))
+    mu = torch.empty((ncols, p), **f64)
+    S = torch.empty((ncols, p, p), **f64)
+    d = torch.empty((ncols, p), **f64)
+    lam = torch.empty((ncols, p), **f64)
+    evec = torch.empty((ncols, p, p), **f64)
+    nll = torch.empty((ncols, nalpha), **f64)
+    filt = torch.zeros((ncols, p), **f64)
+    bias = torch.zeros(ncols, **f64)
+    colstats = torch.empty((3, ncols), **f64)
+    check = _ffi.check
+
+    def stats(m, n_rows, n_loo, status, want_alpha=True):
+        check(L.sf_cmf_column_mean(P(xt), 0, P(m), lines, p, ncols, P(n_rows), P(mu), P(ws), st), "sf_cmf_column_mean")
+        check(L.sf_cmf_covariance(P(xt), 0, P(m), P(n_rows), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
+        check(L.sf_cmf_eigh(P(S), P(n_rows), p, ncols, P(d), P(lam), P(evec), P(status), P(ws), st), "sf_cmf_eigh")
+        if want_alpha:
+            check(L.sf_cmf_loocv(P(xt), 0, P(m), P(n_loo), P(mu), P(d), P(lam), P(evec), P(status), P(alphas), nalpha,
+                                 lines, p, ncols, P(nll), P(aidx_k), P(ws), st), "sf_cmf_loocv")
+
+    check(L.sf_cmf_extract_columns(P(cube), lines, bands, samples, s0, s1, a0 - 1, p, P(xt), P(mask), st), "sf_cmf_extract_columns")
+    if labels is None:
+        stats(mask, nuse_col, nuse_col, status_k, want_alpha=False)      # eigenbasis of the whole column: the PCA axes
+        labels_t = torch.empty((ncols, lines), dtype=torch.uint8, device=dev)
+        scratch = torch.empty(ncols * lines * pcadim, dtype=torch.float32, device=dev)
+        check(L.sf_cmf_kmeans(P(xt), P(mask), P(mu), P(d), P(lam), P(evec), lines, p, ncols, k, pcadim, seed, iters,
+                              P(labels_t), P(scratch), st), "sf_cmf_kmeans")
+    else:
+        lab = labels if torch.is_tensor(labels) else torch.as_tensor(np.ascontiguousarray(labels))
+        if tuple(lab.shape) != (lines, samples):
+            raise ValueError("labels must be [lines, samples]")
+        if int(lab.min()) < 0 or int(lab.max()) >= k:
+            raise ValueError("labels must be cluster ids in 0..%d" % (k - 1))
+        labels_t = lab.to(dev)[:, s0:s1].t().contiguous().to(torch.uint8)
+        check(L.sf_cmf_column_mean(P(xt), 0, P(mask), lines, p, ncols, P(nuse_col), P(mu), P(ws), st), "sf_cmf_column_mean")
+    # ---- the product starts as: NODATA on invalid rows, 0 on valid ones, RGB copied (a zero filter through stage 7)
+    status0 = (nuse_col == 0).to(torch.int32)                           # 1 = column without a valid row: skipped (:303-304)
+    zero_idx = torch.zeros(ncols, **i32)
+    check(L.sf_cmf_score(P(cube), lines, bands, samples, s0, s1, a0 - 1, p, P(filt), P(bias), P(status0), P(zero_idx),
+                         P(nuse_col), rgb[0], rgb[1], rgb[2], nodata, P(out_t), out_samples, out_s0, nb, P(bgmeta), None,
+                         P(ws), st), "sf_cmf_score")
+    alphaidx = torch.full((ncols, k), -2, **i32)
+    status = torch.ones((ncols, k), **i32)
+    labels_valid = torch.where(mask != 0, labels_t, torch.full_like(labels_t, 255))
+    for ki in range(k):
+        mask_k = (labels_valid == ki).to(torch.uint8)
+        stats(mask_k, nuse_k, nuse_col, status_k)
+        check(L.sf_cmf_filter(P(mu), P(d), P(lam), P(evec), P(alphas), P(aidx_k), P(abscf), int(reflectance), p, ncols,
+                              P(status_k), P(filt), P(bias), st), "sf_cmf_filter")
+        check(L.sf_cmf_score_cluster(P(cube), lines, bands, samples, s0, s1, a0 - 1, p, P(filt), P(bias), P(status_k),
+                                     P(aidx_k), P(mask_k), ki, P(out_t), out_samples, out_s0, nb, P(bgmeta), st),
+              "sf_cmf_score_cluster")
+        alphaidx[:, ki] = torch.where(status_k == 1, torch.full_like(aidx_k, -2), aidx_k)
+        status[:, ki] = status_k
+    check(L.sf_cmf_colstats_rows(P(out_t), out_samples, out_s0, nb, P(mask), lines, ncols, nodata, P(colstats), st),
+          "sf_cmf_colstats_rows")
+    return CMFResult(out=out_t, bgmeta=bgmeta, colstats=colstats, alphaidx=alphaidx, nuse=nuse_col, status=status,
+                     labels=labels_valid.t().contiguous())
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -287,8 +287,16 @@ __global__ __launch_bounds__(256) void k_nll(const double *__restrict__ part, in
         rsum += pp[NA16 + i];
       }
       // k_sweep4 hands over beta sum r/q.  beta = 0 (alpha = 1): G = diag S, q = 1 and
-      // sum_k r_k = sum_k sum_b x_kb^2 / S_bb = (n - 1) p.
-      if (rq_scaled) rsum = (beta > 0.0) ? rsum / beta : (n - 1.0) * (double)p;
+      // sum_k r_k = sum_k sum_b x_kb^2 / S_bb = (rows - 1) p, rows = the rows the covariance was made of (the
+      // sweep counts them: a cluster's statistics are swept with the COLUMN's n, robust_mf.py:355-356).
+      if (rq_scaled) {
+        double rows = n;
+        if (nalpha < NA16) {
+          rows = 0.0;
+          for (int sp = 0; sp < nsplit; ++sp) rows += part[((size_t)c * nsplit + sp) * 2 * NA16 + 2 * NA16 - 1];
+        }
+        rsum = (beta > 0.0) ? rsum / beta : (rows - 1.0) * (double)p;
+      }
       if (ld < -744.4400719213812) {
         v = inf;  // det underflowed to 0 -> the reference skips this alpha (robust_mf.py:112-113)
       } else {

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
 #pragma unroll
   for (int u = 0; u < NM; ++u) { P[u] = 1.0; N[u] = 0.0; E[u] = 0; }
   int ntile = 0;
+  int nrowok = 0;   // valid rows seen by this lane (lanes with g == 0 cover every row of the wave's tiles once)
 
   const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
   const uint8_t *mp = mask_t + (size_t)c * L;
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
   if (EXP == 4) r0 = rend;   // timing experiment: prologue + final reduction only
   for (; r0 < rend; r0 += 16 * 4) {
     const bool rowok = rowok_next;
+    nrowok += (rowok && g == 0) ? 1 : 0;
     int opq = 0;
     asm volatile("" : "+v"(opq));  // keeps the loop-invariant LDS operand reads inside the iteration (see k_sweep)
     const double *cfl = cf + opq;
@@ -346,6 +348,14 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
     po[i] = log(pv) + (double)ev * 0.6931471805599453094;
     po[NA16 + i] = rv;   // = beta_i sum_k r_k/q_k: k_nll divides (rq_scaled = 1)
   }
+  // the number of rows this workgroup accumulated, for the beta = 0 term of k_nll: kept in the last padding slot
+  // of the alpha axis (the grid has 201 points, the tiles 208)
+  __syncthreads();
+  int *cred = reinterpret_cast<int *>(sm);
+  for (int off = 32; off > 0; off >>= 1) nrowok += __shfl_xor(nrowok, off, 64);
+  if (lane == 0) cred[wave] = nrowok;
+  __syncthreads();
+  if (tid == 0 && nalpha < NA16) po[2 * NA16 - 1] = (double)(cred[0] + cred[1] + cred[2] + cred[3]);
 }
 
 constexpr size_t SW4_LDS = ((size_t)S4M * S4J * 64 + S4J * S4J * 16 + 4 * S4J) * sizeof(double);

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Golden vectors for the multimodal background (-k 2) by EXECUTING THE REAL REFERENCE (development container only).
+
+Run:  OMP_NUM_THREADS=1 python tests/golden/gen_golden_multimodal.py      (needs /root/reference and scikit-learn)
+
+The reference's MiniBatchKMeans is unseeded (cmf/robust_mf.py:312); numpy's global RandomState, which sklearn
+falls back to, is seeded here so that the run can be repeated, and the labels the reference chose are part of
+the golden anyway: the bgmeta image holds (cluster id, alpha index) per valid pixel (:327, :365).  The parity
+tests inject those labels and compare everything downstream of the clustering.
+"""
+import os
+import sys
+
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gen_golden as G  # noqa: E402
+
+
+def main():
+    G.install_spectral_stub()
+    lib = np.float64(np.loadtxt(G.LIB_TXT))
+    lines, samples, seed = 1600, 5, 555
+    cube = G.make_cube_numpy(lines, samples, seed=seed, abscf_full=lib[:, 2], nodata_column=3)
+    # a second background mode: brighten the scene over part of the flightline (different mean and covariance)
+    cube[600:1150] *= np.float32(1.35)
+    np.random.seed(7)
+    r = G.run_reference_main(cube, extra_args=("-k", "2"), tag="K2")
+    lab = r["bgmeta"][:, :, 0]
+    print("cluster sizes per column:", [(int((lab[:, c] == 0).sum()), int((lab[:, c] == 1).sum())) for c in range(samples)])
+    print("alpha idx:", np.unique(r["bgmeta"][:, :, 1]))
+    np.savez_compressed(os.path.join(HERE, "cmf_K2_multimodal.npz"), seed=seed, lines=lines, samples=samples,
+                        nodata_column=3, bright=np.array([600, 1150, 1.35]), out=r["out"], bgmeta=r["bgmeta"],
+                        colstats=r["colstats"], modelparms=np.array(r["modelparms"]), versions=G.versions())
+
+
+if __name__ == "__main__":
+    main()

@@ -400,3 +400,52 @@ def test_narrow_cube_extract_is_bit_identical(torch_cuda, library):
         assert np.array_equal(x.out, y.out) and np.array_equal(x.bgmeta, y.bgmeta)
         assert np.array_equal(x.alphaidx, y.alphaidx) and np.array_equal(x.nuse, y.nuse)
         assert np.array_equal(x.colstats, y.colstats, equal_nan=True)
+
+
+def _k2_cube(g, library):
+    lines, samples = int(g["lines"]), int(g["samples"])
+    cube = make_cube_numpy(lines, samples, seed=int(g["seed"]), abscf_full=library[:, 2], nodata_column=int(g["nodata_column"]))
+    b0, b1, f = g["bright"]
+    cube[int(b0):int(b1)] *= np.float32(f)
+    return cube
+
+
+def test_multimodal_golden_with_injected_labels(torch_cuda, golden_dir, library):
+    """N1: -k 2 golden of the real reference.  With the reference's own cluster labels injected, everything
+    downstream of the clustering must match: NODATA placement, labels and alpha indices exactly, scores to 1e-4."""
+    g = np.load(os.path.join(golden_dir, "cmf_K2_multimodal.npz"))
+    cube = _k2_cube(g, library)
+    lab = g["bgmeta"][:, :, 0].astype(np.int64)
+    res = cmf.robust_mf(cube, library, kmeans=2, labels=lab, metadata=True, to_numpy=True)
+    ref = g["out"]
+    assert np.array_equal(res.out[..., 3] == -9999.0, ref[..., 3] == -9999.0)
+    assert np.array_equal(res.out[..., :3], ref[..., :3])
+    assert np.array_equal(res.bgmeta, g["bgmeta"])
+    assert score_close(res.out[..., 3], ref[..., 3]).all()
+    ok = g["colstats"][0] > 0
+    assert np.array_equal(res.colstats[0][ok], g["colstats"][0][ok])
+    np.testing.assert_allclose(res.colstats[1:, ok], g["colstats"][1:, ok], rtol=1e-6, atol=1e-9 * np.abs(ref[..., 3]).max())
+
+
+def test_multimodal_device_kmeans(torch_cuda, golden_dir, library):
+    """Device k-means: deterministic (same seed -> same labels), finds the planted bright region the reference's
+    MiniBatchKMeans found (>= 90 % agreement up to a permutation), and the pipeline downstream of ITS labels matches
+    the oracle run with the same labels."""
+    g = np.load(os.path.join(golden_dir, "cmf_K2_multimodal.npz"))
+    cube = _k2_cube(g, library)
+    a = cmf.robust_mf(cube, library, kmeans=2, metadata=True, to_numpy=True, kmeans_seed=3)
+    b = cmf.robust_mf(cube, library, kmeans=2, metadata=True, to_numpy=True, kmeans_seed=3)
+    assert np.array_equal(a.labels, b.labels) and np.array_equal(a.out, b.out)
+    ref_lab = g["bgmeta"][:, :, 0]
+    valid = a.labels != 255
+    for c in range(cube.shape[2]):
+        v = valid[:, c]
+        if not v.any():
+            continue
+        agree = np.mean(a.labels[v, c] == ref_lab[v, c])
+        assert max(agree, 1.0 - agree) >= 0.9, (c, agree)
+    lab = np.where(valid, a.labels, 0).astype(np.int64)
+    o = O.robust_mf_multimodal_oracle(cube, library, lab)
+    assert np.array_equal(a.out[..., 3] == -9999.0, o["out"][..., 3] == -9999.0)
+    assert np.array_equal(a.bgmeta, o["bgmeta"])
+    assert score_close(a.out[..., 3], o["out"][..., 3]).all()

@@ -125,3 +125,17 @@ def test_wrappers(golden_dir):
     np.testing.assert_allclose(O.det(O.cov(a)), g["wrap_det"], rtol=1e-10)
     ev, evec = O.eig(O.cov(a))
     np.testing.assert_allclose(np.sort(ev.real), np.sort(g["wrap_eigvals"].real), rtol=1e-9)
+
+
+def test_multimodal_oracle_reproduces_reference_with_injected_labels(golden_dir, library):
+    """-k 2 golden from the real reference (tests/golden/gen_golden_multimodal.py): with the reference's own cluster
+    labels injected, the restatement reproduces scores, alpha indices and column statistics bit for bit."""
+    g = np.load(os.path.join(golden_dir, "cmf_K2_multimodal.npz"))
+    lines, samples = int(g["lines"]), int(g["samples"])
+    cube = make_cube_numpy(lines, samples, seed=int(g["seed"]), abscf_full=library[:, 2], nodata_column=int(g["nodata_column"]))
+    b0, b1, f = g["bright"]
+    cube[int(b0):int(b1)] *= np.float32(f)
+    o = O.robust_mf_multimodal_oracle(cube, library, g["bgmeta"][:, :, 0].astype(np.int64))
+    assert np.array_equal(o["out"], g["out"])
+    assert np.array_equal(o["bgmeta"], g["bgmeta"])
+    assert np.array_equal(o["colstats"], g["colstats"])

@@ -134,6 +134,12 @@ int sf_cmf_colstats_rows(const double *out, int out_samples, int out_s0, int out
 int sf_cmf_column_profile(const double *img, int lines, int samples, int nbands, int band, double nodata,
                           double *profile, void *scratch, void *stream);
 
+/* Robust variant (triage/cmf_profile.py:124-127, use_robust_stats): profile[5][samples] = npix, median, MAD
+ * (median of |x - median|), and the (1-p) / p percentiles with numpy's 'nearest' rule (srcfinder_util.py:647-653,
+ * called with p = 0.95), all on the float32 cast of the valid positive pixels.  lines <= 32768. */
+int sf_cmf_column_profile_robust(const double *img, int lines, int samples, int nbands, int band, double nodata,
+                                 double p, double *profile, void *stream);
+
 /* Timing hook for bench.py's roofline line: while enabled, every sf_cmf_score launch (direct or
  * inside sf_cmf_run) is bracketed by a fresh pair of HIP events on the launch stream.
  * sf_cmf_score_timing_read() synchronises those events, returns the summed kernel time and the

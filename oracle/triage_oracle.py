@@ -22,3 +22,21 @@ def column_profile(cmf_plane, nodata=-9999.0):
         colmin = np.nanmin(cmf, axis=0)
         colmax = np.nanmax(cmf, axis=0)
     return np.stack([colnum, colavg, colstd, colmin, colmax]).astype(np.float64)
+
+
+def column_profile_robust(cmf_plane, nodata=-9999.0, p=0.95):
+    """use_robust_stats branch (:124-127): nanmedian, nanmedian(|x - med|), extrema(p) = nearest percentiles
+    (srcfinder_util.py:647-653; ``interpolation='nearest'`` is ``method='nearest'`` in numpy >= 1.22)."""
+    nodatav = np.float32(nodata)
+    cmf = np.float32(np.array(cmf_plane, copy=True))
+    cmfnodata = (cmf == nodatav) | np.isnan(cmf)
+    cmfmask = ~cmfnodata & (cmf > 0)
+    cmf[~cmfmask] = np.nan
+    colnum = np.count_nonzero(cmfmask, axis=0)
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        colavg = np.nanmedian(cmf, axis=0)
+        colstd = np.nanmedian(np.abs(cmf - colavg), axis=0)
+        colmin = np.nanpercentile(cmf, axis=0, q=(1 - p) * 100, method="nearest")
+        colmax = np.nanpercentile(cmf, axis=0, q=p * 100, method="nearest")
+    return np.stack([colnum, colavg, colstd, colmin, colmax]).astype(np.float64)

@@ -326,6 +326,106 @@ int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0,
   return 0;
 }
 
+// ---- robust column profile (triage/cmf_profile.py:124-127, use_robust_stats): median, MAD, 5th / 95th percentile
+// ('nearest') of a column's valid positive pixels.  One 1024-thread workgroup per column: the values (float32,
+// as the reference casts them) are gathered into LDS, bitonic-sorted, and the order statistics read off; the
+// MAD is a second sort of |x - median|.  Holds up to 32768 lines.
+namespace {
+constexpr int PR_NT = 1024, PR_CAP = 32768;
+
+__device__ __forceinline__ void lds_bitonic_sort(float *a, int npow2, int tid) {
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npow2; i += PR_NT) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const float x = a[i], y = a[ixj];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+// numpy's method='nearest': round the virtual index (n-1) q half-to-even
+__device__ __forceinline__ int nearest_index(int n, double q) {
+  const double v = (double)(n - 1) * q;
+  const double f = floor(v), g = v - f;
+  int idx = (int)f;
+  if (g > 0.5 || (g == 0.5 && (idx & 1))) ++idx;
+  return idx < 0 ? 0 : (idx >= n ? n - 1 : idx);
+}
+
+__global__ __launch_bounds__(PR_NT) void k_profile_robust(const double *__restrict__ img, int L, int S, int nb, int band,
+                                                           double nodata, double plo, double phi,
+                                                           double *__restrict__ prof) {
+  extern __shared__ float vals[];   // [npow2]
+  __shared__ int cnt;
+  __shared__ float smed;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  int npow2 = 1;
+  while (npow2 < L) npow2 <<= 1;
+  if (tid == 0) cnt = 0;
+  for (int i = tid; i < npow2; i += PR_NT) vals[i] = __builtin_inff();   // +inf pads sort to the end
+  __syncthreads();
+  for (int l = tid; l < L; l += PR_NT) {
+    const double v = img[((size_t)l * S + c) * nb + band];
+    const float vf = (float)v;
+    if (v == v && v != nodata && vf > 0.f) vals[atomicAdd(&cnt, 1)] = vf;   // order is irrelevant: sorted next
+  }
+  __syncthreads();
+  const int n = cnt;
+  const double nanv = __builtin_nan("");
+  if (n == 0) {
+    if (tid == 0) { prof[c] = 0; prof[S + c] = nanv; prof[2 * S + c] = nanv; prof[3 * S + c] = nanv; prof[4 * S + c] = nanv; }
+    return;
+  }
+  lds_bitonic_sort(vals, npow2, tid);
+  if (tid == 0) {
+    const float med = (n & 1) ? vals[n / 2] : (vals[n / 2 - 1] + vals[n / 2]) * 0.5f;   // float32 mean of the two
+    smed = med;
+    prof[c] = (double)n;
+    prof[S + c] = (double)med;
+    prof[3 * S + c] = (double)vals[nearest_index(n, plo)];
+    prof[4 * S + c] = (double)vals[nearest_index(n, phi)];
+  }
+  __syncthreads();
+  const float med = smed;
+  for (int i = tid; i < n; i += PR_NT) vals[i] = fabsf(vals[i] - med);
+  __syncthreads();
+  lds_bitonic_sort(vals, npow2, tid);
+  if (tid == 0) prof[2 * S + c] = (double)((n & 1) ? vals[n / 2] : (vals[n / 2 - 1] + vals[n / 2]) * 0.5f);
+}
+}  // namespace
+
+extern "C" int sf_cmf_column_profile_robust(const double *img, int lines, int samples, int nbands, int band, double nodata,
+                                            double p, double *profile, void *stream) {
+  if (!img || !profile || lines < 1 || samples < 1 || band < 0 || band >= nbands || !(p > 0.0 && p < 1.0)) {
+    sf_set_error("sf_cmf_column_profile_robust: bad argument");
+    return -1;
+  }
+  if (lines > PR_CAP) {
+    sf_set_error("sf_cmf_column_profile_robust: %d lines exceed the LDS-resident sort (max %d)", lines, PR_CAP);
+    return -2;
+  }
+  int npow2 = 1;
+  while (npow2 < lines) npow2 <<= 1;
+  const size_t lds = (size_t)npow2 * sizeof(float);
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_profile_robust),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
+  }
+  // the reference's percentile arguments are computed in float64: (1-p)*100 and p*100, then /100 inside numpy
+  const double plo = ((1.0 - p) * 100.0) / 100.0, phi = (p * 100.0) / 100.0;
+  hipLaunchKernelGGL(k_profile_robust, dim3(samples), dim3(PR_NT), lds, (hipStream_t)stream, img, lines, samples, nbands, band,
+                     nodata, plo, phi, profile);
+  SF_LAUNCH_CHECK("k_profile_robust");
+  return 0;
+}
+
 extern "C" int sf_cmf_column_profile(const double *img, int lines, int samples, int nbands, int band, double nodata,
                                      double *profile, void *scratch, void *stream) {
   if (!img || !profile || !scratch || lines < 1 || samples < 1 || band < 0 || band >= nbands) {

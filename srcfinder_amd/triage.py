@@ -13,11 +13,13 @@ import numpy as np
 from . import _ffi
 
 STATCOLS = ["npix", "avg", "std", "min", "max"]          # triage/cmf_profile.py:97
+ROBUST_STATCOLS = ["npix", "med", "mad", "p05", "p95"]    # triage/cmf_profile.py:95
 
 
-def column_profile(out, nodata=-9999.0, band=-1, to_numpy=True):
+def column_profile(out, nodata=-9999.0, band=-1, to_numpy=True, robust=False, p=0.95):
     """out: [lines, samples, nb] float64 product (device tensor or ndarray) -> profile[5, samples]
-    (npix, avg, std, min, max over valid positive CMF pixels; NaN where a column has none)."""
+    (npix, avg, std, min, max over valid positive CMF pixels; NaN where a column has none), or with ``robust``
+    (npix, median, MAD, (1-p) and p percentiles, 'nearest') as ``use_robust_stats`` selects (:124-127)."""
     import torch
     if not torch.cuda.is_available():
         raise _ffi.SrcfinderError("no GPU visible: srcfinder_amd has no CPU fallback")
@@ -28,6 +30,12 @@ def column_profile(out, nodata=-9999.0, band=-1, to_numpy=True):
     L_, S_, nb = t.shape
     b = band % nb
     prof = torch.empty((5, S_), dtype=torch.float64, device=t.device)
+    if robust:
+        with torch.cuda.device(t.device):
+            _ffi.check(_ffi.lib().sf_cmf_column_profile_robust(_ffi.ptr(t), L_, S_, nb, b, float(nodata), float(p),
+                                                               _ffi.ptr(prof), _ffi.stream_ptr()),
+                       "sf_cmf_column_profile_robust")
+        return prof.cpu().numpy() if to_numpy else prof
     scratch = torch.empty(((L_ + 255) // 256) * S_ * 5, dtype=torch.float64, device=t.device)
     with torch.cuda.device(t.device):
         _ffi.check(_ffi.lib().sf_cmf_column_profile(_ffi.ptr(t), L_, S_, nb, b, float(nodata), _ffi.ptr(prof),
@@ -55,9 +63,9 @@ def systematics_flags(colavg, win=3, nsigma=(1, 2, 3)):
     return coldiff, colsigma, counts
 
 
-def write_column_stats_csv(path, profile):
+def write_column_stats_csv(path, profile, robust=False):
     """``<product>_column_stats.csv`` as triage/cmf_profile.py:136-139 writes it (one row per column)."""
     with open(path, "w") as f:
-        f.write(",".join(STATCOLS) + "\n")
+        f.write(",".join(ROBUST_STATCOLS if robust else STATCOLS) + "\n")
         for i in range(profile.shape[1]):
             f.write(",".join(repr(float(v)) for v in profile[:, i]) + "\n")

@@ -376,6 +376,10 @@ def test_column_profile_and_systematics(torch_cuda, library):
     assert np.array_equal(np.isnan(prof[1]), np.isnan(want[1])) and np.isnan(prof[1][11])
     f = ~np.isnan(want[1])
     np.testing.assert_allclose(prof[1:, f], want[1:, f], rtol=2e-5)
+    rob = triage.column_profile(res.out, robust=True)
+    wantr = TO.column_profile_robust(res.out[..., 3].cpu().numpy())
+    assert np.array_equal(rob[0], wantr[0]) and np.isnan(rob[1][11])
+    assert np.array_equal(rob[1:, f], wantr[1:, f])         # order statistics of float32 values: exact
     avg = prof[1].copy()
     avg[40] += 50 * np.nanstd(avg)                       # a planted systematic column
     coldiff, sigma, counts = triage.systematics_flags(avg)

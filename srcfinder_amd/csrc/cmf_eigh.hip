@@ -30,10 +30,20 @@ __device__ __forceinline__ double dpp_swap(double v) {
   const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi2, lo2);
 }
+__device__ __forceinline__ double sum4(double v) {
+  v += dpp_swap<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_swap<0x4E>(v);   // quad_perm [2,3,0,1]
+  return v;
+}
 __device__ __forceinline__ double sum8(double v) {
   v += dpp_swap<0xB1>(v);   // quad_perm [1,0,3,2]
   v += dpp_swap<0x4E>(v);   // quad_perm [2,3,0,1]
   v += dpp_swap<0x141>(v);  // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ double sum16(double v) {
+  v = sum8(v);
+  v += dpp_swap<0x140>(v);  // row_mirror: the other 8-lane half of the 16-lane row
   return v;
 }
 // 1/sqrt(x) to double precision: hardware estimate + two Newton steps
@@ -64,7 +74,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // RMAX = ceil(p2/8) rows per lane; FULL = (p2 % 8 == 0): every lane owns exactly RMAX rows and all row
 // predicates fold away.  Loads are always unconditional (clamped row, value zeroed afterwards): predicated
 // LDS loads compile to one exec-masked branch + wait EACH and serialise the step (measured 2300 -> ~900 cycles).
-template <int EIG_RMAX, bool FULL>
+template <int EIG_RMAX, bool FULL, int LPP>
 __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict__ nuse, int p, int p2, int LD,
                        double *__restrict__ d_out, double *__restrict__ lam_out, double *__restrict__ evec_out,
                        int32_t *__restrict__ status, double2 *__restrict__ rot, size_t rot_stride) {
@@ -144,10 +154,10 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
   __syncthreads();
 
   const int npairs = p2 >> 1, m = p2 - 1;
-  const int k = tid >> 3, sub = tid & 7;
+  const int k = tid / LPP, sub = tid % LPP;   // LPP lanes share a column pair (rows sub, sub + LPP, ...)
   const bool active = k < npairs;
-  const int nr = (p2 - sub + 7) >> 3;  // rows sub, sub+8, ... owned by this lane
-  double2 *myrot = rot + (size_t)c * rot_stride + k;
+  const int nr = (p2 - sub + LPP - 1) / LPP;  // rows owned by this lane
+  const double2 *myrot = rot + (size_t)c * rot_stride + k;
   // |g_a . g_b| <= tol |g_a||g_b|: the dot product itself carries ~sqrt(p) eps of rounding, so a
   // threshold below that never settles; p*eps leaves off-diagonals <= 1e-14 * min(lam_a, lam_b).
   const double tol = (double)p2 * 2.220446049250313e-16;
@@ -167,24 +177,45 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
       nrm[j] = sacc;
     }
     __syncthreads();
+    // Column residency.  In the circle method pair k of step s is (a, b) = (s + k, s - k) mod m (k = 0: b = m), so the
+    // a-columns of step s+1 are those of step s minus column s plus column s+36: a lane group that FOLLOWS its
+    // a-column keeps it in registers from one step to the next, and only the b-columns (and the one a-column that
+    // changes sides) go through LDS.  Same pairs, same rotations, same results as re-reading both columns every
+    // step -- but half the LDS traffic, and the step is LDS-store bound (ds_write_b64 moves ~85 B/clk per CU).
+    int acol = k;               // this group's a-column: pair index (acol - s) mod m at step s
+    bool reload = true;         // xa has to come from LDS (sweep start, or the column changed sides)
+    double xa[EIG_RMAX];
+#pragma unroll
+    for (int i = 0; i < EIG_RMAX; ++i) xa[i] = 0.0;
     for (int s = 0; s < m; ++s) {
       if (active) {
-        int a, b;
-        rr_pair(s, k, m, a, b);
+        int kk = acol - s;
+        kk = kk < 0 ? kk + m : kk;                       // current pair index of this group, 0 .. npairs-1
+        int bcol = 2 * s - acol;
+        bcol = bcol < 0 ? bcol + m : (bcol >= m ? bcol - m : bcol);
+        const int a = acol, b = (kk == 0) ? m : bcol;
         double *ga = M + a * LD + sub, *gb = M + b * LD + sub;
-        double xa[EIG_RMAX], xb[EIG_RMAX];
+        double xb[EIG_RMAX];
 #pragma unroll
         for (int i = 0; i < EIG_RMAX; ++i) {
           const int ii = FULL ? i : min(i, nr - 1);
-          const double va_ = ga[8 * ii], vb_ = gb[8 * ii];
-          xa[i] = (FULL || i < nr) ? va_ : 0.0;
+          const double vb_ = gb[LPP * ii];
           xb[i] = (FULL || i < nr) ? vb_ : 0.0;
         }
+        if (reload) {
+#pragma unroll
+          for (int i = 0; i < EIG_RMAX; ++i) {
+            const int ii = FULL ? i : min(i, nr - 1);
+            const double va_ = ga[LPP * ii];
+            xa[i] = (FULL || i < nr) ? va_ : 0.0;
+          }
+        }
+        const bool leaving = (kk == 0) || (s == m - 1);  // after this step the a-column is someone's b-column / the sweep ends
         const double aa = nrm[a], bb = nrm[b];
         double ab = 0;
 #pragma unroll
         for (int i = 0; i < EIG_RMAX; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
-        ab = sum8(ab);
+        ab = (LPP == 16) ? sum16(ab) : ((LPP == 8) ? sum8(ab) : sum4(ab));
         const double ab2 = aa * bb;
         double cs = 1.0, sn = 0.0;
         if (ab2 > 0.0 && ab * ab > tol2 * ab2) {  // uniform over the pair's 8 lanes
@@ -200,10 +231,10 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
           sn = ((tau < 0.0) != (gam < 0.0)) ? -sn : sn;
 #pragma unroll
           for (int i = 0; i < EIG_RMAX; ++i) {
-            if (FULL || i < nr) {
-              ga[8 * i] = cs * xa[i] - sn * xb[i];
-              gb[8 * i] = sn * xa[i] + cs * xb[i];
-            }
+            const double na = cs * xa[i] - sn * xb[i];
+            const double nb = sn * xa[i] + cs * xb[i];
+            xa[i] = na;
+            if (FULL || i < nr) gb[LPP * i] = nb;
           }
           if (sub == 0) {
             const double cc = cs * cs, ss = sn * sn, x2 = 2.0 * cs * sn * ab;
@@ -211,7 +242,14 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
             nrm[b] = ss * aa + x2 + cc * bb;
           }
         }
-        if (!chol_ok && sub == 0) myrot[(size_t)(sweep * m + s) * npairs] = make_double2(cs, sn);
+        if (leaving) {
+#pragma unroll
+          for (int i = 0; i < EIG_RMAX; ++i)
+            if (FULL || i < nr) ga[LPP * i] = xa[i];
+        }
+        if (!chol_ok && sub == 0) rot[(size_t)c * rot_stride + (size_t)(sweep * m + s) * npairs + kk] = make_double2(cs, sn);
+        reload = (kk == 0);                              // next step this group owns column s + npairs instead
+        if (kk == 0) { acol = s + npairs; acol = acol >= m ? acol - m : acol; }
       }
       lds_barrier();
     }
@@ -275,14 +313,14 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
 #pragma unroll
         for (int i = 0; i < EIG_RMAX; ++i) {
           const int ii = FULL ? i : min(i, nr - 1);
-          ya[i] = va[8 * ii];
-          yb[i] = vb[8 * ii];
+          ya[i] = va[LPP * ii];
+          yb[i] = vb[LPP * ii];
         }
 #pragma unroll
         for (int i = 0; i < EIG_RMAX; ++i) {
           if (FULL || i < nr) {
-            va[8 * i] = r.x * ya[i] - r.y * yb[i];
-            vb[8 * i] = r.y * ya[i] + r.x * yb[i];
+            va[LPP * i] = r.x * ya[i] - r.y * yb[i];
+            vb[LPP * i] = r.y * ya[i] + r.x * yb[i];
           }
         }
       }
@@ -298,6 +336,8 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
 
 }  // namespace
 
+int g_eigh_lpp = 0;  // sf_debug_set key 7: force 4 or 8 lanes per column pair (0 = built-in choice)
+
 size_t sf_eigh_scratch_bytes(const SfGeom &g) {
   const int p2 = g.p + (g.p & 1);
   return sf_align((size_t)g.ncols * EIG_MAXSWEEP * (p2 - 1) * (p2 / 2) * sizeof(double2));
@@ -306,14 +346,22 @@ size_t sf_eigh_scratch_bytes(const SfGeom &g) {
 int sf_launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, double *d, double *lam, double *evec,
                    int32_t *status, void *scratch, hipStream_t st) {
   const int p2 = g.p + (g.p & 1);
+  // Lanes per column pair: 8 is the measured optimum (tools/probe_eigh.py, one 72x72 matrix: 8 lanes 0.65 ms,
+  // 4 lanes -- 3 waves, one per SIMD, twice the rows per lane -- 0.78 ms, 16 lanes -- 9 waves -- 0.77 ms).
+  // The other two stay reachable through sf_debug_set(7, .) for the production sizes.
+  const int lpp = (g_eigh_lpp == 4 || g_eigh_lpp == 8 || g_eigh_lpp == 16) ? g_eigh_lpp : 8;
+  const bool lpp4 = lpp == 4 && (p2 == 72 || p2 == 84);
+  const bool lpp16 = lpp == 16 && (p2 == 72 || p2 == 84);
   int LD = p2;
-  while ((LD % 32) != 8 && (LD % 32) != 24) ++LD;
+  if (lpp4) { while ((LD % 32) != 12 && (LD % 32) != 20) ++LD; }     // 4 consecutive columns x 4 rows: 64 distinct banks
+  else if (lpp16) { while ((LD % 32) != 16) ++LD; }
+  else { while ((LD % 32) != 8 && (LD % 32) != 24) ++LD; }
   const size_t lds = ((size_t)p2 * LD + 2 * p2) * sizeof(double);
   if (lds > 160 * 1024 - 64 || g.p > SF_MAX_ACTIVE_FUSED) {
     sf_set_error("active window of %d bands exceeds the LDS-resident eigensolver (max %d)", g.p, SF_MAX_ACTIVE_FUSED);
     return -2;
   }
-  int threads = (p2 / 2) * 8;
+  int threads = (p2 / 2) * (lpp4 ? 4 : (lpp16 ? 16 : 8));
   threads = (threads + 63) / 64 * 64;
   if (threads < 64) threads = 64;
   const size_t rot_stride = (size_t)EIG_MAXSWEEP * (p2 - 1) * (p2 / 2);
@@ -326,12 +374,18 @@ int sf_launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, doub
     return 0;
   };
   int rc = -2;
+  if (lpp4) {
+    rc = (p2 == 72) ? go(k_eigh<18, true, 4>) : go(k_eigh<21, true, 4>);
+  } else if (lpp16) {
+    rc = (p2 == 72) ? go(k_eigh<5, false, 16>) : go(k_eigh<6, false, 16>);
+  } else {
   switch (rmax) {
-#define EIG_CASE(R) case R: rc = full ? go(k_eigh<R, true>) : go(k_eigh<R, false>); break;
+#define EIG_CASE(R) case R: rc = full ? go(k_eigh<R, true, 8>) : go(k_eigh<R, false, 8>); break;
     EIG_CASE(1) EIG_CASE(2) EIG_CASE(3) EIG_CASE(4) EIG_CASE(5) EIG_CASE(6)
     EIG_CASE(7) EIG_CASE(8) EIG_CASE(9) EIG_CASE(10) EIG_CASE(11) EIG_CASE(12)
 #undef EIG_CASE
     default: sf_set_error("eigensolver: unsupported size %d", g.p); return -2;
+  }
   }
   if (rc) return rc;
   SF_LAUNCH_CHECK("k_eigh");

@@ -13,7 +13,9 @@ for seed in range(8):
     x = synth_columns(20000, p, 100 + seed); x -= x.mean(0)
     mats.append(np.cov(x.T))
 P = _ffi.ptr
-for nc in (1, 64, 598):
+import itertools
+for lpp, nc in itertools.product((8, 4, 16), (1, 75, 598)):
+    L.sf_debug_set(7, lpp)
     S = torch.as_tensor(np.stack([mats[i % 8] for i in range(nc)])).cuda()
     nuse = torch.full((nc,), 20000, dtype=torch.int32, device="cuda")
     d = torch.empty((nc, p), dtype=torch.float64, device="cuda"); lam = torch.empty_like(d)
@@ -27,4 +29,4 @@ for nc in (1, 64, 598):
     a.record(); run(); run(); run(); b.record(); torch.cuda.synchronize()
     stride = 30 * (p - 1) * (p // 2) * 2   # doubles per column of the rotation log (EIG_MAXSWEEP * steps * pairs * 2)
     sw = ws.view(torch.float64)[: nc * stride : stride].cpu().numpy()
-    print("ncols %5d : %.3f ms per call; rotating sweeps min/max %d/%d" % (nc, a.elapsed_time(b) / 3, sw.min(), sw.max()))
+    print("lanes/pair %d ncols %5d : %.3f ms per call; rotating sweeps min/max %d/%d" % (lpp, nc, a.elapsed_time(b) / 3, sw.min(), sw.max()))

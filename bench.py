@@ -73,15 +73,28 @@ def main():
                            nodata_column=(ncols // 3))
     torch.cuda.synchronize()
 
-    out = torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev)
+    # two product buffers: the gather of flightline i (RCCL, its own stream) overlaps the compute of flightline
+    # i+1, as a production run over many flightlines would pipeline them
+    outs = [torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev) for _ in range(2 if world > 1 else 1)]
+    state = {"i": 0, "pending": None}
 
     def step():
+        out = outs[state["i"] % len(outs)]
+        state["i"] += 1
         r = cmf.robust_mf(cube, lib, out=out, out_column0=0, active=(a0, a1))
         if world > 1:
             # the single RCCL gather of the score image: the float64 CMF band of every
             # rank's block, 8 B/pixel; the RGB copy stays with the rank that read those columns
-            sd.gather_columns(out[..., 3], samples, dst=0)
+            h = sd.gather_columns(out[..., 3], samples, dst=0, async_op=True)
+            if state["pending"] is not None:
+                state["pending"].wait()          # the previous flightline's image, assembled on rank 0
+            state["pending"] = h
         return r
+
+    def drain():
+        if state["pending"] is not None:
+            state["pending"].wait()
+            state["pending"] = None
 
     def barrier():
         if world > 1:
@@ -90,12 +103,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     L = _ffi.lib()
     barrier()
     L.sf_cmf_score_timing(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+    drain()                                      # every gather completes inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     tot_ms = _ffi.C.c_double(0.0)

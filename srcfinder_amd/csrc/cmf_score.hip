@@ -161,20 +161,25 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, i
   }
 }
 
-// npix / mean / std (ddof 0) of the written scores per column (robust_mf.py:388-392).  One 256-thread
-// workgroup per 64 columns: lane = column, the 4 waves split the chunk list, fixed combination order.
-__global__ __launch_bounds__(256) void k_colstats(const double *__restrict__ stat_part, int nchunk, int Cs,
-                                                   const int32_t *__restrict__ nuse, const int32_t *__restrict__ status,
-                                                   double nodata, double *__restrict__ colstats) {
-  __shared__ double red[4][64][2];
+// npix / mean / std (ddof 0) of the written scores per column (robust_mf.py:388-392).  One 1024-thread
+// workgroup per 64 columns: lane = column, the 16 waves split the chunk list (a shard has few columns but
+// hundreds of chunks: the kernel is a chain of dependent-latency loads), fixed combination order.
+__global__ __launch_bounds__(1024) void k_colstats(const double *__restrict__ stat_part, int nchunk, int Cs,
+                                                    const int32_t *__restrict__ nuse, const int32_t *__restrict__ status,
+                                                    double nodata, double *__restrict__ colstats) {
+  __shared__ double red[16][64][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   double a = 0.0, b = 0.0;
-  if (c < Cs)
-    for (int k = wave; k < nchunk; k += 4) {
-      a += stat_part[((size_t)k * Cs + c) * 2];
-      b += stat_part[((size_t)k * Cs + c) * 2 + 1];
+  if (c < Cs) {
+    const double2 *sp = reinterpret_cast<const double2 *>(stat_part);
+#pragma unroll 4
+    for (int k = wave; k < nchunk; k += 16) {
+      const double2 v = sp[(size_t)k * Cs + c];
+      a += v.x;
+      b += v.y;
     }
+  }
   red[wave][lane][0] = a;
   red[wave][lane][1] = b;
   __syncthreads();
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void k_colstats(const double *__restrict__ sta
     return;
   }
   a = 0.0; b = 0.0;
-  for (int w = 0; w < 4; ++w) { a += red[w][lane][0]; b += red[w][lane][1]; }
+  for (int w = 0; w < 16; ++w) { a += red[w][lane][0]; b += red[w][lane][1]; }
   const double n = (double)nuse[c];
   const double mean = a / n;
   double var = b / n - mean * mean;
@@ -320,7 +325,7 @@ int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0,
   (void)samples; (void)s0; (void)p;
   const int lpw = sf_score_lpw(lines, ncols);
   const int nchunk = sf_cdiv(lines, lpw);
-  hipLaunchKernelGGL(k_colstats, dim3(sf_cdiv(ncols, 64)), dim3(256), 0, st,
+  hipLaunchKernelGGL(k_colstats, dim3(sf_cdiv(ncols, 64)), dim3(1024), 0, st,
                      reinterpret_cast<const double *>(stat_scratch), nchunk, ncols, nuse, status, nodata, colstats);
   SF_LAUNCH_CHECK("k_colstats");
   return 0;

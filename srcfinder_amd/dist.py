@@ -16,29 +16,23 @@ def shard_columns(samples: int, world: int, rank: int):
     return rank * samples // world, (rank + 1) * samples // world
 
 
-def gather_columns(block, samples: int, *, group=None, dst: int = 0):
-    """Gather per-rank column blocks ``[lines, ncols_r, ...]`` (or ``[..., ncols_r]`` 2-D stats with columns
-    LAST when ``block.dim() == 2`` or 1) into the full array on ``dst``; other ranks get ``None``.
+class GatherHandle:
+    """An in-flight column gather (``gather_columns(..., async_op=True)``): ``wait()`` returns the assembled array
+    on ``dst`` (``None`` elsewhere).  The collective runs on the backend's own stream; the buffers live here."""
 
-    Blocks are padded to the largest shard so a single fixed-size gather suffices."""
+    def __init__(self, work, send, recv, meta):
+        self.work, self.send, self.recv, self.meta = work, send, recv, meta
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return _assemble(self.recv, *self.meta)
+
+
+def _assemble(recv, shape, cols_last, samples, world, as_int16):
     import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    if block.dtype == torch.int16:      # not a collective dtype everywhere (gloo): ship the bytes
-        pairs = gather_columns(block.contiguous().view(torch.uint8), samples, group=group, dst=dst)
-        return None if pairs is None else pairs.view(torch.int16)
-    cols_last = block.dim() <= 2
-    x = block if not cols_last else block.reshape(-1, block.shape[-1]).transpose(0, 1)   # -> [ncols, ...]
-    if not cols_last:
-        x = block.transpose(0, 1)                                                       # [ncols, lines, ...]
-    maxc = max(b - a for a, b in (shard_columns(samples, world, r) for r in range(world)))
-    send = torch.zeros((maxc,) + tuple(x.shape[1:]), dtype=block.dtype, device=block.device)
-    send[:x.shape[0]].copy_(x)
-    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, recv, dst=dst, group=group)
-    if rank != dst:
+    if recv is None:
         return None
     parts = []
     for r in range(world):
@@ -46,9 +40,39 @@ def gather_columns(block, samples: int, *, group=None, dst: int = 0):
         parts.append(recv[r][:b - a])
     full = torch.cat(parts, dim=0)                                                      # [samples, ...]
     if cols_last:
-        full = full.transpose(0, 1).reshape(tuple(block.shape[:-1]) + (samples,))
-        return full.contiguous()
-    return full.transpose(0, 1).contiguous()                                            # [lines, samples, ...]
+        full = full.transpose(0, 1).reshape(tuple(shape[:-1]) + (samples,)).contiguous()
+    else:
+        full = full.transpose(0, 1).contiguous()                                        # [lines, samples, ...]
+    return full.view(torch.int16) if as_int16 else full
+
+
+def gather_columns(block, samples: int, *, group=None, dst: int = 0, async_op: bool = False):
+    """Gather per-rank column blocks ``[lines, ncols_r, ...]`` (or ``[..., ncols_r]`` 2-D stats with columns
+    LAST when ``block.dim() == 2`` or 1) into the full array on ``dst``; other ranks get ``None``.
+
+    Blocks are padded to the largest shard so a single fixed-size gather suffices.  With ``async_op`` a
+    :class:`GatherHandle` is returned instead and the collective overlaps whatever the caller enqueues next
+    (the next flightline's compute) until ``wait()``."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    as_int16 = block.dtype == torch.int16
+    if as_int16:                        # not a collective dtype everywhere (gloo): ship the bytes
+        block = block.contiguous().view(torch.uint8)
+    cols_last = block.dim() <= 2
+    if cols_last:
+        x = block.reshape(-1, block.shape[-1]).transpose(0, 1)                          # -> [ncols, ...]
+    else:
+        x = block.transpose(0, 1)                                                       # [ncols, lines, ...]
+    maxc = max(b - a for a, b in (shard_columns(samples, world, r) for r in range(world)))
+    send = torch.zeros((maxc,) + tuple(x.shape[1:]), dtype=block.dtype, device=block.device)
+    send[:x.shape[0]].copy_(x)
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    work = dist.gather(send, recv, dst=dst, group=group, async_op=async_op)
+    h = GatherHandle(work if async_op else None, send, recv, (tuple(block.shape), cols_last, samples, world, as_int16))
+    return h if async_op else h.wait()
 
 
 def robust_mf_sharded(cube_shard, library, samples: int, *, group=None, dst: int = 0, compute=None, **kw):

@@ -34,13 +34,19 @@ def _worker(rank, world, port, lines, samples, q):
         return {k: torch.as_tensor(v) for k, v in r.items()}
 
     got = sd.robust_mf_sharded(np.ascontiguousarray(cube[:, :, s0:s1]), lib, samples, compute=compute)
+    # the overlapped form bench.py uses: two gathers in flight, waited in order
+    mine = O.robust_mf_oracle(np.ascontiguousarray(cube[:, :, s0:s1]), lib)
+    h1 = sd.gather_columns(torch.as_tensor(mine["out"][..., 3]), samples, dst=0, async_op=True)
+    h2 = sd.gather_columns(torch.as_tensor(mine["bgmeta"]), samples, dst=0, async_op=True)
+    a1, a2 = h1.wait(), h2.wait()
     if rank == 0:
         ref = O.robust_mf_oracle(cube, lib)
         ok = all(np.array_equal(got[k].numpy(), ref[k], equal_nan=True)
                  for k in ("out", "alphaidx", "nuse", "status", "colstats", "bgmeta"))
+        ok = ok and np.array_equal(a1.numpy(), ref["out"][..., 3]) and np.array_equal(a2.numpy(), ref["bgmeta"])
         q.put(bool(ok))
     else:
-        assert got is None
+        assert got is None and a1 is None and a2 is None
     dist.barrier()
     dist.destroy_process_group()
 

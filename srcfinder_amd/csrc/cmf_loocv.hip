@@ -254,32 +254,48 @@ __global__ __launch_bounds__(256, 1) void k_sweep(const XT *__restrict__ xt, con
 }
 
 // NLL assembly, det over/underflow emulation (rule (i)), NaN-first argmin (numpy.argmin).
-__global__ __launch_bounds__(256) void k_nll(const double *__restrict__ part, int nsplit, const int32_t *__restrict__ nuse,
+// The 201 x p logarithms of a column are spread over all threads into an LDS table when it fits (TBL), and
+// summed per alpha in the original order: same bits as the one-thread-per-alpha loop, a third of its time.
+template <bool TBL>
+__global__ __launch_bounds__(1024) void k_nll(const double *__restrict__ part, int nsplit, const int32_t *__restrict__ nuse,
                                               const double *__restrict__ d, const double *__restrict__ lam,
                                               const int32_t *__restrict__ status, const double *__restrict__ alphas,
                                               int nalpha, int p, int NA16, int rq_scaled,
                                               double *__restrict__ nll_out, int32_t *__restrict__ alphaidx) {
+  extern __shared__ double tbl[];   // TBL: [nalpha][p] log(n beta_i lam_j + alpha_i), then [p] log(100 d_j)
   __shared__ double snll[SF_NALPHA_MAX];
   __shared__ double slogd;
-  const int c = blockIdx.x, tid = threadIdx.x;
+  const int c = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int st = status[c];
   const double n = (double)nuse[c];
   const double inf = __builtin_inf();
+  if (TBL && st == 0) {
+    double *tld = tbl + (size_t)nalpha * p;
+    for (int j = tid; j < p; j += nthr) tld[j] = log(d[(size_t)c * p + j] * 100.0);
+    for (int idx = tid; idx < nalpha * p; idx += nthr) {
+      const int i = idx / p, j = idx - i * p;
+      const double a = alphas[i];
+      const double nb = n * ((1.0 - a) / (n - 1.0));
+      tbl[idx] = log(nb * lam[(size_t)c * p + j] + a);
+    }
+    __syncthreads();
+  }
   if (tid == 0) {
     double s = 0.0;
     if (st == 0)
-      for (int j = 0; j < p; ++j) s += log(d[(size_t)c * p + j] * 100.0);  // diag of cov(100 x), robust_mf.py:94-99
+      for (int j = 0; j < p; ++j)
+        s += TBL ? tbl[(size_t)nalpha * p + j] : log(d[(size_t)c * p + j] * 100.0);  // diag of cov(100 x), robust_mf.py:94-99
     slogd = 2.0 * s;
   }
   __syncthreads();
-  for (int i = tid; i < nalpha; i += 256) {
+  for (int i = tid; i < nalpha; i += nthr) {
     double v = inf;
     if (st == 0) {
       const double a = alphas[i];
       const double beta = (1.0 - a) / (n - 1.0);
       const double nb = n * beta;
       double ld = slogd;
-      for (int j = 0; j < p; ++j) ld += log(nb * lam[(size_t)c * p + j] + a);
+      for (int j = 0; j < p; ++j) ld += TBL ? tbl[(size_t)i * p + j] : log(nb * lam[(size_t)c * p + j] + a);
       double lsum = 0.0, rsum = 0.0;
       for (int sp = 0; sp < nsplit; ++sp) {
         const double *pp = part + ((size_t)c * nsplit + sp) * 2 * NA16;
@@ -370,6 +386,26 @@ int launch_sweep(const XT *xt, const uint8_t *mask_t, const int32_t *nuse, const
 }
 #undef SW_ARGS
 
+int launch_nll(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam, const int32_t *status,
+               const double *alphas, const SfGeom &g, int rq_scaled, double *nll, int32_t *alphaidx, hipStream_t st) {
+  const size_t lds = ((size_t)g.nalpha * g.p + g.p) * sizeof(double);
+  if (lds <= 150 * 1024 && g.ncols <= 256) {   // one 116 KB workgroup per CU: only worth it when the launch is a single round
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+      SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_nll<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+      lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_nll<true>, dim3(g.ncols), dim3(1024), lds, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha,
+                       g.p, g.nu * 16, rq_scaled, nll, alphaidx);
+  } else {
+    hipLaunchKernelGGL(k_nll<false>, dim3(g.ncols), dim3(256), 0, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha,
+                       g.p, g.nu * 16, rq_scaled, nll, alphaidx);
+  }
+  SF_LAUNCH_CHECK("k_nll");
+  return 0;
+}
+
 }  // namespace
 
 int g_sweep_variant = 0;  // sf_debug_set key 4: 0 = built-in choice, 1 = force the 16x16x4 kernels
@@ -377,10 +413,7 @@ int g_sweep_variant = 0;  // sf_debug_set key 4: 0 = built-in choice, 1 = force 
 int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
                          const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
                          hipStream_t st) {
-  hipLaunchKernelGGL(k_nll, dim3(g.ncols), dim3(256), 0, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha, g.p,
-                     g.nu * 16, 0, nll, alphaidx);
-  SF_LAUNCH_CHECK("k_nll");
-  return 0;
+  return launch_nll(part, nsplit, nuse, d, lam, status, alphas, g, 0, nll, alphaidx, st);
 }
 
 static bool sweep4_ok(const SfGeom &g, int xt_f64) {
@@ -415,18 +448,12 @@ int sf_launch_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int
     int rc4 = sf_launch_sweep4((const float *)xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part,
                                g_sweep_variant, st);
     if (rc4) return rc4;
-    hipLaunchKernelGGL(k_nll, dim3(g.ncols), dim3(256), 0, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha, g.p,
-                       g.nu * 16, 1, nll, alphaidx);
-    SF_LAUNCH_CHECK("k_nll");
-    return 0;
+    return launch_nll(part, nsplit, nuse, d, lam, status, alphas, g, 1, nll, alphaidx, st);
   }
   hipLaunchKernelGGL(k_wfrag, dim3(g.ncols), dim3(256), 0, st, evec, d, g.p, g.s4, g.nt, wstride, wfrag);
   SF_LAUNCH_CHECK("k_wfrag");
   int rc = xt_f64 ? launch_sweep((const double *)xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part, st)
                   : launch_sweep((const float *)xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_nll, dim3(g.ncols), dim3(256), 0, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha, g.p,
-                     g.nu * 16, 0, nll, alphaidx);
-  SF_LAUNCH_CHECK("k_nll");
-  return 0;
+  return launch_nll(part, nsplit, nuse, d, lam, status, alphas, g, 0, nll, alphaidx, st);
 }

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into HBM bytes per launch per kernel.
+
+FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md, HBM section; re-calibrated in round 1 on a 4 GiB streaming read:
+the counter reports 2,097,165 KB).  Counter units are KB (1024 B... the calibration fixes the scale: 1 unit = 1 KiB)."""
+import csv, glob, json, sys, collections
+
+def load(d, name):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != name:
+            continue
+        k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].strip()
+        if k.startswith("k_"):
+            acc[k].append(float(r["Counter_Value"]))
+    return acc
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (tools/pmc_traffic.sh)",
+       "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section; calibrated in round 1: a 4 GiB streaming read at 4/8/16 B per lane reports 2,097,165 KB; WRITE_SIZE exact on a 4 GiB copy)",
+       "workload": "598x20000x425, p=72", "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    f = sum(fetch.get(k, [0])) / max(len(fetch.get(k, [])), 1)
+    w = sum(write.get(k, [0])) / max(len(write.get(k, [])), 1)
+    out["kernels"][k] = {"FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w, "launches": len(fetch.get(k, [])),
+                         "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+print(json.dumps(out, indent=1))

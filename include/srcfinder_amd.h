@@ -140,6 +140,11 @@ int sf_cmf_column_profile(const double *img, int lines, int samples, int nbands,
 int sf_cmf_column_profile_robust(const double *img, int lines, int samples, int nbands, int band, double nodata,
                                  double p, double *profile, void *stream);
 
+/* Test hook: the rank-28 factorisation B = U W of the sweep's coefficient matrix (cmf_lowrank.hip), in the
+ * fragment order the sweep reads: ufrag[ncols][18*7*16], wfrag[ncols][13*7*64], lrok[ncols]. */
+int sf_debug_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas,
+                     int nalpha, int p, int ncols, double *ufrag, double *wfrag, int32_t *lrok, void *stream);
+
 /* Timing hook for bench.py's roofline line: while enabled, every sf_cmf_score launch (direct or
  * inside sf_cmf_run) is bracketed by a fresh pair of HIP events on the launch stream.
  * sf_cmf_score_timing_read() synchronises those events, returns the summed kernel time and the

@@ -453,3 +453,44 @@ def test_multimodal_device_kmeans(torch_cuda, golden_dir, library):
     assert np.array_equal(a.out[..., 3] == -9999.0, o["out"][..., 3] == -9999.0)
     assert np.array_equal(a.bgmeta, o["bgmeta"])
     assert score_close(a.out[..., 3], o["out"][..., 3]).all()
+
+
+def test_lowrank_factorisation_of_sweep_coefficients(torch_cuda):
+    """cmf_lowrank.hip: B_ji = beta_i/(n beta_i lam_j + alpha_i) = U W with K = 28, W rows orthonormal, error at the
+    rounding level of B -- on the eigenvalue spectra of flightline-like columns; a near-singular spectrum (n ~ p)
+    is flagged for the full-rank sweep instead."""
+    torch = torch_cuda
+    from srcfinder_amd.synth import synth_columns
+    L = _ffi.lib()
+    lams, ns = [], []
+    for seed, rows in ((100, 20000), (101, 20000), (104, 3000), (105, 3000), (106, 90)):
+        x = synth_columns(rows, 72, seed)
+        x -= x.mean(0)
+        S = np.cov(x.T)
+        dd = np.sqrt(np.diag(S))
+        lams.append(np.linalg.eigvalsh(S / np.outer(dd, dd)))
+        ns.append(rows)
+    lam = np.ascontiguousarray(np.stack(lams))
+    nuse = np.asarray(ns, dtype=np.int32)
+    nc, p = lam.shape
+    al = cmf.alpha_grid()
+    d = lambda a: torch.as_tensor(a).cuda()
+    uf = torch.zeros((nc, 18 * 7 * 16), dtype=torch.float64, device="cuda")
+    wf = torch.zeros((nc, 13 * 7 * 64), dtype=torch.float64, device="cuda")
+    ok = torch.zeros(nc, dtype=torch.int32, device="cuda")
+    status = torch.zeros(nc, dtype=torch.int32, device="cuda")
+    lam_d, nuse_d, al_d = d(lam), d(nuse), d(al)          # keep the device copies alive across the launch
+    _ffi.check(L.sf_debug_lowrank(_ffi.ptr(lam_d), _ffi.ptr(nuse_d), _ffi.ptr(status), _ffi.ptr(al_d), len(al), p, nc,
+                                  _ffi.ptr(uf), _ffi.ptr(wf), _ffi.ptr(ok), _ffi.stream_ptr()), "sf_debug_lowrank")
+    torch.cuda.synchronize()
+    uf, wf, ok = uf.cpu().numpy(), wf.cpu().numpy(), ok.cpu().numpy()
+    assert list(ok[:4]) == [1, 1, 1, 1] and ok[4] == 0, ok      # 90 rows for 72 bands: rank of B above 28
+    for c in range(4):
+        n = float(nuse[c])
+        beta = (1.0 - al) / (n - 1.0)
+        B = beta[None, :] / (n * beta[None, :] * lam[c][:, None] + al[None, :])           # [72, 201]
+        U = -uf[c].reshape(18, 7, 4, 4).transpose(0, 2, 1, 3).reshape(72, 28)            # [jg, mg, q, n] -> [j, m]
+        W = wf[c].reshape(13, 7, 4, 16).transpose(1, 2, 0, 3).reshape(28, 208)           # [M, mg, q, a16] -> [m, alpha]
+        np.testing.assert_allclose(W @ W.T, np.eye(28), atol=1e-13)
+        assert np.abs(U @ W[:, :201] - B).max() <= 2e-14 * np.abs(B).max()
+        assert np.abs(W[:, 201:]).max() <= 1e-15

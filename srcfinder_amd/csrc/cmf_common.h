@@ -177,5 +177,5 @@ int sf_launch_cov4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
 int sf_launch_wfrag4(const double *evec, const double *d, const SfGeom &g, size_t wstride, double *wfrag, hipStream_t st);
 int sf_launch_sweep4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
                      const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,
-                     int nsplit, double *part, int variant, hipStream_t st);
+                     int nsplit, double *part, int variant, void *lr_scratch, hipStream_t st);
 

@@ -408,7 +408,7 @@ int launch_nll(const double *part, int nsplit, const int32_t *nuse, const double
 
 }  // namespace
 
-int g_sweep_variant = 0;  // sf_debug_set key 4: 0 = built-in choice, 1 = force the 16x16x4 kernels
+int g_sweep_variant = 0;  // sf_debug_set key 4: 0 = built-in choice, 1 = force the 16x16x4 kernels, 2 = full-rank 4x4x4 sweep only
 
 int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
                          const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
@@ -428,7 +428,7 @@ size_t sf_wfrag_elems(const SfGeom &g) {
 size_t sf_loocv_scratch_bytes(const SfGeom &g) {
   const int nsplit = sf_sweep_splits(g.lines, g.ncols);
   return sf_align((size_t)g.ncols * sf_wfrag_elems(g) * sizeof(double)) +
-         sf_align((size_t)g.ncols * nsplit * 2 * g.nu * 16 * sizeof(double));
+         sf_align((size_t)g.ncols * nsplit * 2 * g.nu * 16 * sizeof(double)) + sf_lowrank_bytes(g);
 }
 
 int sf_launch_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *d,
@@ -445,8 +445,9 @@ int sf_launch_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int
                                             sf_align((size_t)g.ncols * wstride * sizeof(double)));
   if (sweep4_ok(g, xt_f64)) {
     if (int rcw = sf_launch_wfrag4(evec, d, g, wstride, wfrag, st)) return rcw;
+    void *lr = reinterpret_cast<char *>(part) + sf_align((size_t)g.ncols * nsplit * 2 * g.nu * 16 * sizeof(double));
     int rc4 = sf_launch_sweep4((const float *)xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part,
-                               g_sweep_variant, st);
+                               g_sweep_variant, g_sweep_variant == 2 ? nullptr : lr, st);
     if (rc4) return rc4;
     return launch_nll(part, nsplit, nuse, d, lam, status, alphas, g, 1, nll, alphaidx, st);
   }

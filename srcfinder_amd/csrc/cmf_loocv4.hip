@@ -29,6 +29,10 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xo
 // LDS: c fragments 119,808 B + W blocks 41,472 B + mu = 161,856 B of the 163,840.
 constexpr int S4J = SF_SW4_NJ, S4M = SF_SW4_NM;
 // LDS reads of GEMM2 step t (one per alpha tile of its group of 4; none past the last step)
+constexpr int sw4r_reads(int t) {   // k_sweep4r: SF_LR_K/4 steps per group of 4 alpha tiles
+  const int gr = t / (SF_LR_K / 4), left = S4M - 4 * gr;
+  return left <= 0 ? 0 : (left < 4 ? left : 4);
+}
 constexpr int sw4_reads(int t) {
   const int gr = t / S4J, left = S4M - 4 * gr;
   return left <= 0 ? 0 : (left < 4 ? left : 4);
@@ -94,7 +98,8 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
                                                     const double *__restrict__ lam, const double *__restrict__ wfrag,
                                                     size_t wstride, const int32_t *__restrict__ status,
                                                     const double *__restrict__ alphas, int nalpha, int L, int p,
-                                                    int PS, int rows_per_wg, double *__restrict__ part) {
+                                                    int PS, int rows_per_wg, double *__restrict__ part,
+                                                    const int32_t *__restrict__ lrok) {
   constexpr int NJ = S4J, NM = S4M, NA16 = NM * 16;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *cfrag = sm;                        // [NM][NJ][64]
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
   const int g = lane >> 4, li = lane & 15;
   const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
   double *po = part + ((size_t)c * nsplit + split) * 2 * NA16;
+  if (lrok && lrok[c] != 0) return;   // this column is swept in rank-factored form (k_sweep4r)
   if (status[c] != 0) {
     for (int i = tid; i < 2 * NA16; i += 256) po[i] = 0.0;
     return;
@@ -358,12 +364,290 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
   if (tid == 0 && nalpha < NA16) po[2 * NA16 - 1] = (double)(cred[0] + cred[1] + cred[2] + cred[3]);
 }
 
+// k_sweep4r: the same sweep with GEMM2 through the rank-28 factorisation of its coefficient matrix (cmf_lowrank.hip):
+//   t[row][m] = - sum_j z[row][j] U[j][m]        (126 MFMA per 16 rows; A = U blocks broadcast from LDS, B = z as GEMM1 left it)
+//   q[row][alpha] = 1 + sum_m t[row][m] W[m][alpha]   (364 MFMA; A = t and its three row rotations, B = W fragments in LDS)
+// 814 MFMAs per 16 rows instead of 1260; q differs from the full product by one ulp.  Columns whose factorisation
+// was not accepted (lrok == 0) are left to k_sweep4.
+template <int EXP>
+__global__ __launch_bounds__(256, 1) void k_sweep4r(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+                                                    const int32_t *__restrict__ nuse, const double *__restrict__ mu,
+                                                    const double *__restrict__ ufrag_g, const double *__restrict__ wfrag2_g,
+                                                    const int32_t *__restrict__ lrok, const double *__restrict__ wfrag,
+                                                    size_t wstride, const int32_t *__restrict__ status,
+                                                    const double *__restrict__ alphas, int nalpha, int L, int p,
+                                                    int PS, int rows_per_wg, double *__restrict__ part) {
+  constexpr int NJ = S4J, NM = S4M, NA16 = NM * 16;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int NK = SF_LR_K / 4;            // 7 groups of 4 factor indices
+  double *wfr = sm;                          // [NM][NK][64]  W fragments (GEMM2b B operand)
+  double *wblk = wfr + NM * NK * 64;         // [NJ ig][NJ jg][16]
+  double *ufr = wblk + NJ * NJ * 16;         // [NJ jg][NK][16]  -U blocks (GEMM2a A operand)
+  double *mus = ufr + NJ * NK * 16;          // [72]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  double *po = part + ((size_t)c * nsplit + split) * 2 * NA16;
+  if (status[c] != 0 || lrok[c] == 0) return;   // k_sweep4 takes these columns
+  // ---- prologue: three table copies, loads issued in batches
+  for (int i = tid; i < 4 * NJ; i += 256) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
+  {
+    auto copy = [&](double *dst, const double *src, int nel) {
+      int i = tid;
+      for (; i + 3 * 256 < nel; i += 4 * 256) {
+        const double t0 = src[i], t1 = src[i + 256], t2 = src[i + 512], t3 = src[i + 768];
+        dst[i] = t0; dst[i + 256] = t1; dst[i + 512] = t2; dst[i + 768] = t3;
+      }
+      for (; i < nel; i += 256) dst[i] = src[i];
+    };
+    copy(wblk, wfrag + (size_t)c * wstride, NJ * NJ * 16);
+    copy(ufr, ufrag_g + (size_t)c * (NJ * NK * 16), NJ * NK * 16);
+    copy(wfr, wfrag2_g + (size_t)c * (NM * NK * 64), NM * NK * 64);
+  }
+  __syncthreads();
+
+  double P[NM], N[NM];
+  int E[NM];
+#pragma unroll
+  for (int u = 0; u < NM; ++u) { P[u] = 1.0; N[u] = 0.0; E[u] = 0; }
+  int ntile = 0;
+  int nrowok = 0;   // valid rows seen by this lane (lanes with g == 0 cover every row of the wave's tiles once)
+
+  const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
+  const uint8_t *mp = mask_t + (size_t)c * L;
+  const float *xc = xt + (size_t)c * L * PS + NJ * g;
+  const double *cf = wfr + lane;
+  const double *uf = ufr + 4 * g + (lane & 3);
+  const double *wf = wblk + 4 * g + (lane & 3);
+  const double qnan = __builtin_nan("");
+
+  float xraw[NJ];
+  bool rowok_next;
+  auto fetch = [&](int r0, float (&dst)[NJ], bool &ok) {
+    const int row = r0 + li;
+    ok = (row < rend) && (mp[row < rend ? row : rbeg] != 0);
+    const float *xp = xc + (size_t)(ok ? row : rbeg) * PS;
+#pragma unroll
+    for (int s = 0; s < NJ; s += 2) sf_load2(xp + s, dst[s], dst[s + 1]);
+  };
+  int r0 = rbeg + 16 * wave;
+  if (r0 < rend) fetch(r0, xraw, rowok_next);
+
+  if (EXP == 4) r0 = rend;   // timing experiment: prologue + final reduction only
+  for (; r0 < rend; r0 += 16 * 4) {
+    const bool rowok = rowok_next;
+    nrowok += (rowok && g == 0) ? 1 : 0;
+    int opq = 0;
+    asm volatile("" : "+v"(opq));  // keeps the loop-invariant LDS operand reads inside the iteration (see k_sweep)
+    const double *cfl = cf + opq;
+    const double *wfl = wf + opq;
+    const double *musl = mus + opq;
+    double x[NJ];
+#pragma unroll
+    for (int s = 0; s < NJ; ++s) {
+      const int b = NJ * g + s;
+      x[s] = (rowok && b < p) ? (double)xraw[s] - musl[b] : 0.0;
+    }
+    if (r0 + 64 < rend) fetch(r0 + 64, xraw, rowok_next);
+    // ---- GEMM1: 18 independent chains, one 4-band step at a time.  The A blocks of step s+1 are read (in-order
+    //      asm reads, two per two MFMAs) while step s multiplies; left to itself the scheduler sinks every read
+    //      next to its use and waits for it: 2 MFMAs per LDS round trip.
+    double z[4][NJ];
+    double wa[2][NJ];
+    const unsigned wadr = (unsigned)(size_t)wfl;  // LDS byte address of this lane's slot in block (0, 0)
+    static_for<0, NJ>([&](auto jc) {
+      constexpr int jg = decltype(jc)::value;
+      z[0][jg] = 0.0;
+      wa[0][jg] = lds_ld<jg * 128>(wadr);
+    });
+    if constexpr (EXP == 1) {
+#pragma unroll
+      for (int jg = 0; jg < NJ; ++jg) z[0][jg] = x[jg] + wa[0][jg];
+    } else
+    static_for<0, NJ>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      static_for<0, NJ / 6>([&](auto kc) {
+        constexpr int k = decltype(kc)::value * 6;
+        lds_wait6<0>(wa[s & 1][k], wa[s & 1][k + 1], wa[s & 1][k + 2], wa[s & 1][k + 3], wa[s & 1][k + 4], wa[s & 1][k + 5]);
+      });
+      static_for<0, NJ / 2>([&](auto jc) {
+        constexpr int jg = decltype(jc)::value * 2;
+        if constexpr (s + 1 < NJ) {
+          wa[(s + 1) & 1][jg] = lds_ld<((s + 1) * NJ + jg) * 128>(wadr);
+          wa[(s + 1) & 1][jg + 1] = lds_ld<((s + 1) * NJ + jg + 1) * 128>(wadr);
+        }
+        z[0][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(wa[s & 1][jg], x[s], z[0][jg], 0, 0, 0);
+        z[0][jg + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(wa[s & 1][jg + 1], x[s], z[0][jg + 1], 0, 0, 0);
+      });
+    });
+#pragma unroll
+    for (int jg = 0; jg < NJ; ++jg) z[0][jg] = z[0][jg] * z[0][jg];
+    // ---- GEMM2a: t = -z U, 7 independent chains; the U blocks of step jg+1 are read while step jg multiplies
+    double t4[4][NK];
+    {
+      const unsigned uadr = (unsigned)(size_t)(uf + opq);
+      double ua[2][NK];
+      static_for<0, NK>([&](auto mc) {
+        constexpr int mg = decltype(mc)::value;
+        t4[0][mg] = 0.0;
+        ua[0][mg] = lds_ld<mg * 128>(uadr);
+      });
+      static_for<0, NJ>([&](auto jc) {
+        constexpr int jg = decltype(jc)::value;
+        lds_wait4<0>(ua[jg & 1][0], ua[jg & 1][1], ua[jg & 1][2], ua[jg & 1][3]);
+        lds_wait4<0>(ua[jg & 1][3], ua[jg & 1][4], ua[jg & 1][5], ua[jg & 1][6]);
+        static_for<0, NK>([&](auto mc) {
+          constexpr int mg = decltype(mc)::value;
+          if constexpr (jg + 1 < NJ) ua[(jg + 1) & 1][mg] = lds_ld<((jg + 1) * NK + mg) * 128>(uadr);
+          t4[0][mg] = __builtin_amdgcn_mfma_f64_4x4x4f64(ua[jg & 1][mg], z[0][jg], t4[0][mg], 0, 0, 0);
+        });
+      });
+    }
+#pragma unroll
+    for (int mg = 0; mg < NK; ++mg) {
+      const double tv = t4[0][mg];
+      t4[1][mg] = dpp_row<0x124>(tv);  // row_ror:4
+      t4[2][mg] = dpp_row<0x128>(tv);  // row_ror:8
+      t4[3][mg] = dpp_row<0x12C>(tv);  // row_ror:12
+    }
+    // ---- GEMM2b: q = 1 + t W.  alpha tiles in groups of 4 (16 independent chains), W fragments read DEPTH-1 steps
+    //      ahead through a register ring that runs across group boundaries; row reduction as in k_sweep4.
+    constexpr int TG = 4, NG = (NM + TG - 1) / TG, NSTEP = NG * NK, DEPTH = 4;
+    double br[TG][DEPTH];
+    const unsigned cadr = (unsigned)(size_t)cfl;        // fragment (tile 0, jg 0) of this lane
+    auto loadb = [&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int gr = t / NK, jg = t - gr * NK;
+      static_for<0, TG>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (gr * TG + k < NM) br[k][t % DEPTH] = lds_ld<(k * NK + jg) * 512>(cadr + gr * (TG * NK * 512));
+      });
+    };
+    if constexpr (EXP == 3) {
+#pragma unroll
+      for (int u = 0; u < NM; ++u) N[u] += t4[u & 3][u % NK];
+    } else {
+    static_for<0, DEPTH - 1>(loadb);
+    double acc[2][TG][4];
+    // Row reduction of the TG alpha tiles of group `gr` from accumulator set `st`, in four short stages of
+    // independent instructions (one stage per MFMA step of the NEXT group: a tile's update is a chain of ~10
+    // dependent fp64 operations and, issued in one piece, idles the matrix pipe for its whole latency).
+    double rm01[TG], rm23[TG], rs01[TG], rs23[TG], rm[TG], rnu[TG];
+    int rsg[TG];
+    auto reduce_stage = [&](auto grc, auto stc, auto stagec) {
+      constexpr int gq = decltype(grc)::value, st = decltype(stc)::value, stage = decltype(stagec)::value;
+      constexpr int ntile = (NM - gq * TG) < TG ? (NM - gq * TG) : TG;
+#pragma unroll
+      for (int k = 0; k < ntile; ++k) {
+        const int u = gq * TG + k;
+        // acc[st][k][s] = q for alpha i = 16u + li and row (group (m + s) % 4, index g) of this tile
+        if constexpr (EXP == 2) {
+          if (stage == 0) N[u] += (acc[st][k][0] + acc[st][k][1]) + (acc[st][k][2] + acc[st][k][3]);
+        } else if constexpr (stage == 0) {
+          const double q0 = acc[st][k][0], q1 = acc[st][k][1], q2 = acc[st][k][2], q3 = acc[st][k][3];
+          rm01[k] = q0 * q1; rm23[k] = q2 * q3; rs01[k] = q0 + q1; rs23[k] = q2 + q3;
+          rsg[k] = __double2hiint(q0) | __double2hiint(q1) | __double2hiint(q2) | __double2hiint(q3);
+        } else if constexpr (stage == 1) {
+          rm[k] = rm01[k] * rm23[k];
+          rnu[k] = __builtin_fma(rs01[k], rm23[k], rs23[k] * rm01[k]);
+        } else if constexpr (stage == 2) {
+          rnu[k] = __builtin_fma(N[u], rm[k], rnu[k] * P[u]);   // N m + nu P
+          rm[k] = P[u] * rm[k];                                 // P m
+        } else {
+          const int e = __builtin_amdgcn_frexp_exp(rm[k]);
+          P[u] = __builtin_amdgcn_frexp_mant(rm[k]);
+          const double nn = __builtin_amdgcn_ldexp(rnu[k], -e);
+          N[u] = (rsg[k] < 0) ? qnan : nn;   // some q < 0: log(q) is NaN in the reference
+          E[u] += e;
+        }
+      }
+    };
+    static_for<0, NSTEP>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int gr = t / NK, jg = t - gr * NK, st = gr & 1;
+      constexpr int nt = sw4r_reads(t);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (t + DEPTH - 1 < NSTEP) loadb(std::integral_constant<int, t + DEPTH - 1>{});
+      // in-order returns: everything but the reads of the newer steps t+1 .. t+DEPTH-1 has landed
+      constexpr int newer = sw4r_reads(t + 1) + sw4r_reads(t + 2) + sw4r_reads(t + 3);
+      static_assert(DEPTH == 4 && newer <= 15, "lgkmcnt is a 4-bit counter");
+      if constexpr (nt == 4) lds_wait4<newer>(br[0][t % DEPTH], br[1][t % DEPTH], br[2][t % DEPTH], br[3][t % DEPTH]);
+      else lds_wait1<newer>(br[0][t % DEPTH]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int k = 0; k < nt; ++k) {
+          if constexpr (jg == 0) acc[st][k][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(t4[s][jg], br[k][t % DEPTH], 1.0, 0, 0, 0);
+          else acc[st][k][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(t4[s][jg], br[k][t % DEPTH], acc[st][k][s], 0, 0, 0);
+        }
+      // the previous group's tiles are reduced underneath this group's MFMAs (stages at steps 1, 2, 4, 5)
+      if constexpr (gr > 0 && (jg == 1 || jg == 2 || jg == 4 || jg == 5))
+        reduce_stage(std::integral_constant<int, gr - 1>{}, std::integral_constant<int, 1 - st>{},
+                     std::integral_constant<int, (jg == 1 ? 0 : (jg == 2 ? 1 : (jg == 4 ? 2 : 3)))>{});
+      if constexpr (t == NSTEP - 1) {   // the last group (one tile) has nothing to hide under
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 4>([&](auto sc) {
+          reduce_stage(std::integral_constant<int, gr>{}, std::integral_constant<int, st>{}, sc);
+        });
+      }
+    });
+    }
+    ntile += 1;
+  }
+
+  __syncthreads();
+  double *redP = sm;
+  double *redR = redP + 4 * NA16;
+  int *redE = reinterpret_cast<int *>(redR + 4 * NA16);
+#pragma unroll
+  for (int u = 0; u < NM; ++u) {
+    double pv = P[u], rv = N[u] / P[u] - 4.0 * (double)ntile;   // sum over this lane's rows of (1/q - 1) = beta r/q
+    int ev = E[u];
+#pragma unroll
+    for (int msk = 16; msk <= 32; msk <<= 1) {
+      const double po2 = shfl_xor_d(pv, msk);
+      const int eo = __shfl_xor(ev, msk, 64);
+      rv += shfl_xor_d(rv, msk);
+      const double pm = pv * po2;
+      ev += eo + __builtin_amdgcn_frexp_exp(pm);
+      pv = __builtin_amdgcn_frexp_mant(pm);
+    }
+    if (g == 0) {
+      redP[wave * NA16 + 16 * u + li] = pv;
+      redR[wave * NA16 + 16 * u + li] = rv;
+      redE[wave * NA16 + 16 * u + li] = ev;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < NA16; i += 256) {
+    double pv = 1.0, rv = 0.0;
+    int ev = 0;
+    for (int w = 0; w < 4; ++w) {
+      const double pm = pv * redP[w * NA16 + i];
+      ev += redE[w * NA16 + i] + __builtin_amdgcn_frexp_exp(pm);
+      pv = __builtin_amdgcn_frexp_mant(pm);
+      rv += redR[w * NA16 + i];
+    }
+    po[i] = log(pv) + (double)ev * 0.6931471805599453094;
+    po[NA16 + i] = rv;   // = beta_i sum_k r_k/q_k: k_nll divides (rq_scaled = 1)
+  }
+  // the number of rows this workgroup accumulated, for the beta = 0 term of k_nll: kept in the last padding slot
+  // of the alpha axis (the grid has 201 points, the tiles 208)
+  __syncthreads();
+  int *cred = reinterpret_cast<int *>(sm);
+  for (int off = 32; off > 0; off >>= 1) nrowok += __shfl_xor(nrowok, off, 64);
+  if (lane == 0) cred[wave] = nrowok;
+  __syncthreads();
+  if (tid == 0 && nalpha < NA16) po[2 * NA16 - 1] = (double)(cred[0] + cred[1] + cred[2] + cred[3]);
+}
+
+constexpr size_t SW4R_LDS = ((size_t)S4M * (SF_LR_K / 4) * 64 + S4J * S4J * 16 + S4J * (SF_LR_K / 4) * 16 + 4 * S4J) * sizeof(double);
 constexpr size_t SW4_LDS = ((size_t)S4M * S4J * 64 + S4J * S4J * 16 + 4 * S4J) * sizeof(double);
 
 template <int EXP>
 int launch_sweep4_t(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
                     const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,
-                    int nsplit, double *part, hipStream_t st) {
+                    int nsplit, double *part, hipStream_t st, const int32_t *lrok = nullptr) {
   static bool attr_set = false;
   if (!attr_set) {
     SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4<EXP>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -373,8 +657,25 @@ int launch_sweep4_t(const float *xt, const uint8_t *mask_t, const int32_t *nuse,
   int rows = sf_cdiv(g.lines, nsplit);
   rows = (rows + 63) / 64 * 64;
   hipLaunchKernelGGL(k_sweep4<EXP>, dim3(g.ncols, nsplit), dim3(256), SW4_LDS, st, xt, mask_t, nuse, mu, lam, wfrag,
-                     wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part);
+                     wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part, lrok);
   SF_LAUNCH_CHECK("k_sweep4");
+  return 0;
+}
+
+int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *ufrag,
+                   const double *wfrag2, const int32_t *lrok, const double *wfrag, size_t wstride, const int32_t *status,
+                   const double *alphas, const SfGeom &g, int nsplit, double *part, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4r<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)SW4R_LDS));
+    attr_set = true;
+  }
+  int rows = sf_cdiv(g.lines, nsplit);
+  rows = (rows + 63) / 64 * 64;
+  hipLaunchKernelGGL(k_sweep4r<0>, dim3(g.ncols, nsplit), dim3(256), SW4R_LDS, st, xt, mask_t, nuse, mu, ufrag, wfrag2, lrok,
+                     wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part);
+  SF_LAUNCH_CHECK("k_sweep4r");
   return 0;
 }
 
@@ -388,8 +689,21 @@ int sf_launch_wfrag4(const double *evec, const double *d, const SfGeom &g, size_
 
 int sf_launch_sweep4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
                      const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,
-                     int nsplit, double *part, int variant, hipStream_t st) {
+                     int nsplit, double *part, int variant, void *lr_scratch, hipStream_t st) {
 #define SW4_ARGS xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part, st
+  if (variant == 0 && lr_scratch) {
+    // rank-factored sweep for the columns whose factorisation is accepted, the full-rank kernel for the rest
+    // (it returns at once for the others: a column is swept by exactly one of the two)
+    char *base = reinterpret_cast<char *>(lr_scratch);
+    double *ufrag = reinterpret_cast<double *>(base);
+    double *wfrag2 = reinterpret_cast<double *>(base + sf_align((size_t)g.ncols * S4J * (SF_LR_K / 4) * 16 * sizeof(double)));
+    int32_t *lrok = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(wfrag2) +
+                                                sf_align((size_t)g.ncols * S4M * (SF_LR_K / 4) * 64 * sizeof(double)));
+    if (int rc = sf_launch_lowrank(lam, nuse, status, alphas, g, ufrag, wfrag2, lrok, st)) return rc;
+    if (int rc = launch_sweep4r(xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, wfrag, wstride, status, alphas, g, nsplit, part, st))
+      return rc;
+    return launch_sweep4_t<0>(SW4_ARGS, lrok);
+  }
 #ifdef SF_SWEEP_EXPERIMENTS
   if (variant == 11) return launch_sweep4_t<1>(SW4_ARGS);
   if (variant == 12) return launch_sweep4_t<2>(SW4_ARGS);

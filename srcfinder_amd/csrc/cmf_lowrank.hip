@@ -12,8 +12,9 @@
 // The factorisation is a Householder QR with column pivoting of B^T (208 x 72), stopped after K steps:
 //   B^T P = Q R   =>   B = (P R_K^T) (Q_K^T) + E,   |E| = the largest remaining column norm,
 // backward stable whatever the conditioning (B is numerically singular by design -- no Gram matrix, no
-// inverse).  One 256-thread workgroup per column, the matrix in LDS; ~30 us.  A column whose remaining norm
-// after K steps is not below 3e-15 |R_00| (the rounding floor of the trailing block is ~7e-16 |R_00|) is flagged and swept by the full-rank kernel instead.
+// inverse).  One 576-thread workgroup per column, the matrix in LDS, 8 lanes per column with DPP reductions.  A column whose remaining norm
+// after K steps is not below 3e-15 |R_00| (the rounding floor of the trailing block is ~7e-16 |R_00|), or whose
+// B is badly scaled (|R_00| > 64: a near-singular correlation matrix), is flagged and swept by the full-rank kernel.
 #include "cmf_common.h"
 
 namespace {
@@ -22,28 +23,47 @@ constexpr int LR_P = 4 * SF_SW4_NJ;        // 72
 constexpr int LR_NA = 16 * SF_SW4_NM;      // 208
 constexpr int LR_K = SF_LR_K;              // 28
 constexpr int LR_LDA = LR_NA + 1;          // column stride in LDS (odd: threads on different columns, same row)
-constexpr int LR_TPC = 3;                  // threads per column in the update
+constexpr int LR_TPC = 8;                  // lanes per column in the update (8-lane DPP reductions, no LDS partials)
+constexpr int LR_NT = 576;                 // 72 columns x 8 lanes = 9 waves
 
-__global__ __launch_bounds__(256) void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
-                                                  const int32_t *__restrict__ status, const double *__restrict__ alphas,
-                                                  int nalpha, int p, double *__restrict__ ufrag, double *__restrict__ wfrag,
-                                                  int32_t *__restrict__ lrok) {
+template <int CTRL>
+__device__ __forceinline__ double lr_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lr_sum8(double v) {   // all 8 lanes of an aligned group get the sum
+  v += lr_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += lr_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += lr_dpp<0x141>(v);   // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ double lr_sum16(double v) {
+  v = lr_sum8(v);
+  v += lr_dpp<0x140>(v);   // row_mirror
+  return v;
+}
+
+__global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
+                                                    const int32_t *__restrict__ status, const double *__restrict__ alphas,
+                                                    int nalpha, int p, double *__restrict__ ufrag, double *__restrict__ wfrag,
+                                                    int32_t *__restrict__ lrok) {
   extern __shared__ double A[];                 // [LR_P][LR_LDA] column-major: column j = the 208 coefficients of eigen index j
-  __shared__ double part[LR_P][LR_TPC];         // partial dot products / partial squared norms
-  __shared__ double qpart[LR_K * 9];
-  __shared__ double wred[4];
+  __shared__ double cnorm[LR_P];                // squared norms of the remaining columns below the current row
   __shared__ double tau_s[LR_K];
-  __shared__ double sc[4];                      // [0] tau, [1] 1/(alpha - beta_h)
+  __shared__ double wred[4];
+  __shared__ double sc[2];                      // [0] tau, [1] 1/(alpha - beta_h)
+  __shared__ double pvv[2];
+  __shared__ int pvi[2];
   __shared__ int perm[LR_P];                    // perm[pos] = original column at position pos
-  __shared__ int piv;
-  const int c = blockIdx.x, tid = threadIdx.x;
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   if (status[c] != 0) {
     if (tid == 0) lrok[c] = 0;
     return;
   }
   const double n = (double)nuse[c];
   // ---- B^T: A[j][i] = beta_i / (n beta_i lam_j + alpha_i)   (zero for the padding alpha / eigen indices)
-  for (int idx = tid; idx < LR_P * LR_NA; idx += 256) {
+  for (int idx = tid; idx < LR_P * LR_NA; idx += LR_NT) {
     const int j = idx / LR_NA, i = idx - j * LR_NA;
     double v = 0.0;
     if (i < nalpha && j < p) {
@@ -55,31 +75,31 @@ __global__ __launch_bounds__(256) void k_lowrank(const double *__restrict__ lam,
   }
   if (tid < LR_P) perm[tid] = tid;
   __syncthreads();
-  const int col = tid / LR_TPC, sub = tid - col * LR_TPC;   // update role: column `col`, rows sub, sub+3, ...
-  const bool worker = col < LR_P;
-  // squared norms of all columns
-  if (worker) {
+  const int col = tid >> 3, sub = tid & 7;   // update role: column `col` (0..71), rows sub, sub+8, ...
+  {
     double s = 0.0;
     for (int i = sub; i < LR_NA; i += LR_TPC) { const double v = A[col * LR_LDA + i]; s = __builtin_fma(v, v, s); }
-    part[col][sub] = s;
+    s = lr_sum8(s);
+    if (sub == 0) cnorm[col] = s;
   }
   __syncthreads();
-  double r00 = 0.0, resid = 0.0;
+  double r00 = 0.0;
   for (int s = 0; s < LR_K; ++s) {
-    // ---- pivot: the remaining column of largest norm
-    if (tid == 0) {
-      int best = s;
-      double bn = -1.0;
-      for (int j = s; j < LR_P; ++j) {
-        const double v = (part[j][0] + part[j][1]) + part[j][2];
-        if (v > bn) { bn = v; best = j; }
+    // ---- pivot: the remaining column of largest norm (lowest index on ties), two waves of candidates
+    if (tid < 128) {
+      double bv = (tid >= s && tid < LR_P) ? cnorm[tid] : -1.0;
+      int bi = tid;
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
       }
-      piv = best;
+      if (lane == 0) { pvv[tid >> 6] = bv; pvi[tid >> 6] = bi; }
     }
     __syncthreads();
-    const int pv = piv;
+    const int pv = (pvv[1] > pvv[0]) ? pvi[1] : pvi[0];
     if (pv != s) {
-      for (int i = tid; i < LR_NA; i += 256) {
+      for (int i = tid; i < LR_NA; i += LR_NT) {
         const double t = A[s * LR_LDA + i];
         A[s * LR_LDA + i] = A[pv * LR_LDA + i];
         A[pv * LR_LDA + i] = t;
@@ -89,11 +109,11 @@ __global__ __launch_bounds__(256) void k_lowrank(const double *__restrict__ lam,
     __syncthreads();
     // ---- Householder reflector of column s below the diagonal (LAPACK dlarfg); the norm of the part below the
     //      diagonal is summed directly (the carried column norm minus alpha^2 would cancel)
-    {
+    if (tid < 256) {
       double x2 = 0.0;
       if (tid < LR_NA && tid > s) { const double xv = A[s * LR_LDA + tid]; x2 = xv * xv; }
       for (int off = 32; off > 0; off >>= 1) x2 += __shfl_xor(x2, off, 64);
-      if ((tid & 63) == 0) wred[tid >> 6] = x2;
+      if (lane == 0) wred[tid >> 6] = x2;
     }
     __syncthreads();
     if (tid == 0) {
@@ -109,47 +129,67 @@ __global__ __launch_bounds__(256) void k_lowrank(const double *__restrict__ lam,
       sc[1] = scale;
       tau_s[s] = tau;
       A[s * LR_LDA + s] = betah;   // R_ss
+      if (s == 0) pvv[0] = fabs(betah);
     }
     __syncthreads();
     const double tau = sc[0], scale = sc[1];
-    for (int i = s + 1 + tid; i < LR_NA; i += 256) A[s * LR_LDA + i] *= scale;   // v (v_s = 1 implicit)
-    __syncthreads();
-    // ---- apply H = I - tau v v^T to the remaining columns; partial squared norms of what is left below row s
-    const double *v = A + s * LR_LDA;
-    double w = 0.0;
-    if (worker && col > s) {
-      const double *ac = A + col * LR_LDA;
-      for (int i = s + sub; i < LR_NA; i += LR_TPC) w = __builtin_fma(i == s ? 1.0 : v[i], ac[i], w);
-      part[col][sub] = w;
+    if (s == 0) r00 = pvv[0];
+    // ---- v = x * scale (v_s = 1 implicit), kept in registers by every lane for its rows, written back once
+    double vr[(LR_NA + LR_TPC - 1) / LR_TPC];
+    const double *xs = A + s * LR_LDA;
+#pragma unroll
+    for (int k = 0; k < (LR_NA + LR_TPC - 1) / LR_TPC; ++k) {
+      const int i = sub + LR_TPC * k;
+      vr[k] = (i > s && i < LR_NA) ? xs[i] * scale : ((i == s) ? 1.0 : 0.0);
     }
-    __syncthreads();
-    double wt = 0.0;
-    if (worker && col > s) wt = tau * ((part[col][0] + part[col][1]) + part[col][2]);
-    __syncthreads();   // every partial has been read before part[] is reused for the norms
-    if (worker && col > s) {
-      double *ac = A + col * LR_LDA;
-      double nn = 0.0;
-      for (int i = s + sub; i < LR_NA; i += LR_TPC) {
-        const double nv = __builtin_fma(-wt, i == s ? 1.0 : v[i], ac[i]);
-        ac[i] = nv;
-        if (i > s) nn = __builtin_fma(nv, nv, nn);
+    __syncthreads();   // every lane has its copy of x before column s is overwritten with v
+    if (col == s) {
+#pragma unroll
+      for (int k = 0; k < (LR_NA + LR_TPC - 1) / LR_TPC; ++k) {
+        const int i = sub + LR_TPC * k;
+        if (i > s && i < LR_NA) A[s * LR_LDA + i] = vr[k];
       }
-      part[col][sub] = nn;
-    } else if (worker) {
-      part[col][sub] = 0.0;
+    }
+    // ---- apply H = I - tau v v^T to the remaining columns; squared norms of what is left below row s
+    if (col > s) {
+      double *ac = A + col * LR_LDA;
+      double av[(LR_NA + LR_TPC - 1) / LR_TPC];
+      double w = 0.0;
+#pragma unroll
+      for (int k = 0; k < (LR_NA + LR_TPC - 1) / LR_TPC; ++k) {
+        const int i = sub + LR_TPC * k;
+        av[k] = (i >= s && i < LR_NA) ? ac[i] : 0.0;
+        w = __builtin_fma(vr[k], av[k], w);
+      }
+      const double wt = tau * lr_sum8(w);
+      double nn = 0.0;
+#pragma unroll
+      for (int k = 0; k < (LR_NA + LR_TPC - 1) / LR_TPC; ++k) {
+        const int i = sub + LR_TPC * k;
+        if (i >= s && i < LR_NA) {
+          const double nv = __builtin_fma(-wt, vr[k], av[k]);
+          ac[i] = nv;
+          if (i > s) nn = __builtin_fma(nv, nv, nn);
+        }
+      }
+      nn = lr_sum8(nn);
+      if (sub == 0) cnorm[col] = nn;
+    } else if (sub == 0) {
+      cnorm[col] = 0.0;
     }
     __syncthreads();
-    if (s == 0) r00 = fabs(A[0]);
   }
   {   // what is left after K steps
     double bn = 0.0;
-    for (int j = LR_K; j < LR_P; ++j) bn = fmax(bn, (part[j][0] + part[j][1]) + part[j][2]);
-    resid = sqrt(bn);
+    for (int j = LR_K; j < LR_P; ++j) bn = fmax(bn, cnorm[j]);
+    const double resid = sqrt(bn);
+    // The error bound is relative to |B|: accept only a well-scaled B (largest column norm of B^T <= 64, i.e.
+    // n lam_min not far below 1; a singular R has entries beta/alpha ~ 1e5 for the smallest alphas).
+    if (tid == 0) lrok[c] = (resid <= 3e-15 * r00 && r00 > 0.0 && r00 <= 64.0) ? 1 : 0;
   }
-  if (tid == 0) lrok[c] = (resid <= 3e-15 * r00 && r00 > 0.0) ? 1 : 0;
   // ---- U fragments: ufrag[(jg*NK + mg)*16 + 4q + n] = -U[4jg+q][4mg+n],  U[perm[pos]][m] = R[m][pos]
   double *uo = ufrag + (size_t)c * (SF_SW4_NJ * (LR_K / 4) * 16);
-  for (int idx = tid; idx < LR_P * LR_K; idx += 256) {
+  for (int idx = tid; idx < LR_P * LR_K; idx += LR_NT) {
     const int pos = idx / LR_K, m = idx - pos * LR_K;
     const double r = (m <= pos) ? A[pos * LR_LDA + m] : 0.0;
     const int j = perm[pos];
@@ -157,37 +197,41 @@ __global__ __launch_bounds__(256) void k_lowrank(const double *__restrict__ lam,
     uo[(jg * (LR_K / 4) + mg) * 16 + 4 * q + nn] = -r;
   }
   __syncthreads();
-  // ---- Q_K = H_0 ... H_{K-1} [I_K; 0], formed in the (now free) columns K .. 2K-1 of A
+  // ---- Q_K = H_0 ... H_{K-1} [I_K; 0], formed in the (now free) columns K .. 2K-1 of A; 16 lanes per column
   double *Q = A + LR_K * LR_LDA;
-  for (int idx = tid; idx < LR_K * LR_NA; idx += 256) {
+  for (int idx = tid; idx < LR_K * LR_NA; idx += LR_NT) {
     const int m = idx / LR_NA, i = idx - m * LR_NA;
     Q[m * LR_LDA + i] = (i == m) ? 1.0 : 0.0;
   }
   __syncthreads();
-  const int qcol = tid / 9, qsub = tid - qcol * 9;   // 28 columns x 9 threads = 252
+  const int qcol = tid >> 4, qsub = tid & 15;   // 28 columns x 16 lanes = 448 threads
   for (int s = LR_K - 1; s >= 0; --s) {
     const double *v = A + s * LR_LDA;
     const double tau = tau_s[s];
-    double w = 0.0;
     if (qcol < LR_K) {
-      const double *qc = Q + qcol * LR_LDA;
-      for (int i = s + qsub; i < LR_NA; i += 9) w = __builtin_fma(i == s ? 1.0 : v[i], qc[i], w);
-    }
-    double *pp = qpart;
-    if (qcol < LR_K) pp[qcol * 9 + qsub] = w;
-    __syncthreads();
-    if (qcol < LR_K) {
-      double t = 0.0;
-      for (int e = 0; e < 9; ++e) t += pp[qcol * 9 + e];
-      const double wt = tau * t;
       double *qc = Q + qcol * LR_LDA;
-      for (int i = s + qsub; i < LR_NA; i += 9) qc[i] = __builtin_fma(-wt, i == s ? 1.0 : v[i], qc[i]);
+      double vv[(LR_NA + 15) / 16], qv[(LR_NA + 15) / 16];
+      double w = 0.0;
+#pragma unroll
+      for (int k = 0; k < (LR_NA + 15) / 16; ++k) {
+        const int i = qsub + 16 * k;
+        vv[k] = (i > s && i < LR_NA) ? v[i] : ((i == s) ? 1.0 : 0.0);
+        qv[k] = (i >= s && i < LR_NA) ? qc[i] : 0.0;
+        w = __builtin_fma(vv[k], qv[k], w);
+      }
+      const double wt = tau * lr_sum16(w);
+#pragma unroll
+      for (int k = 0; k < (LR_NA + 15) / 16; ++k) {
+        const int i = qsub + 16 * k;
+        if (i >= s && i < LR_NA) qc[i] = __builtin_fma(-wt, vv[k], qv[k]);
+      }
     }
-    __syncthreads();
+    // columns are independent: no barrier between reflectors
   }
+  __syncthreads();
   // ---- W fragments: wfrag[(M*NK + mg)*64 + lane], lane = 16q + 4mm + n  ->  W[4mg+q][16M + 4mm + n] = Q[alpha][m]
   double *wo = wfrag + (size_t)c * (SF_SW4_NM * (LR_K / 4) * 64);
-  for (int idx = tid; idx < SF_SW4_NM * (LR_K / 4) * 64; idx += 256) {
+  for (int idx = tid; idx < SF_SW4_NM * (LR_K / 4) * 64; idx += LR_NT) {
     const int ln = idx & 63, blk = idx >> 6;
     const int M = blk / (LR_K / 4), mg = blk - M * (LR_K / 4);
     const int q = ln >> 4, a = 16 * M + (ln & 15);
@@ -210,7 +254,7 @@ int sf_launch_lowrank(const double *lam, const int32_t *nuse, const int32_t *sta
     SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lowrank), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_lowrank, dim3(g.ncols), dim3(256), lds, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok);
+  hipLaunchKernelGGL(k_lowrank, dim3(g.ncols), dim3(LR_NT), lds, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok);
   SF_LAUNCH_CHECK("k_lowrank");
   return 0;
 }

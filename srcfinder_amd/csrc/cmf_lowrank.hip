@@ -49,13 +49,12 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
                                                     int nalpha, int p, double *__restrict__ ufrag, double *__restrict__ wfrag,
                                                     int32_t *__restrict__ lrok) {
   extern __shared__ double A[];                 // [LR_P][LR_LDA] column-major: column j = the 208 coefficients of eigen index j
-  __shared__ double cnorm[LR_P];                // squared norms of the remaining columns below the current row
+  __shared__ double cnorm[LR_P];                // squared norms of the remaining columns, rows >= current (-1: pivoted)
+  __shared__ double cnorm2[LR_P];               // the same over the rows below the current one
+  __shared__ int posof[LR_P];                   // step at which a column was pivoted, -1 if never
   __shared__ double tau_s[LR_K];
-  __shared__ double wred[4];
-  __shared__ double sc[2];                      // [0] tau, [1] 1/(alpha - beta_h)
-  __shared__ double pvv[2];
-  __shared__ int pvi[2];
-  __shared__ int perm[LR_P];                    // perm[pos] = original column at position pos
+  __shared__ int perm[LR_K];                    // perm[s] = the column pivoted at step s
+  __shared__ int freecol[LR_K];                 // never-pivoted columns that hold Q_K afterwards
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   if (status[c] != 0) {
     if (tid == 0) lrok[c] = 0;
@@ -73,85 +72,73 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
     }
     A[j * LR_LDA + i] = v;
   }
-  if (tid < LR_P) perm[tid] = tid;
+  if (tid < LR_P) posof[tid] = -1;
   __syncthreads();
   const int col = tid >> 3, sub = tid & 7;   // update role: column `col` (0..71), rows sub, sub+8, ...
   {
-    double s = 0.0;
-    for (int i = sub; i < LR_NA; i += LR_TPC) { const double v = A[col * LR_LDA + i]; s = __builtin_fma(v, v, s); }
-    s = lr_sum8(s);
-    if (sub == 0) cnorm[col] = s;
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = sub; i < LR_NA; i += LR_TPC) {
+      const double v = A[col * LR_LDA + i];
+      s0 = __builtin_fma(v, v, s0);
+      if (i > 0) s1 = __builtin_fma(v, v, s1);
+    }
+    s0 = lr_sum8(s0);
+    s1 = lr_sum8(s1);
+    if (sub == 0) { cnorm[col] = s0; cnorm2[col] = s1; }
   }
   __syncthreads();
+  // Two barriers per step.  No column is physically moved: a pivoted column keeps its place (posof[col] = its step),
+  // every wave finds the pivot for itself (same data, same tie-break), every lane forms the reflector's scalars
+  // from the carried norms -- cnorm = rows >= s, cnorm2 = rows > s, both summed afresh by the update of the
+  // previous step, so nothing is obtained by subtraction.
   double r00 = 0.0;
+  bool mine_done = false;                       // this group's column has been pivoted
   for (int s = 0; s < LR_K; ++s) {
-    // ---- pivot: the remaining column of largest norm (lowest index on ties), two waves of candidates
-    if (tid < 128) {
-      double bv = (tid >= s && tid < LR_P) ? cnorm[tid] : -1.0;
-      int bi = tid;
-      for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(bv, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-      }
-      if (lane == 0) { pvv[tid >> 6] = bv; pvi[tid >> 6] = bi; }
+    double bv = (lane < LR_P) ? cnorm[lane] : -1.0;       // done columns carry -1
+    int bi = lane;
+    if (lane < LR_P - 64) {
+      const double v2 = cnorm[lane + 64];
+      if (v2 > bv) { bv = v2; bi = lane + 64; }
     }
-    __syncthreads();
-    const int pv = (pvv[1] > pvv[0]) ? pvi[1] : pvi[0];
-    if (pv != s) {
-      for (int i = tid; i < LR_NA; i += LR_NT) {
-        const double t = A[s * LR_LDA + i];
-        A[s * LR_LDA + i] = A[pv * LR_LDA + i];
-        A[pv * LR_LDA + i] = t;
-      }
-      if (tid == 0) { const int t = perm[s]; perm[s] = perm[pv]; perm[pv] = t; }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    __syncthreads();
-    // ---- Householder reflector of column s below the diagonal (LAPACK dlarfg); the norm of the part below the
-    //      diagonal is summed directly (the carried column norm minus alpha^2 would cancel)
-    if (tid < 256) {
-      double x2 = 0.0;
-      if (tid < LR_NA && tid > s) { const double xv = A[s * LR_LDA + tid]; x2 = xv * xv; }
-      for (int off = 32; off > 0; off >>= 1) x2 += __shfl_xor(x2, off, 64);
-      if (lane == 0) wred[tid >> 6] = x2;
+    const int pv = bi;
+    const double *xs = A + pv * LR_LDA;
+    const double alpha = xs[s], xn2 = cnorm2[pv];
+    double tau = 0.0, scale = 0.0, betah = alpha;
+    if (xn2 > 0.0) {
+      betah = -copysign(sqrt(alpha * alpha + xn2), alpha);
+      tau = (betah - alpha) / betah;
+      scale = 1.0 / (alpha - betah);
     }
-    __syncthreads();
-    if (tid == 0) {
-      const double alpha = A[s * LR_LDA + s];
-      const double xn2 = (wred[0] + wred[1]) + (wred[2] + wred[3]);
-      double tau = 0.0, scale = 0.0, betah = alpha;
-      if (xn2 > 0.0) {
-        betah = -copysign(sqrt(alpha * alpha + xn2), alpha);
-        tau = (betah - alpha) / betah;
-        scale = 1.0 / (alpha - betah);
-      }
-      sc[0] = tau;
-      sc[1] = scale;
-      tau_s[s] = tau;
-      A[s * LR_LDA + s] = betah;   // R_ss
-      if (s == 0) pvv[0] = fabs(betah);
-    }
-    __syncthreads();
-    const double tau = sc[0], scale = sc[1];
-    if (s == 0) r00 = pvv[0];
-    // ---- v = x * scale (v_s = 1 implicit), kept in registers by every lane for its rows, written back once
+    if (s == 0) r00 = fabs(betah);
+    // v = x * scale (v_s = 1 implicit), in registers of every lane for its rows
     double vr[(LR_NA + LR_TPC - 1) / LR_TPC];
-    const double *xs = A + s * LR_LDA;
 #pragma unroll
     for (int k = 0; k < (LR_NA + LR_TPC - 1) / LR_TPC; ++k) {
       const int i = sub + LR_TPC * k;
       vr[k] = (i > s && i < LR_NA) ? xs[i] * scale : ((i == s) ? 1.0 : 0.0);
     }
-    __syncthreads();   // every lane has its copy of x before column s is overwritten with v
-    if (col == s) {
+    __syncthreads();   // every lane has read column pv (and the norms) before they change
+    if (col == pv) {   // the pivot's own group stores v, R_ss and the bookkeeping while the others update
 #pragma unroll
       for (int k = 0; k < (LR_NA + LR_TPC - 1) / LR_TPC; ++k) {
         const int i = sub + LR_TPC * k;
-        if (i > s && i < LR_NA) A[s * LR_LDA + i] = vr[k];
+        if (i > s && i < LR_NA) A[pv * LR_LDA + i] = vr[k];
       }
-    }
-    // ---- apply H = I - tau v v^T to the remaining columns; squared norms of what is left below row s
-    if (col > s) {
+      if (sub == 0) {
+        A[pv * LR_LDA + s] = betah;
+        tau_s[s] = tau;
+        perm[s] = pv;
+        posof[pv] = s;
+        cnorm[pv] = -1.0;
+      }
+      mine_done = true;
+    } else if (!mine_done) {
+      // ---- apply H = I - tau v v^T; squared norms of what is left in rows > s and in rows > s+1
       double *ac = A + col * LR_LDA;
       double av[(LR_NA + LR_TPC - 1) / LR_TPC];
       double w = 0.0;
@@ -162,7 +149,7 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
         w = __builtin_fma(vr[k], av[k], w);
       }
       const double wt = tau * lr_sum8(w);
-      double nn = 0.0;
+      double nn = 0.0, nn2 = 0.0;
 #pragma unroll
       for (int k = 0; k < (LR_NA + LR_TPC - 1) / LR_TPC; ++k) {
         const int i = sub + LR_TPC * k;
@@ -170,46 +157,53 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
           const double nv = __builtin_fma(-wt, vr[k], av[k]);
           ac[i] = nv;
           if (i > s) nn = __builtin_fma(nv, nv, nn);
+          if (i > s + 1) nn2 = __builtin_fma(nv, nv, nn2);
         }
       }
       nn = lr_sum8(nn);
-      if (sub == 0) cnorm[col] = nn;
-    } else if (sub == 0) {
-      cnorm[col] = 0.0;
+      nn2 = lr_sum8(nn2);
+      if (sub == 0) { cnorm[col] = nn; cnorm2[col] = nn2; }
     }
     __syncthreads();
   }
   {   // what is left after K steps
     double bn = 0.0;
-    for (int j = LR_K; j < LR_P; ++j) bn = fmax(bn, cnorm[j]);
+    for (int j = 0; j < LR_P; ++j) bn = fmax(bn, cnorm[j]);
     const double resid = sqrt(bn);
     // The error bound is relative to |B|: accept only a well-scaled B (largest column norm of B^T <= 64, i.e.
     // n lam_min not far below 1; a singular R has entries beta/alpha ~ 1e5 for the smallest alphas).
     if (tid == 0) lrok[c] = (resid <= 3e-15 * r00 && r00 > 0.0 && r00 <= 64.0) ? 1 : 0;
   }
-  // ---- U fragments: ufrag[(jg*NK + mg)*16 + 4q + n] = -U[4jg+q][4mg+n],  U[perm[pos]][m] = R[m][pos]
+  // ---- U fragments: ufrag[(jg*NK + mg)*16 + 4q + n] = -U[4jg+q][4mg+n];  U[j][m] = R[m][column j]: rows m <= posof[j]
+  //      of a pivoted column (below them sits its reflector), all K rows of the others
   double *uo = ufrag + (size_t)c * (SF_SW4_NJ * (LR_K / 4) * 16);
   for (int idx = tid; idx < LR_P * LR_K; idx += LR_NT) {
-    const int pos = idx / LR_K, m = idx - pos * LR_K;
-    const double r = (m <= pos) ? A[pos * LR_LDA + m] : 0.0;
-    const int j = perm[pos];
+    const int j = idx / LR_K, m = idx - j * LR_K;
+    const int pj = posof[j];
+    const double r = (pj < 0 || m <= pj) ? A[j * LR_LDA + m] : 0.0;
     const int jg = j >> 2, q = j & 3, mg = m >> 2, nn = m & 3;
     uo[(jg * (LR_K / 4) + mg) * 16 + 4 * q + nn] = -r;
   }
   __syncthreads();
-  // ---- Q_K = H_0 ... H_{K-1} [I_K; 0], formed in the (now free) columns K .. 2K-1 of A; 16 lanes per column
-  double *Q = A + LR_K * LR_LDA;
+  // ---- Q_K = H_0 ... H_{K-1} [I_K; 0], formed in K of the columns that were never pivoted (their R entries have
+  //      been exported); reflector s sits in column perm[s].  16 lanes per column.
+  if (tid == 0) {
+    int m = 0;
+    for (int j = 0; j < LR_P && m < LR_K; ++j)
+      if (posof[j] < 0) freecol[m++] = j;
+  }
+  __syncthreads();
   for (int idx = tid; idx < LR_K * LR_NA; idx += LR_NT) {
     const int m = idx / LR_NA, i = idx - m * LR_NA;
-    Q[m * LR_LDA + i] = (i == m) ? 1.0 : 0.0;
+    A[freecol[m] * LR_LDA + i] = (i == m) ? 1.0 : 0.0;
   }
   __syncthreads();
   const int qcol = tid >> 4, qsub = tid & 15;   // 28 columns x 16 lanes = 448 threads
   for (int s = LR_K - 1; s >= 0; --s) {
-    const double *v = A + s * LR_LDA;
+    const double *v = A + perm[s] * LR_LDA;
     const double tau = tau_s[s];
     if (qcol < LR_K) {
-      double *qc = Q + qcol * LR_LDA;
+      double *qc = A + freecol[qcol] * LR_LDA;
       double vv[(LR_NA + 15) / 16], qv[(LR_NA + 15) / 16];
       double w = 0.0;
 #pragma unroll
@@ -235,7 +229,7 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
     const int ln = idx & 63, blk = idx >> 6;
     const int M = blk / (LR_K / 4), mg = blk - M * (LR_K / 4);
     const int q = ln >> 4, a = 16 * M + (ln & 15);
-    wo[idx] = Q[(4 * mg + q) * LR_LDA + a];
+    wo[idx] = A[freecol[4 * mg + q] * LR_LDA + a];
   }
 }
 

@@ -13,6 +13,7 @@ extern int g_sweep_variant;                            // cmf_loocv.hip
 extern int g_cov_variant;                              // cmf_cov.hip
 extern int g_extract_variant;                          // cmf_extract.hip
 extern int g_eigh_lpp;                                 // cmf_eigh.hip
+extern int g_sweep4r_waves;                            // cmf_loocv4.hip
 
 namespace {
 thread_local char g_err[512] = "";
@@ -256,6 +257,7 @@ int sf_debug_set(int key, int value) {
     case 5: g_cov_variant = value; return 0;
     case 6: g_extract_variant = value; return 0;
     case 7: g_eigh_lpp = value; return 0;
+    case 8: g_sweep4r_waves = value; return 0;
     default: sf_set_error("sf_debug_set: unknown key %d", key); return -1;
   }
 }

@@ -6,6 +6,9 @@
 #include "cmf_common.h"
 #include <type_traits>
 
+int g_sweep4r_waves = 4;   // sf_debug_set key 8: waves per workgroup of the rank-factored sweep (4; 8 = two waves per SIMD:
+                           // measured slower, the 128+128 register split it forces spills the VALU-visible state)
+
 namespace {
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
@@ -369,8 +372,11 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
 //   q[row][alpha] = 1 + sum_m t[row][m] W[m][alpha]   (364 MFMA; A = t and its three row rotations, B = W fragments in LDS)
 // 814 MFMAs per 16 rows instead of 1260; q differs from the full product by one ulp.  Columns whose factorisation
 // was not accepted (lrok == 0) are left to k_sweep4.
-template <int EXP>
-__global__ __launch_bounds__(256, 1) void k_sweep4r(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+// NW waves per workgroup share the LDS tables: with NW = 8 every SIMD holds two waves of the same workgroup and
+// one wave's LDS reads, DPP moves and waits run under the other's MFMAs (the tables allow only one workgroup per
+// CU, and with a single wave per SIMD every non-MFMA instruction is a bubble in the matrix pipe).
+template <int EXP, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
                                                     const int32_t *__restrict__ nuse, const double *__restrict__ mu,
                                                     const double *__restrict__ ufrag_g, const double *__restrict__ wfrag2_g,
                                                     const int32_t *__restrict__ lrok, const double *__restrict__ wfrag,
@@ -390,15 +396,16 @@ __global__ __launch_bounds__(256, 1) void k_sweep4r(const float *__restrict__ xt
   double *po = part + ((size_t)c * nsplit + split) * 2 * NA16;
   if (status[c] != 0 || lrok[c] == 0) return;   // k_sweep4 takes these columns
   // ---- prologue: three table copies, loads issued in batches
-  for (int i = tid; i < 4 * NJ; i += 256) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
+  for (int i = tid; i < 4 * NJ; i += 64 * NW) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
   {
     auto copy = [&](double *dst, const double *src, int nel) {
+      constexpr int NT = 64 * NW;
       int i = tid;
-      for (; i + 3 * 256 < nel; i += 4 * 256) {
-        const double t0 = src[i], t1 = src[i + 256], t2 = src[i + 512], t3 = src[i + 768];
-        dst[i] = t0; dst[i + 256] = t1; dst[i + 512] = t2; dst[i + 768] = t3;
+      for (; i + 3 * NT < nel; i += 4 * NT) {
+        const double t0 = src[i], t1 = src[i + NT], t2 = src[i + 2 * NT], t3 = src[i + 3 * NT];
+        dst[i] = t0; dst[i + NT] = t1; dst[i + 2 * NT] = t2; dst[i + 3 * NT] = t3;
       }
-      for (; i < nel; i += 256) dst[i] = src[i];
+      for (; i < nel; i += NT) dst[i] = src[i];
     };
     copy(wblk, wfrag + (size_t)c * wstride, NJ * NJ * 16);
     copy(ufr, ufrag_g + (size_t)c * (NJ * NK * 16), NJ * NK * 16);
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep4r(const float *__restrict__ xt
   if (r0 < rend) fetch(r0, xraw, rowok_next);
 
   if (EXP == 4) r0 = rend;   // timing experiment: prologue + final reduction only
-  for (; r0 < rend; r0 += 16 * 4) {
+  for (; r0 < rend; r0 += 16 * NW) {
     const bool rowok = rowok_next;
     nrowok += (rowok && g == 0) ? 1 : 0;
     int opq = 0;
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep4r(const float *__restrict__ xt
       const int b = NJ * g + s;
       x[s] = (rowok && b < p) ? (double)xraw[s] - musl[b] : 0.0;
     }
-    if (r0 + 64 < rend) fetch(r0 + 64, xraw, rowok_next);
+    if (r0 + 16 * NW < rend) fetch(r0 + 16 * NW, xraw, rowok_next);
     // ---- GEMM1: 18 independent chains, one 4-band step at a time.  The A blocks of step s+1 are read (in-order
     //      asm reads, two per two MFMAs) while step s multiplies; left to itself the scheduler sinks every read
     //      next to its use and waits for it: 2 MFMAs per LDS round trip.
@@ -597,8 +604,8 @@ __global__ __launch_bounds__(256, 1) void k_sweep4r(const float *__restrict__ xt
 
   __syncthreads();
   double *redP = sm;
-  double *redR = redP + 4 * NA16;
-  int *redE = reinterpret_cast<int *>(redR + 4 * NA16);
+  double *redR = redP + NW * NA16;
+  int *redE = reinterpret_cast<int *>(redR + NW * NA16);
 #pragma unroll
   for (int u = 0; u < NM; ++u) {
     double pv = P[u], rv = N[u] / P[u] - 4.0 * (double)ntile;   // sum over this lane's rows of (1/q - 1) = beta r/q
@@ -619,10 +626,10 @@ __global__ __launch_bounds__(256, 1) void k_sweep4r(const float *__restrict__ xt
     }
   }
   __syncthreads();
-  for (int i = tid; i < NA16; i += 256) {
+  for (int i = tid; i < NA16; i += 64 * NW) {
     double pv = 1.0, rv = 0.0;
     int ev = 0;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const double pm = pv * redP[w * NA16 + i];
       ev += redE[w * NA16 + i] + __builtin_amdgcn_frexp_exp(pm);
       pv = __builtin_amdgcn_frexp_mant(pm);
@@ -638,7 +645,11 @@ __global__ __launch_bounds__(256, 1) void k_sweep4r(const float *__restrict__ xt
   for (int off = 32; off > 0; off >>= 1) nrowok += __shfl_xor(nrowok, off, 64);
   if (lane == 0) cred[wave] = nrowok;
   __syncthreads();
-  if (tid == 0 && nalpha < NA16) po[2 * NA16 - 1] = (double)(cred[0] + cred[1] + cred[2] + cred[3]);
+  if (tid == 0 && nalpha < NA16) {
+    int tot = 0;
+    for (int w = 0; w < NW; ++w) tot += cred[w];
+    po[2 * NA16 - 1] = (double)tot;
+  }
 }
 
 constexpr size_t SW4R_LDS = ((size_t)S4M * (SF_LR_K / 4) * 64 + S4J * S4J * 16 + S4J * (SF_LR_K / 4) * 16 + 4 * S4J) * sizeof(double);
@@ -667,14 +678,22 @@ int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
                    const double *alphas, const SfGeom &g, int nsplit, double *part, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4r<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4r<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)SW4R_LDS));
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4r<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)SW4R_LDS));
     attr_set = true;
   }
   int rows = sf_cdiv(g.lines, nsplit);
-  rows = (rows + 63) / 64 * 64;
-  hipLaunchKernelGGL(k_sweep4r<0>, dim3(g.ncols, nsplit), dim3(256), SW4R_LDS, st, xt, mask_t, nuse, mu, ufrag, wfrag2, lrok,
-                     wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part);
+  if (g_sweep4r_waves == 4) {
+    rows = (rows + 63) / 64 * 64;
+    hipLaunchKernelGGL((k_sweep4r<0, 4>), dim3(g.ncols, nsplit), dim3(256), SW4R_LDS, st, xt, mask_t, nuse, mu, ufrag, wfrag2,
+                       lrok, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part);
+  } else {
+    rows = (rows + 127) / 128 * 128;
+    hipLaunchKernelGGL((k_sweep4r<0, 8>), dim3(g.ncols, nsplit), dim3(512), SW4R_LDS, st, xt, mask_t, nuse, mu, ufrag, wfrag2,
+                       lrok, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part);
+  }
   SF_LAUNCH_CHECK("k_sweep4r");
   return 0;
 }

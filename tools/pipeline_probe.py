@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Two whole flightlines in flight on two HIP streams (inter-flightline pipelining): throughput and kernel times."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from srcfinder_amd import cmf
+from srcfinder_amd.synth import make_cube_torch
+
+lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
+lines = 20000
+cube = make_cube_torch(lines, 598, seed=1, abscf_full=lib[:, 2])
+outs = [torch.empty((lines, 598, 4), dtype=torch.float64, device="cuda") for _ in range(2)]
+bufs = {}
+def get(cls, nbytes, device):
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    if key not in bufs or bufs[key].numel() < nbytes:
+        bufs[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return bufs[key]
+cmf._Workspace.get = classmethod(get)
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+def run(n, concurrent):
+    for i in range(n):
+        with torch.cuda.stream(streams[i % 2] if concurrent else streams[0]):
+            cmf.robust_mf(cube, lib, out=outs[i % 2])
+for mode in (False, True, False, True):
+    run(2, mode); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(10, mode); torch.cuda.synchronize()
+    print("pipelined " if mode else "sequential", "%.3f ms per flightline" % ((time.perf_counter() - t0) / 10 * 1e3))

@@ -6,8 +6,8 @@
 #include "cmf_common.h"
 #include <type_traits>
 
-int g_sweep4r_waves = 4;   // sf_debug_set key 8: waves per workgroup of the rank-factored sweep (4; 8 = two waves per SIMD:
-                           // measured slower, the 128+128 register split it forces spills the VALU-visible state)
+int g_sweep4r_waves = 8;   // sf_debug_set key 8: waves per workgroup of the rank-factored sweep (8 = two waves per SIMD
+                           // sharing one copy of the LDS tables: -9 %; needs every operand in arch VGPRs, see VG)
 
 namespace {
 
@@ -58,27 +58,31 @@ __global__ void k_wfrag4(const double *__restrict__ evec, const double *__restri
 
 // LDS reads (into AGPRs: MFMA operands only, keeps the VALU-visible file free) the compiler may not move or merge: issue order = source order, completion is awaited explicitly with
 // lds_wait<N>() whose operands tie the loaded registers to the wait (nothing can read them before it).
-template <int OFF>
+template <int OFF, bool VG = false>
 __device__ __forceinline__ double lds_ld(unsigned addr) {
   double r;
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=a"(r) : "v"(addr), "n"(OFF));
+  if constexpr (VG) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=a"(r) : "v"(addr), "n"(OFF));
   return r;
 }
 template <int CNT>
 __device__ __forceinline__ void lds_wait(double &a, double &b) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT));
 }
-template <int CNT>
+template <int CNT, bool VG = false>
 __device__ __forceinline__ void lds_wait1(double &a) {
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(a) : "n"(CNT));
+  if constexpr (VG) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT));
+  else asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(a) : "n"(CNT));
 }
-template <int CNT>
+template <int CNT, bool VG = false>
 __device__ __forceinline__ void lds_wait4(double &a, double &b, double &c, double &d) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+a"(a), "+a"(b), "+a"(c), "+a"(d) : "n"(CNT));
+  if constexpr (VG) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT));
+  else asm volatile("s_waitcnt lgkmcnt(%4)" : "+a"(a), "+a"(b), "+a"(c), "+a"(d) : "n"(CNT));
 }
-template <int CNT>
+template <int CNT, bool VG = false>
 __device__ __forceinline__ void lds_wait6(double &a, double &b, double &c, double &d, double &e, double &f) {
-  asm volatile("s_waitcnt lgkmcnt(%6)" : "+a"(a), "+a"(b), "+a"(c), "+a"(d), "+a"(e), "+a"(f) : "n"(CNT));
+  if constexpr (VG) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(CNT));
+  else asm volatile("s_waitcnt lgkmcnt(%6)" : "+a"(a), "+a"(b), "+a"(c), "+a"(d), "+a"(e), "+a"(f) : "n"(CNT));
 }
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -384,6 +388,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
                                                     const double *__restrict__ alphas, int nalpha, int L, int p,
                                                     int PS, int rows_per_wg, double *__restrict__ part) {
   constexpr int NJ = S4J, NM = S4M, NA16 = NM * 16;
+  constexpr bool VG = (NW == 8);   // two waves per SIMD: 256 registers per wave, all of them arch VGPRs (no 'a' operands)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NK = SF_LR_K / 4;            // 7 groups of 4 factor indices
   double *wfr = sm;                          // [NM][NK][64]  W fragments (GEMM2b B operand)
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
     static_for<0, NJ>([&](auto jc) {
       constexpr int jg = decltype(jc)::value;
       z[0][jg] = 0.0;
-      wa[0][jg] = lds_ld<jg * 128>(wadr);
+      wa[0][jg] = lds_ld<jg * 128, VG>(wadr);
     });
     if constexpr (EXP == 1) {
 #pragma unroll
@@ -475,13 +480,13 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
       constexpr int s = decltype(sc)::value;
       static_for<0, NJ / 6>([&](auto kc) {
         constexpr int k = decltype(kc)::value * 6;
-        lds_wait6<0>(wa[s & 1][k], wa[s & 1][k + 1], wa[s & 1][k + 2], wa[s & 1][k + 3], wa[s & 1][k + 4], wa[s & 1][k + 5]);
+        lds_wait6<0, VG>(wa[s & 1][k], wa[s & 1][k + 1], wa[s & 1][k + 2], wa[s & 1][k + 3], wa[s & 1][k + 4], wa[s & 1][k + 5]);
       });
       static_for<0, NJ / 2>([&](auto jc) {
         constexpr int jg = decltype(jc)::value * 2;
         if constexpr (s + 1 < NJ) {
-          wa[(s + 1) & 1][jg] = lds_ld<((s + 1) * NJ + jg) * 128>(wadr);
-          wa[(s + 1) & 1][jg + 1] = lds_ld<((s + 1) * NJ + jg + 1) * 128>(wadr);
+          wa[(s + 1) & 1][jg] = lds_ld<((s + 1) * NJ + jg) * 128, VG>(wadr);
+          wa[(s + 1) & 1][jg + 1] = lds_ld<((s + 1) * NJ + jg + 1) * 128, VG>(wadr);
         }
         z[0][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(wa[s & 1][jg], x[s], z[0][jg], 0, 0, 0);
         z[0][jg + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(wa[s & 1][jg + 1], x[s], z[0][jg + 1], 0, 0, 0);
@@ -497,15 +502,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
       static_for<0, NK>([&](auto mc) {
         constexpr int mg = decltype(mc)::value;
         t4[0][mg] = 0.0;
-        ua[0][mg] = lds_ld<mg * 128>(uadr);
+        ua[0][mg] = lds_ld<mg * 128, VG>(uadr);
       });
       static_for<0, NJ>([&](auto jc) {
         constexpr int jg = decltype(jc)::value;
-        lds_wait4<0>(ua[jg & 1][0], ua[jg & 1][1], ua[jg & 1][2], ua[jg & 1][3]);
-        lds_wait4<0>(ua[jg & 1][3], ua[jg & 1][4], ua[jg & 1][5], ua[jg & 1][6]);
+        lds_wait4<0, VG>(ua[jg & 1][0], ua[jg & 1][1], ua[jg & 1][2], ua[jg & 1][3]);
+        lds_wait4<0, VG>(ua[jg & 1][3], ua[jg & 1][4], ua[jg & 1][5], ua[jg & 1][6]);
         static_for<0, NK>([&](auto mc) {
           constexpr int mg = decltype(mc)::value;
-          if constexpr (jg + 1 < NJ) ua[(jg + 1) & 1][mg] = lds_ld<((jg + 1) * NK + mg) * 128>(uadr);
+          if constexpr (jg + 1 < NJ) ua[(jg + 1) & 1][mg] = lds_ld<((jg + 1) * NK + mg) * 128, VG>(uadr);
           t4[0][mg] = __builtin_amdgcn_mfma_f64_4x4x4f64(ua[jg & 1][mg], z[0][jg], t4[0][mg], 0, 0, 0);
         });
       });
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
       constexpr int gr = t / NK, jg = t - gr * NK;
       static_for<0, TG>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        if constexpr (gr * TG + k < NM) br[k][t % DEPTH] = lds_ld<(k * NK + jg) * 512>(cadr + gr * (TG * NK * 512));
+        if constexpr (gr * TG + k < NM) br[k][t % DEPTH] = lds_ld<(k * NK + jg) * 512, VG>(cadr + gr * (TG * NK * 512));
       });
     };
     if constexpr (EXP == 3) {
@@ -571,15 +576,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
     };
     static_for<0, NSTEP>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
-      constexpr int gr = t / NK, jg = t - gr * NK, st = gr & 1;
+      constexpr int gr = t / NK, jg = t - gr * NK, st = VG ? 0 : (gr & 1);
       constexpr int nt = sw4r_reads(t);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (t + DEPTH - 1 < NSTEP) loadb(std::integral_constant<int, t + DEPTH - 1>{});
       // in-order returns: everything but the reads of the newer steps t+1 .. t+DEPTH-1 has landed
       constexpr int newer = sw4r_reads(t + 1) + sw4r_reads(t + 2) + sw4r_reads(t + 3);
       static_assert(DEPTH == 4 && newer <= 15, "lgkmcnt is a 4-bit counter");
-      if constexpr (nt == 4) lds_wait4<newer>(br[0][t % DEPTH], br[1][t % DEPTH], br[2][t % DEPTH], br[3][t % DEPTH]);
-      else lds_wait1<newer>(br[0][t % DEPTH]);
+      if constexpr (nt == 4) lds_wait4<newer, VG>(br[0][t % DEPTH], br[1][t % DEPTH], br[2][t % DEPTH], br[3][t % DEPTH]);
+      else lds_wait1<newer, VG>(br[0][t % DEPTH]);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -588,9 +593,14 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
           else acc[st][k][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(t4[s][jg], br[k][t % DEPTH], acc[st][k][s], 0, 0, 0);
         }
       // the previous group's tiles are reduced underneath this group's MFMAs (stages at steps 1, 2, 4, 5)
-      if constexpr (gr > 0 && (jg == 1 || jg == 2 || jg == 4 || jg == 5))
+      if constexpr (!VG && gr > 0 && (jg == 1 || jg == 2 || jg == 4 || jg == 5))
         reduce_stage(std::integral_constant<int, gr - 1>{}, std::integral_constant<int, 1 - st>{},
                      std::integral_constant<int, (jg == 1 ? 0 : (jg == 2 ? 1 : (jg == 4 ? 2 : 3)))>{});
+      if constexpr (VG && jg == NK - 1 && t != NSTEP - 1) {   // one accumulator set: reduce at once (the SIMD's other wave fills the pipe)
+        static_for<0, 4>([&](auto sc) {
+          reduce_stage(std::integral_constant<int, gr>{}, std::integral_constant<int, 0>{}, sc);
+        });
+      }
       if constexpr (t == NSTEP - 1) {   // the last group (one tile) has nothing to hide under
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, 4>([&](auto sc) {

@@ -49,17 +49,21 @@ __device__ __forceinline__ void score_fma(const float (&x)[SC_LPI][SC_UB], const
 
 // WGL: the 64 filter vectors are read from a transposed global copy wT[band][column] (L2-resident) instead of
 // LDS -- for windows too wide for a [p][64] float64 LDS tile.
-template <bool RGB, int SC_LPI, int SC_UB, bool WGL>
-__global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs,
+// CW: 64-column blocks per workgroup.  With CW = 2 the two halves of a 128-column block read ADJACENT 256-byte row
+// segments at the same time from the same CU, so the 128-byte lines straddling their boundary are fetched once
+// (the row stride, 2392 B, is not a multiple of the line size: every segment starts mid-line).
+template <bool RGB, int SC_LPI, int SC_UB, bool WGL, int CW = 1>
+__global__ __launch_bounds__(256 * CW) void k_score(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs,
                                                 int b0, int p, const double *__restrict__ filt,
                                                 const double *__restrict__ bias, const int32_t *__restrict__ status,
                                                 const int32_t *__restrict__ alphaidx, int rgb0, int rgb1, int rgb2,
                                                 double nodata, double *__restrict__ out, int oS, int os0,
                                                 int16_t *__restrict__ bgmeta, double *__restrict__ stat_part,
                                                 int lines_per_wg, int ncb, int nchunk, int xcdmap, const double *__restrict__ wT, int ldw) {
-  extern __shared__ __attribute__((aligned(16))) double ws[];  // [p][64]
-  __shared__ double sred[4][64][2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) double ws_all[];  // [CW][p][64]
+  __shared__ double sred[4 * CW][64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int half = wv >> 2, wave = wv & 3;
   int cbi, chunk;
   if (xcdmap) {
     if (!sf_xcd_map(blockIdx.x, ncb, nchunk, cbi, chunk)) return;
@@ -68,16 +72,19 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, i
     chunk = blockIdx.x / ncb;
     if (chunk >= nchunk) return;
   }
-  const int colbase = cbi * 64;
-  const int ncol = min(64, Cs - colbase);
+  const int colbase = min(cbi * 64 * CW + 64 * half, Cs - 1);   // (a second half past the last column idles on it)
+  const int ncol = (cbi * 64 * CW + 64 * half < Cs) ? min(64, Cs - colbase) : 0;
   const bool colok = lane < ncol;
-  const int lanec = colok ? lane : ncol - 1;  // idle lanes re-read the last column (in bounds), never write
+  const int lanec = colok ? lane : max(ncol - 1, 0);  // idle lanes re-read the last column (in bounds), never write
   const int col = colbase + lanec;
+  double *ws = ws_all + (size_t)half * p * 64;
 
   if (!WGL) {
-    for (int idx = tid; idx < 64 * p; idx += 256) {
-      const int cl = idx / p, b = idx - cl * p;
-      ws[b * 64 + cl] = (cl < ncol) ? filt[(size_t)(colbase + cl) * p + b] : 0.0;
+    for (int idx = tid; idx < CW * 64 * p; idx += 256 * CW) {
+      const int hh = idx / (64 * p), r = idx - hh * (64 * p);
+      const int cl = r / p, b = r - cl * p;
+      const int cc = cbi * 64 * CW + 64 * hh + cl;
+      ws_all[(size_t)hh * p * 64 + b * 64 + cl] = (cc < Cs) ? filt[(size_t)cc * p + b] : 0.0;
     }
   }
   const double *wsrc = WGL ? (wT + colbase + lanec - lane) : ws;   // wsrc[b*wld + lane] is this lane's weight
@@ -148,12 +155,12 @@ __global__ __launch_bounds__(256) void k_score(const float *__restrict__ cube, i
     }
   }
   if (stat_part) {
-    sred[wave][lane][0] = s1;
-    sred[wave][lane][1] = s2;
+    sred[wv][lane][0] = s1;
+    sred[wv][lane][1] = s2;
     __syncthreads();
     if (wave == 0 && colok) {
       double a = 0.0, b = 0.0;
-      for (int w = 0; w < 4; ++w) { a += sred[w][lane][0]; b += sred[w][lane][1]; }
+      for (int w = 0; w < 4; ++w) { a += sred[4 * half + w][lane][0]; b += sred[4 * half + w][lane][1]; }
       double *o = stat_part + ((size_t)chunk * Cs + col) * 2;
       o[0] = a;
       o[1] = b;
@@ -267,22 +274,22 @@ __global__ void k_filt_transpose(const double *__restrict__ filt, int Cs, int p,
   wT[i] = (c < Cs) ? filt[(size_t)c * p + b] : 0.0;
 }
 
-template <bool RGB, int LPI, int UB, bool WGL = false>
+template <bool RGB, int LPI, int UB, bool WGL = false, int CW = 1>
 int launch_score_t(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
                    const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx, int rgb0,
                    int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0, int16_t *bgmeta,
                    double *stat_part, int lpw, hipStream_t st, const double *wT = nullptr, int ldw = 0) {
-  const size_t lds = WGL ? 0 : (size_t)p * 64 * sizeof(double);
+  const size_t lds = WGL ? 0 : (size_t)CW * p * 64 * sizeof(double);
   static size_t lds_set = 0;
   if (lds > lds_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<RGB, LPI, UB, WGL>),
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<RGB, LPI, UB, WGL, CW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set = lds;
   }
   const int nchunk = sf_cdiv(lines, lpw);
-  const int ncb = sf_cdiv(ncols, 64);
+  const int ncb = sf_cdiv(ncols, 64 * CW);
   const int nblk = g_score_xcd ? sf_xcd_grid(ncb, nchunk) : ncb * nchunk;
-  hipLaunchKernelGGL((k_score<RGB, LPI, UB, WGL>), dim3(nblk), dim3(256), lds, st, cube, lines, bands, samples, s0, ncols, b0,
+  hipLaunchKernelGGL((k_score<RGB, LPI, UB, WGL, CW>), dim3(nblk), dim3(256 * CW), lds, st, cube, lines, bands, samples, s0, ncols, b0,
                      p, filt, bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, out_samples, out_s0, bgmeta, stat_part,
                      lpw, ncb, nchunk, g_score_xcd, wT, ldw);
   SF_LAUNCH_CHECK("k_score");
@@ -315,6 +322,9 @@ int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0
     case 4: return launch_score_t<true, 2, 8>(SC_ARGS);
     case 5: return launch_score_t<true, 8, 8>(SC_ARGS);
     case 6: return launch_score_t<true, 4, 8>(SC_ARGS);
+    case 7: return launch_score_t<true, 8, 4, false, 2>(SC_ARGS);
+    case 8: return launch_score_t<true, 4, 8, false, 2>(SC_ARGS);
+    case 9: return launch_score_t<true, 4, 4, false, 2>(SC_ARGS);
     default: return launch_score_t<true, 8, 4>(SC_ARGS);  // measured best (tools/tune_score.py)
   }
 }

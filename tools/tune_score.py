@@ -28,7 +28,7 @@ def run():
                               60, 42, 24, -9999.0, P(out), samples, 0, 4, None, None, P(ws), _ffi.stream_ptr()), "score")
 
 cfgs = []
-for variant, lpw, xcd in itertools.product([0, 1, 3, 4, 5, 6], [0, 32, 48, 64, 112], [0, 1]):
+for variant, lpw, xcd in itertools.product([0, 7, 8, 9], [0, 32, 64, 128], [1]):
     cfgs.append((variant, lpw, xcd))
 res = {c: [] for c in cfgs}
 for rnd in range(4):
@@ -38,6 +38,9 @@ for rnd in range(4):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); run(); b.record(); torch.cuda.synchronize()
         res[c].append(a.elapsed_time(b))
-names = {0: "8x4", 1: "2x16", 3: "4x4", 4: "2x8", 5: "8x8", 6: "4x8"}
+names = {0: "8x4", 1: "2x16", 3: "4x4", 4: "2x8", 5: "8x8", 6: "4x8", 7: "8x4/128", 8: "4x8/128", 9: "4x4/128"}
+L.sf_debug_set(1, 0); L.sf_debug_set(2, 0); run(); torch.cuda.synchronize(); ref = out.clone()
+for v in (7, 8, 9):
+    L.sf_debug_set(1, v); out.zero_(); run(); torch.cuda.synchronize(); print("variant", v, "bit-identical to default:", bool(torch.equal(out, ref)))
 for c in sorted(cfgs, key=lambda c: np.median(res[c])):
     print("LPIxUB %-5s lpw %4d xcd %d : median %.3f ms min %.3f  -> %.0f GB/s" % (names[c[0]], c[1], c[2], np.median(res[c]), min(res[c]), 332 * lines * samples / np.median(res[c]) / 1e6))

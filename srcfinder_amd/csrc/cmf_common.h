@@ -117,10 +117,11 @@ static inline int sf_sweep_splits(int lines, int ncols) {
   return best;
 }
 static inline int sf_score_lines_per_wg(int lines, int ncols) {
-  // 64-line chunks measured best on the full flightline (tools/tune_score.py: several resident rounds of
-  // short workgroups beat one round of long ones); keep at least ~1 round of 1024 workgroups on small shards
+  // 32-line chunks (one 8-line batch per wave: the workgroup has no line loop at all) measured best on the full
+  // flightline (tools/tune_score.py: 0.81 ms against 0.86 ms for 64 lines, many short workgroups beat fewer long
+  // ones); keep at least ~1 round of 1024 workgroups on small shards
   int colblocks = sf_cdiv(ncols, 64);
-  int lpw = 64;
+  int lpw = 32;
   while (lpw > 16 && (long)colblocks * sf_cdiv(lines, lpw) < 1024) lpw -= 16;
   return lpw;
 }

@@ -28,7 +28,7 @@ def run():
                               60, 42, 24, -9999.0, P(out), samples, 0, 4, None, None, P(ws), _ffi.stream_ptr()), "score")
 
 cfgs = []
-for variant, lpw, xcd in itertools.product([0, 7, 8, 9], [0, 32, 64, 128], [1]):
+for variant, lpw, xcd in itertools.product([0], [16, 24, 32, 40, 48, 64, 80], [1]):
     cfgs.append((variant, lpw, xcd))
 res = {c: [] for c in cfgs}
 for rnd in range(4):

@@ -78,11 +78,12 @@ static inline SfGeom sf_geom(int lines, int p, int ncols, int nalpha) {
 
 // split counts (deterministic functions of the geometry so that results do not depend on the GPU)
 static inline int sf_extract_lines_per_wg(int lines, int ncols) {
-  // <= 250 line chunks: every chunk leaves a partial-sum record per column that the mean kernel reads back.
+  // <= 500 line chunks (measured: 250 -> 2.05 ms, 500 -> 1.91 ms, 1000 -> 1.97 ms + a slower mean kernel): every
+  // chunk leaves a partial-sum record per column that the mean kernel reads back.
   // Deliberately independent of the number of columns: the chunk boundaries fix the order in which a column's
   // masked sum is accumulated, and that must not depend on how the columns are sharded over ranks.
   (void)ncols;
-  int lpw = sf_cdiv(lines, 250);
+  int lpw = sf_cdiv(lines, 500);
   lpw = (lpw + 3) / 4 * 4;
   return lpw < 4 ? 4 : lpw;
 }

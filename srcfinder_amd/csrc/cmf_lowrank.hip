@@ -25,6 +25,8 @@ constexpr int LR_K = SF_LR_K;              // 28
 constexpr int LR_LDA = LR_NA + 1;          // column stride in LDS (odd: threads on different columns, same row)
 constexpr int LR_TPC = 8;                  // lanes per column in the update (8-lane DPP reductions, no LDS partials)
 constexpr int LR_NT = 576;                 // 72 columns x 8 lanes = 9 waves
+constexpr int LR_PK = 4;                   // row slots (of 8 rows) that can touch the diagonal: 8 * 4 = 32 > K
+static_assert(LR_TPC * LR_PK >= LR_K + 1 && LR_NA % LR_TPC == 0, "row slots");
 
 template <int CTRL>
 __device__ __forceinline__ double lr_dpp(double v) {
@@ -37,6 +39,15 @@ __device__ __forceinline__ double lr_sum8(double v) {   // all 8 lanes of an ali
   v += lr_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
   v += lr_dpp<0x141>(v);   // row_half_mirror
   return v;
+}
+// one exchange of an 8-lane argmax: keep the larger value, on equal values the lower index
+template <int CTRL>
+__device__ __forceinline__ void lr_argmax_step(double &v, int &i) {
+  const double ov = lr_dpp<CTRL>(v);
+  const int oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xF, 0xF, true);
+  const bool take = (ov > v) || (ov == v && oi < i);
+  v = take ? ov : v;
+  i = take ? oi : i;
 }
 __device__ __forceinline__ double lr_sum16(double v) {
   v = lr_sum8(v);
@@ -53,6 +64,7 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
   __shared__ double cnorm2[LR_P];               // the same over the rows below the current one
   __shared__ int posof[LR_P];                   // step at which a column was pivoted, -1 if never
   __shared__ double tau_s[LR_K];
+  __shared__ double s_al[LR_NA], s_be[LR_NA], s_lam[LR_P];
   __shared__ int perm[LR_K];                    // perm[s] = the column pivoted at step s
   __shared__ int freecol[LR_K];                 // never-pivoted columns that hold Q_K afterwards
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -61,16 +73,20 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
     return;
   }
   const double n = (double)nuse[c];
-  // ---- B^T: A[j][i] = beta_i / (n beta_i lam_j + alpha_i)   (zero for the padding alpha / eigen indices)
+  // ---- B^T: A[j][i] = beta_i / (n beta_i lam_j + alpha_i)   (zero for the padding alpha / eigen indices).
+  //      alpha, beta and lam are staged in LDS first: two dependent global loads per entry would dominate the kernel.
+  for (int i = tid; i < LR_NA; i += LR_NT) {
+    const double a = (i < nalpha) ? alphas[i] : 1.0;
+    s_al[i] = a;
+    s_be[i] = (i < nalpha) ? (1.0 - a) / (n - 1.0) : 0.0;
+  }
+  for (int j = tid; j < LR_P; j += LR_NT) s_lam[j] = (j < p) ? lam[(size_t)c * p + j] : 1.0;
+  __syncthreads();
   for (int idx = tid; idx < LR_P * LR_NA; idx += LR_NT) {
     const int j = idx / LR_NA, i = idx - j * LR_NA;
-    double v = 0.0;
-    if (i < nalpha && j < p) {
-      const double a = alphas[i];
-      const double beta = (1.0 - a) / (n - 1.0);
-      v = beta / ((n * beta) * lam[(size_t)c * p + j] + a);
-    }
-    A[j * LR_LDA + i] = v;
+    const double a = s_al[i], beta = s_be[i];
+    const double v = beta / ((n * beta) * s_lam[j] + a);
+    A[j * LR_LDA + i] = (i < nalpha && j < p) ? v : 0.0;
   }
   if (tid < LR_P) posof[tid] = -1;
   __syncthreads();
@@ -94,40 +110,53 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
   double r00 = 0.0;
   bool mine_done = false;                       // this group's column has been pivoted
   for (int s = 0; s < LR_K; ++s) {
-    double bv = (lane < LR_P) ? cnorm[lane] : -1.0;       // done columns carry -1
-    int bi = lane;
-    if (lane < LR_P - 64) {
-      const double v2 = cnorm[lane + 64];
-      if (v2 > bv) { bv = v2; bi = lane + 64; }
+    // pivot = the remaining column of largest norm (lowest index on ties; pivoted columns carry -1).  Every 8-lane
+    // group scans all 72 candidates (9 per lane) and finishes with three DPP exchanges: no cross-wave traffic, no
+    // ds_bpermute chain (six dependent LDS-crossbar round trips were the longest part of the step).
+    double bv = cnorm[sub];
+    int bi = sub;
+#pragma unroll
+    for (int k = 1; k < LR_P / LR_TPC; ++k) {
+      const double v2 = cnorm[sub + LR_TPC * k];
+      if (v2 > bv) { bv = v2; bi = sub + LR_TPC * k; }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ov = __shfl_xor(bv, off, 64);
-      const int oi = __shfl_xor(bi, off, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
+    lr_argmax_step<0xB1>(bv, bi);
+    lr_argmax_step<0x4E>(bv, bi);
+    lr_argmax_step<0x141>(bv, bi);
     const int pv = bi;
     const double *xs = A + pv * LR_LDA;
     const double alpha = xs[s], xn2 = cnorm2[pv];
     double tau = 0.0, scale = 0.0, betah = alpha;
     if (xn2 > 0.0) {
-      betah = -copysign(sqrt(alpha * alpha + xn2), alpha);
-      tau = (betah - alpha) / betah;
-      scale = 1.0 / (alpha - betah);
+      const double h2 = __builtin_fma(alpha, alpha, xn2);
+      double y = __builtin_amdgcn_rsq(h2);                     // 1/sqrt(h2): hardware estimate + two Newton steps
+      y = y * __builtin_fma(-0.5 * h2 * y, y, 1.5);
+      y = y * __builtin_fma(-0.5 * h2 * y, y, 1.5);
+      betah = -copysign(h2 * y, alpha);
+      const double den = alpha - betah;                        // same sign as alpha, |den| >= |alpha|: no cancellation
+      double rd = __builtin_amdgcn_rcp(den);
+      rd = rd * __builtin_fma(-den, rd, 2.0);
+      rd = rd * __builtin_fma(-den, rd, 2.0);
+      scale = rd;
+      tau = den * (y * (alpha < 0.0 ? -1.0 : 1.0));            // (betah - alpha)/betah = den / (sign(alpha) sqrt(h2))
     }
     if (s == 0) r00 = fabs(betah);
     // v = x * scale (v_s = 1 implicit), in registers of every lane for its rows
     double vr[(LR_NA + LR_TPC - 1) / LR_TPC];
+    // rows >= 32 are below every diagonal position (s < 28): only the first four row slots need the predicates
 #pragma unroll
-    for (int k = 0; k < (LR_NA + LR_TPC - 1) / LR_TPC; ++k) {
+    for (int k = 0; k < LR_PK; ++k) {
       const int i = sub + LR_TPC * k;
-      vr[k] = (i > s && i < LR_NA) ? xs[i] * scale : ((i == s) ? 1.0 : 0.0);
+      vr[k] = (i > s) ? xs[i] * scale : ((i == s) ? 1.0 : 0.0);
     }
+#pragma unroll
+    for (int k = LR_PK; k < LR_NA / LR_TPC; ++k) vr[k] = xs[sub + LR_TPC * k] * scale;
     __syncthreads();   // every lane has read column pv (and the norms) before they change
     if (col == pv) {   // the pivot's own group stores v, R_ss and the bookkeeping while the others update
 #pragma unroll
-      for (int k = 0; k < (LR_NA + LR_TPC - 1) / LR_TPC; ++k) {
+      for (int k = 0; k < LR_NA / LR_TPC; ++k) {
         const int i = sub + LR_TPC * k;
-        if (i > s && i < LR_NA) A[pv * LR_LDA + i] = vr[k];
+        if (k >= LR_PK || i > s) A[pv * LR_LDA + i] = vr[k];
       }
       if (sub == 0) {
         A[pv * LR_LDA + s] = betah;
@@ -143,23 +172,32 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
       double av[(LR_NA + LR_TPC - 1) / LR_TPC];
       double w = 0.0;
 #pragma unroll
-      for (int k = 0; k < (LR_NA + LR_TPC - 1) / LR_TPC; ++k) {
+      for (int k = 0; k < LR_NA / LR_TPC; ++k) {
         const int i = sub + LR_TPC * k;
-        av[k] = (i >= s && i < LR_NA) ? ac[i] : 0.0;
+        av[k] = (k >= LR_PK || i >= s) ? ac[i] : 0.0;
         w = __builtin_fma(vr[k], av[k], w);
       }
       const double wt = tau * lr_sum8(w);
       double nn = 0.0, nn2 = 0.0;
 #pragma unroll
-      for (int k = 0; k < (LR_NA + LR_TPC - 1) / LR_TPC; ++k) {
+      for (int k = 0; k < LR_PK; ++k) {
         const int i = sub + LR_TPC * k;
-        if (i >= s && i < LR_NA) {
+        if (i >= s) {
           const double nv = __builtin_fma(-wt, vr[k], av[k]);
           ac[i] = nv;
           if (i > s) nn = __builtin_fma(nv, nv, nn);
           if (i > s + 1) nn2 = __builtin_fma(nv, nv, nn2);
         }
       }
+      double nb = 0.0;
+#pragma unroll
+      for (int k = LR_PK; k < LR_NA / LR_TPC; ++k) {
+        const double nv = __builtin_fma(-wt, vr[k], av[k]);
+        ac[sub + LR_TPC * k] = nv;
+        nb = __builtin_fma(nv, nv, nb);
+      }
+      nn += nb;
+      nn2 += nb;
       nn = lr_sum8(nn);
       nn2 = lr_sum8(nn2);
       if (sub == 0) { cnorm[col] = nn; cnorm2[col] = nn2; }

@@ -211,8 +211,10 @@ __global__ __launch_bounds__(512) void k_mean(const double *__restrict__ sum_par
   for (int b0 = 0; b0 < p; b0 += 64) {
     const int b = b0 + lane;
     double s = 0;
-    if (b < p)
+    if (b < p) {
+#pragma unroll 8
       for (int ch = wave; ch < nch; ch += 8) s += sum_part[((size_t)ch * Cs + c) * PS + b];
+    }
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && b < p) {

@@ -136,6 +136,95 @@ __global__ __launch_bounds__(256, 1) void k_syrk4(const float *__restrict__ xt, 
   }
 }
 
+// k_syrk4d: the same product with TWO waves per SIMD in one workgroup.  Waves w and w+4 (the same SIMD) take the same
+// 16 rows but one half each of the 171 tiles (86 / 85): 172 accumulator registers fit the 256 a wave may have at
+// two waves per SIMD, so nothing is pinned and nothing lives in AGPRs, and one wave's loads, mean reads and
+// conversions run under the other's MFMAs.  Price: both waves convert the rows (54 VALU per 86 MFMAs).
+constexpr int C4_HALF = (C4_NTRI + 1) / 2;   // 86
+
+template <int H>
+__device__ __forceinline__ void syrk4d_tile(double (&acc)[C4_HALF], const double (&f)[C4_NG]) {
+  static_for<0, C4_NG>([&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    static_for<I, C4_NG>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      constexpr int t = tri_index(I, J);
+      if constexpr ((t < C4_HALF) == (H == 0))
+        acc[t - H * C4_HALF] = __builtin_amdgcn_mfma_f64_4x4x4f64(f[I], f[J], acc[t - H * C4_HALF], 0, 0, 0);
+    });
+  });
+}
+
+__global__ __launch_bounds__(512, 1) void k_syrk4d(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+                                                    const double *__restrict__ mu, int L, int p, int rows_per_wg,
+                                                    double *__restrict__ part) {
+  constexpr int NG = C4_NG, PS = 4 * C4_NG;
+  __shared__ double red[4][C4_NTRI][16];
+  __shared__ double mus[PS];
+  __shared__ double zeros[NG];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wave = wv & 3, half = wv >> 2;
+  const int q = lane >> 4, m = (lane >> 2) & 3, n = lane & 3;
+  const int c = blockIdx.x, split = blockIdx.y;
+  for (int i = tid; i < PS; i += 512) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
+  if (tid < NG) zeros[tid] = 0.0;
+  __syncthreads();
+  const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
+  const uint8_t *mp = mask_t + (size_t)c * L;
+  const float *xc = xt + (size_t)c * L * PS + NG * n;
+  const int rlane = 4 * m + q;
+  double acc[C4_HALF];
+#pragma unroll
+  for (int t = 0; t < C4_HALF; ++t) acc[t] = 0.0;
+  constexpr int DEPTH = 1;   // the SIMD's other wave covers the latency; a second tile in flight would spill
+  float xraw[DEPTH][NG];
+  uint8_t mk[DEPTH];
+  auto fetch = [&](int r0, auto sc) {
+    constexpr int sl = decltype(sc)::value;
+    const int row = r0 + rlane;
+    const int rr = row < rend ? row : rbeg;
+    mk[sl] = mp[rr];
+    const float *xp = xc + (size_t)rr * PS;
+#pragma unroll
+    for (int s = 0; s < NG; s += 2) sf_load2(xp + s, xraw[sl][s], xraw[sl][s + 1]);
+  };
+  int r0 = rbeg + 16 * wave;
+  static_for<0, DEPTH>([&](auto sc) { fetch(r0 + 64 * decltype(sc)::value, sc); });
+  for (; r0 < rend; r0 += 64 * DEPTH) {
+    static_for<0, DEPTH>([&](auto sc) {
+      constexpr int sl = decltype(sc)::value;
+      const int rt = r0 + 64 * sl;
+      const bool ok = (rt + rlane < rend) && mk[sl] != 0;
+      int opq = 0;
+      asm volatile("" : "+v"(opq));
+      const double *musl = (ok ? mus + NG * n : zeros) + opq;
+      double f[NG];
+#pragma unroll
+      for (int I = 0; I < NG; ++I) {
+        const float xv = (ok && NG * n + I < p) ? xraw[sl][I] : 0.0f;
+        f[I] = (double)xv - musl[I];
+      }
+      fetch(rt + 64 * DEPTH, sc);
+      if (half == 0) syrk4d_tile<0>(acc, f);   // wave-uniform
+      else syrk4d_tile<1>(acc, f);
+    });
+  }
+#pragma unroll
+  for (int t = 0; t < C4_HALF; ++t) {
+    double v = acc[t];
+    v += dpp_row<0x124>(v);
+    v += dpp_row<0x128>(v);
+    const int tt = t + half * C4_HALF;
+    if (m == 0 && tt < C4_NTRI) red[wave][tt][4 * q + n] = v;
+  }
+  __syncthreads();
+  double *po = part + ((size_t)c * gridDim.y + split) * (C4_NTRI * 16);
+  for (int i = tid; i < C4_NTRI * 16; i += 512) {
+    const int t = i >> 4, e = i & 15;
+    po[i] = (red[0][t][e] + red[1][t][e]) + (red[2][t][e] + red[3][t][e]);
+  }
+}
+
 // part[c][split][tile][4 i + j] -> cov[c][band(I,i)][band(J,j)] (and its mirror), band(I, i) = 18 i + I
 __global__ __launch_bounds__(256) void k_syrk4_reduce(const double *__restrict__ part, int nsplit,
                                                        const int32_t *__restrict__ nuse, int p, double *__restrict__ cov) {
@@ -174,14 +263,17 @@ int sf_launch_cov4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
   int rows = sf_cdiv(g.lines, nsplit);
   rows = (rows + 127) / 128 * 128;   // whole prefetch rings: 4 waves x 16 rows x depth 2
   double *part = reinterpret_cast<double *>(scratch);
-#ifdef SF_SWEEP_EXPERIMENTS
   extern int g_cov_variant;
+#ifdef SF_SWEEP_EXPERIMENTS
   if (g_cov_variant == 11)
     hipLaunchKernelGGL(k_syrk4<1>, dim3(g.ncols, nsplit), dim3(256), 0, st, xt, mask_t, mu, g.lines, g.p, rows, part);
   else if (g_cov_variant == 12)
     hipLaunchKernelGGL(k_syrk4<2>, dim3(g.ncols, nsplit), dim3(256), 0, st, xt, mask_t, mu, g.lines, g.p, rows, part);
   else
 #endif
+  if (g_cov_variant == 3) {   // two waves per SIMD, each half of the tiles: measured slower (1.62 vs 1.45 ms), kept as an option
+    hipLaunchKernelGGL(k_syrk4d, dim3(g.ncols, nsplit), dim3(512), 0, st, xt, mask_t, mu, g.lines, g.p, rows, part);
+  } else
   hipLaunchKernelGGL(k_syrk4<0>, dim3(g.ncols, nsplit), dim3(256), 0, st, xt, mask_t, mu, g.lines, g.p, rows, part);
   SF_LAUNCH_CHECK("k_syrk4");
   hipLaunchKernelGGL(k_syrk4_reduce, dim3(g.ncols, 4), dim3(256), 0, st, part, nsplit, nuse, g.p, cov);

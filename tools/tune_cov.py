@@ -8,7 +8,7 @@ import torch
 from srcfinder_amd import _ffi, cmf
 from srcfinder_amd.synth import make_cube_torch
 
-variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1]
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 2, 1]
 lines, samples, p, a0 = 20000, 598, 72, 351
 lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
 cube = make_cube_torch(lines, samples, seed=1, abscf_full=lib[:, 2])

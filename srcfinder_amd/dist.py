@@ -10,6 +10,8 @@ agnostic -- the CPU tests drive it with ``gloo``.
 """
 from __future__ import annotations
 
+import numpy as np
+
 
 def shard_columns(samples: int, world: int, rank: int):
     """Contiguous, balanced: sizes differ by at most one column (598 over 8 -> 74/75)."""
@@ -34,15 +36,18 @@ def _assemble(recv, shape, cols_last, samples, world, as_int16):
     import torch
     if recv is None:
         return None
-    parts = []
-    for r in range(world):
-        a, b = shard_columns(samples, world, r)
-        parts.append(recv[r][:b - a])
-    full = torch.cat(parts, dim=0)                                                      # [samples, ...]
+    # one pass: every rank's [ncols_r, ...] block is written straight into its column range of the final layout
     if cols_last:
-        full = full.transpose(0, 1).reshape(tuple(shape[:-1]) + (samples,)).contiguous()
+        full = torch.empty((int(np.prod(shape[:-1])) if len(shape) > 1 else 1, samples), dtype=recv[0].dtype, device=recv[0].device)
+        for r in range(world):
+            a, b = shard_columns(samples, world, r)
+            full[:, a:b].copy_(recv[r][:b - a].transpose(0, 1))
+        full = full.reshape(tuple(shape[:-1]) + (samples,))
     else:
-        full = full.transpose(0, 1).contiguous()                                        # [lines, samples, ...]
+        full = torch.empty((shape[0], samples) + tuple(shape[2:]), dtype=recv[0].dtype, device=recv[0].device)
+        for r in range(world):
+            a, b = shard_columns(samples, world, r)
+            full[:, a:b].copy_(recv[r][:b - a].transpose(0, 1))
     return full.view(torch.int16) if as_int16 else full
 
 

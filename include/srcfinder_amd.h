@@ -140,8 +140,9 @@ int sf_cmf_column_profile(const double *img, int lines, int samples, int nbands,
 int sf_cmf_column_profile_robust(const double *img, int lines, int samples, int nbands, int band, double nodata,
                                  double p, double *profile, void *stream);
 
-/* Test hook: the rank-28 factorisation B = U W of the sweep's coefficient matrix (cmf_lowrank.hip), in the
- * fragment order the sweep reads: ufrag[ncols][18*7*16], wfrag[ncols][13*7*64], lrok[ncols]. */
+/* Test hook: the rank-28 / rank-36 factorisation B = U W of the sweep's coefficient matrix (cmf_lowrank.hip), in
+ * the fragment order the sweep reads: ufrag[ncols][18*9*16], wfrag[ncols][13*9*64], lrok[ncols] (0 full rank,
+ * 1 rank 28, 2 rank 36). */
 int sf_debug_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas,
                      int nalpha, int p, int ncols, double *ufrag, double *wfrag, int32_t *lrok, void *stream);
 

@@ -168,7 +168,7 @@ int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0,
                        const int32_t *status, double nodata, double *colstats, hipStream_t st);
 // cmf_loocv4.hip: the production-window sweep (p in 69..72, 201-point grid) on the 4x4x4 fp64 MFMA
 constexpr int SF_SW4_NJ = 18, SF_SW4_NM = 13;
-constexpr int SF_LR_K = 28;   // rank of the factored sweep coefficients (cmf_lowrank.hip)
+constexpr int SF_LR_K = 28, SF_LR_K2 = 36;   // ranks of the factored sweep coefficients (cmf_lowrank.hip); fragments use the K2 layout
 size_t sf_lowrank_bytes(const SfGeom &g);
 int sf_launch_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas, const SfGeom &g,
                       double *ufrag, double *wfrag, int32_t *lrok, hipStream_t st);

@@ -32,8 +32,8 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xo
 // LDS: c fragments 119,808 B + W blocks 41,472 B + mu = 161,856 B of the 163,840.
 constexpr int S4J = SF_SW4_NJ, S4M = SF_SW4_NM;
 // LDS reads of GEMM2 step t (one per alpha tile of its group of 4; none past the last step)
-constexpr int sw4r_reads(int t) {   // k_sweep4r: SF_LR_K/4 steps per group of 4 alpha tiles
-  const int gr = t / (SF_LR_K / 4), left = S4M - 4 * gr;
+constexpr int sw4r_reads(int t, int nk) {   // k_sweep4r: nk steps per group of 4 alpha tiles
+  const int gr = t / nk, left = S4M - 4 * gr;
   return left <= 0 ? 0 : (left < 4 ? left : 4);
 }
 constexpr int sw4_reads(int t) {
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
 // NW waves per workgroup share the LDS tables: with NW = 8 every SIMD holds two waves of the same workgroup and
 // one wave's LDS reads, DPP moves and waits run under the other's MFMAs (the tables allow only one workgroup per
 // CU, and with a single wave per SIMD every non-MFMA instruction is a bubble in the matrix pipe).
-template <int EXP, int NW>
+template <int EXP, int NW, int NK>   // NK = rank / 4: 7 (rank 28, lrok == 1) or 9 (rank 36, lrok == 2)
 __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
                                                     const int32_t *__restrict__ nuse, const double *__restrict__ mu,
                                                     const double *__restrict__ ufrag_g, const double *__restrict__ wfrag2_g,
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
   constexpr int NJ = S4J, NM = S4M, NA16 = NM * 16;
   constexpr bool VG = (NW == 8);   // two waves per SIMD: 256 registers per wave, all of them arch VGPRs (no 'a' operands)
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  constexpr int NK = SF_LR_K / 4;            // 7 groups of 4 factor indices
+  constexpr int NK2 = SF_LR_K2 / 4;          // stride of the global fragment layout (shared by both ranks)
   double *wfr = sm;                          // [NM][NK][64]  W fragments (GEMM2b B operand)
   double *wblk = wfr + NM * NK * 64;         // [NJ ig][NJ jg][16]
   double *ufr = wblk + NJ * NJ * 16;         // [NJ jg][NK][16]  -U blocks (GEMM2a A operand)
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
   const int g = lane >> 4, li = lane & 15;
   const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
   double *po = part + ((size_t)c * nsplit + split) * 2 * NA16;
-  if (status[c] != 0 || lrok[c] == 0) return;   // k_sweep4 takes these columns
+  if (status[c] != 0 || lrok[c] != (NK == SF_LR_K / 4 ? 1 : 2)) return;   // another instantiation / k_sweep4 takes these columns
   // ---- prologue: three table copies, loads issued in batches
   for (int i = tid; i < 4 * NJ; i += 64 * NW) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
   {
@@ -413,8 +413,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
       for (; i < nel; i += NT) dst[i] = src[i];
     };
     copy(wblk, wfrag + (size_t)c * wstride, NJ * NJ * 16);
-    copy(ufr, ufrag_g + (size_t)c * (NJ * NK * 16), NJ * NK * 16);
-    copy(wfr, wfrag2_g + (size_t)c * (NM * NK * 64), NM * NK * 64);
+    {   // the first NK of the NK2 factor groups of every (jg) / (M) block
+      const double *us = ufrag_g + (size_t)c * (NJ * NK2 * 16);
+      for (int i = tid; i < NJ * NK * 16; i += 64 * NW) {
+        const int blk = i / (NK * 16), r = i - blk * (NK * 16);
+        ufr[i] = us[blk * (NK2 * 16) + r];
+      }
+      const double *ws = wfrag2_g + (size_t)c * (NM * NK2 * 64);
+      for (int i = tid; i < NM * NK * 64; i += 64 * NW) {
+        const int blk = i / (NK * 64), r = i - blk * (NK * 64);
+        wfr[i] = ws[blk * (NK2 * 64) + r];
+      }
+    }
   }
   __syncthreads();
 
@@ -508,6 +518,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
         constexpr int jg = decltype(jc)::value;
         lds_wait4<0, VG>(ua[jg & 1][0], ua[jg & 1][1], ua[jg & 1][2], ua[jg & 1][3]);
         lds_wait4<0, VG>(ua[jg & 1][3], ua[jg & 1][4], ua[jg & 1][5], ua[jg & 1][6]);
+        if constexpr (NK > 7) lds_wait4<0, VG>(ua[jg & 1][NK - 4], ua[jg & 1][NK - 3], ua[jg & 1][NK - 2], ua[jg & 1][NK - 1]);
         static_for<0, NK>([&](auto mc) {
           constexpr int mg = decltype(mc)::value;
           if constexpr (jg + 1 < NJ) ua[(jg + 1) & 1][mg] = lds_ld<((jg + 1) * NK + mg) * 128, VG>(uadr);
@@ -577,11 +588,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
     static_for<0, NSTEP>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
       constexpr int gr = t / NK, jg = t - gr * NK, st = VG ? 0 : (gr & 1);
-      constexpr int nt = sw4r_reads(t);
+      constexpr int nt = sw4r_reads(t, NK);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (t + DEPTH - 1 < NSTEP) loadb(std::integral_constant<int, t + DEPTH - 1>{});
       // in-order returns: everything but the reads of the newer steps t+1 .. t+DEPTH-1 has landed
-      constexpr int newer = sw4r_reads(t + 1) + sw4r_reads(t + 2) + sw4r_reads(t + 3);
+      constexpr int newer = sw4r_reads(t + 1, NK) + sw4r_reads(t + 2, NK) + sw4r_reads(t + 3, NK);
       static_assert(DEPTH == 4 && newer <= 15, "lgkmcnt is a 4-bit counter");
       if constexpr (nt == 4) lds_wait4<newer, VG>(br[0][t % DEPTH], br[1][t % DEPTH], br[2][t % DEPTH], br[3][t % DEPTH]);
       else lds_wait1<newer, VG>(br[0][t % DEPTH]);
@@ -662,7 +673,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
   }
 }
 
-constexpr size_t SW4R_LDS = ((size_t)S4M * (SF_LR_K / 4) * 64 + S4J * S4J * 16 + S4J * (SF_LR_K / 4) * 16 + 4 * S4J) * sizeof(double);
+constexpr size_t sw4r_lds(int nk) { return ((size_t)S4M * nk * 64 + S4J * S4J * 16 + S4J * nk * 16 + 4 * S4J) * sizeof(double); }
 constexpr size_t SW4_LDS = ((size_t)S4M * S4J * 64 + S4J * S4J * 16 + 4 * S4J) * sizeof(double);
 
 template <int EXP>
@@ -686,24 +697,28 @@ int launch_sweep4_t(const float *xt, const uint8_t *mask_t, const int32_t *nuse,
 int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *ufrag,
                    const double *wfrag2, const int32_t *lrok, const double *wfrag, size_t wstride, const int32_t *status,
                    const double *alphas, const SfGeom &g, int nsplit, double *part, hipStream_t st) {
+  constexpr int NK1 = SF_LR_K / 4, NK2 = SF_LR_K2 / 4;
   static bool attr_set = false;
   if (!attr_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4r<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)SW4R_LDS));
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4r<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)SW4R_LDS));
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4r<0, 8, NK1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)sw4r_lds(NK1)));
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4r<0, 4, NK1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)sw4r_lds(NK1)));
+    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4r<0, 4, NK2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)sw4r_lds(NK2)));
     attr_set = true;
   }
   int rows = sf_cdiv(g.lines, nsplit);
-  if (g_sweep4r_waves == 4) {
-    rows = (rows + 63) / 64 * 64;
-    hipLaunchKernelGGL((k_sweep4r<0, 4>), dim3(g.ncols, nsplit), dim3(256), SW4R_LDS, st, xt, mask_t, nuse, mu, ufrag, wfrag2,
-                       lrok, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part);
-  } else {
-    rows = (rows + 127) / 128 * 128;
-    hipLaunchKernelGGL((k_sweep4r<0, 8>), dim3(g.ncols, nsplit), dim3(512), SW4R_LDS, st, xt, mask_t, nuse, mu, ufrag, wfrag2,
-                       lrok, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part);
-  }
+  rows = (rows + 127) / 128 * 128;
+#define SW4R_ARGS xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part
+  if (g_sweep4r_waves == 4)
+    hipLaunchKernelGGL((k_sweep4r<0, 4, NK1>), dim3(g.ncols, nsplit), dim3(256), sw4r_lds(NK1), st, SW4R_ARGS);
+  else
+    hipLaunchKernelGGL((k_sweep4r<0, 8, NK1>), dim3(g.ncols, nsplit), dim3(512), sw4r_lds(NK1), st, SW4R_ARGS);
+  SF_LAUNCH_CHECK("k_sweep4r");
+  // rank 36 (lrok == 2): one wave per SIMD (the wider t registers do not fit two)
+  hipLaunchKernelGGL((k_sweep4r<0, 4, NK2>), dim3(g.ncols, nsplit), dim3(256), sw4r_lds(NK2), st, SW4R_ARGS);
+#undef SW4R_ARGS
   SF_LAUNCH_CHECK("k_sweep4r");
   return 0;
 }
@@ -725,9 +740,9 @@ int sf_launch_sweep4(const float *xt, const uint8_t *mask_t, const int32_t *nuse
     // (it returns at once for the others: a column is swept by exactly one of the two)
     char *base = reinterpret_cast<char *>(lr_scratch);
     double *ufrag = reinterpret_cast<double *>(base);
-    double *wfrag2 = reinterpret_cast<double *>(base + sf_align((size_t)g.ncols * S4J * (SF_LR_K / 4) * 16 * sizeof(double)));
+    double *wfrag2 = reinterpret_cast<double *>(base + sf_align((size_t)g.ncols * S4J * (SF_LR_K2 / 4) * 16 * sizeof(double)));
     int32_t *lrok = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(wfrag2) +
-                                                sf_align((size_t)g.ncols * S4M * (SF_LR_K / 4) * 64 * sizeof(double)));
+                                                sf_align((size_t)g.ncols * S4M * (SF_LR_K2 / 4) * 64 * sizeof(double)));
     if (int rc = sf_launch_lowrank(lam, nuse, status, alphas, g, ufrag, wfrag2, lrok, st)) return rc;
     if (int rc = launch_sweep4r(xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, wfrag, wstride, status, alphas, g, nsplit, part, st))
       return rc;

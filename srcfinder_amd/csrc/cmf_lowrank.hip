@@ -21,12 +21,14 @@ namespace {
 
 constexpr int LR_P = 4 * SF_SW4_NJ;        // 72
 constexpr int LR_NA = 16 * SF_SW4_NM;      // 208
-constexpr int LR_K = SF_LR_K;              // 28
+constexpr int LR_K = SF_LR_K;              // 28: the fast rank
+constexpr int LR_K2 = SF_LR_K2;            // 36: second chance for spectra with a wider eigenvalue range
+constexpr int LR_NK2 = LR_K2 / 4;          // fragment layout stride (both ranks share the 36-wide layout)
 constexpr int LR_LDA = LR_NA + 1;          // column stride in LDS (odd: threads on different columns, same row)
 constexpr int LR_TPC = 8;                  // lanes per column in the update (8-lane DPP reductions, no LDS partials)
 constexpr int LR_NT = 576;                 // 72 columns x 8 lanes = 9 waves
-constexpr int LR_PK = 4;                   // row slots (of 8 rows) that can touch the diagonal: 8 * 4 = 32 > K
-static_assert(LR_TPC * LR_PK >= LR_K + 1 && LR_NA % LR_TPC == 0, "row slots");
+constexpr int LR_PK = 5;                   // row slots (of 8 rows) that can touch the diagonal: 8 * 5 = 40 > K2
+static_assert(LR_TPC * LR_PK >= LR_K2 + 1 && LR_NA % LR_TPC == 0, "row slots");
 
 template <int CTRL>
 __device__ __forceinline__ double lr_dpp(double v) {
@@ -63,10 +65,10 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
   __shared__ double cnorm[LR_P];                // squared norms of the remaining columns, rows >= current (-1: pivoted)
   __shared__ double cnorm2[LR_P];               // the same over the rows below the current one
   __shared__ int posof[LR_P];                   // step at which a column was pivoted, -1 if never
-  __shared__ double tau_s[LR_K];
+  __shared__ double tau_s[LR_K2];
   __shared__ double s_al[LR_NA], s_be[LR_NA], s_lam[LR_P];
-  __shared__ int perm[LR_K];                    // perm[s] = the column pivoted at step s
-  __shared__ int freecol[LR_K];                 // never-pivoted columns that hold Q_K afterwards
+  __shared__ int perm[LR_K2];                   // perm[s] = the column pivoted at step s
+  __shared__ int freecol[LR_K2];                 // never-pivoted columns that hold Q_K afterwards
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   if (status[c] != 0) {
     if (tid == 0) lrok[c] = 0;
@@ -109,7 +111,13 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
   // previous step, so nothing is obtained by subtraction.
   double r00 = 0.0;
   bool mine_done = false;                       // this group's column has been pivoted
-  for (int s = 0; s < LR_K; ++s) {
+  int kuse = 0;                                 // accepted rank: LR_K, LR_K2 or 0 (full-rank sweep)
+  for (int s = 0; s < LR_K2; ++s) {
+    if (s == LR_K) {   // rank 28 reached: is the trailing block already at the rounding floor?  (same answer in every thread)
+      double bn = 0.0;
+      for (int j = 0; j < LR_P; ++j) bn = fmax(bn, cnorm[j]);
+      if (sqrt(bn) <= 3e-15 * r00 && r00 > 0.0) { kuse = LR_K; break; }
+    }
     // pivot = the remaining column of largest norm (lowest index on ties; pivoted columns carry -1).  Every 8-lane
     // group scans all 72 candidates (9 per lane) and finishes with three DPP exchanges: no cross-wave traffic, no
     // ds_bpermute chain (six dependent LDS-crossbar round trips were the longest part of the step).
@@ -204,43 +212,45 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
     }
     __syncthreads();
   }
-  {   // what is left after K steps
+  if (kuse == 0) {   // what is left after K2 steps
     double bn = 0.0;
     for (int j = 0; j < LR_P; ++j) bn = fmax(bn, cnorm[j]);
-    const double resid = sqrt(bn);
-    // The error bound is relative to |B|: accept only a well-scaled B (largest column norm of B^T <= 64, i.e.
-    // n lam_min not far below 1; a singular R has entries beta/alpha ~ 1e5 for the smallest alphas).
-    if (tid == 0) lrok[c] = (resid <= 3e-15 * r00 && r00 > 0.0 && r00 <= 64.0) ? 1 : 0;
+    if (sqrt(bn) <= 3e-15 * r00 && r00 > 0.0) kuse = LR_K2;
   }
+  // The error bound is relative to |B|: accept only a well-scaled B (largest column norm of B^T <= 64, i.e.
+  // n lam_min not far below 1; a singular R has entries beta/alpha ~ 1e5 for the smallest alphas).
+  if (r00 > 64.0) kuse = 0;
+  if (tid == 0) lrok[c] = (kuse == LR_K) ? 1 : ((kuse == LR_K2) ? 2 : 0);
+  if (kuse == 0) return;
   // ---- U fragments: ufrag[(jg*NK + mg)*16 + 4q + n] = -U[4jg+q][4mg+n];  U[j][m] = R[m][column j]: rows m <= posof[j]
   //      of a pivoted column (below them sits its reflector), all K rows of the others
-  double *uo = ufrag + (size_t)c * (SF_SW4_NJ * (LR_K / 4) * 16);
-  for (int idx = tid; idx < LR_P * LR_K; idx += LR_NT) {
-    const int j = idx / LR_K, m = idx - j * LR_K;
+  double *uo = ufrag + (size_t)c * (SF_SW4_NJ * LR_NK2 * 16);
+  for (int idx = tid; idx < LR_P * LR_K2; idx += LR_NT) {
+    const int j = idx / LR_K2, m = idx - j * LR_K2;
     const int pj = posof[j];
-    const double r = (pj < 0 || m <= pj) ? A[j * LR_LDA + m] : 0.0;
+    const double r = (m < kuse && (pj < 0 || m <= pj)) ? A[j * LR_LDA + m] : 0.0;
     const int jg = j >> 2, q = j & 3, mg = m >> 2, nn = m & 3;
-    uo[(jg * (LR_K / 4) + mg) * 16 + 4 * q + nn] = -r;
+    uo[(jg * LR_NK2 + mg) * 16 + 4 * q + nn] = -r;
   }
   __syncthreads();
   // ---- Q_K = H_0 ... H_{K-1} [I_K; 0], formed in K of the columns that were never pivoted (their R entries have
   //      been exported); reflector s sits in column perm[s].  16 lanes per column.
   if (tid == 0) {
     int m = 0;
-    for (int j = 0; j < LR_P && m < LR_K; ++j)
+    for (int j = 0; j < LR_P && m < kuse; ++j)
       if (posof[j] < 0) freecol[m++] = j;
   }
   __syncthreads();
-  for (int idx = tid; idx < LR_K * LR_NA; idx += LR_NT) {
+  for (int idx = tid; idx < kuse * LR_NA; idx += LR_NT) {
     const int m = idx / LR_NA, i = idx - m * LR_NA;
     A[freecol[m] * LR_LDA + i] = (i == m) ? 1.0 : 0.0;
   }
   __syncthreads();
-  const int qcol = tid >> 4, qsub = tid & 15;   // 28 columns x 16 lanes = 448 threads
-  for (int s = LR_K - 1; s >= 0; --s) {
+  const int qcol = tid >> 4, qsub = tid & 15;   // up to 36 columns x 16 lanes = 576 threads
+  for (int s = kuse - 1; s >= 0; --s) {
     const double *v = A + perm[s] * LR_LDA;
     const double tau = tau_s[s];
-    if (qcol < LR_K) {
+    if (qcol < kuse) {
       double *qc = A + freecol[qcol] * LR_LDA;
       double vv[(LR_NA + 15) / 16], qv[(LR_NA + 15) / 16];
       double w = 0.0;
@@ -262,20 +272,20 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
   }
   __syncthreads();
   // ---- W fragments: wfrag[(M*NK + mg)*64 + lane], lane = 16q + 4mm + n  ->  W[4mg+q][16M + 4mm + n] = Q[alpha][m]
-  double *wo = wfrag + (size_t)c * (SF_SW4_NM * (LR_K / 4) * 64);
-  for (int idx = tid; idx < SF_SW4_NM * (LR_K / 4) * 64; idx += LR_NT) {
+  double *wo = wfrag + (size_t)c * (SF_SW4_NM * LR_NK2 * 64);
+  for (int idx = tid; idx < SF_SW4_NM * LR_NK2 * 64; idx += LR_NT) {
     const int ln = idx & 63, blk = idx >> 6;
-    const int M = blk / (LR_K / 4), mg = blk - M * (LR_K / 4);
+    const int M = blk / LR_NK2, mg = blk - M * LR_NK2;
     const int q = ln >> 4, a = 16 * M + (ln & 15);
-    wo[idx] = A[freecol[4 * mg + q] * LR_LDA + a];
+    wo[idx] = (4 * mg + q < kuse) ? A[freecol[4 * mg + q] * LR_LDA + a] : 0.0;
   }
 }
 
 }  // namespace
 
 size_t sf_lowrank_bytes(const SfGeom &g) {
-  return sf_align((size_t)g.ncols * SF_SW4_NJ * (LR_K / 4) * 16 * sizeof(double)) +
-         sf_align((size_t)g.ncols * SF_SW4_NM * (LR_K / 4) * 64 * sizeof(double)) + sf_align((size_t)g.ncols * sizeof(int32_t));
+  return sf_align((size_t)g.ncols * SF_SW4_NJ * LR_NK2 * 16 * sizeof(double)) +
+         sf_align((size_t)g.ncols * SF_SW4_NM * LR_NK2 * 64 * sizeof(double)) + sf_align((size_t)g.ncols * sizeof(int32_t));
 }
 
 int sf_launch_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas, const SfGeom &g,

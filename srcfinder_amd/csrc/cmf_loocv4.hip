@@ -383,7 +383,8 @@ template <int EXP, int NW, int NK>   // NK = rank / 4: 7 (rank 28, lrok == 1) or
 __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
                                                     const int32_t *__restrict__ nuse, const double *__restrict__ mu,
                                                     const double *__restrict__ ufrag_g, const double *__restrict__ wfrag2_g,
-                                                    const int32_t *__restrict__ lrok, const double *__restrict__ wfrag,
+                                                    const int32_t *__restrict__ lrok, const double *__restrict__ lam,
+                                                    const double *__restrict__ wfrag,
                                                     size_t wstride, const int32_t *__restrict__ status,
                                                     const double *__restrict__ alphas, int nalpha, int L, int p,
                                                     int PS, int rows_per_wg, double *__restrict__ part) {
@@ -400,8 +401,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
   const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
   double *po = part + ((size_t)c * nsplit + split) * 2 * NA16;
   if (status[c] != 0 || lrok[c] != (NK == SF_LR_K / 4 ? 1 : 2)) return;   // another instantiation / k_sweep4 takes these columns
-  // ---- prologue: three table copies, loads issued in batches
-  for (int i = tid; i < 4 * NJ; i += 64 * NW) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
+  // ---- prologue: three table copies
   {
     auto copy = [&](double *dst, const double *src, int nel) {
       constexpr int NT = 64 * NW;
@@ -412,7 +412,16 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
       }
       for (; i < nel; i += NT) dst[i] = src[i];
     };
-    copy(wblk, wfrag + (size_t)c * wstride, NJ * NJ * 16);
+    // W blocks scaled by 1/sqrt(lam_j): GEMM1 then yields the whitened coordinates y_j/sqrt(lam_j) (unit variance) and
+    // z their squares, which is what the row-scaled factorisation of cmf_lowrank.hip multiplies
+    for (int i = tid; i < 4 * NJ; i += 64 * NW) mus[i] = (i < p) ? 1.0 / sqrt(lam[(size_t)c * p + i]) : 1.0;   // (mus: scratch here)
+    __syncthreads();
+    {
+      const double *wsrc = wfrag + (size_t)c * wstride;
+      for (int i = tid; i < NJ * NJ * 16; i += 64 * NW) wblk[i] = wsrc[i] * mus[4 * ((i >> 4) % NJ) + (i & 3)];
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * NJ; i += 64 * NW) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
     {   // the first NK of the NK2 factor groups of every (jg) / (M) block
       const double *us = ufrag_g + (size_t)c * (NJ * NK2 * 16);
       for (int i = tid; i < NJ * NK * 16; i += 64 * NW) {
@@ -695,7 +704,7 @@ int launch_sweep4_t(const float *xt, const uint8_t *mask_t, const int32_t *nuse,
 }
 
 int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *ufrag,
-                   const double *wfrag2, const int32_t *lrok, const double *wfrag, size_t wstride, const int32_t *status,
+                   const double *wfrag2, const int32_t *lrok, const double *lam, const double *wfrag, size_t wstride, const int32_t *status,
                    const double *alphas, const SfGeom &g, int nsplit, double *part, hipStream_t st) {
   constexpr int NK1 = SF_LR_K / 4, NK2 = SF_LR_K2 / 4;
   static bool attr_set = false;
@@ -710,7 +719,7 @@ int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
   }
   int rows = sf_cdiv(g.lines, nsplit);
   rows = (rows + 127) / 128 * 128;
-#define SW4R_ARGS xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part
+#define SW4R_ARGS xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part
   if (g_sweep4r_waves == 4)
     hipLaunchKernelGGL((k_sweep4r<0, 4, NK1>), dim3(g.ncols, nsplit), dim3(256), sw4r_lds(NK1), st, SW4R_ARGS);
   else
@@ -744,7 +753,7 @@ int sf_launch_sweep4(const float *xt, const uint8_t *mask_t, const int32_t *nuse
     int32_t *lrok = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(wfrag2) +
                                                 sf_align((size_t)g.ncols * S4M * (SF_LR_K2 / 4) * 64 * sizeof(double)));
     if (int rc = sf_launch_lowrank(lam, nuse, status, alphas, g, ufrag, wfrag2, lrok, st)) return rc;
-    if (int rc = launch_sweep4r(xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, wfrag, wstride, status, alphas, g, nsplit, part, st))
+    if (int rc = launch_sweep4r(xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam, wfrag, wstride, status, alphas, g, nsplit, part, st))
       return rc;
     return launch_sweep4_t<0>(SW4_ARGS, lrok);
   }

@@ -4,7 +4,7 @@
 // for every row k: 72 x 208 coefficients.  B is a Cauchy matrix in disguise, B_ji = (1/(n-1)) / (x_j + g_i) with
 // x_j = n lam_j/(n-1), g_i = alpha_i/(1-alpha_i), and its numerical rank is ~25: the singular values fall by a decade
 // every 1.6 (sigma_26/sigma_0 < 1e-16 on flightline-like spectra).  So per column
-//        B = U W + E,   U (72 x K), W (K x 208) with orthonormal rows,   K = 28,   |E| <= ~1e-16 |B|,
+//        B' = diag(lam) B = U W + E,   U (72 x K), W (K x 208) with orthonormal rows,   K = 28 (36),   |E| <= ~1e-15 |B'|,
 // and the sweep multiplies z by U (72 x 28) and then by W (28 x 208) instead of by B: 44 % fewer flops in the
 // product that is 3/4 of the kernel, with q changing by one ulp (numpy model: max |dq| = 1.1e-16, identical NLL
 // argmin on every test spectrum).
@@ -13,8 +13,8 @@
 //   B^T P = Q R   =>   B = (P R_K^T) (Q_K^T) + E,   |E| = the largest remaining column norm,
 // backward stable whatever the conditioning (B is numerically singular by design -- no Gram matrix, no
 // inverse).  One 576-thread workgroup per column, the matrix in LDS, 8 lanes per column with DPP reductions.  A column whose remaining norm
-// after K steps is not below 3e-15 |R_00| (the rounding floor of the trailing block is ~7e-16 |R_00|), or whose
-// B is badly scaled (|R_00| > 64: a near-singular correlation matrix), is flagged and swept by the full-rank kernel.
+// after K steps is not below 1e-14 |R_00| (q then moves by <= 72 x 1e-14 x |R_00| ~ 5e-16; the rounding floor is ~7e-16 |R_00|), or whose
+// correlation matrix is not safely positive definite (condition > 1e10), is flagged and swept by the full-rank kernel.
 #include "cmf_common.h"
 
 namespace {
@@ -86,9 +86,18 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
   __syncthreads();
   for (int idx = tid; idx < LR_P * LR_NA; idx += LR_NT) {
     const int j = idx / LR_NA, i = idx - j * LR_NA;
-    const double a = s_al[i], beta = s_be[i];
-    const double v = beta / ((n * beta) * s_lam[j] + a);
+    const double a = s_al[i], beta = s_be[i], lj = s_lam[j];
+    const double v = lj * beta / ((n * beta) * lj + a);
     A[j * LR_LDA + i] = (i < nalpha && j < p) ? v : 0.0;
+  }
+  // (row-scaled: what is factored is B'_ji = lam_j B_ji, all entries in [0, 1/n); the sweep feeds it the whitened
+  //  squares z_j / lam_j -- of order one whatever the spectrum -- so the factorisation error is relative to what each
+  //  eigen-direction actually contributes to q, not to the largest entry of B, which is 1/(n lam_min).)
+  bool lam_ok = true;
+  {
+    double lmin = 1.7976931348623157e308, lmax = 0.0;
+    for (int j = 0; j < p; ++j) { lmin = fmin(lmin, s_lam[j]); lmax = fmax(lmax, s_lam[j]); }
+    lam_ok = (lmin > 1e-10 * lmax) && (lmax <= 1.7976931348623157e308);   // positive definite, condition < 1e10
   }
   if (tid < LR_P) posof[tid] = -1;
   __syncthreads();
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
     if (s == LR_K) {   // rank 28 reached: is the trailing block already at the rounding floor?  (same answer in every thread)
       double bn = 0.0;
       for (int j = 0; j < LR_P; ++j) bn = fmax(bn, cnorm[j]);
-      if (sqrt(bn) <= 3e-15 * r00 && r00 > 0.0) { kuse = LR_K; break; }
+      if (sqrt(bn) <= 1e-14 * r00 && r00 > 0.0) { kuse = LR_K; break; }
     }
     // pivot = the remaining column of largest norm (lowest index on ties; pivoted columns carry -1).  Every 8-lane
     // group scans all 72 candidates (9 per lane) and finishes with three DPP exchanges: no cross-wave traffic, no
@@ -215,11 +224,9 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
   if (kuse == 0) {   // what is left after K2 steps
     double bn = 0.0;
     for (int j = 0; j < LR_P; ++j) bn = fmax(bn, cnorm[j]);
-    if (sqrt(bn) <= 3e-15 * r00 && r00 > 0.0) kuse = LR_K2;
+    if (sqrt(bn) <= 1e-14 * r00 && r00 > 0.0) kuse = LR_K2;
   }
-  // The error bound is relative to |B|: accept only a well-scaled B (largest column norm of B^T <= 64, i.e.
-  // n lam_min not far below 1; a singular R has entries beta/alpha ~ 1e5 for the smallest alphas).
-  if (r00 > 64.0) kuse = 0;
+  if (!lam_ok) kuse = 0;   // (near-)singular or indefinite correlation matrix: the full-rank kernel
   if (tid == 0) lrok[c] = (kuse == LR_K) ? 1 : ((kuse == LR_K2) ? 2 : 0);
   if (kuse == 0) return;
   // ---- U fragments: ufrag[(jg*NK + mg)*16 + 4q + n] = -U[4jg+q][4mg+n];  U[j][m] = R[m][column j]: rows m <= posof[j]

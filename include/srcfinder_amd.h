@@ -117,7 +117,9 @@ int sf_cmf_kmeans(const float *xt, const uint8_t *mask_t, const double *mu, cons
 
 /* Matched filter of ONE cluster (:377-386): rows with rowmask_t[ncols][lines] != 0 get their score in the last
  * band of `out` (0 when status == 2, :371-374) and the (cluster, alpha index) pair in bgmeta (:327, :365); every
- * other pixel is left as it is (initialise the product with sf_cmf_score and an all-zero filter first). */
+ * other pixel is left as it is (initialise the product with sf_cmf_score and an all-zero filter first).
+ * cluster == -32768 leaves the cluster band of bgmeta alone (cluster rejection, :321-327, where the pass of a
+ * rejected cluster re-scores the rows of the others). */
 int sf_cmf_score_cluster(const float *cube, int lines, int bands, int samples, int s0, int s1, int b0, int p,
                          const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,
                          const uint8_t *rowmask_t, int cluster, double *out, int out_samples, int out_s0, int out_bands,

@@ -241,18 +241,23 @@ def robust_mf_oracle(cube_bil: np.ndarray, library: np.ndarray, *, gas="ch4", re
 
 def robust_mf_multimodal_oracle(cube_bil: np.ndarray, library: np.ndarray, labels: np.ndarray, *, gas="ch4",
                                 reflectance=False, rgb_bands=(60, 42, 24), nodata=-9999.0, active=None,
-                                shrinkage=looshrinkage):
+                                shrinkage=looshrinkage, reject=False, full=False):
     """Multimodal (k > 1) column loop of cmf/robust_mf.py:297-397 with the cluster labels INJECTED
     (labels[lines, samples], ids >= 0; what the reference's unseeded MiniBatchKMeans chose, :312-313, as stored
-    in its bgmeta image, :327).  No rejection (-r) and no full-column regulariser (-f).  Per cluster of a
-    column (:336-386): its own mean, looshrinkage with n = the COLUMN's valid-row count (the reference passes
-    `nuse`, :355-356, not the cluster size), its own inverse and matched filter.
+    in its bgmeta image, :327).  Per cluster of a column (:336-386): its own mean, looshrinkage with n = the
+    COLUMN's valid-row count (the reference passes `nuse`, :355-356, not the cluster size), its own inverse and
+    matched filter.
+    reject (-r, :317-332): a cluster with fewer than int((a1-a0)*1.2) rows is relabelled -l (label 0 cannot be:
+    -0 == 0); its rows are never scored, and in its turn of the loop the model of ALL non-rejected rows is fitted and
+    written over those rows (:341); the column statistics cover the non-rejected rows (:388).
+    full (-f, :354): the shrinkage target is the covariance of the whole column instead of diag(S).
     Returns dict(out, bgmeta, colstats, alphaidx[samples, k] (-2 = cluster absent), status[samples, k])."""
     lines, nbands, samples = cube_bil.shape
     lib = np.float64(np.asarray(library))
     abscf_full = lib[:, 2] if lib.ndim == 2 else lib
     a0, a1 = active if active is not None else active_window(gas, reflectance)
     abscf = abscf_full[a0 - 1:a1]
+    bgminsamp = int((a1 - a0) * 1.2)                                               # :200
     alphas = alpha_grid()
     nll = np.zeros(len(alphas))
     nrgb = len(rgb_bands)
@@ -270,20 +275,30 @@ def robust_mf_multimodal_oracle(cube_bil: np.ndarray, library: np.ndarray, label
         nuse = icol.shape[0]
         if nuse == 0:
             continue
-        bglabels = labels[use, col]
-        for ki in np.unique(bglabels):
-            kmask = bglabels == ki
-            bgmeta[use[kmask], col, 0] = ki                                        # :327
+        bglabels = np.int64(labels[use, col]).copy()
+        bgulab = np.unique(bglabels)
+        for i, l in enumerate(bgulab.copy()):
+            lmask = bglabels == l
+            if reject and lmask.sum() < bgminsamp:                                 # :321-324
+                bglabels[lmask] = -l
+                bgulab[i] = -l
+            bgmeta[use[lmask], col, 0] = bgulab[i]                                 # :327
+        if (bgulab < 0).all():                                                     # :330-332
+            bglabels, bgulab = abs(bglabels), abs(bgulab)
+        for ki in bgulab:
+            kmask = (bglabels == ki) if ki >= 0 else (bglabels >= 0)               # :341
             icol_ki = icol[kmask, :].copy()
             mu = np.mean(icol_ki, axis=0)
+            icol_reg = icol - mu if full else []                                   # :354
             try:
-                c, aidx = shrinkage(icol_ki - mu, alphas, nll, nuse)               # n = nuse of the column (:355)
-                alphaidx[col, ki] = aidx
+                # n = nuse of the column (:355)
+                c, aidx = shrinkage(icol_ki - mu, alphas, nll, nuse, icol_reg) if full else shrinkage(icol_ki - mu, alphas, nll, nuse)
+                alphaidx[col, abs(ki)] = aidx
                 cinv = inv(c)
                 bgmeta[use[kmask], col, 1] = aidx
             except sla.LinAlgError:
                 out[use[kmask], col, -1] = 0
-                status[col, ki] = 2
+                status[col, abs(ki)] = 2
                 continue
             xc = icol_ki - mu
             target = abscf.copy()
@@ -291,7 +306,7 @@ def robust_mf_multimodal_oracle(cube_bil: np.ndarray, library: np.ndarray, label
             normalizer = target.dot(cinv).dot(target.T)
             mf = (xc.dot(cinv).dot(target.T)) / normalizer
             out[use[kmask], col, -1] = mf if reflectance else mf * PPM_SCALING
-        colpix = out[use, col, -1]
+        colpix = out[use[bglabels >= 0], col, -1]                                  # :388
         colstats[0, col] = nuse
         colstats[1, col] = np.mean(colpix)
         colstats[2, col] = np.std(colpix)

@@ -56,10 +56,15 @@ def alpha_grid():
     return 10.0 ** np.arange(aminexp, amaxexp + astep, astep)
 
 
-def model_parameters(reflectance=False, active=(351, 422), modelname="looshrinkage", bgmodes=1):
+def model_parameters(reflectance=False, active=(351, 422), modelname="looshrinkage", bgmodes=1, pcadim=6, reject=False,
+                     regfull=False):
     """The ``model parameters`` header string the reference writes (robust_mf.py:246-259)."""
     bgmodel = "unimodal" if bgmodes == 1 else "multimodal"
     s = "modelname=%s, bgmodel=%s" % (modelname, bgmodel)
+    if bgmodes > 1:
+        s += ", bgmodes=%d, pcadim=%d, reject=%s" % (bgmodes, pcadim, bool(reject))
+        if modelname == "looshrinkage":
+            s += ", regfull=%s" % bool(regfull)
     if modelname == "looshrinkage":
         s += ", aminexp=-10.0, amaxexp=0.0, astep=0.05"
     s += ", reflectance=%s, active_bands=[%d, %d]" % (bool(reflectance), active[0], active[1])
@@ -138,9 +143,8 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
                a reference bgmeta image) injects them; ``result.labels`` holds the labels used.
     """
     torch = _torch()
-    if reject or full:
-        raise NotImplementedError("cluster rejection (-r) and the full-column regulariser (-f) are not built "
-                                  "(SURVEY.md §8 N1)")
+    if full:
+        raise NotImplementedError("the full-column regulariser (-f) is not built (SURVEY.md §8 N1)")
     kmeans = int(kmeans)
     if kmeans < 1 or kmeans > 8:
         raise ValueError("kmeans must be in 1..8")
@@ -194,8 +198,10 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
             r = rgb_bands if nb == 4 else (0, 0, 0)
             res = _multimodal(torch, L, cube_bil, lines, bands, samples, s0, s1, a0, p, abscf, alphas, nalpha,
                               bool(reflectance), r, float(nodata), out_t, out_samples, out_s0, nb, bgmeta, kmeans,
-                              int(pcadim), labels, int(kmeans_seed), int(kmeans_iters))
-            res.modelparms = model_parameters(reflectance, (a0, a1), bgmodes=kmeans)
+                              int(pcadim), labels, int(kmeans_seed), int(kmeans_iters), bool(reject), bool(full),
+                              int((a1 - a0) * 1.2))                                     # bgminsamp, robust_mf.py:200
+            res.modelparms = model_parameters(reflectance, (a0, a1), bgmodes=kmeans, pcadim=int(pcadim), reject=reject,
+                                              regfull=full)
             if to_numpy:
                 for k in ("out", "bgmeta", "colstats", "alphaidx", "nuse", "status", "labels"):
                     v = getattr(res, k)
@@ -222,9 +228,13 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
 
 
 def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alphas, nalpha, reflectance, rgb, nodata,
-                out_t, out_samples, out_s0, nb, bgmeta, k, pcadim, labels, seed, iters):
-    """Multimodal column loop (robust_mf.py:306-386, no -r / -f): stage entry points of the C ABI, once per
-    cluster with the row mask  valid & (label == ki);  stage 5 gets the COLUMN's valid-row count as n (:355-356)."""
+                out_t, out_samples, out_s0, nb, bgmeta, k, pcadim, labels, seed, iters, reject=False, full=False,
+                bgminsamp=85):
+    """Multimodal column loop (robust_mf.py:306-386): stage entry points of the C ABI, once per cluster with the row
+    mask  valid & (label == ki);  stage 5 gets the COLUMN's valid-row count as n (:355-356).
+    reject (-r, :317-341): clusters of fewer than bgminsamp rows (never label 0: -0 == 0, :323) are relabelled -l in the
+    cluster band and never scored; in their turn of the loop the model of ALL non-rejected rows is fitted and written
+    over those rows.  If every cluster of a column is rejected none is (:330-332)."""
     if p > 96:
         raise NotImplementedError("multimodal background needs an active window of <= 96 bands")
     dev = cube.device
@@ -280,18 +290,38 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
     alphaidx = torch.full((ncols, k), -2, **i32)
     status = torch.ones((ncols, k), **i32)
     labels_valid = torch.where(mask != 0, labels_t, torch.full_like(labels_t, 255))
+    keep = None
+    if reject:
+        counts = torch.stack([(labels_valid == ki).sum(1) for ki in range(k)], 1)          # [ncols, k]
+        present = counts > 0
+        rej = present & (counts < bgminsamp)
+        rej[:, 0] = False                                                                  # -0 == 0 (:323)
+        lab_idx = labels_valid.clamp(max=k - 1).long()
+        if bgmeta is not None:      # cluster band: -l for the rows of a rejected cluster (written before :330's abs())
+            lab16 = labels_valid.to(torch.int16)
+            meta0 = torch.where(mask != 0, torch.where(torch.gather(rej, 1, lab_idx), -lab16, lab16), torch.zeros_like(lab16))
+            bgmeta[:, out_s0:out_s0 + ncols, 0] = meta0.t()
+        rej &= ~((rej | ~present).all(1, keepdim=True))                                    # all rejected -> none (:330-332)
+        keep = ((mask != 0) & ~torch.gather(rej, 1, lab_idx)).to(torch.uint8)
     for ki in range(k):
         mask_k = (labels_valid == ki).to(torch.uint8)
+        if reject:
+            mask_k = torch.where(rej[:, ki, None], keep, mask_k)
         stats(mask_k, nuse_k, nuse_col, status_k)
         check(L.sf_cmf_filter(P(mu), P(d), P(lam), P(evec), P(alphas), P(aidx_k), P(abscf), int(reflectance), p, ncols,
                               P(status_k), P(filt), P(bias), st), "sf_cmf_filter")
         check(L.sf_cmf_score_cluster(P(cube), lines, bands, samples, s0, s1, a0 - 1, p, P(filt), P(bias), P(status_k),
-                                     P(aidx_k), P(mask_k), ki, P(out_t), out_samples, out_s0, nb, P(bgmeta), st),
+                                     P(aidx_k), P(mask_k), -32768 if reject else ki, P(out_t), out_samples, out_s0, nb,
+                                     P(bgmeta), st),
               "sf_cmf_score_cluster")
         alphaidx[:, ki] = torch.where(status_k == 1, torch.full_like(aidx_k, -2), aidx_k)
         status[:, ki] = status_k
-    check(L.sf_cmf_colstats_rows(P(out_t), out_samples, out_s0, nb, P(mask), lines, ncols, nodata, P(colstats), st),
-          "sf_cmf_colstats_rows")
+    check(L.sf_cmf_colstats_rows(P(out_t), out_samples, out_s0, nb, P(mask if keep is None else keep), lines, ncols, nodata,
+                                 P(colstats), st), "sf_cmf_colstats_rows")
+    if keep is not None:            # rows of a rejected cluster are never written: they stay NODATA (:266, :341)
+        out_t[:, out_s0:out_s0 + ncols, nb - 1].masked_fill_(((mask != 0) & (keep == 0)).t(), nodata)
+    if keep is not None:            # the count column stays the number of valid rows (:389), mean/std skip rejected rows (:388)
+        colstats[0] = torch.where(nuse_col > 0, nuse_col.to(torch.float64), colstats[0])
     return CMFResult(out=out_t, bgmeta=bgmeta, colstats=colstats, alphaidx=alphaidx, nuse=nuse_col, status=status,
                      labels=labels_valid.t().contiguous())
 

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_score_cluster(const float *__restrict__
     const size_t pix = (size_t)l * oS + os0 + col;
     out[pix * ob + (ob - 1)] = (st == 2) ? 0.0 : (acc - mybias);   // singular C: the mode's rows get 0 (:373)
     if (bgmeta) {
-      bgmeta[pix * 2] = (int16_t)cluster;
+      if (cluster != -32768) bgmeta[pix * 2] = (int16_t)cluster;   // -32768: the caller owns the cluster band (-r)
       if (st == 0) bgmeta[pix * 2 + 1] = (int16_t)ai;
     }
   }

@@ -36,5 +36,35 @@ def main():
                         colstats=r["colstats"], modelparms=np.array(r["modelparms"]), versions=G.versions())
 
 
+def main_reject_full():
+    """-k 3 -r (cluster rejection) and -k 2 -f (full-column regulariser), same recipe."""
+    G.install_spectral_stub()
+    lib = np.float64(np.loadtxt(G.LIB_TXT))
+    lines, samples, seed = 1200, 5, 556
+    cube = G.make_cube_numpy(lines, samples, seed=seed, abscf_full=lib[:, 2], nodata_column=1)
+    cube[500:900] *= np.float32(1.35)
+    # a handful of very bright rows: k-means gives them a cluster of their own, smaller than int(71*1.2) = 85 rows
+    cube[1000:1040] *= np.float32(2.6)
+    np.random.seed(11)
+    r = G.run_reference_main(cube, extra_args=("-k", "3", "-r"), tag="K3R")
+    lab = r["bgmeta"][:, :, 0]
+    print("-k 3 -r cluster ids per column:", [sorted(set(np.unique(lab[:, c]).tolist())) for c in range(samples)])
+    print("   sizes:", [[int((lab[:, c] == v).sum()) for v in np.unique(lab[:, c])] for c in range(samples)])
+    np.savez_compressed(os.path.join(HERE, "cmf_K3_reject.npz"), seed=seed, lines=lines, samples=samples,
+                        nodata_column=1, bright=np.array([[500, 900, 1.35], [1000, 1040, 2.6]]), out=r["out"],
+                        bgmeta=r["bgmeta"], colstats=r["colstats"], modelparms=np.array(r["modelparms"]),
+                        versions=G.versions())
+    np.random.seed(12)
+    r = G.run_reference_main(cube, extra_args=("-k", "2", "-f"), tag="K2F")
+    print("-k 2 -f alpha idx:", np.unique(r["bgmeta"][:, :, 1]))
+    np.savez_compressed(os.path.join(HERE, "cmf_K2_full.npz"), seed=seed, lines=lines, samples=samples,
+                        nodata_column=1, bright=np.array([[500, 900, 1.35], [1000, 1040, 2.6]]), out=r["out"],
+                        bgmeta=r["bgmeta"], colstats=r["colstats"], modelparms=np.array(r["modelparms"]),
+                        versions=G.versions())
+
+
 if __name__ == "__main__":
+    if "--reject-full" in sys.argv:
+        main_reject_full()
+        sys.exit(0)
     main()

@@ -431,6 +431,54 @@ def test_multimodal_golden_with_injected_labels(torch_cuda, golden_dir, library)
     np.testing.assert_allclose(res.colstats[1:, ok], g["colstats"][1:, ok], rtol=1e-6, atol=1e-9 * np.abs(ref[..., 3]).max())
 
 
+def _bright_cube(g, library):
+    cube = make_cube_numpy(int(g["lines"]), int(g["samples"]), seed=int(g["seed"]), abscf_full=library[:, 2],
+                           nodata_column=int(g["nodata_column"]))
+    for b0, b1, f in g["bright"]:
+        cube[int(b0):int(b1)] *= np.float32(f)
+    return cube
+
+
+def _check_multimodal(res, ref_out, ref_bgmeta, ref_colstats):
+    assert np.array_equal(res.out[..., 3] == -9999.0, ref_out[..., 3] == -9999.0)
+    assert np.array_equal(res.out[..., :3], ref_out[..., :3])
+    assert np.array_equal(res.bgmeta, ref_bgmeta)
+    assert score_close(res.out[..., 3], ref_out[..., 3]).all()
+    ok = ref_colstats[0] > 0
+    assert np.array_equal(res.colstats[0][ok], ref_colstats[0][ok])
+    np.testing.assert_allclose(res.colstats[1:, ok], ref_colstats[1:, ok], rtol=1e-6, atol=1e-9 * np.abs(ref_out[..., 3]).max())
+
+
+def test_multimodal_cluster_rejection_golden(torch_cuda, golden_dir, library):
+    """N1 -r: -k 3 -r golden of the real reference (a 38-40 row cluster rejected in four columns).  Rejected rows stay
+    NODATA with cluster id -1, cluster 0's rows carry the model of all kept rows, statistics skip rejected rows."""
+    g = np.load(os.path.join(golden_dir, "cmf_K3_reject.npz"))
+    cube = _bright_cube(g, library)
+    lab = np.abs(g["bgmeta"][:, :, 0].astype(np.int64))
+    res = cmf.robust_mf(cube, library, kmeans=3, reject=True, labels=lab, metadata=True, to_numpy=True)
+    assert (res.bgmeta[..., 0] < 0).any()
+    _check_multimodal(res, g["out"], g["bgmeta"], g["colstats"])
+    assert res.modelparms == str(g["modelparms"])
+
+
+def test_multimodal_cluster_rejection_label_zero_and_all_rejected(torch_cuda, golden_dir, library):
+    """The -r corner cases against the oracle: a small cluster with label 0 cannot be flagged (-0 == 0, :323), and a
+    column whose clusters are ALL flagged proceeds without rejection but keeps the negative ids in bgmeta (:327-332)."""
+    g = np.load(os.path.join(golden_dir, "cmf_K3_reject.npz"))
+    cube = _bright_cube(g, library)
+    lab = np.abs(g["bgmeta"][:, :, 0].astype(np.int64))
+    swapped = np.where(lab == 0, 1, np.where(lab == 1, 0, lab))          # the 40-row cluster becomes label 0
+    small = np.ones_like(lab)                                               # labels {1, 2}, both below 85 rows
+    small[:, 0] = 2 - (np.arange(lab.shape[0]) % 2)
+    cube_small = cube.copy()
+    cube_small[150:] = -9999.0                                              # 143 valid rows in every column
+    for cb, lb in ((cube, swapped), (cube_small, small)):
+        res = cmf.robust_mf(cb, library, kmeans=3, reject=True, labels=lb, metadata=True, to_numpy=True)
+        o = O.robust_mf_multimodal_oracle(cb, library, lb, reject=True)
+        _check_multimodal(res, o["out"], o["bgmeta"], o["colstats"])
+    assert (o["bgmeta"][..., 0] < 0).any()
+
+
 def test_multimodal_device_kmeans(torch_cuda, golden_dir, library):
     """Device k-means: deterministic (same seed -> same labels), finds the planted bright region the reference's
     MiniBatchKMeans found (>= 90 % agreement up to a permutation), and the pipeline downstream of ITS labels matches

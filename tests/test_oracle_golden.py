@@ -139,3 +139,32 @@ def test_multimodal_oracle_reproduces_reference_with_injected_labels(golden_dir,
     assert np.array_equal(o["out"], g["out"])
     assert np.array_equal(o["bgmeta"], g["bgmeta"])
     assert np.array_equal(o["colstats"], g["colstats"])
+
+
+def _reject_full_cube(g, library):
+    cube = make_cube_numpy(int(g["lines"]), int(g["samples"]), seed=int(g["seed"]), abscf_full=library[:, 2],
+                           nodata_column=int(g["nodata_column"]))
+    for b0, b1, f in g["bright"]:
+        cube[int(b0):int(b1)] *= np.float32(f)
+    return cube
+
+
+def test_multimodal_oracle_reproduces_reference_with_cluster_rejection(golden_dir, library):
+    """-k 3 -r golden from the real reference: a 38-40 row cluster is relabelled -1 in four columns, never scored, and
+    the model of the remaining rows overwrites cluster 0's scores (robust_mf.py:317-341).  Bit for bit."""
+    g = np.load(os.path.join(golden_dir, "cmf_K3_reject.npz"))
+    assert (g["bgmeta"][:, :, 0] < 0).any()
+    o = O.robust_mf_multimodal_oracle(_reject_full_cube(g, library), library, np.abs(g["bgmeta"][:, :, 0].astype(np.int64)),
+                                      reject=True)
+    assert np.array_equal(o["out"], g["out"])
+    assert np.array_equal(o["bgmeta"], g["bgmeta"])
+    assert np.array_equal(o["colstats"], g["colstats"])
+
+
+def test_multimodal_oracle_reproduces_reference_with_full_regulariser(golden_dir, library):
+    """-k 2 -f golden from the real reference: shrinkage target = covariance of the whole column (:354, :99)."""
+    g = np.load(os.path.join(golden_dir, "cmf_K2_full.npz"))
+    o = O.robust_mf_multimodal_oracle(_reject_full_cube(g, library), library, g["bgmeta"][:, :, 0].astype(np.int64), full=True)
+    assert np.array_equal(o["out"], g["out"])
+    assert np.array_equal(o["bgmeta"], g["bgmeta"])
+    assert np.array_equal(o["colstats"], g["colstats"])

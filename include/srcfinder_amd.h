@@ -63,6 +63,13 @@ int sf_cmf_covariance(const void *xt, int xt_f64, const uint8_t *mask_t, const i
 int sf_cmf_eigh(const double *cov, const int32_t *nuse, int p, int ncols, double *d, double *lam,
                 double *evec, int32_t *status, void *scratch, void *stream);
 
+/* Stage 4, full shrinkage target (multimodal -f: T = cov(I_reg), robust_mf.py:99, :131, :354) -- the same restatement one
+ * congruence further: target = L L^T (Cholesky), eigendecomposition of L^-1 S L^-T, and outputs d = diag(L),
+ * evec_j = D (L^-T v_j) chosen so that stages 5-7 run unchanged (they only form D^-1 evec^T and 2 sum log d = log det T).
+ * r_tmp, l_tmp: caller-owned [ncols][p][p] float64 temporaries.  status 2 when the target is not positive definite. */
+int sf_cmf_eigh_general(const double *cov, const double *target, const int32_t *nuse, int p, int ncols, double *r_tmp,
+                        double *l_tmp, double *d, double *lam, double *evec, int32_t *status, void *scratch, void *stream);
+
 /* Stage 5 -- leave-one-out NLL for every alpha (robust_mf.py:105-117) and its argmin (:121-127):
  * nll[ncols][nalpha] (inf where the reference's det over/underflows), alphaidx[ncols] (-1 if none). */
 int sf_cmf_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu,

@@ -143,8 +143,6 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
                a reference bgmeta image) injects them; ``result.labels`` holds the labels used.
     """
     torch = _torch()
-    if full:
-        raise NotImplementedError("the full-column regulariser (-f) is not built (SURVEY.md §8 N1)")
     kmeans = int(kmeans)
     if kmeans < 1 or kmeans > 8:
         raise ValueError("kmeans must be in 1..8")
@@ -234,7 +232,9 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
     mask  valid & (label == ki);  stage 5 gets the COLUMN's valid-row count as n (:355-356).
     reject (-r, :317-341): clusters of fewer than bgminsamp rows (never label 0: -0 == 0, :323) are relabelled -l in the
     cluster band and never scored; in their turn of the loop the model of ALL non-rejected rows is fitted and written
-    over those rows.  If every cluster of a column is rejected none is (:330-332)."""
+    over those rows.  If every cluster of a column is rejected none is (:330-332).
+    full (-f, :354): the shrinkage target of every cluster is the covariance of the WHOLE column (numpy.cov removes the
+    mean again, so the cluster mean subtracted at :354 drops out) -> sf_cmf_eigh_general instead of sf_cmf_eigh."""
     if p > 96:
         raise NotImplementedError("multimodal background needs an active window of <= 96 bands")
     dev = cube.device
@@ -258,10 +258,16 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
     colstats = torch.empty((3, ncols), **f64)
     check = _ffi.check
 
+    target = r_tmp = l_tmp = None
+
     def stats(m, n_rows, n_loo, status, want_alpha=True):
         check(L.sf_cmf_column_mean(P(xt), 0, P(m), lines, p, ncols, P(n_rows), P(mu), P(ws), st), "sf_cmf_column_mean")
         check(L.sf_cmf_covariance(P(xt), 0, P(m), P(n_rows), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
-        check(L.sf_cmf_eigh(P(S), P(n_rows), p, ncols, P(d), P(lam), P(evec), P(status), P(ws), st), "sf_cmf_eigh")
+        if target is not None:
+            check(L.sf_cmf_eigh_general(P(S), P(target), P(n_rows), p, ncols, P(r_tmp), P(l_tmp), P(d), P(lam), P(evec),
+                                        P(status), P(ws), st), "sf_cmf_eigh_general")
+        else:
+            check(L.sf_cmf_eigh(P(S), P(n_rows), p, ncols, P(d), P(lam), P(evec), P(status), P(ws), st), "sf_cmf_eigh")
         if want_alpha:
             check(L.sf_cmf_loocv(P(xt), 0, P(m), P(n_loo), P(mu), P(d), P(lam), P(evec), P(status), P(alphas), nalpha,
                                  lines, p, ncols, P(nll), P(aidx_k), P(ws), st), "sf_cmf_loocv")
@@ -281,6 +287,10 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
             raise ValueError("labels must be cluster ids in 0..%d" % (k - 1))
         labels_t = lab.to(dev)[:, s0:s1].t().contiguous().to(torch.uint8)
         check(L.sf_cmf_column_mean(P(xt), 0, P(mask), lines, p, ncols, P(nuse_col), P(mu), P(ws), st), "sf_cmf_column_mean")
+        if full:
+            check(L.sf_cmf_covariance(P(xt), 0, P(mask), P(nuse_col), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
+    if full:                        # S holds the whole column's covariance at this point on both routes
+        target, r_tmp, l_tmp = S.clone(), torch.empty_like(S), torch.empty_like(S)
     # ---- the product starts as: NODATA on invalid rows, 0 on valid ones, RGB copied (a zero filter through stage 7)
     status0 = (nuse_col == 0).to(torch.int32)                           # 1 = column without a valid row: skipped (:303-304)
     zero_idx = torch.zeros(ncols, **i32)
@@ -378,13 +388,10 @@ def looshrinkage(I_zm, alphas, nll, n, I_reg=[]):
     ``I_zm`` [rows, p] zero-mean float64 samples, ``alphas`` the candidate grid, ``nll`` a float64 array of
     the same length that is FILLED IN PLACE, ``n`` the sample count used in beta and 1/(2n) (the reference
     passes the column's ``nuse`` even for a cluster subset).  Returns ``(C, mindex)`` with
-    ``C = (1-alpha) S + alpha diag(S)`` on the unscaled data and ``mindex = -1`` (alpha = 0) when every
-    candidate's NLL is +inf.
+    ``C = (1-alpha) S + alpha T`` on the unscaled data, ``T = diag(S)`` or, with a non-empty ``I_reg`` [rows', p],
+    ``T = cov(I_reg)`` (:99, :131), and ``mindex = -1`` (alpha = 0) when every candidate's NLL is +inf.
     """
     torch = _torch()
-    if len(I_reg) != 0:
-        raise NotImplementedError("full-covariance regulariser (I_reg, -f) belongs to the multimodal branch "
-                                  "(SURVEY.md §8 N1) and is not built")
     alphas_np = np.ascontiguousarray(alphas, dtype=np.float64)
     xt, mask, rows, p = _upload_rows(I_zm)
     if p > 96:
@@ -408,8 +415,19 @@ def looshrinkage(I_zm, alphas, nll, n, I_reg=[]):
     st = _ffi.stream_ptr()
     _ffi.check(L.sf_cmf_covariance(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nrows), _ffi.ptr(mu), rows, p, 1,
                                    _ffi.ptr(S), _ffi.ptr(ws), st), "sf_cmf_covariance")
-    _ffi.check(L.sf_cmf_eigh(_ffi.ptr(S), _ffi.ptr(nrows), p, 1, _ffi.ptr(d), _ffi.ptr(lam), _ffi.ptr(evec),
-                             _ffi.ptr(status), _ffi.ptr(ws), st), "sf_cmf_eigh")
+    T_np = None
+    if len(I_reg) != 0:
+        T_np = cov(I_reg)
+        if T_np.shape != (p, p):
+            raise ValueError("I_reg must have the same number of columns as I_zm")
+        T_d = torch.as_tensor(np.ascontiguousarray(T_np[None]), device=dev)
+        r_tmp, l_tmp = torch.empty_like(S), torch.empty_like(S)
+        _ffi.check(L.sf_cmf_eigh_general(_ffi.ptr(S), _ffi.ptr(T_d), _ffi.ptr(nrows), p, 1, _ffi.ptr(r_tmp), _ffi.ptr(l_tmp),
+                                         _ffi.ptr(d), _ffi.ptr(lam), _ffi.ptr(evec), _ffi.ptr(status), _ffi.ptr(ws), st),
+                   "sf_cmf_eigh_general")
+    else:
+        _ffi.check(L.sf_cmf_eigh(_ffi.ptr(S), _ffi.ptr(nrows), p, 1, _ffi.ptr(d), _ffi.ptr(lam), _ffi.ptr(evec),
+                                 _ffi.ptr(status), _ffi.ptr(ws), st), "sf_cmf_eigh")
     _ffi.check(L.sf_cmf_loocv(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nloo), _ffi.ptr(mu), _ffi.ptr(d),
                               _ffi.ptr(lam), _ffi.ptr(evec), _ffi.ptr(status), _ffi.ptr(al), nalpha, rows, p, 1,
                               _ffi.ptr(nll_d), _ffi.ptr(aidx), _ffi.ptr(ws), st), "sf_cmf_loocv")
@@ -417,6 +435,6 @@ def looshrinkage(I_zm, alphas, nll, n, I_reg=[]):
     mindex = int(aidx.item())
     alpha = float(alphas_np[mindex]) if mindex >= 0 else 0.0
     S = S[0].cpu().numpy()
-    T = np.diag(np.diag(S))
+    T = np.diag(np.diag(S)) if T_np is None else T_np
     Cmat = (1.0 - alpha) * S + alpha * T                               # robust_mf.py:130-134
     return Cmat, mindex

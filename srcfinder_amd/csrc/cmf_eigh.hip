@@ -77,7 +77,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int EIG_RMAX, bool FULL, int LPP>
 __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict__ nuse, int p, int p2, int LD,
                        double *__restrict__ d_out, double *__restrict__ lam_out, double *__restrict__ evec_out,
-                       int32_t *__restrict__ status, double2 *__restrict__ rot, size_t rot_stride) {
+                       int32_t *__restrict__ status, double2 *__restrict__ rot, size_t rot_stride, int unit) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *M = sm;                    // [p2][LD] column-major: M[col*LD + row]; G in phase 1, V in phase 2
   double *dv = sm + (size_t)p2 * LD;  // [p2]
@@ -91,7 +91,7 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
   if (tid < 2) flag[tid] = 0;
   for (int i = tid; i < p2; i += nthr) {
     double v = 0.0;
-    if (i < p) v = sqrt(S[(size_t)i * p + i]);
+    if (i < p) v = unit ? 1.0 : sqrt(S[(size_t)i * p + i]);   // unit: the matrix is already whitened (cmf_general.hip)
     dv[i] = v;
   }
   __syncthreads();
@@ -106,7 +106,7 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
   if (n <= 0) st = 1;
   else if (n < 2 || flag[0]) st = 2;
   if (tid == 0) status[c] = st;
-  for (int i = tid; i < p; i += nthr) d_out[(size_t)c * p + i] = dv[i];
+  if (!unit) for (int i = tid; i < p; i += nthr) d_out[(size_t)c * p + i] = dv[i];
   if (st != 0) {
     for (int i = tid; i < p; i += nthr) lam_out[(size_t)c * p + i] = 0.0;
     for (int i = tid; i < p * p; i += nthr) evec_out[(size_t)c * p * p + i] = ((i / p) == (i % p)) ? 1.0 : 0.0;
@@ -343,8 +343,19 @@ size_t sf_eigh_scratch_bytes(const SfGeom &g) {
   return sf_align((size_t)g.ncols * EIG_MAXSWEEP * (p2 - 1) * (p2 / 2) * sizeof(double2));
 }
 
+static int launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, double *d, double *lam, double *evec,
+                       int32_t *status, void *scratch, int unit, hipStream_t st);
 int sf_launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, double *d, double *lam, double *evec,
                    int32_t *status, void *scratch, hipStream_t st) {
+  return launch_eigh(cov, nuse, g, d, lam, evec, status, scratch, 0, st);
+}
+// the same solver on an already whitened matrix: no diagonal scaling, d is not written
+int sf_launch_eigh_unit(const double *cov, const int32_t *nuse, const SfGeom &g, double *d, double *lam, double *evec,
+                        int32_t *status, void *scratch, hipStream_t st) {
+  return launch_eigh(cov, nuse, g, d, lam, evec, status, scratch, 1, st);
+}
+static int launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, double *d, double *lam, double *evec,
+                       int32_t *status, void *scratch, int unit, hipStream_t st) {
   const int p2 = g.p + (g.p & 1);
   // Lanes per column pair: 8 is the measured optimum (tools/probe_eigh.py, one 72x72 matrix: 8 lanes 0.65 ms,
   // 4 lanes -- 3 waves, one per SIMD, twice the rows per lane -- 0.78 ms, 16 lanes -- 9 waves -- 0.77 ms).
@@ -370,7 +381,7 @@ int sf_launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, doub
   auto go = [&](auto kern) -> int {
     SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(g.ncols), dim3(threads), lds, st, cov, nuse, g.p, p2, LD, d, lam, evec, status,
-                       reinterpret_cast<double2 *>(scratch), rot_stride);
+                       reinterpret_cast<double2 *>(scratch), rot_stride, unit);
     return 0;
   };
   int rc = -2;

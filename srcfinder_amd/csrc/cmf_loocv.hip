@@ -302,16 +302,23 @@ __global__ __launch_bounds__(1024) void k_nll(const double *__restrict__ part, i
         lsum += pp[i];
         rsum += pp[NA16 + i];
       }
-      // k_sweep4 hands over beta sum r/q.  beta = 0 (alpha = 1): G = diag S, q = 1 and
-      // sum_k r_k = sum_k sum_b x_kb^2 / S_bb = (rows - 1) p, rows = the rows the covariance was made of (the
-      // sweep counts them: a cluster's statistics are swept with the COLUMN's n, robust_mf.py:355-356).
+      // k_sweep4 hands over beta sum r/q.  beta <= 0 (the last grid point, alpha = 1 + 3e-13): q = 1 to rounding and
+      // sum_k r_k = sum_j (sum_k y_kj^2) / (n beta lam_j + alpha) = (rows - 1) sum_j lam_j / (n beta lam_j + alpha)
+      // (= (rows - 1) p / alpha for the diagonal target, where sum lam = trace R = p), rows = the rows the covariance
+      // was made of (the sweep counts them: a cluster's statistics are swept with the COLUMN's n, robust_mf.py:355-356).
       if (rq_scaled) {
         double rows = n;
         if (nalpha < NA16) {
           rows = 0.0;
           for (int sp = 0; sp < nsplit; ++sp) rows += part[((size_t)c * nsplit + sp) * 2 * NA16 + 2 * NA16 - 1];
         }
-        rsum = (beta > 0.0) ? rsum / beta : (rows - 1.0) * (double)p;
+        if (beta > 0.0) {
+          rsum = rsum / beta;
+        } else {
+          double tr = 0.0;
+          for (int j = 0; j < p; ++j) { const double lj = lam[(size_t)c * p + j]; tr += lj / (nb * lj + a); }
+          rsum = (rows - 1.0) * tr;
+        }
       }
       if (ld < -744.4400719213812) {
         v = inf;  // det underflowed to 0 -> the reference skips this alpha (robust_mf.py:112-113)

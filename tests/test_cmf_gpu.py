@@ -479,6 +479,40 @@ def test_multimodal_cluster_rejection_label_zero_and_all_rejected(torch_cuda, go
     assert (o["bgmeta"][..., 0] < 0).any()
 
 
+def test_multimodal_full_regulariser_golden(torch_cuda, golden_dir, library):
+    """N1 -f: -k 2 -f golden of the real reference (shrinkage target = covariance of the whole column; the selected
+    alpha indices sit at the ends of the grid: 0, 2 and 200).  Generalised whitening path, sf_cmf_eigh_general."""
+    g = np.load(os.path.join(golden_dir, "cmf_K2_full.npz"))
+    cube = _bright_cube(g, library)
+    lab = g["bgmeta"][:, :, 0].astype(np.int64)
+    res = cmf.robust_mf(cube, library, kmeans=2, full=True, labels=lab, metadata=True, to_numpy=True)
+    _check_multimodal(res, g["out"], g["bgmeta"], g["colstats"])
+    assert res.modelparms == str(g["modelparms"])
+    # and with the device's own labels against the oracle fed the same labels
+    res = cmf.robust_mf(cube, library, kmeans=2, full=True, metadata=True, to_numpy=True, kmeans_seed=5)
+    lab = np.where(res.labels != 255, res.labels, 0).astype(np.int64)
+    o = O.robust_mf_multimodal_oracle(cube, library, lab, full=True)
+    _check_multimodal(res, o["out"], o["bgmeta"], o["colstats"])
+
+
+def test_looshrinkage_function_with_full_target(torch_cuda):
+    """looshrinkage(I_zm, alphas, nll, n, I_reg) with a non-empty I_reg (robust_mf.py:99, :131): same index, NLL curve and
+    final covariance as the faithful oracle."""
+    from srcfinder_amd.synth import synth_columns
+    x = synth_columns(900, 72, 321)
+    sub = x[100:400] - x[100:400].mean(0)
+    reg = x - x[100:400].mean(0)
+    al = cmf.alpha_grid()
+    nll_o, nll_g = np.zeros(len(al)), np.zeros(len(al))
+    c_o, i_o = O.looshrinkage(sub, al, nll_o, 900, reg)
+    c_g, i_g = cmf.looshrinkage(sub, al, nll_g, 900, reg)
+    assert i_g == i_o
+    fin = np.isfinite(nll_o)
+    assert np.array_equal(np.isfinite(nll_g), fin)
+    np.testing.assert_allclose(nll_g[fin], nll_o[fin], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(c_g, c_o, rtol=1e-10, atol=1e-12 * np.abs(c_o).max())
+
+
 def test_multimodal_device_kmeans(torch_cuda, golden_dir, library):
     """Device k-means: deterministic (same seed -> same labels), finds the planted bright region the reference's
     MiniBatchKMeans found (>= 90 % agreement up to a permutation), and the pipeline downstream of ITS labels matches

@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-columns", type=int, default=8)
     ap.add_argument("--active", type=str, default="", help="a0,a1 (1-based inclusive) override of the active window, e.g. 1,425")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="flightlines in flight per GPU (srcfinder_amd.inflight); 0 = auto: 1 for >= 400 columns per "
+                         "rank (the score kernel then runs alone and its HIP-event time is its isolated duration), else 3")
     args = ap.parse_args()
 
     import torch
@@ -53,8 +56,13 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("SF_BENCH_FORCE_DIST") == "1"   # exercise the gather path on one GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if force_dist:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
@@ -73,34 +81,57 @@ def main():
                            nodata_column=(ncols // 3))
     torch.cuda.synchronize()
 
-    # two product buffers: the gather of flightline i (RCCL, its own stream) overlaps the compute of flightline
-    # i+1, as a production run over many flightlines would pipeline them
-    outs = [torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev) for _ in range(2 if world > 1 else 1)]
-    state = {"i": 0, "pending": None}
+    # A production run works through a queue of flightlines: `depth` of them are in flight on this GPU, each on its own
+    # HIP stream with its own scratch and product buffer (srcfinder_amd/inflight.py), so one flightline's latency-bound
+    # stages (eigensolver, rank factorisation: one workgroup per column) run beside another's streaming stages; the
+    # gather of flightline i (RCCL, its own stream) overlaps the compute of the following ones.  Every step is still
+    # one complete pass over the whole flightline and all K of them finish inside the timed region.
+    from srcfinder_amd.inflight import FlightlinePipeline
+    depth = args.in_flight if args.in_flight > 0 else (1 if ncols >= 400 else 3)
+    pipe = FlightlinePipeline(depth, dev)
+    outs = [torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev) for _ in range(depth)]
+    pending = [None] * depth                     # per slot: (gather handle, event "the slot's product has been packed")
+    comm = torch.cuda.Stream(device=dev)         # packs and feeds the collective; never the stream submit() waits on
+    state = {"last": None}
 
     def step():
-        out = outs[state["i"] % len(outs)]
-        state["i"] += 1
-        r = cmf.robust_mf(cube, lib, out=out, out_column0=0, active=(a0, a1))
-        if world > 1:
+        slot = pipe.slot_of_next()
+        if pending[slot] is not None:
+            h, packed = pending[slot]
+            pipe.streams[slot].wait_event(packed)    # flightline i - depth's scores have left this slot's product buffer
+            with torch.cuda.stream(comm):
+                h.wait()                             # its image, assembled on rank 0
+            pending[slot] = None
+        t = pipe.submit(cube, lib, out=outs[slot], out_column0=0, active=(a0, a1))
+        if world > 1 or force_dist:
             # the single RCCL gather of the score image: the float64 CMF band of every
             # rank's block, 8 B/pixel; the RGB copy stays with the rank that read those columns
-            h = sd.gather_columns(out[..., 3], samples, dst=0, async_op=True)
-            if state["pending"] is not None:
-                state["pending"].wait()          # the previous flightline's image, assembled on rank 0
-            state["pending"] = h
-        return r
+            with torch.cuda.stream(comm):
+                t.wait(comm)                         # only the comm stream waits for the slot's compute
+                h = sd.gather_columns(outs[slot][..., 3], samples, dst=0, async_op=True)
+                packed = torch.cuda.Event()
+                packed.record(comm)
+            pending[slot] = (h, packed)
+        state["last"] = t
+        return t.result
 
     def drain():
-        if state["pending"] is not None:
-            state["pending"].wait()
-            state["pending"] = None
+        with torch.cuda.stream(comm):
+            for i in range(depth):
+                if pending[i] is not None:
+                    pending[i][0].wait()
+                    pending[i] = None
+        comm.synchronize()
+        pipe.synchronize()
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(depth):                       # setup, not warmup: every slot allocates its scratch once
+        step()
+    drain()
     for _ in range(args.warmup):
         step()
     drain()
@@ -110,6 +141,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+    t_enq = time.perf_counter() - t0             # host time to enqueue the K steps (diagnostic)
     drain()                                      # every gather completes inside the timed region
     barrier()
     dt = time.perf_counter() - t0
@@ -145,6 +177,8 @@ def main():
                                    "window %d..%d (p=%d%s), 201-point LOO shrinkage sweep, unimodal"
                                    % (samples, lines, BANDS, a0, a1, p, ", CH4 radiance" if (a0, a1) == (351, 422) else ""),
                        "parallelism": "columns sharded over %d rank(s), one RCCL gather" % world,
+                       "in_flight": "%d flightlines in flight per GPU (one HIP stream each)" % depth,
+                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
                        "output": "float64 BIP [lines, samples, (R,G,B,CMF)]"},
             "roofline": {"bound": "hbm", "kernel": "k_score<true>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -154,7 +188,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cube, lib, lines, ncols, args.cpu_columns, res)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -104,19 +104,41 @@ class CMFResult:
 
 
 class _Workspace:
-    """One growable device scratch buffer per (device) -- the C ABI never allocates."""
+    """One growable device scratch buffer per (device, stream) -- the C ABI never allocates.  Flightlines in flight on
+    different streams (inflight.py) must not share scratch."""
     _bufs = {}
 
     @classmethod
     def get(cls, nbytes, device):
         torch = _torch()
-        key = str(device)
+        key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
         buf = cls._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             cls._bufs[key] = None
             buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
             cls._bufs[key] = buf
         return buf
+
+
+_CONSTS = {}
+
+
+def _device_const(arr, dev):
+    """Small read-only host table -> device tensor, uploaded ONCE per (device, content).  A pageable host-to-device
+    copy blocks the host until everything queued before it on the stream has finished; done per call it would put the
+    host in lockstep with the GPU and nothing could be pipelined (tools/host_overhead_probe.py: 2.25 -> 0.1 ms
+    of host time per robust_mf call)."""
+    torch = _torch()
+    arr = np.ascontiguousarray(arr)
+    key = (str(dev), arr.dtype.str, arr.tobytes())
+    t = _CONSTS.get(key)
+    if t is None:
+        if len(_CONSTS) > 64:
+            _CONSTS.clear()
+        t = torch.as_tensor(arr, device=dev)
+        torch.cuda.current_stream(dev).synchronize()      # usable from any stream from now on
+        _CONSTS[key] = t
+    return t
 
 
 def _abscf_from_library(library, a0, a1):
@@ -167,9 +189,9 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
     p = a1 - a0 + 1
     s0, s1 = (0, samples) if columns is None else (int(columns[0]), int(columns[1]))
     ncols = s1 - s0
-    abscf = torch.as_tensor(_abscf_from_library(library, a0, a1), device=dev)
+    abscf = _device_const(_abscf_from_library(library, a0, a1), dev)
     alphas_np = alpha_grid()
-    alphas = torch.as_tensor(alphas_np, device=dev)
+    alphas = _device_const(alphas_np, dev)
     nalpha = len(alphas_np)
     nb = 4 if len(rgb_bands) == 3 else 1
     with torch.cuda.device(dev):

@@ -615,3 +615,22 @@ def test_rank36_sweep_on_wide_spectrum_columns(torch_cuda, library):
     nod = o["out"][..., 3] == -9999.0
     assert np.array_equal(res.out[..., 3] == -9999.0, nod)
     assert score_close(res.out[..., 3][~nod], o["out"][..., 3][~nod]).all()
+
+
+def test_flightline_pipeline_matches_sequential_calls(torch_cuda, library):
+    """srcfinder_amd.inflight: three flightlines in flight on three streams (own scratch each) give the bits of three
+    sequential robust_mf calls, whatever the interleaving."""
+    torch = torch_cuda
+    from srcfinder_amd.inflight import FlightlinePipeline
+    cubes = [torch.as_tensor(make_cube_numpy(700 + 40 * i, 70, seed=300 + i, abscf_full=library[:, 2], nodata_column=5 * i)).cuda()
+             for i in range(5)]
+    seq = [cmf.robust_mf(c, library, metadata=True) for c in cubes]
+    torch.cuda.synchronize()
+    pipe = FlightlinePipeline(depth=3)
+    tickets = [pipe.submit(c, library, metadata=True) for c in cubes]
+    for t, s in zip(tickets, seq):
+        r = t.synchronize()
+        assert torch.equal(r.out, s.out) and torch.equal(r.bgmeta, s.bgmeta) and torch.equal(r.alphaidx, s.alphaidx)
+        assert torch.equal(r.colstats, s.colstats)
+    with pytest.raises(ValueError):
+        pipe.submit(cubes[0], library, to_numpy=True)

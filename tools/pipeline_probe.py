@@ -9,8 +9,10 @@ from srcfinder_amd.synth import make_cube_torch
 
 lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
 lines = 20000
-cube = make_cube_torch(lines, 598, seed=1, abscf_full=lib[:, 2])
-outs = [torch.empty((lines, 598, 4), dtype=torch.float64, device="cuda") for _ in range(2)]
+NS = int(sys.argv[1]) if len(sys.argv) > 1 else 598
+DEPTH = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+cube = make_cube_torch(lines, NS, seed=1, abscf_full=lib[:, 2])
+outs = [torch.empty((lines, NS, 4), dtype=torch.float64, device="cuda") for _ in range(DEPTH)]
 bufs = {}
 def get(cls, nbytes, device):
     key = (str(device), torch.cuda.current_stream().cuda_stream)
@@ -18,12 +20,12 @@ def get(cls, nbytes, device):
         bufs[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     return bufs[key]
 cmf._Workspace.get = classmethod(get)
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+streams = [torch.cuda.Stream() for _ in range(DEPTH)]
 def run(n, concurrent):
     for i in range(n):
-        with torch.cuda.stream(streams[i % 2] if concurrent else streams[0]):
-            cmf.robust_mf(cube, lib, out=outs[i % 2])
+        with torch.cuda.stream(streams[i % DEPTH] if concurrent else streams[0]):
+            cmf.robust_mf(cube, lib, out=outs[i % DEPTH])
 for mode in (False, True, False, True):
-    run(2, mode); torch.cuda.synchronize()
-    t0 = time.perf_counter(); run(10, mode); torch.cuda.synchronize()
-    print("pipelined " if mode else "sequential", "%.3f ms per flightline" % ((time.perf_counter() - t0) / 10 * 1e3))
+    run(DEPTH, mode); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(40, mode); torch.cuda.synchronize()
+    print(NS, "pipelined " if mode else "sequential", "%.3f ms per flightline" % ((time.perf_counter() - t0) / 40 * 1e3))

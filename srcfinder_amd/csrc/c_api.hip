@@ -117,6 +117,23 @@ int sf_fail_hip(hipError_t e, const char *what) {
   return (int)e > 0 ? (int)e : 1;
 }
 
+#include <map>
+#include <mutex>
+#include <utility>
+int sf_lds_attr(const void *fn, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, size_t> have;
+  int dev = 0;
+  SF_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  size_t &cur = have[std::make_pair(dev, fn)];
+  if (bytes > cur) {
+    SF_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    cur = bytes;
+  }
+  return 0;
+}
+
 extern "C" {
 
 int sf_version(void) { return 100; }

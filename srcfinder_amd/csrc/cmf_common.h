@@ -21,6 +21,10 @@ int sf_fail_hip(hipError_t e, const char *what);
     if (_e != hipSuccess) return sf_fail_hip(_e, name); \
   } while (0)
 
+// Raise a kernel's dynamic-LDS limit to `bytes` on the CURRENT device (the attribute is per device and per function;
+// remembered per (device, function) so the driver is asked only when the size grows).  Thread safe.  c_api.hip
+int sf_lds_attr(const void *fn, size_t bytes);
+
 static inline int sf_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t sf_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 

@@ -379,7 +379,7 @@ static int launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, 
   const int rmax = (p2 + 7) / 8;
   const bool full = (p2 % 8) == 0;
   auto go = [&](auto kern) -> int {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(g.ncols), dim3(threads), lds, st, cov, nuse, g.p, p2, LD, d, lam, evec, status,
                        reinterpret_cast<double2 *>(scratch), rot_stride, unit);
     return 0;

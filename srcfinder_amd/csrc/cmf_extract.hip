@@ -351,15 +351,9 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
   const int cs = (TL * pbmax) | 1;
   const size_t lds = (size_t)64 * cs * sizeof(float);
   const bool fuse = sum_part != nullptr && p <= XT_PBMAX;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const int maxlds = 64 * ((TL * XT_PBMAX) | 1) * (int)sizeof(float);
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract<TL, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract<TL, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
-    attr_set = true;
-  }
+  const size_t maxlds = (size_t)64 * ((TL * XT_PBMAX) | 1) * sizeof(float);
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract<TL, true>), maxlds)) return rc;
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract<TL, false>), maxlds)) return rc;
   int lpw;
   const int nchunk = extract_chunks(lines, ncols, &lpw);
   // a compact narrow cube (a rank's shard): the flat kernel, if a tile of at least one line fits
@@ -368,12 +362,7 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
     int tl = (XF_NT * XF_MAXLD) / (p * ncols);
     if (tl > 4) tl = 4;
     const size_t ldsf = ((size_t)tl * p * ncols + (size_t)tl * ncols) * sizeof(float);
-    static size_t lds_set = 0;
-    if (ldsf > lds_set) {
-      SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_extract_flat),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * 1024)));
-      lds_set = 64 * 1024;
-    }
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_flat), ldsf > 64 * 1024 ? ldsf : (size_t)64 * 1024)) return rc;
     hipLaunchKernelGGL(k_extract_flat, dim3(nchunk), dim3(XF_NT), ldsf, st, cube, lines, bands, samples, b0, p, PS, tl, xt,
                        mask_t, lpw, fuse ? sum_part : nullptr, fuse ? cnt_part : nullptr);
     SF_LAUNCH_CHECK("k_extract_flat");

@@ -145,8 +145,8 @@ extern "C" int sf_cmf_eigh_general(const double *cov, const double *target, cons
   hipStream_t st = (hipStream_t)stream;
   const int LD = p | 1;
   const size_t lds = ((size_t)2 * p * LD + p) * sizeof(double);
-  SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gen_whiten), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gen_back), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_gen_whiten), lds)) return rc;
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_gen_back), lds)) return rc;
   hipLaunchKernelGGL(k_gen_whiten, dim3(ncols), dim3(GW_NT), lds, st, cov, target, nuse, p, LD, r_tmp, l_tmp, d);
   SF_LAUNCH_CHECK("k_gen_whiten");
   if (int rc = sf_launch_eigh_unit(r_tmp, nuse, sf_geom(1, p, ncols, 1), nullptr, lam, evec, status, scratch, st)) return rc;

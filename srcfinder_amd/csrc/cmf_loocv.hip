@@ -354,12 +354,7 @@ int launch_sweep_t(const XT *xt, const uint8_t *mask_t, const int32_t *nuse, con
     sf_set_error("alpha grid x active window (%d x %d) does not fit the LDS-resident sweep", g.nalpha, g.p);
     return -2;
   }
-  static size_t lds_set = 0;
-  if (need > lds_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep<NT, S4C, NUC, WREG, XT>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-    lds_set = need;
-  }
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep<NT, S4C, NUC, WREG, XT>), need)) return rc;
   int rows = sf_cdiv(g.lines, nsplit);
   rows = (rows + 63) / 64 * 64;
   hipLaunchKernelGGL((k_sweep<NT, S4C, NUC, WREG, XT>), dim3(g.ncols, nsplit), dim3(256), need, st, xt, mask_t, nuse, mu,
@@ -397,12 +392,7 @@ int launch_nll(const double *part, int nsplit, const int32_t *nuse, const double
                const double *alphas, const SfGeom &g, int rq_scaled, double *nll, int32_t *alphaidx, hipStream_t st) {
   const size_t lds = ((size_t)g.nalpha * g.p + g.p) * sizeof(double);
   if (lds <= 150 * 1024 && g.ncols <= 256) {   // one 116 KB workgroup per CU: only worth it when the launch is a single round
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-      SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_nll<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
-      lds_set = lds;
-    }
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_nll<true>), lds)) return rc;
     hipLaunchKernelGGL(k_nll<true>, dim3(g.ncols), dim3(1024), lds, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha,
                        g.p, g.nu * 16, rq_scaled, nll, alphaidx);
   } else {

@@ -689,12 +689,7 @@ template <int EXP>
 int launch_sweep4_t(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
                     const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,
                     int nsplit, double *part, hipStream_t st, const int32_t *lrok = nullptr) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4<EXP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)SW4_LDS));
-    attr_set = true;
-  }
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4<EXP>), SW4_LDS)) return rc;
   int rows = sf_cdiv(g.lines, nsplit);
   rows = (rows + 63) / 64 * 64;
   hipLaunchKernelGGL(k_sweep4<EXP>, dim3(g.ncols, nsplit), dim3(256), SW4_LDS, st, xt, mask_t, nuse, mu, lam, wfrag,
@@ -707,16 +702,9 @@ int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
                    const double *wfrag2, const int32_t *lrok, const double *lam, const double *wfrag, size_t wstride, const int32_t *status,
                    const double *alphas, const SfGeom &g, int nsplit, double *part, hipStream_t st) {
   constexpr int NK1 = SF_LR_K / 4, NK2 = SF_LR_K2 / 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4r<0, 8, NK1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)sw4r_lds(NK1)));
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4r<0, 4, NK1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)sw4r_lds(NK1)));
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep4r<0, 4, NK2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)sw4r_lds(NK2)));
-    attr_set = true;
-  }
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4r<0, 8, NK1>), sw4r_lds(NK1))) return rc;
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4r<0, 4, NK1>), sw4r_lds(NK1))) return rc;
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4r<0, 4, NK2>), sw4r_lds(NK2))) return rc;
   int rows = sf_cdiv(g.lines, nsplit);
   rows = (rows + 127) / 128 * 128;
 #define SW4R_ARGS xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part

@@ -298,11 +298,7 @@ size_t sf_lowrank_bytes(const SfGeom &g) {
 int sf_launch_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas, const SfGeom &g,
                       double *ufrag, double *wfrag, int32_t *lrok, hipStream_t st) {
   const size_t lds = (size_t)LR_P * LR_LDA * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lowrank), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_lowrank), lds)) return rc;
   hipLaunchKernelGGL(k_lowrank, dim3(g.ncols), dim3(LR_NT), lds, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok);
   SF_LAUNCH_CHECK("k_lowrank");
   return 0;

@@ -282,12 +282,7 @@ int sf_cmf_score_cluster(const float *cube, int lines, int bands, int samples, i
   }
   const int lpw = 64;
   const size_t lds = (size_t)p * 64 * sizeof(double);
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_cluster), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-    lds_set = lds;
-  }
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_score_cluster), lds)) return rc;
   hipLaunchKernelGGL(k_score_cluster, dim3(sf_cdiv(ncols, 64), sf_cdiv(lines, lpw)), dim3(256), lds, (hipStream_t)stream,
                      cube, lines, bands, samples, s0, ncols, b0, p, filt, bias, status, alphaidx, rowmask_t, cluster, out,
                      out_samples, out_s0, out_bands, bgmeta, lpw);

@@ -280,12 +280,7 @@ int launch_score_t(const float *cube, int lines, int bands, int samples, int s0,
                    int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0, int16_t *bgmeta,
                    double *stat_part, int lpw, hipStream_t st, const double *wT = nullptr, int ldw = 0) {
   const size_t lds = WGL ? 0 : (size_t)CW * p * 64 * sizeof(double);
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<RGB, LPI, UB, WGL, CW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set = lds;
-  }
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_score<RGB, LPI, UB, WGL, CW>), lds)) return rc;
   const int nchunk = sf_cdiv(lines, lpw);
   const int ncb = sf_cdiv(ncols, 64 * CW);
   const int nblk = g_score_xcd ? sf_xcd_grid(ncb, nchunk) : ncb * nchunk;
@@ -427,12 +422,7 @@ extern "C" int sf_cmf_column_profile_robust(const double *img, int lines, int sa
   int npow2 = 1;
   while (npow2 < lines) npow2 <<= 1;
   const size_t lds = (size_t)npow2 * sizeof(float);
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    SF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_profile_robust),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set = lds;
-  }
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_profile_robust), lds)) return rc;
   // the reference's percentile arguments are computed in float64: (1-p)*100 and p*100, then /100 inside numpy
   const double plo = ((1.0 - p) * 100.0) / 100.0, phi = (p * 100.0) / 100.0;
   hipLaunchKernelGGL(k_profile_robust, dim3(samples), dim3(PR_NT), lds, (hipStream_t)stream, img, lines, samples, nbands, band,

@@ -206,6 +206,21 @@ int sf_cnn_conv_split3(const float *in, int N, int H, int W, int Cin, int ld_in,
 int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, const float *fcb, const float *plane,
                 long long tile0, float nodata, float *out, void *stream);
 
+/* FCN shift-and-stitch, the reference's approximate fast mode (cnn/fcn_pred_pipeline.py).
+ * sf_cnn_fcn_prepare: ClampCH4 + Normalize of the plane, embedded at (top, left) = divmod(shift, scale) in a zero canvas
+ *   out[nshift][Hc][Wc], Hc = H + (scale - H % scale) + scale (FlightlineShiftStitch, :32-65).
+ * sf_cnn_conv1_image: conv1 (7x7 s2 p3, folded BN + ReLU) over whole images img[N][Hc][Wc] -> NHWC [N][Ho][Wo][64]
+ *   (float32, or float16 when out_f16); the rest of the trunk is sf_cnn_maxpool / sf_cnn_conv / sf_cnn_conv_split3,
+ *   the 1x1 head (:158-160) is sf_cnn_head with HW = 1.
+ * sf_cnn_fcn_stitch: stitch_stack (:67-92) + the NODATA mask (:249) for the prediction maps pred[nshift][Hq][Wq] of
+ *   shifts shift0..: writes their pixels of out[H][W]. */
+int sf_cnn_fcn_prepare(const float *plane, int H, int W, float vmin, float vmax, float mean, float stdv, int scale,
+                       int shift0, int nshift, int Hc, int Wc, float *out, void *stream);
+int sf_cnn_conv1_image(const float *img, int N, int Hc, int Wc, const float *w, const float *bias, void *out, int out_f16,
+                       void *stream);
+int sf_cnn_fcn_stitch(const float *pred, int nshift, int shift0, int scale, int Hq, int Wq, const float *plane, int H, int W,
+                      float nodata, float *out, void *stream);
+
 /* ---- reduced-precision option of the CNN scorer (NOT the parity path): float16 activations/weights, fp32 accumulate on
  * v_mfma_f32_32x32x16_f16 -- the precision class of the reference's own cuDNN-TF32 default on recent GPUs.  Same
  * operators, arguments as the fp32 entry points; activation / weight pointers are float16 (passed as void*). */

@@ -11,6 +11,8 @@ Restated semantics:
   * stem / inception / pools (ceil_mode) / head                                       googlenet1.py:60-89,:110-163,:184-228
   * ClampCH4, Normalize, Pad(128,128,127,127), window [row:row+256, col:col+256]      cnn_pred_pipeline.py:19-58,:126-157
   * softmax(logits)[:,1], reshape, -9999 where the input plane is -9999               cnn_pred_pipeline.py:173-189
+  * FCN shift-and-stitch fast mode (FlightlineShiftStitch, model conversion, stitch_stack)  fcn_pred_pipeline.py:32-92,:157-160,:225-249
+    pinned by ``tests/golden/cnn_fcn_golden.npz`` (``tests/golden/gen_golden_fcn.py``, the reference's own classes)
 """
 from __future__ import annotations
 
@@ -45,8 +47,9 @@ def inception(x, sd, name):
     return torch.cat([b1, b2, b3, b4], 1)
 
 
-def googlenet_forward(x, sd, taps=None):
-    """x [N,1,256,256] float32 -> logits [N,2].  ``taps`` (dict) collects named intermediate activations."""
+def googlenet_forward(x, sd, taps=None, fcn=False):
+    """x [N,1,256,256] float32 -> logits [N,2] (``fcn``: x [N,1,H,W] -> logit maps [N,2,H/32,W/32]).
+    ``taps`` (dict) collects named intermediate activations."""
     def tap(k, v):
         if taps is not None:
             taps[k] = v
@@ -64,6 +67,8 @@ def googlenet_forward(x, sd, taps=None):
     x = tap("maxpool4", F.max_pool2d(x, 2, stride=2, ceil_mode=True))
     x = tap("inception5a", inception(x, sd, "inception5a"))
     x = tap("inception5b", inception(x, sd, "inception5b"))
+    if fcn:   # fcn_pred_pipeline.py:157-160: children()[:-5] drops aux1, aux2, avgpool, dropout, fc; fc becomes a 1x1 conv
+        return F.conv2d(x, _t(sd["fc.weight"])[:, :, None, None], _t(sd["fc.bias"]))
     x = torch.flatten(F.adaptive_avg_pool2d(x, (1, 1)), 1)
     return F.linear(x, _t(sd["fc.weight"]), _t(sd["fc.bias"]))       # dropout is the identity in eval
 
@@ -100,3 +105,31 @@ def predict_plane(plane, sd, mean, std, batch=8, indices=None):
     p = p.reshape(h, w)
     p[plane == -9999] = -9999
     return p
+
+
+def fcn_predict_plane(plane, sd, mean, std, scale=32, batch=16, vmin=0, vmax=4000):
+    """The FCN shift-and-stitch saliency map (fcn_pred_pipeline.py): for every shift idx in [0, scale^2),
+    top, left = divmod(idx, scale): transform -> ZeroPad2d((0, pad1, 0, pad0)), pad = scale - n % scale (:44-48) ->
+    ZeroPad2d((left, scale-left, top, scale-top)) (:55-65) -> converted model -> softmax[:, 1]; then stitch_stack
+    (:67-92): stitched[scale-top-1::scale, scale-left-1::scale] = pred, crop [scale//2 : n + scale//2]; -9999 mask."""
+    plane = np.asarray(plane)
+    h, w = plane.shape
+    t = (torch.clamp(torch.as_tensor(plane, dtype=torch.float), vmin, vmax) - torch.tensor(mean)) / torch.tensor(std)
+    pad0, pad1 = scale - h % scale, scale - w % scale
+    t = F.pad(t[None], (0, pad1, 0, pad0))
+    preds = []
+    with torch.no_grad():
+        for a in range(0, scale * scale, batch):
+            xs = []
+            for idx in range(a, min(a + batch, scale * scale)):
+                top, left = divmod(idx, scale)
+                xs.append(F.pad(t, (left, scale - left, top, scale - top)))
+            preds.append(torch.softmax(googlenet_forward(torch.stack(xs), sd, fcn=True), dim=1)[:, 1])
+    pred = torch.cat(preds).numpy()
+    stitched = np.zeros((pred.shape[1] * scale, pred.shape[2] * scale))
+    for idx in range(scale * scale):
+        top, left = divmod(idx, scale)
+        stitched[scale - top - 1::scale, scale - left - 1::scale] = pred[idx]
+    stitched = stitched[scale // 2:h + scale // 2, scale // 2:w + scale // 2]
+    stitched[plane == -9999] = -9999
+    return stitched.astype(np.float32), pred.astype(np.float32)

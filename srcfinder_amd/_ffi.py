@@ -39,6 +39,9 @@ SIGNATURES = {
     "sf_cnn_conv_split3": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, i32, vp, i32, i32,
                                  vp, i32, i32, vp]),
     "sf_cnn_head": (i32, [vp, i32, i32, i32, vp, vp, vp, i64, f32, vp, vp]),
+    "sf_cnn_fcn_prepare": (i32, [vp, i32, i32, f32, f32, f32, f32, i32, i32, i32, i32, i32, vp, vp]),
+    "sf_cnn_conv1_image": (i32, [vp, i32, i32, i32, vp, vp, vp, i32, vp]),
+    "sf_cnn_fcn_stitch": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, f32, vp, vp]),
     "sf_cnn_conv1_f16": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp, vp]),
     "sf_cnn_maxpool_f16": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "sf_cnn_conv_f16": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, i32, i32, vp]),

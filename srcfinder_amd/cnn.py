@@ -229,6 +229,46 @@ class GoogLeNetHIP(object):
         self._conv(pooled, name + ".branch4.1", y, c1 + c3 + c5)
         return y
 
+    def _trunk(self, a1, taps=None):
+        """maxpool1 .. inception5b on the conv1 activations a1 [N, H, W, 64] (googlenet1.py:61-86)."""
+        x = self._pool(a1, "pool1", 3, 2, 0)
+        a3 = self._buf("conv2", x.shape)
+        self._conv(x, "conv2", a3, 0)
+        a4 = self._buf("conv3", tuple(x.shape[:3]) + (192,))
+        self._conv(a3, "conv3", a4, 0)
+        x = self._pool(a4, "pool2", 3, 2, 0)
+        for spec in INCEPTION:
+            x = self._inception(x, spec)
+            if taps is not None:
+                taps[spec[0]] = x.clone()
+            if spec[0] == "inception3b":
+                x = self._pool(x, "pool3", 3, 2, 0)
+            elif spec[0] == "inception4e":
+                x = self._pool(x, "pool4", 2, 2, 0)
+        return x
+
+    def forward_fcn(self, canvas, out=None):
+        """Fully convolutional pass (fcn_pred_pipeline.py:157-160, :229-231): canvas [N, Hc, Wc] float32 (already
+        transformed) -> softmax(final_conv(trunk))[:, 1] as [N, Hc/32, Wc/32] float32."""
+        torch = _torch()
+        L = _ffi.lib()
+        N, Hc, Wc = canvas.shape
+        with torch.cuda.device(self.device):
+            st = _ffi.stream_ptr()
+            Ho, Wo = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+            a1 = self._buf("conv1", (N, Ho, Wo, 64))
+            w, b = self.w["conv1"]
+            _ffi.check(L.sf_cnn_conv1_image(_ffi.ptr(canvas), N, Hc, Wc, _ffi.ptr(w), _ffi.ptr(b), _ffi.ptr(a1),
+                                            int(self.half), st), "sf_cnn_conv1_image")
+            x = self._trunk(a1)
+            n, hq, wq, cc = x.shape
+            if out is None:
+                out = torch.empty((n, hq, wq), dtype=torch.float32, device=self.device)
+            _ffi.check(getattr(L, "sf_cnn_head" + self.sfx)(_ffi.ptr(x), n * hq * wq, 1, cc, _ffi.ptr(self.fcw),
+                                                            _ffi.ptr(self.fcb), None, C.c_longlong(0), NODATA,
+                                                            _ffi.ptr(out), st), "sf_cnn_head")
+        return out
+
     def forward_tiles(self, padded, width, tile0, ntiles, plane=None, out=None, taps=None):
         """Score tiles tile0..tile0+ntiles-1 of the padded plane; writes ``out[tile0:tile0+ntiles]`` (float32)."""
         torch = _torch()
@@ -240,21 +280,7 @@ class GoogLeNetHIP(object):
             w, b = self.w["conv1"]
             _ffi.check(getattr(L, "sf_cnn_conv1" + self.sfx)(_ffi.ptr(padded), Hp, Wp, width, C.c_longlong(tile0), ntiles,
                                                              _ffi.ptr(w), _ffi.ptr(b), _ffi.ptr(a1), st), "sf_cnn_conv1")
-            x = self._pool(a1, "pool1", 3, 2, 0)
-            a3 = self._buf("conv2", x.shape)
-            self._conv(x, "conv2", a3, 0)
-            a4 = self._buf("conv3", (ntiles, 64, 64, 192))
-            self._conv(a3, "conv3", a4, 0)
-            x = self._pool(a4, "pool2", 3, 2, 0)
-            rec = {} if taps is not None else None
-            for spec in INCEPTION:
-                x = self._inception(x, spec)
-                if taps is not None:
-                    taps[spec[0]] = x.clone()
-                if spec[0] == "inception3b":
-                    x = self._pool(x, "pool3", 3, 2, 0)
-                elif spec[0] == "inception4e":
-                    x = self._pool(x, "pool4", 2, 2, 0)
+            x = self._trunk(a1, taps)
             if taps is not None:
                 taps["conv1"] = a1.clone()
             N, H, W, Cc = x.shape
@@ -289,4 +315,41 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
         n = min(batch, i1 - t0)
         net.forward_tiles(ds.x, W, t0, n, plane=ds.plane, out=out)
     out = out.view(H, W)
+    return out.cpu().numpy() if to_numpy else out
+
+
+def fcn_predict_flightline(cmf2d, model="COVID_QC", weights=None, scale=32, batch=8, net=None, to_numpy=False,
+                           precision="fp32", shifts=None):
+    """The reference's FCN shift-and-stitch fast mode (cnn/fcn_pred_pipeline.py:32-95, :157-160, :225-249): the trunk
+    runs fully convolutionally over the whole flightline once per (top, left) shift, the 1x1 head gives one
+    probability per ``scale`` x ``scale`` cell and the ``scale**2`` maps are interlaced.  An approximation of
+    :func:`predict_flightline` by construction (the reference's own), ~44x cheaper.
+
+    shifts : optional (s0, s1) range of shift indices (multi-GPU: shifts are independent; other pixels stay 0)
+    """
+    torch = _torch()
+    if scale != 32:
+        raise ValueError("the GoogLeNet trunk has a total stride of 32")
+    if net is None:
+        if weights is None:
+            raise ValueError("weights (a GoogLeNet state_dict) are required")      # the script exits 1 (:139-141)
+        net = GoogLeNetHIP(weights, precision=precision)
+    vmin, vmax, mean, std = _parse_transform(model)
+    plane = cmf2d if torch.is_tensor(cmf2d) else torch.from_numpy(np.array(cmf2d, dtype=np.float32, order="C", copy=True))
+    plane = plane.to(device=net.device, dtype=torch.float32).contiguous()
+    H, W = plane.shape
+    Hc, Wc = H + (scale - H % scale) + scale, W + (scale - W % scale) + scale       # div_pad + shift pad (:44-65)
+    out = torch.zeros((H, W), dtype=torch.float32, device=net.device)
+    s0, s1 = (0, scale * scale) if shifts is None else shifts
+    L = _ffi.lib()
+    with torch.cuda.device(net.device):
+        st = _ffi.stream_ptr()
+        canvas = torch.empty((batch, Hc, Wc), dtype=torch.float32, device=net.device)
+        for a in range(s0, s1, batch):
+            n = min(batch, s1 - a)
+            _ffi.check(L.sf_cnn_fcn_prepare(_ffi.ptr(plane), H, W, float(vmin), float(vmax), float(mean), float(std), scale,
+                                            a, n, Hc, Wc, _ffi.ptr(canvas), st), "sf_cnn_fcn_prepare")
+            pred = net.forward_fcn(canvas[:n])
+            _ffi.check(L.sf_cnn_fcn_stitch(_ffi.ptr(pred), n, a, scale, pred.shape[1], pred.shape[2], _ffi.ptr(plane), H, W,
+                                           NODATA, _ffi.ptr(out), st), "sf_cnn_fcn_stitch")
     return out.cpu().numpy() if to_numpy else out

@@ -173,3 +173,79 @@ def test_fp16_option_is_close_but_separate(gold):
     v = want != -9999
     np.testing.assert_allclose(sal[v], want[v], rtol=2e-2, atol=5e-3)
     assert np.abs(sal[v] - want[v]).max() > 0          # it really is a different arithmetic
+
+
+# ---- FCN shift-and-stitch (the reference's approximate fast mode, cnn/fcn_pred_pipeline.py) -------------------------
+@pytest.fixture(scope="module")
+def fcn_gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "cnn_fcn_golden.npz"))
+
+
+def _logit(p):
+    p = np.clip(p.astype(np.float64), 1e-300, 1.0)
+    return np.log(p) - np.log1p(-np.minimum(p, 1.0 - 1e-16))
+
+
+def test_fcn_canvas_is_bit_exact(fcn_gold, net):
+    """FlightlineShiftStitch.__getitem__ (:55-65): transform, divisibility pad, shift pad -- one shifted canvas."""
+    import torch
+    from srcfinder_amd import _ffi
+    g = fcn_gold
+    H, W, scale = int(g["H"]), int(g["W"]), int(g["scale"])
+    Hc, Wc = g["canvas_5_9"].shape
+    assert (Hc, Wc) == (H + (scale - H % scale) + scale, W + (scale - W % scale) + scale)
+    plane = torch.as_tensor(g["plane"]).cuda()
+    out = torch.empty((2, Hc, Wc), dtype=torch.float32, device="cuda")
+    _ffi.check(_ffi.lib().sf_cnn_fcn_prepare(_ffi.ptr(plane), H, W, 0.0, 4000.0, float(g["mean"]), float(g["std"]), scale,
+                                             5 * scale + 8, 2, Hc, Wc, _ffi.ptr(out), _ffi.stream_ptr()), "prepare")
+    assert np.array_equal(out[1].cpu().numpy(), g["canvas_5_9"])
+
+
+def test_fcn_shift_and_stitch_matches_reference(fcn_gold, net):
+    """Whole fast mode against the golden made by the reference's FlightlineShiftStitch / stitch_stack around its
+    converted model: NODATA placement exact; probabilities to 2e-6 absolute + 5e-3 relative -- the per-cell logits of
+    the un-pooled head reach +-35, so a float32 logit error of 1e-4 relative is up to 4e-3 relative in a saturated
+    probability; where the probability is not saturated the logit difference itself is held to 5e-3."""
+    g = fcn_gold
+    sal = cnn.fcn_predict_flightline(g["plane"], "COVID_QC", net=net, batch=16, to_numpy=True)
+    want = g["saliency"]
+    assert sal.shape == want.shape and sal.dtype == np.float32
+    assert np.array_equal(sal == -9999, want == -9999)
+    v = want != -9999
+    np.testing.assert_allclose(sal[v], want[v], rtol=5e-3, atol=2e-6)
+    mid = v & (want > 1e-6) & (want < 1 - 1e-6)
+    assert mid.sum() > 200
+    assert np.abs(_logit(sal[mid]) - _logit(want[mid])).max() < 5e-3
+
+
+def test_fcn_batch_and_shift_range_invariance(fcn_gold, net):
+    """Batch size does not change a bit; disjoint shift ranges (the multi-GPU split) tile the image exactly."""
+    import torch
+    g = fcn_gold
+    a = cnn.fcn_predict_flightline(g["plane"], "COVID_QC", net=net, batch=16)
+    b = cnn.fcn_predict_flightline(g["plane"], "COVID_QC", net=net, batch=5)
+    assert torch.equal(a, b)
+    lo = cnn.fcn_predict_flightline(g["plane"], "COVID_QC", net=net, batch=16, shifts=(0, 400))
+    hi = cnn.fcn_predict_flightline(g["plane"], "COVID_QC", net=net, batch=16, shifts=(400, 1024))
+    assert torch.equal(torch.where(lo != 0, lo, hi), a)
+
+
+def test_fcn_command_line(fcn_gold, tmp_path):
+    """cli_fcn_pred on an ENVI raster of the golden plane reproduces the golden saliency raster."""
+    import torch
+    from srcfinder_amd import cli_fcn_pred, envi
+    g = fcn_gold
+    H, W = int(g["H"]), int(g["W"])
+    inp = str(tmp_path / "ang_fcn_ch4mf")
+    mm = envi.create_image(inp, {"lines": H, "samples": W, "bands": 1, "data ignore value": -9999}, np.float32, "bsq")
+    mm[0] = g["plane"]
+    mm.flush()
+    wpath = str(tmp_path / "COVID_QC.pt")
+    torch.save({k: torch.as_tensor(v) for k, v in synthetic_state_dict(seed=2024).items()}, wpath)
+    assert cli_fcn_pred.main([inp, "-g", "0", "-b", "16", "-o", str(tmp_path), "--weights", wpath]) == 0
+    sal, smeta = envi.open_memmap(str(tmp_path / "ang_fcn_ch4mf_saliency.img"))
+    assert (smeta["lines"], smeta["samples"], smeta["bands"], smeta["data type"]) == (H, W, 1, 4)
+    got, want = np.asarray(sal)[0], g["saliency"]
+    assert np.array_equal(got == -9999, want == -9999)
+    v = want != -9999
+    np.testing.assert_allclose(got[v], want[v], rtol=5e-3, atol=2e-6)

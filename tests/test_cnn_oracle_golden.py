@@ -64,3 +64,16 @@ def test_predict_subset(gold, sd):
     want = gold["saliency24"].reshape(-1)[idx]
     assert np.array_equal(got == -9999, want == -9999)
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
+
+
+def test_fcn_shift_and_stitch_oracle_matches_reference(golden_dir, sd):
+    """oracle.fcn_predict_plane against the golden of the reference's FlightlineShiftStitch / converted model /
+    stitch_stack (tests/golden/gen_golden_fcn.py): same torch ops on the same machine class -> bit-identical stack
+    and saliency map."""
+    g = np.load(os.path.join(golden_dir, "cnn_fcn_golden.npz"))
+    torch.set_num_threads(8)
+    sal, stack = O.fcn_predict_plane(g["plane"], sd, float(g["mean"]), float(g["std"]), scale=int(g["scale"]))
+    assert stack.shape == g["predstack"].shape
+    np.testing.assert_allclose(stack, g["predstack"], rtol=1e-5, atol=1e-9)
+    assert np.array_equal(sal == -9999, g["saliency"] == -9999)
+    np.testing.assert_allclose(sal, g["saliency"], rtol=1e-5, atol=1e-9)

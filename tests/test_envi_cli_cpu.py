@@ -3,7 +3,7 @@ import os
 
 import numpy as np
 
-from srcfinder_amd import cli_cnn_pred, cli_robust_mf, envi
+from srcfinder_amd import cli_cnn_pred, cli_fcn_pred, cli_robust_mf, envi
 
 
 def test_envi_roundtrip_all_interleaves(tmp_path):
@@ -55,6 +55,15 @@ def test_cli_flag_sets_match_the_reference():
 
 def test_cnn_cli_exits_1_without_weights(tmp_path):
     assert cli_cnn_pred.main([str(tmp_path / "x.img"), "--weights", str(tmp_path / "missing.pt")]) == 1
+
+
+def test_fcn_cli_flag_set_and_missing_weights(tmp_path):
+    """cnn/fcn_pred_pipeline.py:95-121: same flags, same defaults (band 1, scale 32, batch 8), exit 1 without weights."""
+    f = cli_fcn_pred.build_parser().parse_args(["flight.img"])
+    assert (f.band, f.scale, f.model, f.gpus, f.batch, f.output) == (1, 32, "COVID_QC", [-1], 8, ".")
+    f = cli_fcn_pred.build_parser().parse_args(["flight.img", "-n", "4", "-s", "32", "-m", "Permian_QC", "-g", "0", "1", "-b", "4", "-o", "o"])
+    assert (f.band, f.scale, f.model, f.gpus, f.batch, f.output) == (4, 32, "Permian_QC", [0, 1], 4, "o")
+    assert cli_fcn_pred.main([str(tmp_path / "x.img"), "--weights", str(tmp_path / "missing.pt")]) == 1
 
 
 def test_systematics_flags_host_logic(tmp_path):

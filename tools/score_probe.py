@@ -11,7 +11,7 @@ from srcfinder_amd.synth import make_cube_torch
 
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 lpw = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-lines, samples, p = 20000, 598, 72
+lines, samples, p = 20000, int(os.environ.get('SF_PROBE_SAMPLES', '598')), 72
 lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
 cube = make_cube_torch(lines, samples, seed=1, abscf_full=lib[:, 2])
 L = _ffi.lib()
@@ -34,4 +34,4 @@ a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 a.record()
 for _ in range(5): run()
 b.record(); torch.cuda.synchronize()
-print("variant %d lpw %d: %.4f ms per launch, checksum %.6e" % (variant, lpw, a.elapsed_time(b) / 5, float(out[..., 3].sum())))
+print("samples %d " % samples + "variant %d lpw %d: %.4f ms per launch, checksum %.6e" % (variant, lpw, a.elapsed_time(b) / 5, float(out[..., 3].sum())), "| %.3f ns per kilo-pixel" % (a.elapsed_time(b) / 5 * 1e6 / (lines * samples / 1e3)))

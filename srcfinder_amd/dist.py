@@ -99,3 +99,64 @@ def robust_mf_sharded(cube_shard, library, samples: int, *, group=None, dst: int
         fields[name] = gather_columns(v, samples, group=group, dst=dst)
     import torch.distributed as dist
     return fields if dist.get_rank(group) == dst else None
+
+
+# ------------------------------------------------------------------------------------------------------
+# CNN saliency map over the GPUs of one node (CNN row): replaces the reference's DataParallel,
+# which replicates the model and scatters / gathers every batch (cnn/cnn_pred_pipeline.py:113-116)
+# ------------------------------------------------------------------------------------------------------
+def shard_rows(rows: int, world: int, rank: int):
+    """Contiguous, balanced row ranges of the output image (20000 over 8 -> 2500 each)."""
+    return rank * rows // world, (rank + 1) * rows // world
+
+
+def gather_rows(block, rows: int, *, group=None, dst: int = 0):
+    """Gather per-rank row blocks ``[rows_r, W]`` into ``[rows, W]`` on ``dst`` (``None`` elsewhere): row blocks of a
+    row-major image are contiguous, so the assembly is one concatenation of the received (padded) blocks."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    maxr = max(b - a for a, b in (shard_rows(rows, world, r) for r in range(world)))
+    send = torch.zeros((maxr,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    send[:block.shape[0]].copy_(block)
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    parts = []
+    for r in range(world):
+        a, b = shard_rows(rows, world, r)
+        parts.append(recv[r][:b - a])
+    return torch.cat(parts, 0)
+
+
+def predict_flightline_sharded(cmf2d, *, group=None, dst: int = 0, compute=None, **kw):
+    """Tile scorer: every rank holds the whole CMF plane (69 MB padded for a 598 x 20000 flightline) and its own weight
+    copy, scores the rows ``shard_rows(H, world, rank)`` and the float32 blocks are gathered once (6 MB per rank).
+    ``compute(cmf2d, rows=(r0, r1), **kw) -> [H, W]`` defaults to :func:`srcfinder_amd.cnn.predict_flightline`."""
+    import torch.distributed as dist
+    if compute is None:
+        from .cnn import predict_flightline as compute
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    H = cmf2d.shape[0]
+    r0, r1 = shard_rows(H, world, rank)
+    sal = compute(cmf2d, rows=(r0, r1), **kw)
+    return gather_rows(sal[r0:r1], H, group=group, dst=dst)
+
+
+def fcn_predict_flightline_sharded(cmf2d, *, scale: int = 32, group=None, dst: int = 0, compute=None, **kw):
+    """FCN shift-and-stitch: the scale^2 shifts are independent; rank r runs the shift range
+    ``shard_rows(scale^2, world, r)``.  Each shift owns a disjoint set of pixels (one per scale x scale cell) and a
+    rank leaves the others at 0, so ONE sum-reduce to ``dst`` assembles the map exactly (x + 0 == x in float32; a NODATA
+    pixel is written by the rank whose shift owns it).
+    ``compute(cmf2d, shifts=(s0, s1), **kw) -> [H, W]`` defaults to :func:`srcfinder_amd.cnn.fcn_predict_flightline`."""
+    import torch.distributed as dist
+    if compute is None:
+        from .cnn import fcn_predict_flightline as compute
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    s0, s1 = shard_rows(scale * scale, world, rank)
+    part = compute(cmf2d, shifts=(s0, s1), scale=scale, **kw).contiguous()
+    dist.reduce(part, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return part if rank == dst else None

@@ -73,3 +73,54 @@ def test_shard_columns_cover_everything():
         assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
         sizes = [b - a for a, b in edges]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _cnn_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    from srcfinder_amd import dist as sd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W, scale = 37, 11, 4
+    g = torch.Generator().manual_seed(5)
+    plane = torch.rand((H, W), generator=g)
+    plane[3, 4] = -9999.0
+    full = torch.where(plane == -9999.0, plane, plane * 2 + 1)            # stand-in "saliency": a pixelwise function
+
+    def tiles(p, rows=None, **kw):                                         # the contract of cnn.predict_flightline(rows=)
+        out = torch.zeros_like(p)
+        out[rows[0]:rows[1]] = full[rows[0]:rows[1]]
+        return out
+
+    def fcn(p, shifts=None, scale=32, **kw):                               # the contract of cnn.fcn_predict_flightline(shifts=)
+        out = torch.zeros_like(p)
+        for idx in range(*shifts):
+            top, left = divmod(idx, scale)
+            ys = torch.arange(H)[(torch.arange(H) + scale // 2) % scale == scale - top - 1]
+            xs = torch.arange(W)[(torch.arange(W) + scale // 2) % scale == scale - left - 1]
+            out[ys[:, None], xs[None, :]] = full[ys[:, None], xs[None, :]]
+        return out
+
+    a = sd.predict_flightline_sharded(plane, compute=tiles)
+    b = sd.fcn_predict_flightline_sharded(plane, scale=scale, compute=fcn)
+    if rank == 0:
+        q.put(bool(torch.equal(a, full) and torch.equal(b, full)))
+    else:
+        assert a is None and b is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cnn_row_shards_and_fcn_shift_shards(world):
+    """Row sharding + gather of the tile scorer and shift sharding + sum-reduce of the FCN mode (uneven shards)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + world) % 2000
+    procs = [ctx.Process(target=_cnn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -63,6 +63,15 @@ int sf_cmf_covariance(const void *xt, int xt_f64, const uint8_t *mask_t, const i
 int sf_cmf_eigh(const double *cov, const int32_t *nuse, int p, int ncols, double *d, double *lam,
                 double *evec, int32_t *status, void *scratch, void *stream);
 
+/* Stages 3-5 in one call for windows of 97..512 bands (reflectance -R 5..420, full-band 1..425), where the
+ * LDS-resident kernels do not fit: batched float64 GEMMs + a global-memory Jacobi (cmf_wide.hip).  Same outputs as
+ * sf_cmf_covariance + sf_cmf_eigh + sf_cmf_loocv.  nrows = the rows the covariance is made of, nloo = the n of beta
+ * and 1/(2n) (NULL: nrows) -- the function-level looshrinkage(I_zm, alphas, nll, n) passes them separately
+ * (robust_mf.py:92-117).  scratch >= sf_cmf_workspace_bytes(lines, p, ncols, nalpha). */
+int sf_cmf_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nrows, const int32_t *nloo,
+                      const double *mu, const double *alphas, int nalpha, int lines, int p, int ncols, double *cov, double *d,
+                      double *lam, double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, void *stream);
+
 /* Stage 4, full shrinkage target (multimodal -f: T = cov(I_reg), robust_mf.py:99, :131, :354) -- the same restatement one
  * congruence further: target = L L^T (Cholesky), eigendecomposition of L^-1 S L^-T, and outputs d = diag(L),
  * evec_j = D (L^-T v_j) chosen so that stages 5-7 run unchanged (they only form D^-1 evec^T and 2 sum log d = log det T).

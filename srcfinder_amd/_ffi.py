@@ -25,6 +25,7 @@ SIGNATURES = {
     "sf_cmf_column_mean": (i32, [vp, i32, vp, i32, i32, i32, vp, vp, vp, vp]),
     "sf_cmf_covariance": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "sf_cmf_eigh": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "sf_cmf_wide_stats": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "sf_cmf_eigh_general": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "sf_cmf_loocv": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "sf_cmf_filter": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),

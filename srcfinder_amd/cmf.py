@@ -374,6 +374,23 @@ def _upload_rows(a):
     return xt, mask, n, p
 
 
+def _wide_stats(torch, L, xt, mask, nrows, nloo, mu, alphas, rows, p, S, ws, nll=None, aidx=None):
+    """sf_cmf_wide_stats on ONE float64 matrix (function-level entries with more than 96 bands)."""
+    dev = xt.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    nalpha = alphas.numel()
+    d, lam = torch.empty((1, p), **f64), torch.empty((1, p), **f64)
+    evec = torch.empty((1, p, p), **f64)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    nll = torch.empty((1, nalpha), **f64) if nll is None else nll
+    aidx = torch.empty(1, dtype=torch.int32, device=dev) if aidx is None else aidx
+    _ffi.check(L.sf_cmf_wide_stats(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nrows), _ffi.ptr(nloo), _ffi.ptr(mu),
+                                   _ffi.ptr(alphas), nalpha, rows, p, 1, _ffi.ptr(S), _ffi.ptr(d), _ffi.ptr(lam),
+                                   _ffi.ptr(evec), _ffi.ptr(status), _ffi.ptr(nll), _ffi.ptr(aidx), _ffi.ptr(ws),
+                                   _ffi.stream_ptr()), "sf_cmf_wide_stats")
+    return nll, aidx
+
+
 def cov(A, **kwargs):
     """Sample covariance with MATLAB semantics: rows are samples, ``ddof=1`` (robust_mf.py:52-70).
 
@@ -385,19 +402,25 @@ def cov(A, **kwargs):
     if isinstance(A, torch.Tensor):
         A = A.detach().cpu().numpy()
     xt, mask, n, p = _upload_rows(A)
-    if p > 96:
-        raise NotImplementedError("cov(): more than 96 features is outside the fused statistics path")
+    if p > 512:
+        raise NotImplementedError("cov(): more than 512 features")
     L = _ffi.lib()
     dev = xt.device
-    ws = _Workspace.get(L.sf_cmf_workspace_bytes(n, p, 1, 1), dev)
     nuse = torch.empty(1, dtype=torch.int32, device=dev)
     mu = torch.empty((1, p), dtype=torch.float64, device=dev)
     S = torch.empty((1, p, p), dtype=torch.float64, device=dev)
     st = _ffi.stream_ptr()
-    _ffi.check(L.sf_cmf_column_mean(_ffi.ptr(xt), 1, _ffi.ptr(mask), n, p, 1, _ffi.ptr(nuse), _ffi.ptr(mu),
-                                    _ffi.ptr(ws), st), "sf_cmf_column_mean")
-    _ffi.check(L.sf_cmf_covariance(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nuse), _ffi.ptr(mu), n, p, 1,
-                                   _ffi.ptr(S), _ffi.ptr(ws), st), "sf_cmf_covariance")
+    if p > 96:      # wide window: the batched-GEMM path computes S on the way to its eigendecomposition
+        ws = _Workspace.get(L.sf_cmf_workspace_bytes(n, p, 1, 1), dev)
+        _ffi.check(L.sf_cmf_column_mean(_ffi.ptr(xt), 1, _ffi.ptr(mask), n, p, 1, _ffi.ptr(nuse), _ffi.ptr(mu),
+                                        _ffi.ptr(ws), st), "sf_cmf_column_mean")
+        _wide_stats(torch, L, xt, mask, nuse, None, mu, torch.ones(1, dtype=torch.float64, device=dev), n, p, S, ws)
+    else:
+        ws = _Workspace.get(L.sf_cmf_workspace_bytes(n, p, 1, 1), dev)
+        _ffi.check(L.sf_cmf_column_mean(_ffi.ptr(xt), 1, _ffi.ptr(mask), n, p, 1, _ffi.ptr(nuse), _ffi.ptr(mu),
+                                        _ffi.ptr(ws), st), "sf_cmf_column_mean")
+        _ffi.check(L.sf_cmf_covariance(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nuse), _ffi.ptr(mu), n, p, 1,
+                                       _ffi.ptr(S), _ffi.ptr(ws), st), "sf_cmf_covariance")
     S = S[0].cpu().numpy()
     if ddof != 1:
         S = S * ((n - 1.0) / (n - float(ddof)))
@@ -416,8 +439,10 @@ def looshrinkage(I_zm, alphas, nll, n, I_reg=[]):
     torch = _torch()
     alphas_np = np.ascontiguousarray(alphas, dtype=np.float64)
     xt, mask, rows, p = _upload_rows(I_zm)
-    if p > 96:
-        raise NotImplementedError("looshrinkage(): more than 96 bands is outside the fused statistics path")
+    if p > 512:
+        raise NotImplementedError("looshrinkage(): more than 512 bands")
+    if p > 96 and len(I_reg) != 0:
+        raise NotImplementedError("looshrinkage(): a full shrinkage target with more than 96 bands")
     L = _ffi.lib()
     dev = xt.device
     nalpha = len(alphas_np)
@@ -435,6 +460,13 @@ def looshrinkage(I_zm, alphas, nll, n, I_reg=[]):
     aidx = torch.empty(1, dtype=torch.int32, device=dev)
     al = torch.as_tensor(alphas_np, device=dev)
     st = _ffi.stream_ptr()
+    if p > 96:      # wide window (e.g. the reference's own -R run, p = 416; full-band p = 425): batched-GEMM path
+        _wide_stats(torch, L, xt, mask, nrows, nloo, mu, al, rows, p, S, ws, nll_d, aidx)
+        nll[:] = nll_d[0].cpu().numpy()
+        mindex = int(aidx.item())
+        alpha = float(alphas_np[mindex]) if mindex >= 0 else 0.0
+        S = S[0].cpu().numpy()
+        return (1.0 - alpha) * S + alpha * np.diag(np.diag(S)), mindex
     _ffi.check(L.sf_cmf_covariance(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nrows), _ffi.ptr(mu), rows, p, 1,
                                    _ffi.ptr(S), _ffi.ptr(ws), st), "sf_cmf_covariance")
     T_np = None

@@ -181,6 +181,18 @@ int sf_cmf_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_
                          alphaidx, scratch, (hipStream_t)stream);
 }
 
+int sf_cmf_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nrows, const int32_t *nloo,
+                      const double *mu, const double *alphas, int nalpha, int lines, int p, int ncols, double *cov, double *d,
+                      double *lam, double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, void *stream) {
+  if (!xt || !mask_t || !nrows || !mu || !alphas || !cov || !d || !lam || !evec || !status || !nll || !alphaidx || !scratch) {
+    sf_set_error("null pointer");
+    return -1;
+  }
+  if (lines < 1 || p < 1 || ncols < 1 || nalpha < 1) { sf_set_error("sf_cmf_wide_stats: bad geometry"); return -1; }
+  return sf_launch_wide_stats(xt, xt_f64, mask_t, nrows, nloo, mu, alphas, sf_geom(lines, p, ncols, nalpha), cov, d, lam, evec,
+                              status, nll, alphaidx, scratch, (hipStream_t)stream);
+}
+
 int sf_cmf_filter(const double *mu, const double *d, const double *lam, const double *evec, const double *alphas,
                   const int32_t *alphaidx, const double *abscf, int reflectance, int p, int ncols, int32_t *status,
                   double *filt, double *bias, void *stream) {
@@ -240,8 +252,8 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
     if ((rc = sf_launch_extract(cube, lines, bands, samples, s0, ncols, b0, p, w.xt, w.mask_t, nullptr, nullptr, st)))
       return rc;
     if ((rc = sf_launch_mean(w.xt, 0, w.mask_t, g, nuse, w.mu, w.scratch, st))) return rc;
-    if ((rc = sf_launch_wide_stats(w.xt, w.mask_t, nuse, w.mu, alphas, g, w.cov, w.d, w.lam, w.evec, status, nll, alphaidx,
-                                   w.scratch, st)))
+    if ((rc = sf_launch_wide_stats(w.xt, 0, w.mask_t, nuse, nullptr, w.mu, alphas, g, w.cov, w.d, w.lam, w.evec, status, nll,
+                                   alphaidx, w.scratch, st)))
       return rc;
   } else {
     if (sf_extract_fuses_sum(p)) {  // column sums ride along with the transpose (per-chunk partials in scratch)

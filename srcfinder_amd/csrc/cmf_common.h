@@ -157,9 +157,9 @@ int sf_launch_filter(const double *mu, const double *d, const double *lam, const
                      const int32_t *alphaidx, const double *abscf, int reflectance, const SfGeom &g,
                      int32_t *status, double *filt, double *bias, hipStream_t st);
 size_t sf_wide_scratch_bytes(const SfGeom &g);
-int sf_launch_wide_stats(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *alphas,
-                         const SfGeom &g, double *cov, double *d, double *lam, double *evec, int32_t *status,
-                         double *nll, int32_t *alphaidx, void *scratch, hipStream_t st);
+int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const int32_t *nloo,
+                         const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
+                         double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st);
 int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
                          const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
                          hipStream_t st);

@@ -16,11 +16,12 @@ namespace {
 
 constexpr int WD_BM = 64, WD_BN = 64, WD_BK = 16, WD_LD = 80;  // LDS row stride 16 (mod 32) doubles
 
-__global__ void k_center(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t, const double *__restrict__ mu,
+template <typename XT>
+__global__ void k_center(const XT *__restrict__ xt, const uint8_t *__restrict__ mask_t, const double *__restrict__ mu,
                          int L, int p, int PS, int c0, double *__restrict__ xc) {
   const int c = blockIdx.y;  // column within the batch
   const size_t tot = (size_t)L * p;
-  const float *xs = xt + (size_t)(c0 + c) * L * PS;
+  const XT *xs = xt + (size_t)(c0 + c) * L * PS;
   const uint8_t *mp = mask_t + (size_t)(c0 + c) * L;
   const double *m = mu + (size_t)(c0 + c) * p;
   double *o = xc + (size_t)c * tot;
@@ -401,21 +402,22 @@ size_t sf_wide_scratch_bytes(const SfGeom &g) {
 }
 
 // stages 3-5 (covariance, eigendecomposition, LOO sweep + argmin) for windows too wide for the fused kernels
-int sf_launch_wide_stats(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *alphas,
-                         const SfGeom &g, double *cov, double *d, double *lam, double *evec, int32_t *status,
-                         double *nll, int32_t *alphaidx, void *scratch, hipStream_t st);
+int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const int32_t *nloo,
+                         const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
+                         double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st);
 
 int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
                          const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
                          hipStream_t st);
 
-int sf_launch_wide_stats(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *alphas,
-                         const SfGeom &g, double *cov, double *d, double *lam, double *evec, int32_t *status,
-                         double *nll, int32_t *alphaidx, void *scratch, hipStream_t st) {
+int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const int32_t *nloo,
+                         const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
+                         double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st) {
   if (g.p > 512 || g.nalpha > SF_NALPHA_MAX) {
     sf_set_error("wide statistics path supports up to 512 bands and %d alphas", SF_NALPHA_MAX);
     return -2;
   }
+  if (!nloo) nloo = nuse;
   const int L = g.lines, p = g.p, NA16 = g.nu * 16, p2 = g.p + (g.p & 1);
   const int bc = sf_wide_batch(g);
   const int nsplit = wide_nll_splits(g);
@@ -433,7 +435,14 @@ int sf_launch_wide_stats(const float *xt, const uint8_t *mask_t, const int32_t *
   double *gv = Cm + (size_t)bc * p * NA16;
   for (int c0 = 0; c0 < g.ncols; c0 += bc) {
     const int nb = (g.ncols - c0 < bc) ? g.ncols - c0 : bc;
-    hipLaunchKernelGGL(k_center, dim3(256, nb), dim3(256), 0, st, xt, mask_t, mu, L, p, g.ps, c0, xc);
+    // nuse: the rows the covariance is made of (ddof 1); nloo: the n of beta and of 1/(2n) (robust_mf.py:109, :116) --
+    // the same number in the column loop, separate in the function-level looshrinkage(I_zm, alphas, nll, n)
+    if (xt_f64)
+      hipLaunchKernelGGL(k_center<double>, dim3(256, nb), dim3(256), 0, st, reinterpret_cast<const double *>(xt), mask_t, mu,
+                         L, p, g.ps, c0, xc);
+    else
+      hipLaunchKernelGGL(k_center<float>, dim3(256, nb), dim3(256), 0, st, reinterpret_cast<const float *>(xt), mask_t, mu,
+                         L, p, g.ps, c0, xc);
     SF_LAUNCH_CHECK("k_center");
     // S = X~^T X~  (A = X~ stored [K = L][M = p] -> TA)
     hipLaunchKernelGGL((k_dgemm<true, false>), dim3(sf_cdiv(p, WD_BM), sf_cdiv(p, WD_BN), nb), dim3(256), 0, st, xc, p,
@@ -445,7 +454,7 @@ int sf_launch_wide_stats(const float *xt, const uint8_t *mask_t, const int32_t *
     SF_LAUNCH_CHECK("k_eigh_global");
     hipLaunchKernelGGL(k_wmat, dim3(64, nb), dim3(256), 0, st, evec, d, p, c0, W);
     SF_LAUNCH_CHECK("k_wmat");
-    hipLaunchKernelGGL(k_cmat, dim3(64, nb), dim3(256), 0, st, lam, nuse, status, alphas, g.nalpha, NA16, p, c0, Cm);
+    hipLaunchKernelGGL(k_cmat, dim3(64, nb), dim3(256), 0, st, lam, nloo, status, alphas, g.nalpha, NA16, p, c0, Cm);
     SF_LAUNCH_CHECK("k_cmat");
     hipLaunchKernelGGL((k_dgemm<false, true>), dim3(sf_cdiv(L, WD_BM), sf_cdiv(p, WD_BN), nb), dim3(256), 0, st, xc, p,
                        (size_t)L * p, W, p, (size_t)p * p, z, p, (size_t)L * p, L, p, p, 1.0);
@@ -453,9 +462,9 @@ int sf_launch_wide_stats(const float *xt, const uint8_t *mask_t, const int32_t *
     hipLaunchKernelGGL((k_dgemm<false, false>), dim3(sf_cdiv(L, WD_BM), sf_cdiv(NA16, WD_BN), nb), dim3(256), 0, st, z, p,
                        (size_t)L * p, Cm, NA16, (size_t)p * NA16, rm, NA16, (size_t)L * NA16, L, NA16, p, 1.0);
     SF_LAUNCH_CHECK("k_dgemm(r)");
-    hipLaunchKernelGGL(k_nllrows, dim3(nb, nsplit), dim3(256), 0, st, rm, nuse, status, alphas, g.nalpha, NA16, L, rows,
+    hipLaunchKernelGGL(k_nllrows, dim3(nb, nsplit), dim3(256), 0, st, rm, nloo, status, alphas, g.nalpha, NA16, L, rows,
                        c0, nsplit, part);
     SF_LAUNCH_CHECK("k_nllrows");
   }
-  return sf_launch_nll_finish(part, nsplit, nuse, d, lam, status, alphas, g, nll, alphaidx, st);
+  return sf_launch_nll_finish(part, nsplit, nloo, d, lam, status, alphas, g, nll, alphaidx, st);
 }

@@ -310,6 +310,32 @@ def test_looshrinkage_function_against_reference_golden(torch_cuda, golden_dir, 
     np.testing.assert_allclose(Cm, g[name + "_C"], rtol=1e-11, atol=1e-14 * np.abs(g[name + "_C"]).max())
 
 
+@pytest.mark.parametrize("name,rtol", [("n2000_p425", 1e-10), ("n300_p425", 1e-5)])
+def test_looshrinkage_function_full_band_golden(torch_cuda, golden_dir, name, rtol):
+    """The p = 425 goldens of the real reference through the function-level entry (wide path, float64 input).
+    Known deviation: scipy's det is a running product of LU pivots and over/underflows when a
+    PREFIX does, the HIP path decides from the total log-determinant -- at the edge of the representable range one or
+    two grid points are finite here and inf there.  They sit at the finite/inf boundary, never at the minimum: the
+    selected index, the common finite values and the final covariance agree (n300: n < p, G is near-singular at the
+    small alphas and the reference's own LU inverse is only good to ~1e-6 there)."""
+    g = np.load(os.path.join(golden_dir, "cmf_looshrinkage_cases.npz"))
+    n, p, seed, scale = g[name + "_spec"]
+    x = synth_columns(int(n), int(p), int(seed), float(scale))
+    nll = np.zeros(201)
+    Cm, mindex = cmf.looshrinkage(x - x.mean(axis=0), g["alphas"], nll, int(n))
+    ref = g[name + "_nll"]
+    assert mindex == int(g[name + "_mindex"])
+    fa, fb = np.isfinite(nll), np.isfinite(ref)
+    bad = np.nonzero(fa != fb)[0]
+    assert len(bad) <= 2 and np.all(fa[bad])                  # finite here, inf in the reference
+    for i in bad:                                             # ... and adjacent to the reference's own inf region
+        assert (not fb[max(i - 1, 0)]) or (not fb[min(i + 1, 200)]) or any(j in bad for j in (i - 1, i + 1))
+    both = fa & fb
+    np.testing.assert_allclose(nll[both], ref[both], rtol=rtol)
+    np.testing.assert_allclose(np.diag(Cm), g[name + "_Cdiag"], rtol=1e-11)
+    np.testing.assert_allclose(Cm[::17, ::13], g[name + "_Csub"], rtol=1e-10, atol=1e-13 * np.abs(g[name + "_Csub"]).max())
+
+
 def test_looshrinkage_constant_band(torch_cuda, golden_dir):
     g = np.load(os.path.join(golden_dir, "cmf_looshrinkage_cases.npz"))
     n, p, seed, scale = g["const_band_spec"]
@@ -634,3 +660,20 @@ def test_flightline_pipeline_matches_sequential_calls(torch_cuda, library):
         assert torch.equal(r.colstats, s.colstats)
     with pytest.raises(ValueError):
         pipe.submit(cubes[0], library, to_numpy=True)
+
+
+def test_wide_function_level_entries_separate_n_and_cov(torch_cuda):
+    """looshrinkage() / cov() beyond 96 bands go through sf_cmf_wide_stats on float64 input; the n of beta may differ
+    from the row count (the multimodal caller's convention) -- against the faithful oracle."""
+    x = synth_columns(700, 130, 4242)
+    sub = x[:400] - x[:400].mean(0)
+    al = cmf.alpha_grid()
+    nll_o, nll_g = np.zeros(len(al)), np.zeros(len(al))
+    c_o, i_o = O.looshrinkage(sub, al, nll_o, 700)
+    c_g, i_g = cmf.looshrinkage(sub, al, nll_g, 700)
+    assert i_g == i_o
+    fin = np.isfinite(nll_o)
+    assert np.array_equal(np.isfinite(nll_g), fin)
+    np.testing.assert_allclose(nll_g[fin], nll_o[fin], rtol=1e-9)
+    np.testing.assert_allclose(c_g, c_o, rtol=1e-10, atol=1e-13 * np.abs(c_o).max())
+    np.testing.assert_allclose(cmf.cov(x), np.cov(x.T), rtol=1e-10, atol=1e-13 * np.abs(np.cov(x.T)).max())

@@ -8,7 +8,8 @@
 
 #include "cmf_common.h"
 
-extern int g_score_variant, g_score_lpw, g_score_xcd;  // cmf_score.hip
+extern int g_score_variant, g_score_lpw, g_score_xcd;
+extern int g_wide_eigh_variant;   // cmf_wide.hip  // cmf_score.hip
 extern int g_sweep_variant;                            // cmf_loocv.hip
 extern int g_cov_variant;                              // cmf_cov.hip
 extern int g_extract_variant;                          // cmf_extract.hip
@@ -287,6 +288,7 @@ int sf_debug_set(int key, int value) {
     case 6: g_extract_variant = value; return 0;
     case 7: g_eigh_lpp = value; return 0;
     case 8: g_sweep4r_waves = value; return 0;
+    case 10: g_wide_eigh_variant = value; return 0;
     default: sf_set_error("sf_debug_set: unknown key %d", key); return -1;
   }
 }

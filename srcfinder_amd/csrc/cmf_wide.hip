@@ -220,7 +220,11 @@ constexpr int EG_RMAX = 32;  // rows per lane at 16 lanes per pair: p2 <= 512
 __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ cov, const int32_t *__restrict__ nuse, int p,
                                                        int p2, int c0, double *__restrict__ d_out,
                                                        double *__restrict__ lam_out, double *__restrict__ evec_out,
-                                                       int32_t *__restrict__ status, double *__restrict__ gscratch) {
+                                                       int32_t *__restrict__ status, double *__restrict__ gscratch,
+                                                       int mode, int32_t *__restrict__ cflag) {
+  // mode 0: the whole decomposition here.  mode 1: status, d and the Cholesky factor only (G = L left in gscratch for
+  // the blocked Jacobi below; cflag = 0 ok, 1 not positive definite -> mode 2, 2 nothing to do).  mode 2: the whole
+  // decomposition, only for the matrices mode 1 flagged 1 (Jacobi on R with V accumulated alongside).
   __shared__ double dv[512], nrm[512];
   __shared__ int flag[2];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ 
   double *V = G + (size_t)p2 * p2;
   const int n = nuse[c];
   const int LD = p2;
+  if (mode == 2 && cflag[blockIdx.x] != 1) return;
   if (tid < 2) flag[tid] = 0;
   for (int i = tid; i < p2; i += nthr) dv[i] = (i < p) ? sqrt(S[(size_t)i * p + i]) : 0.0;
   __syncthreads();
@@ -246,6 +251,7 @@ __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ 
   if (st != 0) {
     for (int i = tid; i < p; i += nthr) lam_out[(size_t)c * p + i] = 0.0;
     for (int i = tid; i < p * p; i += nthr) evec_out[(size_t)c * p * p + i] = ((i / p) == (i % p)) ? 1.0 : 0.0;
+    if (mode == 1 && tid == 0) cflag[blockIdx.x] = 2;
     return;
   }
   auto load_R = [&]() {
@@ -285,6 +291,10 @@ __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ 
     __syncthreads();
     load_R();
     for (int i = tid; i < p2 * p2; i += nthr) V[i] = ((i / p2) == (i % p2)) ? 1.0 : 0.0;
+  }
+  if (mode == 1) {
+    if (tid == 0) cflag[blockIdx.x] = chol_ok ? 0 : 1;
+    return;
   }
   __syncthreads();
 
@@ -381,18 +391,250 @@ __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ 
   }
 }
 
+
+// ---- blocked one-sided Jacobi for the wide windows -----------------------------------------------------------------
+// k_eigh_global moves the whole p2 x p2 factor through ONE CU's memory pipe every step (p2 - 1 steps a sweep, 2.9 MB
+// each at p = 425): ~30 GB/s per workgroup, 3 s for a 598-column flightline.  Here the factor is cut into blocks of 16
+// columns; a workgroup takes a PAIR of blocks into LDS (2 x 16 x LDr doubles, 111 KB at p = 425) and rotates the 256
+// cross pairs (a_i, b_j) in 16 conflict-free steps -- group i of 16 lanes keeps column a_i in registers for the whole
+// visit, the b columns travel through LDS -- then writes both blocks back.  The block pairs of a step are disjoint
+// (circle method over the blocks), so one launch per step does all of them for all matrices: a sweep is nblk - 1
+// (or nblk) launches instead of p2 - 1 passes over the matrix, and the pairs INSIDE a block are swept in the first
+// launch of the sweep, where every block appears exactly once.  Every pair is met once per sweep: a cyclic Jacobi in
+// a blocked order.  Same rotation formula, threshold and carried norms as k_eigh_global.
+constexpr int BJ_B = 16;        // columns per block
+constexpr int BJ_NT = 256;      // 16 groups of 16 lanes
+
+__device__ __forceinline__ bool bj_rotation(double aa, double bb, double ab, double tol2, double &cs, double &sn) {
+  const double ab2 = aa * bb;
+  if (!(ab2 > 0.0 && ab * ab > tol2 * ab2)) return false;
+  const double tau = bb - aa, gam = 2.0 * ab;
+  const double rinv = 1.0 / sqrt(tau * tau + gam * gam);
+  const double c2 = fabs(tau) * rinv;
+  const double h = 0.5 + 0.5 * c2;
+  cs = sqrt(h);
+  sn = fabs(gam) * rinv * 0.5 / cs;
+  sn = ((tau < 0.0) != (gam < 0.0)) ? -sn : sn;
+  return true;
+}
+
+__global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratch, int p2, int LDr, int nblk, int mblk, int step,
+                                                     const int32_t *__restrict__ cflag, const int32_t *__restrict__ done,
+                                                     int32_t *__restrict__ rot) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];   // [2][BJ_B][LDr], then nrm[2 * BJ_B]
+  double *nrm = sm + (size_t)2 * BJ_B * LDr;
+  __shared__ int any;
+  const int mtx = blockIdx.y;
+  if (cflag[mtx] != 0 || done[mtx]) return;
+  // circle method over mblk (even) block slots; slot >= nblk is the dummy
+  int ba, bb;
+  rr_pair_w(step, blockIdx.x, mblk - 1, ba, bb);
+  const bool has_a = ba < nblk, has_b = bb < nblk;
+  if (!has_a && !has_b) return;
+  if (!has_a) { ba = bb; }                       // a lone block: only its inner sweep (step 0)
+  const bool lone = !(has_a && has_b);
+  if (lone && step != 0) return;
+  const int tid = threadIdx.x, grp = tid >> 4, sub = tid & 15;
+  double *G = gscratch + (size_t)mtx * 2 * p2 * p2;
+  const int nr = (p2 - sub + 15) >> 4;
+  const double tol = (double)p2 * 2.220446049250313e-16, tol2 = tol * tol;
+  if (tid == 0) any = 0;
+  // ---- load: columns [ba*16, +16) -> sm[0..15], [bb*16, +16) -> sm[16..31]; columns past p2 are zero
+  // (a block is BJ_B * p2 CONTIGUOUS doubles of the column-major factor; p2 and LDr are even: 16-byte moves, 8 in
+  //  flight per lane -- with one 8-byte load at a time a workgroup pulls ~4 GB/s and the copy dominates the visit)
+  constexpr int BJ_U = 8;
+  const int half = p2 >> 1;
+  for (int cblk = 0; cblk < (lone ? 1 : 2); ++cblk) {
+    const int c0 = (cblk == 0 ? ba : bb) * BJ_B;
+    const int ncv = min(BJ_B, p2 - c0);                    // real columns of this block
+    const int n2 = ncv * half;
+    const double2 *src = reinterpret_cast<const double2 *>(G + (size_t)c0 * p2);
+    for (int base = tid; base < BJ_B * half; base += BJ_NT * BJ_U) {
+      double2 v[BJ_U];
+#pragma unroll
+      for (int u = 0; u < BJ_U; ++u) {
+        const int idx = base + BJ_NT * u;
+        v[u] = (idx < n2) ? src[idx] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < BJ_U; ++u) {
+        const int idx = base + BJ_NT * u;
+        if (idx < BJ_B * half) {
+          const int cc = idx / half, r2 = idx - cc * half;
+          *reinterpret_cast<double2 *>(sm + (size_t)(cblk * BJ_B + cc) * LDr + 2 * r2) = v[u];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int ncolw = lone ? BJ_B : 2 * BJ_B;
+  for (int j = grp; j < ncolw; j += 16) {       // exact squared norms of the columns in LDS
+    double sacc = 0.0;
+    for (int i = 0; i < nr; ++i) { const double x = sm[(size_t)j * LDr + sub + 16 * i]; sacc = __builtin_fma(x, x, sacc); }
+    sacc = vshfl_sum16(sacc);
+    if (sub == 0) nrm[j] = sacc;
+  }
+  __syncthreads();
+  bool rotated = false;
+  // ---- the pairs inside each block, once per sweep: 15 steps of 8 pairs per block (groups 0-7: block a, 8-15: block b)
+  if (step == 0) {
+    const int blk = grp >> 3, k = grp & 7;
+    const bool work = !(lone && blk == 1);
+    for (int s = 0; s < BJ_B - 1; ++s) {
+      if (work) {
+        int a, b;
+        rr_pair_w(s, k, BJ_B - 1, a, b);
+        double *ga = sm + (size_t)(blk * BJ_B + a) * LDr + sub, *gb = sm + (size_t)(blk * BJ_B + b) * LDr + sub;
+        double xa[EG_RMAX], xb[EG_RMAX];
+#pragma unroll
+        for (int i = 0; i < EG_RMAX; ++i) {
+          const int ii = min(i, nr - 1);
+          const double u = ga[16 * ii], v = gb[16 * ii];
+          xa[i] = i < nr ? u : 0.0;
+          xb[i] = i < nr ? v : 0.0;
+        }
+        double ab = 0.0;
+#pragma unroll
+        for (int i = 0; i < EG_RMAX; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
+        ab = vshfl_sum16(ab);
+        const double aa = nrm[blk * BJ_B + a], bbn = nrm[blk * BJ_B + b];
+        double cs, sn;
+        if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {
+          rotated = true;
+#pragma unroll
+          for (int i = 0; i < EG_RMAX; ++i) {
+            if (i < nr) {
+              ga[16 * i] = cs * xa[i] - sn * xb[i];
+              gb[16 * i] = sn * xa[i] + cs * xb[i];
+            }
+          }
+          if (sub == 0) {
+            const double cc = cs * cs, ss = sn * sn, x2 = 2.0 * cs * sn * ab;
+            nrm[blk * BJ_B + a] = cc * aa - x2 + ss * bbn;
+            nrm[blk * BJ_B + b] = ss * aa + x2 + cc * bbn;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- the 256 cross pairs: group i owns a_i (registers), meets b_(i + t) mod 16 at step t
+  if (!lone) {
+    double xa[EG_RMAX];
+    double *ga = sm + (size_t)grp * LDr + sub;
+#pragma unroll
+    for (int i = 0; i < EG_RMAX; ++i) { const int ii = min(i, nr - 1); const double u = ga[16 * ii]; xa[i] = i < nr ? u : 0.0; }
+    double aa = nrm[grp];
+    for (int t = 0; t < BJ_B; ++t) {
+      const int j = (grp + t) & (BJ_B - 1);
+      double *gb = sm + (size_t)(BJ_B + j) * LDr + sub;
+      double xb[EG_RMAX];
+#pragma unroll
+      for (int i = 0; i < EG_RMAX; ++i) { const int ii = min(i, nr - 1); const double v = gb[16 * ii]; xb[i] = i < nr ? v : 0.0; }
+      double ab = 0.0;
+#pragma unroll
+      for (int i = 0; i < EG_RMAX; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
+      ab = vshfl_sum16(ab);
+      const double bbn = nrm[BJ_B + j];
+      double cs, sn;
+      if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {
+        rotated = true;
+#pragma unroll
+        for (int i = 0; i < EG_RMAX; ++i) {
+          const double na = cs * xa[i] - sn * xb[i], nb = sn * xa[i] + cs * xb[i];
+          xa[i] = na;
+          if (i < nr) gb[16 * i] = nb;
+        }
+        const double cc = cs * cs, ss = sn * sn, x2 = 2.0 * cs * sn * ab;
+        if (sub == 0) nrm[BJ_B + j] = ss * aa + x2 + cc * bbn;
+        aa = cc * aa - x2 + ss * bbn;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < EG_RMAX; ++i) if (i < nr) ga[16 * i] = xa[i];
+  }
+  if (rotated) any = 1;
+  __syncthreads();
+  // ---- store
+  for (int cblk = 0; cblk < (lone ? 1 : 2); ++cblk) {
+    const int c0 = (cblk == 0 ? ba : bb) * BJ_B;
+    const int n2 = min(BJ_B, p2 - c0) * half;
+    double2 *dst = reinterpret_cast<double2 *>(G + (size_t)c0 * p2);
+#pragma unroll 4
+    for (int idx = tid; idx < n2; idx += BJ_NT) {
+      const int cc = idx / half, r2 = idx - cc * half;
+      dst[idx] = *reinterpret_cast<const double2 *>(sm + (size_t)(cblk * BJ_B + cc) * LDr + 2 * r2);
+    }
+  }
+  if (tid == 0 && any) rot[mtx] = 1;
+}
+
+// after a sweep: a matrix without a rotation is finished
+__global__ void k_blockjac_flags(int nb, int32_t *__restrict__ done, int32_t *__restrict__ rot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  if (!rot[i]) done[i] = 1;
+  rot[i] = 0;
+}
+
+// a matrix still rotating after the last sweep goes to the single-workgroup kernel (mode 2), which has its own cap
+__global__ void k_blockjac_leftover(int nb, int32_t *__restrict__ cflag, const int32_t *__restrict__ done) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb && cflag[i] == 0 && !done[i]) cflag[i] = 1;
+}
+
+// eigenvalues = squared column norms of the orthogonalised factor, eigenvectors = normalised columns
+__global__ __launch_bounds__(512) void k_blockjac_finish(const double *__restrict__ gscratch, int p, int p2, int c0,
+                                                          const int32_t *__restrict__ cflag, double *__restrict__ lam_out,
+                                                          double *__restrict__ evec_out) {
+  __shared__ double nrm[512];
+  if (cflag[blockIdx.x] != 0) return;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int c = c0 + blockIdx.x;
+  const double *G = gscratch + (size_t)blockIdx.x * 2 * p2 * p2;
+  for (int j = tid; j < p; j += nthr) {
+    double sacc = 0;
+    for (int r = 0; r < p2; ++r) { const double x = G[(size_t)j * p2 + r]; sacc += x * x; }
+    nrm[j] = sacc;
+    lam_out[(size_t)c * p + j] = sacc;
+  }
+  __syncthreads();
+  for (int i = tid; i < p * p; i += nthr) {
+    const int j = i / p, b = i - j * p;
+    const double s2 = nrm[j];
+    evec_out[(size_t)c * p * p + i] = s2 > 0.0 ? G[(size_t)j * p2 + b] / sqrt(s2) : ((j == b) ? 1.0 : 0.0);
+  }
+}
+
 }  // namespace
 
 // scratch per column of a batch: X~ + Z (L x p each), r (L x NA16), W (p x p), C (p x NA16), G|V (2 p2^2)
 static size_t wide_col_bytes(const SfGeom &g) {
   const size_t L = g.lines, p = g.p, na = (size_t)g.nu * 16, p2 = g.p + (g.p & 1);
-  return sf_align((2 * L * p + L * na + p * p + p * na + 2 * p2 * p2) * sizeof(double));
+  return sf_align((2 * L * p + L * na + p * p + p * na + 2 * p2 * p2) * sizeof(double) + 64);   // + 3 flag words per column
 }
 int sf_wide_batch(const SfGeom &g) {
   const size_t per = wide_col_bytes(g);
   size_t b = ((size_t)8 << 30) / per;
   if (b < 1) b = 1;
   if (b > (size_t)g.ncols) b = g.ncols;
+  if (b < (size_t)g.ncols && b >= 8) {
+    // the blocked Jacobi runs one 111 KB workgroup per CU, (block pairs) x (matrices of the batch) workgroups per
+    // launch: pick the batch in [b/2, b] whose launches fill their last round of 256 CUs best (p = 425: 36 columns
+    // -> 504 workgroups = 1.97 rounds, against 47 -> 658 = 2.57 rounds paid as 3)
+    const int p2 = g.p + (g.p & 1);
+    const int nblk = sf_cdiv(p2, 16), npair = (nblk + (nblk & 1)) / 2;
+    double best = 0.0;
+    size_t pick = b;
+    for (size_t c = b; c >= b / 2 && c >= 1; --c) {
+      const double wg = (double)npair * (double)c;
+      const double rounds = (double)((long long)((wg + 255.0) / 256.0));
+      const double fill = wg / (256.0 * rounds);
+      if (fill > best + 1e-9) { best = fill; pick = c; }
+    }
+    b = pick;
+  }
   return (int)b;
 }
 static int wide_nll_splits(const SfGeom &g) { return sf_cdiv(g.lines, 512) > 64 ? 64 : sf_cdiv(g.lines, 512); }
@@ -409,6 +651,43 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
 int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
                          const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
                          hipStream_t st);
+
+int g_wide_eigh_variant = 0;   // sf_debug_set(10, 1): the single-workgroup k_eigh_global for every matrix
+
+// eigendecomposition of a batch of nb correlation matrices (columns c0 .. c0+nb-1)
+static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int c0, int nb, double *d, double *lam, double *evec,
+                     int32_t *status, double *gv, int32_t *cflag, int32_t *done, int32_t *rot, hipStream_t st) {
+  if (g_wide_eigh_variant == 1) {
+    hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 0, cflag);
+    SF_LAUNCH_CHECK("k_eigh_global");
+    return 0;
+  }
+  hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 1, cflag);
+  SF_LAUNCH_CHECK("k_eigh_global(prep)");
+  SF_HIP(hipMemsetAsync(done, 0, (size_t)nb * sizeof(int32_t), st));
+  SF_HIP(hipMemsetAsync(rot, 0, (size_t)nb * sizeof(int32_t), st));
+  const int nblk = sf_cdiv(p2, BJ_B), mblk = nblk + (nblk & 1);
+  int LDr = p2;
+  while ((LDr % 32) != 16) ++LDr;
+  const size_t lds = ((size_t)2 * BJ_B * LDr + 2 * BJ_B) * sizeof(double);
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac), lds)) return rc;
+  const int nsteps = (mblk > 1) ? mblk - 1 : 1;
+  for (int sweep = 0; sweep < 20; ++sweep) {       // converged matrices drop out by their flag; no host round trip
+    // (10-12 sweeps on flightline-like spectra; a matrix still rotating after 20 is redone by k_eigh_global, mode 2)
+    for (int s = 0; s < nsteps; ++s) {
+      hipLaunchKernelGGL(k_blockjac, dim3(mblk / 2 > 0 ? mblk / 2 : 1, nb), dim3(BJ_NT), lds, st, gv, p2, LDr, nblk, mblk > 1 ? mblk : 2, s,
+                         cflag, done, rot);
+    }
+    hipLaunchKernelGGL(k_blockjac_flags, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, done, rot);
+  }
+  SF_LAUNCH_CHECK("k_blockjac");
+  hipLaunchKernelGGL(k_blockjac_leftover, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, cflag, done);
+  hipLaunchKernelGGL(k_blockjac_finish, dim3(nb), dim3(512), 0, st, gv, p, p2, c0, cflag, lam, evec);
+  SF_LAUNCH_CHECK("k_blockjac_finish");
+  hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 2, cflag);
+  SF_LAUNCH_CHECK("k_eigh_global(fallback)");
+  return 0;
+}
 
 int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const int32_t *nloo,
                          const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
@@ -433,6 +712,7 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
   double *W = rm + (size_t)bc * L * NA16;
   double *Cm = W + (size_t)bc * p * p;
   double *gv = Cm + (size_t)bc * p * NA16;
+  int32_t *flags = reinterpret_cast<int32_t *>(gv + (size_t)bc * 2 * p2 * p2);   // cflag | done | rot, bc each
   for (int c0 = 0; c0 < g.ncols; c0 += bc) {
     const int nb = (g.ncols - c0 < bc) ? g.ncols - c0 : bc;
     // nuse: the rows the covariance is made of (ddof 1); nloo: the n of beta and of 1/(2n) (robust_mf.py:109, :116) --
@@ -450,8 +730,7 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
     SF_LAUNCH_CHECK("k_dgemm(syrk)");
     hipLaunchKernelGGL(k_scale_cov, dim3(64, nb), dim3(256), 0, st, cov, nuse, p, c0);
     SF_LAUNCH_CHECK("k_scale_cov");
-    hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv);
-    SF_LAUNCH_CHECK("k_eigh_global");
+    if (int rc = wide_eigh(cov, nuse, p, p2, c0, nb, d, lam, evec, status, gv, flags, flags + bc, flags + 2 * bc, st)) return rc;
     hipLaunchKernelGGL(k_wmat, dim3(64, nb), dim3(256), 0, st, evec, d, p, c0, W);
     SF_LAUNCH_CHECK("k_wmat");
     hipLaunchKernelGGL(k_cmat, dim3(64, nb), dim3(256), 0, st, lam, nloo, status, alphas, g.nalpha, NA16, p, c0, Cm);

@@ -33,7 +33,9 @@ __global__ void k_center(const XT *__restrict__ xt, const uint8_t *__restrict__ 
 
 // C[M x N] = op(A) B, float64, batched over blockIdx.z.  TA: A is stored [K x M] (row-major) instead of [M x K].
 // SQUARE: C = (A B).^2.  Scalar predicated loads (any size); 64x64 block, 4 waves of 32x32, BK = 16.
-template <bool TA, bool SQUARE>
+// SYM (the covariance, C = A^T A with B = A, M = N): only the tiles on and below the diagonal are computed, each
+// written to both triangles.
+template <bool TA, bool SQUARE, bool SYM = false>
 __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, int lda, size_t sA,
                                                 const double *__restrict__ B, int ldb, size_t sB,
                                                 double *__restrict__ Cm, int ldc, size_t sC, int M, int N, int K,
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, int
   const int g = lane >> 4, li = lane & 15;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * WD_BM, n0 = blockIdx.y * WD_BN;
+  if (SYM && n0 > m0) return;
   A += (size_t)blockIdx.z * sA;
   B += (size_t)blockIdx.z * sB;
   Cm += (size_t)blockIdx.z * sC;
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, int
           double v = acc[i][j][r] * scale;
           if (SQUARE) v = v * v;
           Cm[(size_t)m * ldc + n] = v;
+          if (SYM && n0 < m0) Cm[(size_t)n * ldc + m] = v;
         }
       }
 }
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ 
   // mode 0: the whole decomposition here.  mode 1: status, d and the Cholesky factor only (G = L left in gscratch for
   // the blocked Jacobi below; cflag = 0 ok, 1 not positive definite -> mode 2, 2 nothing to do).  mode 2: the whole
   // decomposition, only for the matrices mode 1 flagged 1 (Jacobi on R with V accumulated alongside).
+  // mode 3: like mode 1 without the factorisation -- R is left in gscratch for the blocked Cholesky (k_chol_*).
   __shared__ double dv[512], nrm[512];
   __shared__ int flag[2];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -263,6 +268,10 @@ __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ 
     }
   };
   load_R();
+  if (mode == 3) {
+    if (tid == 0) cflag[blockIdx.x] = 0;
+    return;
+  }
   __syncthreads();
   bool chol_ok = true;
   for (int kk = 0; kk < p; ++kk) {
@@ -391,6 +400,99 @@ __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ 
   }
 }
 
+
+// ---- blocked right-looking Cholesky of the batch (R = L L^T in place, lower triangle of the column-major buffer) ----
+// k_eigh_global factors a 425 x 425 matrix with ONE workgroup and three barriers per column (13.7 ms per batch).  Here:
+// per 16-column panel, k_chol_panel (one workgroup per matrix, the panel in LDS) factors the diagonal block and
+// solves the rows below it, then k_chol_trail applies the rank-16 update to the trailing lower triangle with one
+// workgroup per 64 x 64 tile and matrix.  A non-positive pivot flags the matrix (cflag = 1 -> k_eigh_global, mode 2).
+constexpr int CH_B = 16;
+__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ gscratch, int p, int p2, int kb,
+                                                     int32_t *__restrict__ cflag) {
+  extern __shared__ __attribute__((aligned(16))) double pan[];   // [CH_B][H]: column j of the panel, rows k0 .. p-1
+  __shared__ int bad;
+  const int mtx = blockIdx.x, tid = threadIdx.x;
+  if (cflag[mtx] != 0) return;
+  double *G = gscratch + (size_t)mtx * 2 * p2 * p2;
+  const int k0 = kb * CH_B, nc = min(CH_B, p - k0), H = p - k0;
+  if (tid == 0) bad = 0;
+  for (int i = tid; i < nc * H; i += 256) {
+    const int j = i / H, r = i - j * H;
+    pan[j * H + r] = G[(size_t)(k0 + j) * p2 + k0 + r];
+  }
+  __syncthreads();
+  for (int j = 0; j < nc; ++j) {
+    const double dk = pan[j * H + j];
+    if (!(dk > 0.0) || !(dk <= 1.79769313486231570e+308)) { if (tid == 0) bad = 1; break; }   // uniform
+    const double rk = 1.0 / sqrt(dk);
+    __syncthreads();
+    for (int r = j + tid; r < H; r += 256) pan[j * H + r] = (r == j) ? dk * rk : pan[j * H + r] * rk;
+    __syncthreads();
+    const int rem = nc - j - 1;                      // columns j+1 .. nc-1 of the panel, rows >= their own index
+    for (int e = tid; e < rem * (H - j - 1); e += 256) {
+      const int jj = e / (H - j - 1), rr = e - jj * (H - j - 1);
+      const int c2 = j + 1 + jj, r = j + 1 + rr;
+      if (r >= c2) pan[c2 * H + r] = __builtin_fma(-pan[j * H + r], pan[j * H + c2], pan[c2 * H + r]);
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (bad) {
+    if (tid == 0) cflag[mtx] = 1;
+    return;
+  }
+  for (int i = tid; i < nc * H; i += 256) {
+    const int j = i / H, r = i - j * H;
+    if (r >= j) G[(size_t)(k0 + j) * p2 + k0 + r] = pan[j * H + r];
+  }
+}
+
+// A[i][j] -= sum_k L[i][k] L[j][k] for i >= j in the trailing block (rows / columns >= k1 = (kb + 1) * 16)
+__global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ gscratch, int p, int p2, int kb,
+                                                     const int32_t *__restrict__ cflag) {
+  __shared__ double Li[64][CH_B + 1], Lj[64][CH_B + 1];
+  const int mtx = blockIdx.z, tid = threadIdx.x;
+  if (cflag[mtx] != 0) return;
+  const int k0 = kb * CH_B, k1 = k0 + CH_B;
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (tj > ti) return;                               // lower triangle of tiles
+  const int i0 = k1 + ti * 64, j0 = k1 + tj * 64;
+  if (i0 >= p || j0 >= p) return;
+  double *G = gscratch + (size_t)mtx * 2 * p2 * p2;
+  for (int e = tid; e < 64 * CH_B; e += 256) {
+    const int k = e / 64, r = e - k * 64;
+    Li[r][k] = (i0 + r < p) ? G[(size_t)(k0 + k) * p2 + i0 + r] : 0.0;
+    Lj[r][k] = (j0 + r < p) ? G[(size_t)(k0 + k) * p2 + j0 + r] : 0.0;
+  }
+  __syncthreads();
+  // thread (ri, cj): rows ri, ri+16, ri+32, ri+48 of columns cj, cj+16, ... (consecutive lanes: consecutive rows)
+  const int ri = tid & 15, cj = tid >> 4;
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    const int c = cj + 16 * cc, col = j0 + c;
+    if (col >= p) continue;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = ri + 16 * rr, row = i0 + r;
+      if (row >= p || row < col) continue;
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < CH_B; ++k) acc = __builtin_fma(Li[r][k], Lj[c][k], acc);
+      G[(size_t)col * p2 + row] -= acc;
+    }
+  }
+}
+
+// after the factorisation: zero the strict upper triangle and the padding (G = L)
+__global__ void k_chol_clean(double *__restrict__ gscratch, int p, int p2, const int32_t *__restrict__ cflag) {
+  const int mtx = blockIdx.y;
+  if (cflag[mtx] != 0) return;
+  double *G = gscratch + (size_t)mtx * 2 * p2 * p2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p2 * p2; i += gridDim.x * blockDim.x) {
+    const int col = i / p2, row = i - col * p2;
+    if (row < col || col >= p || row >= p) G[i] = 0.0;
+  }
+}
 
 // ---- blocked one-sided Jacobi for the wide windows -----------------------------------------------------------------
 // k_eigh_global moves the whole p2 x p2 factor through ONE CU's memory pipe every step (p2 - 1 steps a sweep, 2.9 MB
@@ -662,8 +764,23 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
     SF_LAUNCH_CHECK("k_eigh_global");
     return 0;
   }
-  hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 1, cflag);
+  hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 3, cflag);
   SF_LAUNCH_CHECK("k_eigh_global(prep)");
+  {
+    const size_t plds = (size_t)CH_B * p * sizeof(double);
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_chol_panel), plds)) return rc;
+    const int npan = sf_cdiv(p, CH_B);
+    for (int kb = 0; kb < npan; ++kb) {
+      hipLaunchKernelGGL(k_chol_panel, dim3(nb), dim3(256), plds, st, gv, p, p2, kb, cflag);
+      const int rem = p - (kb + 1) * CH_B;
+      if (rem > 0) {
+        const int nt = sf_cdiv(rem, 64);
+        hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt, nb), dim3(256), 0, st, gv, p, p2, kb, cflag);
+      }
+    }
+    hipLaunchKernelGGL(k_chol_clean, dim3(64, nb), dim3(256), 0, st, gv, p, p2, cflag);
+    SF_LAUNCH_CHECK("k_chol");
+  }
   SF_HIP(hipMemsetAsync(done, 0, (size_t)nb * sizeof(int32_t), st));
   SF_HIP(hipMemsetAsync(rot, 0, (size_t)nb * sizeof(int32_t), st));
   const int nblk = sf_cdiv(p2, BJ_B), mblk = nblk + (nblk & 1);
@@ -725,7 +842,7 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
                          L, p, g.ps, c0, xc);
     SF_LAUNCH_CHECK("k_center");
     // S = X~^T X~  (A = X~ stored [K = L][M = p] -> TA)
-    hipLaunchKernelGGL((k_dgemm<true, false>), dim3(sf_cdiv(p, WD_BM), sf_cdiv(p, WD_BN), nb), dim3(256), 0, st, xc, p,
+    hipLaunchKernelGGL((k_dgemm<true, false, true>), dim3(sf_cdiv(p, WD_BM), sf_cdiv(p, WD_BN), nb), dim3(256), 0, st, xc, p,
                        (size_t)L * p, xc, p, (size_t)L * p, cov + (size_t)c0 * p * p, p, (size_t)p * p, p, p, L, 1.0);
     SF_LAUNCH_CHECK("k_dgemm(syrk)");
     hipLaunchKernelGGL(k_scale_cov, dim3(64, nb), dim3(256), 0, st, cov, nuse, p, c0);

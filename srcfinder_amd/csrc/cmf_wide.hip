@@ -203,6 +203,27 @@ __global__ __launch_bounds__(256) void k_nllrows(const double *__restrict__ Rm, 
 // columns; if R is not positive definite, Jacobi on R with V accumulated alongside.  All waves of the workgroup
 // run on one CU and share its L1, so plain loads/stores ordered by __syncthreads() (which drains vmcnt) are
 // coherent; 16 lanes per pair keep a pair's two columns in registers between the dot product and the rotation.
+// 16-lane butterfly sum with DPP lane swaps (no LDS crossbar round trips, cf. cmf_eigh.hip)
+template <int CTRL>
+__device__ __forceinline__ double wd_dpp_swap(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double dpp_sum16(double v) {
+  v += wd_dpp_swap<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += wd_dpp_swap<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += wd_dpp_swap<0x141>(v);  // row_half_mirror
+  v += wd_dpp_swap<0x140>(v);  // row_mirror
+  return v;
+}
+__device__ __forceinline__ double wd_rsqrt(double x) {   // hardware estimate + two Newton steps
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+  y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
 __device__ __forceinline__ double vshfl_sum16(double v) {
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
@@ -511,11 +532,12 @@ __device__ __forceinline__ bool bj_rotation(double aa, double bb, double ab, dou
   const double ab2 = aa * bb;
   if (!(ab2 > 0.0 && ab * ab > tol2 * ab2)) return false;
   const double tau = bb - aa, gam = 2.0 * ab;
-  const double rinv = 1.0 / sqrt(tau * tau + gam * gam);
-  const double c2 = fabs(tau) * rinv;
-  const double h = 0.5 + 0.5 * c2;
-  cs = sqrt(h);
-  sn = fabs(gam) * rinv * 0.5 / cs;
+  const double rinv = wd_rsqrt(__builtin_fma(tau, tau, gam * gam));
+  const double c2 = fabs(tau) * rinv;              // |cos 2 theta|
+  const double h = __builtin_fma(0.5, c2, 0.5);    // cos^2 theta in [0.5, 1]
+  const double rh = wd_rsqrt(h);
+  cs = h * rh;
+  sn = fabs(gam) * rinv * 0.5 * rh;
   sn = ((tau < 0.0) != (gam < 0.0)) ? -sn : sn;
   return true;
 }
@@ -573,7 +595,7 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
   for (int j = grp; j < ncolw; j += 16) {       // exact squared norms of the columns in LDS
     double sacc = 0.0;
     for (int i = 0; i < nr; ++i) { const double x = sm[(size_t)j * LDr + sub + 16 * i]; sacc = __builtin_fma(x, x, sacc); }
-    sacc = vshfl_sum16(sacc);
+    sacc = dpp_sum16(sacc);
     if (sub == 0) nrm[j] = sacc;
   }
   __syncthreads();
@@ -598,7 +620,7 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
         double ab = 0.0;
 #pragma unroll
         for (int i = 0; i < EG_RMAX; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
-        ab = vshfl_sum16(ab);
+        ab = dpp_sum16(ab);
         const double aa = nrm[blk * BJ_B + a], bbn = nrm[blk * BJ_B + b];
         double cs, sn;
         if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {
@@ -636,7 +658,7 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
       double ab = 0.0;
 #pragma unroll
       for (int i = 0; i < EG_RMAX; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
-      ab = vshfl_sum16(ab);
+      ab = dpp_sum16(ab);
       const double bbn = nrm[BJ_B + j];
       double cs, sn;
       if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {

@@ -694,6 +694,116 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
   if (tid == 0 && any) rot[mtx] = 1;
 }
 
+// Steps > 0 of a sweep: cross pairs only.  Group i of 16 lanes takes column a_i straight from global memory into
+// registers (rows sub, sub + 16, ...: 128-byte segments) and puts it back at the end; only the b block goes through
+// LDS (55 KB at p = 425) -- two workgroups per CU, so one's copies run under the other's rotations.
+__global__ __launch_bounds__(BJ_NT) void k_blockjac_x(double *__restrict__ gscratch, int p2, int LDr, int nblk, int mblk, int step,
+                                                       const int32_t *__restrict__ cflag, const int32_t *__restrict__ done,
+                                                       int32_t *__restrict__ rot) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];   // [BJ_B][LDr] (the b block), then nrm[BJ_B]
+  double *nrm = sm + (size_t)BJ_B * LDr;
+  __shared__ int any;
+  const int mtx = blockIdx.y;
+  if (cflag[mtx] != 0 || done[mtx]) return;
+  int ba, bb;
+  rr_pair_w(step, blockIdx.x, mblk - 1, ba, bb);
+  if (ba >= nblk || bb >= nblk) return;          // a lone block has nothing to do outside step 0
+  const int tid = threadIdx.x, grp = tid >> 4, sub = tid & 15;
+  double *G = gscratch + (size_t)mtx * 2 * p2 * p2;
+  const int nr = (p2 - sub + 15) >> 4;
+  const double tol = (double)p2 * 2.220446049250313e-16, tol2 = tol * tol;
+  if (tid == 0) any = 0;
+  constexpr int BJ_U = 8;
+  const int half = p2 >> 1;
+  {
+    const int c0 = bb * BJ_B;
+    const int n2 = min(BJ_B, p2 - c0) * half;
+    const double2 *src = reinterpret_cast<const double2 *>(G + (size_t)c0 * p2);
+    for (int base = tid; base < BJ_B * half; base += BJ_NT * BJ_U) {
+      double2 v[BJ_U];
+#pragma unroll
+      for (int u = 0; u < BJ_U; ++u) {
+        const int idx = base + BJ_NT * u;
+        v[u] = (idx < n2) ? src[idx] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < BJ_U; ++u) {
+        const int idx = base + BJ_NT * u;
+        if (idx < BJ_B * half) {
+          const int cc = idx / half, r2 = idx - cc * half;
+          *reinterpret_cast<double2 *>(sm + (size_t)cc * LDr + 2 * r2) = v[u];
+        }
+      }
+    }
+  }
+  // this group's a column (zero past the last real column)
+  const int acol = ba * BJ_B + grp;
+  double *ga = G + (size_t)min(acol, p2 - 1) * p2 + sub;
+  double xa[EG_RMAX];
+#pragma unroll
+  for (int i = 0; i < EG_RMAX; ++i) {
+    const int ii = min(i, nr - 1);
+    const double u = ga[16 * ii];
+    xa[i] = (i < nr && acol < p2) ? u : 0.0;
+  }
+  double aa = 0.0;
+#pragma unroll
+  for (int i = 0; i < EG_RMAX; ++i) aa = __builtin_fma(xa[i], xa[i], aa);
+  aa = dpp_sum16(aa);
+  __syncthreads();
+  {
+    double sacc = 0.0;                            // exact squared norm of b column grp
+    for (int i = 0; i < nr; ++i) { const double x = sm[(size_t)grp * LDr + sub + 16 * i]; sacc = __builtin_fma(x, x, sacc); }
+    sacc = dpp_sum16(sacc);
+    if (sub == 0) nrm[grp] = sacc;
+  }
+  __syncthreads();
+  bool rotated = false;
+  for (int t = 0; t < BJ_B; ++t) {
+    const int j = (grp + t) & (BJ_B - 1);
+    double *gb = sm + (size_t)j * LDr + sub;
+    double xb[EG_RMAX];
+#pragma unroll
+    for (int i = 0; i < EG_RMAX; ++i) { const int ii = min(i, nr - 1); const double v = gb[16 * ii]; xb[i] = i < nr ? v : 0.0; }
+    double ab = 0.0;
+#pragma unroll
+    for (int i = 0; i < EG_RMAX; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
+    ab = dpp_sum16(ab);
+    const double bbn = nrm[j];
+    double cs, sn;
+    if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {
+      rotated = true;
+#pragma unroll
+      for (int i = 0; i < EG_RMAX; ++i) {
+        const double na = cs * xa[i] - sn * xb[i], nb = sn * xa[i] + cs * xb[i];
+        xa[i] = na;
+        if (i < nr) gb[16 * i] = nb;
+      }
+      const double cc = cs * cs, ss = sn * sn, x2 = 2.0 * cs * sn * ab;
+      if (sub == 0) nrm[j] = ss * aa + x2 + cc * bbn;
+      aa = cc * aa - x2 + ss * bbn;
+    }
+    __syncthreads();
+  }
+  if (rotated) any = 1;
+  if (acol < p2) {
+#pragma unroll
+    for (int i = 0; i < EG_RMAX; ++i) if (i < nr) ga[16 * i] = xa[i];
+  }
+  __syncthreads();
+  {
+    const int c0 = bb * BJ_B;
+    const int n2 = min(BJ_B, p2 - c0) * half;
+    double2 *dst = reinterpret_cast<double2 *>(G + (size_t)c0 * p2);
+#pragma unroll 4
+    for (int idx = tid; idx < n2; idx += BJ_NT) {
+      const int cc = idx / half, r2 = idx - cc * half;
+      dst[idx] = *reinterpret_cast<const double2 *>(sm + (size_t)cc * LDr + 2 * r2);
+    }
+  }
+  if (tid == 0 && any) rot[mtx] = 1;
+}
+
 // after a sweep: a matrix without a rotation is finished
 __global__ void k_blockjac_flags(int nb, int32_t *__restrict__ done, int32_t *__restrict__ rot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -810,12 +920,15 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
   while ((LDr % 32) != 16) ++LDr;
   const size_t lds = ((size_t)2 * BJ_B * LDr + 2 * BJ_B) * sizeof(double);
   if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac), lds)) return rc;
+  const size_t ldsx = ((size_t)BJ_B * LDr + BJ_B) * sizeof(double);
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac_x), ldsx)) return rc;
   const int nsteps = (mblk > 1) ? mblk - 1 : 1;
   for (int sweep = 0; sweep < 20; ++sweep) {       // converged matrices drop out by their flag; no host round trip
     // (10-12 sweeps on flightline-like spectra; a matrix still rotating after 20 is redone by k_eigh_global, mode 2)
-    for (int s = 0; s < nsteps; ++s) {
-      hipLaunchKernelGGL(k_blockjac, dim3(mblk / 2 > 0 ? mblk / 2 : 1, nb), dim3(BJ_NT), lds, st, gv, p2, LDr, nblk, mblk > 1 ? mblk : 2, s,
-                         cflag, done, rot);
+    hipLaunchKernelGGL(k_blockjac, dim3(mblk / 2 > 0 ? mblk / 2 : 1, nb), dim3(BJ_NT), lds, st, gv, p2, LDr, nblk, mblk > 1 ? mblk : 2, 0,
+                       cflag, done, rot);
+    for (int s = 1; s < nsteps; ++s) {
+      hipLaunchKernelGGL(k_blockjac_x, dim3(mblk / 2, nb), dim3(BJ_NT), ldsx, st, gv, p2, LDr, nblk, mblk, s, cflag, done, rot);
     }
     hipLaunchKernelGGL(k_blockjac_flags, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, done, rot);
   }

@@ -67,3 +67,16 @@ class FlightlinePipeline:
     def synchronize(self):
         for st in self.streams:
             st.synchronize()
+
+    def close(self):
+        """Wait for everything in flight and release the scratch buffers of this pipeline's streams."""
+        self.synchronize()
+        for st in self.streams:
+            cmf._Workspace._bufs.pop((str(self.device), int(st.cuda_stream)), None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

@@ -660,6 +660,10 @@ def test_flightline_pipeline_matches_sequential_calls(torch_cuda, library):
         assert torch.equal(r.colstats, s.colstats)
     with pytest.raises(ValueError):
         pipe.submit(cubes[0], library, to_numpy=True)
+    keys = [(str(pipe.device), int(st.cuda_stream)) for st in pipe.streams]
+    assert all(k in cmf._Workspace._bufs for k in keys)
+    pipe.close()
+    assert not any(k in cmf._Workspace._bufs for k in keys)           # the slots' scratch is released
 
 
 def test_wide_function_level_entries_separate_n_and_cov(torch_cuda):

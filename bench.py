@@ -183,6 +183,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_score<true>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "bytes_per_pixel": bytes_per_pixel,
+                         # the same launch priced with SURVEY.md §8(d)'s score-only figure (4p + 8 B/pixel), i.e. not
+                         # counting the RGB bands this kernel also reads and the 24 B of them it writes per pixel
+                         "frac_score_only_4p_plus_8": round((4 * p + 8) * lines * ncols / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                         if score_ms > 0 else 0.0,
                          "avg_launch_ms": round(score_ms, 4), "launches": nlaunch.value},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -701,3 +701,28 @@ def test_wide_path_block_geometries(torch_cuda, rows, p):
     assert len(bad) == 0 or (bad[-1] - bad[0] == len(bad) - 1 and i_o not in bad)
     np.testing.assert_allclose(nll_g[both], nll_o[both], rtol=1e-8)
     np.testing.assert_allclose(c_g, c_o, rtol=1e-9, atol=1e-12 * np.abs(c_o).max())
+
+
+def test_cli_multimodal_flags_reach_the_device_path(torch_cuda, tmp_path, library):
+    """cli_robust_mf -k 3 -r -f -m on an ENVI file == robust_mf(kmeans=3, reject=True, full=True) on the same cube
+    (device k-means, default seed), header string with the reference's multimodal fields (robust_mf.py:246-259)."""
+    from srcfinder_amd import cli_robust_mf, envi
+    cube = make_cube_numpy(700, 6, seed=808, abscf_full=library[:, 2], nodata_lines=3, nodata_column=4)
+    cube[200:420] *= np.float32(1.4)
+    cube[600:630] *= np.float32(2.5)
+    inp = str(tmp_path / "ang_mm_rdn")
+    mm = envi.create_image(inp, {"lines": 700, "samples": 6, "bands": 425, "data ignore value": -9999}, np.float32, "bil")
+    mm[...] = cube
+    mm.flush()
+    libpath = str(tmp_path / "ang_ch4_unit_3col_425chan.txt")
+    np.savetxt(libpath, library, fmt="%.12f")
+    outp = str(tmp_path / "ang_mm_ch4mf")
+    assert cli_robust_mf.main(["-k", "3", "-r", "-f", "-m", inp, libpath, outp]) == 0
+    prod, meta = envi.open_memmap(outp)
+    bg, _ = envi.open_memmap(outp + "_bgmeta")
+    ref = cmf.robust_mf(cube, np.loadtxt(libpath), kmeans=3, reject=True, full=True, metadata=True, to_numpy=True)
+    assert np.array_equal(np.asarray(prod), ref.out) and np.array_equal(np.asarray(bg), ref.bgmeta)
+    assert meta["model parameters"] == ("{ modelname=looshrinkage, bgmodel=multimodal, bgmodes=3, pcadim=6, reject=True, "
+                                        "regfull=True, aminexp=-10.0, amaxexp=0.0, astep=0.05, reflectance=False, "
+                                        "active_bands=[351, 422] }")
+    assert len(np.unique(np.asarray(bg)[..., 0])) >= 3          # clusters were found (a rejected one shows as -id)

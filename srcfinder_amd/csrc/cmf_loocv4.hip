@@ -156,9 +156,9 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
   __syncthreads();
 
   double P[NM], N[NM];
-  int E[NM];
+  int E[NM], sg[NM];   // sg: OR of the sign words of every q seen (a negative q makes log(q), hence the NLL, NaN in the reference)
 #pragma unroll
-  for (int u = 0; u < NM; ++u) { P[u] = 1.0; N[u] = 0.0; E[u] = 0; }
+  for (int u = 0; u < NM; ++u) { P[u] = 1.0; N[u] = 0.0; E[u] = 0; sg[u] = 0; }
   int ntile = 0;
   int nrowok = 0;   // valid rows seen by this lane (lanes with g == 0 cover every row of the wave's tiles once)
 
@@ -263,7 +263,6 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
     // independent instructions (one stage per MFMA step of the NEXT group: a tile's update is a chain of ~10
     // dependent fp64 operations and, issued in one piece, idles the matrix pipe for its whole latency).
     double rm01[TG], rm23[TG], rs01[TG], rs23[TG], rm[TG], rnu[TG];
-    int rsg[TG];
     auto reduce_stage = [&](auto grc, auto stc, auto stagec) {
       constexpr int gq = decltype(grc)::value, st = decltype(stc)::value, stage = decltype(stagec)::value;
       constexpr int ntile = (NM - gq * TG) < TG ? (NM - gq * TG) : TG;
@@ -276,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
         } else if constexpr (stage == 0) {
           const double q0 = acc[st][k][0], q1 = acc[st][k][1], q2 = acc[st][k][2], q3 = acc[st][k][3];
           rm01[k] = q0 * q1; rm23[k] = q2 * q3; rs01[k] = q0 + q1; rs23[k] = q2 + q3;
-          rsg[k] = __double2hiint(q0) | __double2hiint(q1) | __double2hiint(q2) | __double2hiint(q3);
+          sg[u] |= __double2hiint(q0) | __double2hiint(q1) | __double2hiint(q2) | __double2hiint(q3);   // any q < 0 so far
         } else if constexpr (stage == 1) {
           rm[k] = rm01[k] * rm23[k];
           rnu[k] = __builtin_fma(rs01[k], rm23[k], rs23[k] * rm01[k]);
@@ -287,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
           const int e = __builtin_amdgcn_frexp_exp(rm[k]);
           P[u] = __builtin_amdgcn_frexp_mant(rm[k]);
           const double nn = __builtin_amdgcn_ldexp(rnu[k], -e);
-          N[u] = (rsg[k] < 0) ? qnan : nn;   // some q < 0: log(q) is NaN in the reference
+          N[u] = nn;
           E[u] += e;
         }
       }
@@ -332,6 +331,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
 #pragma unroll
   for (int u = 0; u < NM; ++u) {
     double pv = P[u], rv = N[u] / P[u] - 4.0 * (double)ntile;   // sum over this lane's rows of (1/q - 1) = beta r/q
+    if (sg[u] < 0) rv = qnan;                                      // applied once, here, instead of per 16-row tile
     int ev = E[u];
 #pragma unroll
     for (int msk = 16; msk <= 32; msk <<= 1) {
@@ -438,9 +438,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
   __syncthreads();
 
   double P[NM], N[NM];
-  int E[NM];
+  int E[NM], sg[NM];   // sg: OR of the sign words of every q seen (a negative q makes log(q), hence the NLL, NaN in the reference)
 #pragma unroll
-  for (int u = 0; u < NM; ++u) { P[u] = 1.0; N[u] = 0.0; E[u] = 0; }
+  for (int u = 0; u < NM; ++u) { P[u] = 1.0; N[u] = 0.0; E[u] = 0; sg[u] = 0; }
   int ntile = 0;
   int nrowok = 0;   // valid rows seen by this lane (lanes with g == 0 cover every row of the wave's tiles once)
 
@@ -565,7 +565,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
     // independent instructions (one stage per MFMA step of the NEXT group: a tile's update is a chain of ~10
     // dependent fp64 operations and, issued in one piece, idles the matrix pipe for its whole latency).
     double rm01[TG], rm23[TG], rs01[TG], rs23[TG], rm[TG], rnu[TG];
-    int rsg[TG];
     auto reduce_stage = [&](auto grc, auto stc, auto stagec) {
       constexpr int gq = decltype(grc)::value, st = decltype(stc)::value, stage = decltype(stagec)::value;
       constexpr int ntile = (NM - gq * TG) < TG ? (NM - gq * TG) : TG;
@@ -578,7 +577,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
         } else if constexpr (stage == 0) {
           const double q0 = acc[st][k][0], q1 = acc[st][k][1], q2 = acc[st][k][2], q3 = acc[st][k][3];
           rm01[k] = q0 * q1; rm23[k] = q2 * q3; rs01[k] = q0 + q1; rs23[k] = q2 + q3;
-          rsg[k] = __double2hiint(q0) | __double2hiint(q1) | __double2hiint(q2) | __double2hiint(q3);
+          sg[u] |= __double2hiint(q0) | __double2hiint(q1) | __double2hiint(q2) | __double2hiint(q3);   // any q < 0 so far
         } else if constexpr (stage == 1) {
           rm[k] = rm01[k] * rm23[k];
           rnu[k] = __builtin_fma(rs01[k], rm23[k], rs23[k] * rm01[k]);
@@ -589,7 +588,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
           const int e = __builtin_amdgcn_frexp_exp(rm[k]);
           P[u] = __builtin_amdgcn_frexp_mant(rm[k]);
           const double nn = __builtin_amdgcn_ldexp(rnu[k], -e);
-          N[u] = (rsg[k] < 0) ? qnan : nn;   // some q < 0: log(q) is NaN in the reference
+          N[u] = nn;
           E[u] += e;
         }
       }
@@ -639,6 +638,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
 #pragma unroll
   for (int u = 0; u < NM; ++u) {
     double pv = P[u], rv = N[u] / P[u] - 4.0 * (double)ntile;   // sum over this lane's rows of (1/q - 1) = beta r/q
+    if (sg[u] < 0) rv = qnan;                                      // applied once, here, instead of per 16-row tile
     int ev = E[u];
 #pragma unroll
     for (int msk = 16; msk <= 32; msk <<= 1) {

@@ -726,3 +726,20 @@ def test_cli_multimodal_flags_reach_the_device_path(torch_cuda, tmp_path, librar
                                         "regfull=True, aminexp=-10.0, amaxexp=0.0, astep=0.05, reflectance=False, "
                                         "active_bands=[351, 422] }")
     assert len(np.unique(np.asarray(bg)[..., 0])) >= 3          # clusters were found (a rejected one shows as -id)
+
+
+def test_wide_eigensolver_variants_agree(torch_cuda, golden_dir, library):
+    """The blocked eigensolver of the wide path (default) and the single-workgroup kernel it replaced (debug key 10)
+    give the same product on the reference's reflectance configuration (p = 416): alpha indices exact, scores 1e-9."""
+    L = _ffi.lib()
+    cube = make_cube_numpy(300, 5, seed=4, abscf_full=library[:, 2], nodata_column=2)
+    a = cmf.robust_mf(cube, library, reflectance=True, to_numpy=True)
+    L.sf_debug_set(10, 1)
+    try:
+        b = cmf.robust_mf(cube, library, reflectance=True, to_numpy=True)
+    finally:
+        L.sf_debug_set(10, 0)
+    assert np.array_equal(a.alphaidx, b.alphaidx) and np.array_equal(a.status, b.status)
+    nod = a.out[..., 3] == -9999.0
+    assert np.array_equal(nod, b.out[..., 3] == -9999.0)
+    np.testing.assert_allclose(a.out[..., 3][~nod], b.out[..., 3][~nod], rtol=1e-9, atol=1e-12 * np.abs(b.out[..., 3][~nod]).max())

@@ -8,6 +8,7 @@
 // 256-byte runs of one column's consecutive (line, band) values.  HBM-bound: 4p B read + 4p B written
 // per pixel.
 #include "cmf_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -135,6 +136,135 @@ __global__ __launch_bounds__(256) void k_extract(const float *__restrict__ cube,
     if (wave == 0) {
       cnt_part[chunk * Cs + colbase + lane] = nvalid;
       for (int b = p; b < PS; ++b) o[b] = 0.0;
+    }
+  }
+}
+
+// Software-pipelined form of k_extract<TL, true> for a single band chunk (p <= XT_PBMAX, the production window): the
+// (line, band) rows of tile i+1 are requested into registers BEFORE tile i is taken out of LDS, and the barriers
+// order LDS only (s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads() would drain vmcnt and with it the prefetch), so the
+// global loads of one tile stay in flight under the validity test, the xt stores and the column sums of the previous
+// one.  Measured on the full flightline: loads alone 1.59 ms, stores alone 1.13 ms, unpipelined 2.01 ms, this 1.43 ms.
+// The band count is a template parameter: with runtime trip counts every load and LDS store sits in its own
+// exec-masked block with a vmcnt(0) wait (174 VGPRs, two workgroups per CU, 2.49 ms).
+// Same arithmetic, same order of the masked sums: bit-identical outputs.
+__device__ __forceinline__ void xt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// (152 VGPRs: three workgroups per CU; forcing four -- 128 VGPRs -- spills and is slower: 1.96 against 1.43 ms)
+template <int TL, int P>
+__global__ __launch_bounds__(256) void k_extract_pipe(const float *__restrict__ cube, int L, int B, int C, int s0,
+                                                       int Cs, int b0, int PS, float *__restrict__ xt,
+                                                       uint8_t *__restrict__ mask_t, int lines_per_wg, int cs, int ncb,
+                                                       int nchunk, double *__restrict__ sum_part, int *__restrict__ cnt_part) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ uint8_t vf[64][4];
+  static_assert((TL * P) % 4 == 0, "rows of a tile split evenly over the four waves");
+  constexpr int NSUM = (P + 3) / 4;
+  constexpr int NLD = TL * P / 4;                          // rows per wave per tile: row = wave + 4 u
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int cbi, chunk;
+  if (!sf_xcd_map(blockIdx.x, ncb, nchunk, cbi, chunk)) return;
+  const int colbase = cbi * 64;
+  const int ncol = min(64, Cs - colbase);
+  const bool colok = lane < ncol;
+  const int lbeg = chunk * lines_per_wg;
+  const int lend = min(L, lbeg + lines_per_wg);
+  const int lanec = colok ? lane : ncol - 1;
+  const float *cbase = cube + (size_t)(s0 + colbase) + (size_t)b0 * C;
+  double sums[NSUM];
+  int nvalid = 0;
+#pragma unroll
+  for (int i = 0; i < NSUM; ++i) sums[i] = 0.0;
+  float v[NLD];
+  // rows of the tile starting at line l0 -> registers; lines past the chunk alias its last line (loaded, not stored)
+  auto request = [&](int l0) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int rr = wave + 4 * u;
+      const int l = rr / P, b = rr - l * P;                // wave-uniform
+      const int line = min(l0 + l, lend - 1);
+      v[u] = (cbase + ((size_t)line * B + b) * C)[lanec];
+    }
+  };
+  auto body = [&](int l0, auto fullc) {
+    constexpr bool FULL = decltype(fullc)::value;
+    const int nl = FULL ? TL : min(TL, lend - l0);
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int rr = wave + 4 * u;
+      if (FULL || rr < nl * P) tile[lane * cs + rr] = v[u];
+    }
+    xt_lds_barrier();
+    if (l0 + TL < lend) request(l0 + TL);                 // in flight until the top of the next iteration
+    if (FULL || wave < nl) {
+      if (wave < TL) {
+        bool ok = true;
+        const float *tp = tile + lane * cs + wave * P;
+#pragma unroll 8
+        for (int b = 0; b < P; ++b) ok = ok & sf_valid(tp[b]);
+        vf[lane][wave] = ok ? 1 : 0;
+      }
+    }
+    xt_lds_barrier();                                     // vf of this tile is complete
+    if (P == PS) {
+      const int nel = nl * P;
+      for (int c = wave; c < ncol; c += 4) {
+        float *dst = xt + ((size_t)(colbase + c) * L + l0) * PS;
+        const float *src = tile + c * cs;
+        for (int k = lane; k < nel; k += 64) dst[k] = src[k];
+      }
+    } else {
+      for (int c = wave; c < ncol; c += 4) {
+        for (int l = 0; l < nl; ++l) {
+          float *dst = xt + ((size_t)(colbase + c) * L + l0 + l) * PS;
+          const float *src = tile + c * cs + l * P;
+          for (int b = lane; b < PS; b += 64) dst[b] = (b < P) ? src[b] : 0.f;
+        }
+      }
+    }
+    {
+      bool vl[TL];
+#pragma unroll
+      for (int l = 0; l < TL; ++l) vl[l] = (FULL || l < nl) && vf[lane][l];
+      if (wave == 0) {
+#pragma unroll
+        for (int l = 0; l < TL; ++l) nvalid += vl[l] ? 1 : 0;
+      }
+      const float *tp = tile + lane * cs;
+#pragma unroll
+      for (int i = 0; i < NSUM; ++i) {
+        const int b = wave + 4 * i;
+        if (b < P) {
+#pragma unroll
+          for (int l = 0; l < TL; ++l)
+            if (vl[l]) sums[i] += (double)tp[l * P + b];
+        }
+      }
+    }
+    if (wave == 0 && colok) {
+      uint8_t *mp = mask_t + (size_t)(colbase + lane) * L + l0;
+      if (TL == 2 && nl == 2 && (((size_t)(colbase + lane) * L + l0) & 1) == 0) {
+        *reinterpret_cast<uint16_t *>(mp) = *reinterpret_cast<const uint16_t *>(&vf[lane][0]);
+      } else {
+        for (int l = 0; l < nl; ++l) mp[l] = vf[lane][l];
+      }
+    }
+    xt_lds_barrier();                                     // tile and vf are rewritten by the next iteration
+  };
+  if (lbeg < lend) request(lbeg);
+  int l0 = lbeg;
+  for (; l0 + TL <= lend; l0 += TL) body(l0, std::true_type{});
+  if (l0 < lend) body(l0, std::false_type{});
+  if (colok) {
+    double *o = sum_part + ((size_t)chunk * Cs + colbase + lane) * PS;
+#pragma unroll
+    for (int i = 0; i < NSUM; ++i) {
+      const int b = wave + 4 * i;
+      if (b < P) o[b] = sums[i];
+    }
+    if (wave == 0) {
+      cnt_part[chunk * Cs + colbase + lane] = nvalid;
+      for (int b = P; b < PS; ++b) o[b] = 0.0;
     }
   }
 }
@@ -335,7 +465,7 @@ __global__ __launch_bounds__(XF_NT) void k_extract_flat(const float *__restrict_
 
 }  // namespace
 
-int g_extract_variant = 0;  // sf_debug_set key 6: 1 = never use the flat (narrow-cube) kernel
+int g_extract_variant = 0;  // sf_debug_set key 6: 1 = never use the flat (narrow-cube) kernel, 2 = the unpipelined blocked kernel
 
 static int extract_chunks(int lines, int ncols, int *lpw_out) {
   const int lpw = sf_extract_lines_per_wg(lines, ncols);
@@ -369,7 +499,11 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
     return 0;
   }
   const int ncb = sf_cdiv(ncols, 64);
-  if (fuse)
+  if (fuse && g_extract_variant != 2 && p == 72) {     // the production window: software-pipelined kernel
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_pipe<TL, 72>), maxlds)) return rc;
+    hipLaunchKernelGGL((k_extract_pipe<TL, 72>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), lds, st, cube, lines, bands, samples,
+                       s0, ncols, b0, PS, xt, mask_t, lpw, cs, ncb, nchunk, sum_part, cnt_part);
+  } else if (fuse)
     hipLaunchKernelGGL((k_extract<TL, true>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), lds, st, cube, lines, bands,
                        samples, s0, ncols, b0, p, PS, xt, mask_t, lpw, pbmax, cs, ncb, nchunk, sum_part, cnt_part);
   else

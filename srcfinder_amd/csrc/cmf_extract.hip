@@ -208,10 +208,16 @@ __global__ __launch_bounds__(256) void k_extract_pipe(const float *__restrict__ 
     xt_lds_barrier();                                     // vf of this tile is complete
     if (P == PS) {
       const int nel = nl * P;
+      constexpr int NST = (TL * P + 63) / 64;
       for (int c = wave; c < ncol; c += 4) {
         float *dst = xt + ((size_t)(colbase + c) * L + l0) * PS;
         const float *src = tile + c * cs;
-        for (int k = lane; k < nel; k += 64) dst[k] = src[k];
+        float r[NST];
+#pragma unroll
+        for (int j = 0; j < NST; ++j) r[j] = src[min(lane + 64 * j, nel - 1)];   // the LDS reads first, then the stores
+#pragma unroll
+        for (int j = 0; j < NST; ++j)
+          if (lane + 64 * j < nel) dst[lane + 64 * j] = r[j];
       }
     } else {
       for (int c = wave; c < ncol; c += 4) {
@@ -371,11 +377,11 @@ __global__ __launch_bounds__(XF_NT) void k_extract_flat(const float *__restrict_
                                                        int p, int PS, int TL, float *__restrict__ xt,
                                                        uint8_t *__restrict__ mask_t, int lines_per_wg,
                                                        double *__restrict__ sum_part, int *__restrict__ cnt_part) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];   // [TL][p][C], then int vf[TL][C]
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [TL][p][C] rounded up to whole XF_NT rows, then int vf[TL][C]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int chunk = blockIdx.x;
   const int rowlen = p * C;
-  int *vf = reinterpret_cast<int *>(tile + (size_t)TL * rowlen);
+  int *vf = reinterpret_cast<int *>(tile + (size_t)XF_NT * ((TL * rowlen + XF_NT - 1) / XF_NT));
   const int lbeg = chunk * lines_per_wg, lend = min(L, lbeg + lines_per_wg);
   const bool fuse = sum_part != nullptr;
   double sums[XF_MAXSUM];
@@ -399,12 +405,16 @@ __global__ __launch_bounds__(XF_NT) void k_extract_flat(const float *__restrict_
   for (int l0 = lbeg; l0 < lend; l0 += TL) {
     const int nl = min(TL, lend - l0);
     const int n = nl * rowlen;
+    // whole rows of XF_NT floats (a uniform trip count: per-lane predicates would put every store in its own
+    // exec-masked block with a vmcnt(0) wait); the clamped duplicates of the last row land in the slack before vf
+    const int kmax = (n + XF_NT - 1) / XF_NT;
 #pragma unroll
     for (int k = 0; k < XF_MAXLD; ++k)
-      if (tid + XF_NT * k < n) tile[tid + XF_NT * k] = v[k];
+      if (k < kmax) tile[tid + XF_NT * k] = v[k];
     for (int i = tid; i < nl * C; i += XF_NT) vf[i] = 1;
+    // LDS-only barriers from here on: __syncthreads() would wait for the tile requested next (vmcnt(0))
+    xt_lds_barrier();
     if (l0 + TL < lend) fetch(l0 + TL);
-    __syncthreads();
     // ---- validity of (line, column): four threads share the bands of one pixel
     for (int i = tid; i < nl * C * 4; i += XF_NT) {
       const int qd = i & 3, lc = i >> 2;
@@ -414,17 +424,24 @@ __global__ __launch_bounds__(XF_NT) void k_extract_flat(const float *__restrict_
       for (int b = qd; b < p; b += 4) ok = ok & sf_valid(tp[b * C]);
       if (!ok) vf[lc] = 0;   // benign race: every writer stores 0
     }
-    __syncthreads();
+    xt_lds_barrier();
     // ---- LDS -> xt: a wave writes the nl*PS contiguous floats of a column
     const int nel = nl * PS;
+    constexpr int XF_NST = (4 * XT_PBMAX + 63) / 64;        // <= 4 lines x 80 floats per column: 5 elements per lane
     for (int c = wave; c < C; c += XF_NT / 64) {
       float *dst = xt + ((size_t)c * L + l0) * PS;
-#pragma unroll 4
-      for (int k = lane; k < nel; k += 64) {
+      float r[XF_NST];
+#pragma unroll
+      for (int j = 0; j < XF_NST; ++j) {                     // all LDS reads first (clamped), then the stores
+        const int k = min(lane + 64 * j, nel - 1);
         const int l = (k >= PS) + (k >= 2 * PS) + (k >= 3 * PS);
         const int b = k - l * PS;
-        dst[k] = (b < p) ? tile[(size_t)l * rowlen + b * C + c] : 0.f;
+        const float t = tile[(size_t)l * rowlen + min(b, p - 1) * C + c];
+        r[j] = (b < p) ? t : 0.f;
       }
+#pragma unroll
+      for (int j = 0; j < XF_NST; ++j)
+        if (lane + 64 * j < nel) dst[lane + 64 * j] = r[j];
     }
     for (int i = tid; i < nl * C; i += XF_NT) {
       const int l = i / C, c = i - l * C;
@@ -445,7 +462,7 @@ __global__ __launch_bounds__(XF_NT) void k_extract_flat(const float *__restrict_
       if (tid < C)
         for (int l = 0; l < nl; ++l) nvalid += vf[l * C + tid];
     }
-    __syncthreads();
+    xt_lds_barrier();
   }
   if (fuse) {
 #pragma unroll
@@ -491,7 +508,7 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
       ncols <= 256 && g_extract_variant != 1) {
     int tl = (XF_NT * XF_MAXLD) / (p * ncols);
     if (tl > 4) tl = 4;
-    const size_t ldsf = ((size_t)tl * p * ncols + (size_t)tl * ncols) * sizeof(float);
+    const size_t ldsf = ((size_t)XF_NT * (((size_t)tl * p * ncols + XF_NT - 1) / XF_NT) + (size_t)tl * ncols) * sizeof(float);
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_flat), ldsf > 64 * 1024 ? ldsf : (size_t)64 * 1024)) return rc;
     hipLaunchKernelGGL(k_extract_flat, dim3(nchunk), dim3(XF_NT), ldsf, st, cube, lines, bands, samples, b0, p, PS, tl, xt,
                        mask_t, lpw, fuse ? sum_part : nullptr, fuse ? cnt_part : nullptr);

@@ -89,7 +89,7 @@ class CMFResult:
     alphaidx [samples] int32 (-1: every NLL was inf; untouched columns -2)
     nuse     [samples] int32 valid rows per column
     status   [samples] int32: 0 ok, 1 no valid rows, 2 singular covariance
-    nll      [samples, 201] float64 or None
+    nll      [samples, 201] float64 or None ([samples, k, 201] per cluster when kmeans > 1)
     """
     out: object
     bgmeta: object
@@ -213,17 +213,15 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
         nll = torch.empty((ncols, nalpha), dtype=torch.float64, device=dev) if return_nll else None
         L = _ffi.lib()
         if kmeans > 1:
-            if return_nll:
-                raise NotImplementedError("return_nll with kmeans > 1")
             r = rgb_bands if nb == 4 else (0, 0, 0)
             res = _multimodal(torch, L, cube_bil, lines, bands, samples, s0, s1, a0, p, abscf, alphas, nalpha,
                               bool(reflectance), r, float(nodata), out_t, out_samples, out_s0, nb, bgmeta, kmeans,
                               int(pcadim), labels, int(kmeans_seed), int(kmeans_iters), bool(reject), bool(full),
-                              int((a1 - a0) * 1.2))                                     # bgminsamp, robust_mf.py:200
+                              int((a1 - a0) * 1.2), bool(return_nll))                   # bgminsamp, robust_mf.py:200
             res.modelparms = model_parameters(reflectance, (a0, a1), bgmodes=kmeans, pcadim=int(pcadim), reject=reject,
                                               regfull=full)
             if to_numpy:
-                for k in ("out", "bgmeta", "colstats", "alphaidx", "nuse", "status", "labels"):
+                for k in ("out", "bgmeta", "colstats", "alphaidx", "nuse", "status", "labels", "nll"):
                     v = getattr(res, k)
                     if v is not None:
                         setattr(res, k, v.cpu().numpy())
@@ -249,7 +247,7 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
 
 def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alphas, nalpha, reflectance, rgb, nodata,
                 out_t, out_samples, out_s0, nb, bgmeta, k, pcadim, labels, seed, iters, reject=False, full=False,
-                bgminsamp=85):
+                bgminsamp=85, return_nll=False):
     """Multimodal column loop (robust_mf.py:306-386): stage entry points of the C ABI, once per cluster with the row
     mask  valid & (label == ki);  stage 5 gets the COLUMN's valid-row count as n (:355-356).
     reject (-r, :317-341): clusters of fewer than bgminsamp rows (never label 0: -0 == 0, :323) are relabelled -l in the
@@ -321,6 +319,7 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
                          P(ws), st), "sf_cmf_score")
     alphaidx = torch.full((ncols, k), -2, **i32)
     status = torch.ones((ncols, k), **i32)
+    nll_all = torch.full((ncols, k, nalpha), float("inf"), **f64) if return_nll else None   # per cluster (absent: inf)
     labels_valid = torch.where(mask != 0, labels_t, torch.full_like(labels_t, 255))
     keep = None
     if reject:
@@ -348,6 +347,8 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
               "sf_cmf_score_cluster")
         alphaidx[:, ki] = torch.where(status_k == 1, torch.full_like(aidx_k, -2), aidx_k)
         status[:, ki] = status_k
+        if nll_all is not None:
+            nll_all[:, ki] = torch.where((status_k == 0)[:, None], nll, nll_all[:, ki])
     check(L.sf_cmf_colstats_rows(P(out_t), out_samples, out_s0, nb, P(mask if keep is None else keep), lines, ncols, nodata,
                                  P(colstats), st), "sf_cmf_colstats_rows")
     if keep is not None:            # rows of a rejected cluster are never written: they stay NODATA (:266, :341)
@@ -355,7 +356,7 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
     if keep is not None:            # the count column stays the number of valid rows (:389), mean/std skip rejected rows (:388)
         colstats[0] = torch.where(nuse_col > 0, nuse_col.to(torch.float64), colstats[0])
     return CMFResult(out=out_t, bgmeta=bgmeta, colstats=colstats, alphaidx=alphaidx, nuse=nuse_col, status=status,
-                     labels=labels_valid.t().contiguous())
+                     labels=labels_valid.t().contiguous(), nll=nll_all)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -743,3 +743,27 @@ def test_wide_eigensolver_variants_agree(torch_cuda, golden_dir, library):
     nod = a.out[..., 3] == -9999.0
     assert np.array_equal(nod, b.out[..., 3] == -9999.0)
     np.testing.assert_allclose(a.out[..., 3][~nod], b.out[..., 3][~nod], rtol=1e-9, atol=1e-12 * np.abs(b.out[..., 3][~nod]).max())
+
+
+def test_multimodal_return_nll(torch_cuda, golden_dir, library):
+    """return_nll with kmeans > 1: one NLL curve per (column, cluster); its argmin is the cluster's alpha index and it
+    equals the curve looshrinkage() computes for the cluster's rows with n = the column's valid-row count."""
+    g = np.load(os.path.join(golden_dir, "cmf_K2_multimodal.npz"))
+    cube = _k2_cube(g, library)
+    lab = g["bgmeta"][:, :, 0].astype(np.int64)
+    res = cmf.robust_mf(cube, library, kmeans=2, labels=lab, return_nll=True, to_numpy=True)
+    assert res.nll.shape == (cube.shape[2], 2, 201)
+    for c in range(cube.shape[2]):
+        for k in range(2):
+            if res.status[c, k] == 0:
+                assert int(np.argmin(res.nll[c, k])) == int(res.alphaidx[c, k])
+            else:
+                assert np.all(np.isinf(res.nll[c, k]))
+    c, k = 0, 1
+    x = np.float64(cube[:, 350:422, c])
+    valid = ((~(x < 0)) & np.isfinite(x)).all(axis=1)
+    rows = x[valid & (lab[:, c] == k)]
+    nll = np.zeros(201)
+    O.looshrinkage(rows - rows.mean(0), cmf.alpha_grid(), nll, int(valid.sum()))
+    fin = np.isfinite(nll)
+    np.testing.assert_allclose(res.nll[c, k][fin], nll[fin], rtol=1e-9)

@@ -767,3 +767,25 @@ def test_multimodal_return_nll(torch_cuda, golden_dir, library):
     O.looshrinkage(rows - rows.mean(0), cmf.alpha_grid(), nll, int(valid.sum()))
     fin = np.isfinite(nll)
     np.testing.assert_allclose(res.nll[c, k][fin], nll[fin], rtol=1e-9)
+
+
+def test_integration_md_ctypes_stub_runs(torch_cuda, library):
+    """The ctypes stub printed in INTEGRATION.md section 2 is executed as written (its variables are the reference script's
+    locals) and must reproduce robust_mf(): the documentation a maintainer would paste is tested code."""
+    import re
+    torch = torch_cuda
+    md = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    stub = next(b for b in blocks if "L.sf_cmf_run(" in b and "C.CDLL" in b)
+    stub = stub.replace('C.CDLL("libsrcfinder_amd.so")', "C.CDLL(_ffi.LIB_PATH)")
+    cube = make_cube_numpy(300, 9, seed=21, abscf_full=library[:, 2], nodata_column=4)
+    nrows, nbands, ncols = cube.shape
+    active = cmf.active_window("ch4", False)
+    env = dict(np=np, _ffi=_ffi, img_mm=cube, nrows=nrows, nbands=nbands, ncols=ncols, active=list(active),
+               abscf=np.ascontiguousarray(library[active[0] - 1:active[1], 2]), alphas=cmf.alpha_grid(), reflectance=False,
+               rgb_bands=[60, 42, 24], nodata=-9999.0, savebgmeta=True,
+               outimg_mm=np.zeros((nrows, ncols, 4)), bgimg_mm=np.zeros((nrows, ncols, 2), np.int16))
+    exec(compile(stub, "INTEGRATION.md#stub", "exec"), env)
+    ref = cmf.robust_mf(cube, library, metadata=True, to_numpy=True)
+    assert np.array_equal(env["outimg_mm"], ref.out) and np.array_equal(env["bgimg_mm"], ref.bgmeta)
+    assert np.array_equal(env["colnum"], ref.colstats[0]) and np.array_equal(env["colavg"], ref.colstats[1])

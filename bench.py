@@ -187,7 +187,11 @@ def main():
                          # counting the RGB bands this kernel also reads and the 24 B of them it writes per pixel
                          "frac_score_only_4p_plus_8": round((4 * p + 8) * lines * ncols / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                          if score_ms > 0 else 0.0,
-                         "avg_launch_ms": round(score_ms, 4), "launches": nlaunch.value},
+                         "avg_launch_ms": round(score_ms, 4), "launches": nlaunch.value,
+                         "measured": ("the kernel alone on the device (one flightline in flight)" if depth == 1 else
+                                      "in situ: kernels of the %d other flightlines in flight share the device, so this is "
+                                      "a lower bound of the kernel's own rate (run --in-flight 1 for the isolated number)"
+                                      % (depth - 1))},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cube, lib, lines, ncols, args.cpu_columns, res)

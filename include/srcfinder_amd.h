@@ -59,7 +59,7 @@ int sf_cmf_covariance(const void *xt, int xt_f64, const uint8_t *mask_t, const i
 /* Stage 4 -- symmetric eigendecomposition of the correlation matrix R = D^-1 S D^-1 (the restated
  * form of the 201 det+inverse calls at robust_mf.py:105-117): d[ncols][p] = sqrt(diag S),
  * lam[ncols][p], evec[ncols][p][p] (evec[c][j][:] is eigenvector j), status[ncols] (2 when a band has
- * zero or non-finite variance, 1 when nuse == 0). */
+ * zero or non-finite variance, 1 when nuse == 0, 3 when nuse == 1 -- resolved by stage 6). */
 int sf_cmf_eigh(const double *cov, const int32_t *nuse, int p, int ncols, double *d, double *lam,
                 double *evec, int32_t *status, void *scratch, void *stream);
 
@@ -89,9 +89,11 @@ int sf_cmf_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_
 /* Stage 6 -- shrunk covariance C = (1-a)S + a diag(S) (robust_mf.py:130-134), solve, normalise
  * (:363,:378-381): filt[ncols][p] = scale * C^-1 t / (t^T C^-1 t), bias[ncols] = mu . filt, with
  * t = abscf*mu (radiance) or abscf-mu (reflectance != 0); scale = 1e5 or 1 (:383-386).
- * status is updated to 2 where C is singular. */
+ * status is updated to 2 where C is singular.  A column with exactly ONE valid row (status 3 from stage 4) ends as the
+ * reference leaves it: numpy.cov divides by n - 1 = 0, every NLL is NaN, argmin picks index 0 and the score is NaN --
+ * alphaidx := 0, filt = bias = NaN, status := 0. */
 int sf_cmf_filter(const double *mu, const double *d, const double *lam, const double *evec,
-                  const double *alphas, const int32_t *alphaidx, const double *abscf, int reflectance,
+                  const double *alphas, int32_t *alphaidx, const double *abscf, int reflectance,
                   int p, int ncols, int32_t *status, double *filt, double *bias, void *stream);
 
 /* Stage 7 -- the per-pixel matched filter score and output assembly (robust_mf.py:377-397, :266):

@@ -195,7 +195,7 @@ int sf_cmf_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const i
 }
 
 int sf_cmf_filter(const double *mu, const double *d, const double *lam, const double *evec, const double *alphas,
-                  const int32_t *alphaidx, const double *abscf, int reflectance, int p, int ncols, int32_t *status,
+                  int32_t *alphaidx, const double *abscf, int reflectance, int p, int ncols, int32_t *status,
                   double *filt, double *bias, void *stream) {
   if (!mu || !d || !lam || !evec || !alphas || !alphaidx || !abscf || !status || !filt || !bias) {
     sf_set_error("null pointer");

@@ -154,7 +154,7 @@ int sf_launch_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int
                     const double *lam, const double *evec, const int32_t *status, const double *alphas,
                     const SfGeom &g, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st);
 int sf_launch_filter(const double *mu, const double *d, const double *lam, const double *evec, const double *alphas,
-                     const int32_t *alphaidx, const double *abscf, int reflectance, const SfGeom &g,
+                     int32_t *alphaidx, const double *abscf, int reflectance, const SfGeom &g,
                      int32_t *status, double *filt, double *bias, hipStream_t st);
 size_t sf_wide_scratch_bytes(const SfGeom &g);
 int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const int32_t *nloo,

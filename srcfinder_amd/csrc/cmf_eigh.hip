@@ -104,7 +104,8 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
   __syncthreads();
   int st = 0;
   if (n <= 0) st = 1;
-  else if (n < 2 || flag[0]) st = 2;
+  else if (n == 1) st = 3;   // one valid row: numpy.cov (ddof 1) is NaN, every NLL is NaN, argmin = 0, C and the score are NaN
+  else if (flag[0]) st = 2;
   if (tid == 0) status[c] = st;
   if (!unit) for (int i = tid; i < p; i += nthr) d_out[(size_t)c * p + i] = dv[i];
   if (st != 0) {

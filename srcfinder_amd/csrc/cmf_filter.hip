@@ -12,7 +12,7 @@ namespace {
 
 __global__ __launch_bounds__(128) void k_filter(const double *__restrict__ mu, const double *__restrict__ d,
                                                  const double *__restrict__ lam, const double *__restrict__ evec,
-                                                 const double *__restrict__ alphas, const int32_t *__restrict__ alphaidx,
+                                                 const double *__restrict__ alphas, int32_t *__restrict__ alphaidx,
                                                  const double *__restrict__ abscf, int reflectance, int p,
                                                  int32_t *__restrict__ status, double *__restrict__ filt,
                                                  double *__restrict__ bias) {
@@ -26,6 +26,15 @@ __global__ __launch_bounds__(128) void k_filter(const double *__restrict__ mu, c
   const double *muc = mu + (size_t)c * p, *dc = d + (size_t)c * p, *lc = lam + (size_t)c * p;
   const double *ev = evec + (size_t)c * p * p;
   double *fo = filt + (size_t)c * p;
+  if (status[c] == 3) {
+    // exactly one valid row (robust_mf.py:52-70, :92-127): cov() divides by n - 1 = 0 -> a NaN covariance, every NLL is
+    // NaN, numpy.argmin of an all-NaN vector is 0 and NaN != inf, so alpha = alphas[0]; C is NaN, scipy's inv
+    // (check_finite=False) does not raise, and the row's score is NaN.  Reproduced with a NaN filter on a status-0 column.
+    const double qn = __builtin_nan("");
+    for (int b = tid; b < p; b += 128) fo[b] = qn;
+    if (tid == 0) { bias[c] = qn; alphaidx[c] = 0; status[c] = 0; }
+    return;
+  }
   if (status[c] != 0) {  // 1: no valid rows; 2: singular -> the reference writes 0 for the valid rows
     for (int b = tid; b < p; b += 128) fo[b] = 0.0;
     if (tid == 0) bias[c] = 0.0;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(128) void k_filter(const double *__restrict__ mu, c
 }  // namespace
 
 int sf_launch_filter(const double *mu, const double *d, const double *lam, const double *evec, const double *alphas,
-                     const int32_t *alphaidx, const double *abscf, int reflectance, const SfGeom &g, int32_t *status,
+                     int32_t *alphaidx, const double *abscf, int reflectance, const SfGeom &g, int32_t *status,
                      double *filt, double *bias, hipStream_t st) {
   const size_t lds = (size_t)3 * g.p * sizeof(double);
   hipLaunchKernelGGL(k_filter, dim3(g.ncols), dim3(128), lds, st, mu, d, lam, evec, alphas, alphaidx, abscf, reflectance,

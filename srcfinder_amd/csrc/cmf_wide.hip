@@ -271,7 +271,8 @@ __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ 
   __syncthreads();
   int st = 0;
   if (n <= 0) st = 1;
-  else if (n < 2 || flag[0]) st = 2;
+  else if (n == 1) st = 3;   // one valid row: numpy.cov (ddof 1) is NaN, every NLL is NaN, argmin = 0, C and the score are NaN
+  else if (flag[0]) st = 2;
   if (tid == 0) status[c] = st;
   for (int i = tid; i < p; i += nthr) d_out[(size_t)c * p + i] = dv[i];
   if (st != 0) {

@@ -789,3 +789,24 @@ def test_integration_md_ctypes_stub_runs(torch_cuda, library):
     ref = cmf.robust_mf(cube, library, metadata=True, to_numpy=True)
     assert np.array_equal(env["outimg_mm"], ref.out) and np.array_equal(env["bgimg_mm"], ref.bgmeta)
     assert np.array_equal(env["colnum"], ref.colstats[0]) and np.array_equal(env["colavg"], ref.colstats[1])
+
+
+def test_column_with_a_single_valid_row(torch_cuda, library):
+    """Found by tools/fuzz_parity.py: with ONE valid row numpy.cov (ddof 1) is NaN, every NLL is NaN, argmin returns 0,
+    inv() of the NaN matrix does not raise, and the reference writes a NaN score with alpha index 0 (not 0.0, not NODATA)."""
+    cube = make_cube_numpy(120, 4, seed=5, abscf_full=library[:, 2], nodata_column=-1, nodata_lines=0)
+    cube[:, 380, 2] = -9999.0
+    cube[57, 380, 2] = 1.0                        # the only valid row of column 2
+    res = cmf.robust_mf(cube, library, metadata=True, to_numpy=True)
+    with np.errstate(all="ignore"):
+        o = O.robust_mf_oracle(cube, library)
+    assert res.nuse[2] == 1 and o["nuse"][2] == 1
+    assert np.array_equal(res.status, o["status"]) and res.status[2] == 0
+    assert np.array_equal(res.alphaidx, o["alphaidx"]) and res.alphaidx[2] == 0
+    assert np.array_equal(res.bgmeta, o["bgmeta"])
+    assert np.isnan(res.out[57, 2, 3]) and np.isnan(o["out"][57, 2, 3])
+    assert np.array_equal(np.isnan(res.out[..., 3]), np.isnan(o["out"][..., 3]))
+    assert np.array_equal(res.out[..., 3] == -9999.0, o["out"][..., 3] == -9999.0)
+    assert np.isnan(res.colstats[1, 2]) and np.isnan(o["colstats"][1, 2]) and res.colstats[0, 2] == 1
+    ok = [0, 1, 3]
+    assert score_close(res.out[:, ok, 3], o["out"][:, ok, 3]).all()

@@ -320,7 +320,15 @@ __global__ __launch_bounds__(1024) void k_nll(const double *__restrict__ part, i
           rsum = (rows - 1.0) * tr;
         }
       }
-      if (ld < -744.4400719213812) {
+      // det in the denormal range: the reference's product of LU pivots is ROUNDED to a multiple of 2^-1074 before
+      // log() sees it -- a true determinant in [2^-1075, 2^-1074) rounds up to the smallest denormal (a finite NLL with
+      // log det = -744.44), below 2^-1075 it rounds to 0 (skipped).  exp() here rounds the same way; the rounding of the
+      // reference's INTERMEDIATE products (at most the last two factors) is not reproduced.
+      if (ld < -708.0) {
+        const double dt = exp(ld);
+        ld = (dt > 0.0) ? log(dt) : -inf;
+      }
+      if (ld < -745.2) {
         v = inf;  // det underflowed to 0 -> the reference skips this alpha (robust_mf.py:112-113)
       } else {
         if (ld >= 709.782712893384) ld = inf;  // det overflowed -> log(inf)

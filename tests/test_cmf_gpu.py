@@ -254,8 +254,8 @@ def test_odd_and_unusual_windows(torch_cuda, library, active):
 
 
 def test_degenerate_shapes(torch_cuda, library):
-    """One column; fewer lines than a tile; a column with a single valid row (status 2 here, NaN in the reference:
-    documented deviation) next to normal ones; +inf inside the window invalidates the row."""
+    """One column; fewer lines than a tile; a column with a single valid row (NaN score, alpha index 0, as the reference)
+    next to normal ones; +inf inside the window invalidates the row."""
     cube = make_cube_numpy(90, 1, seed=61, abscf_full=library[:, 2], nodata_lines=0, nodata_column=-1)
     cube[5, 360, 0] = np.inf
     res = cmf.robust_mf(cube, library, to_numpy=True)
@@ -271,7 +271,7 @@ def test_degenerate_shapes(torch_cuda, library):
     cube = make_cube_numpy(40, 4, seed=63, abscf_full=library[:, 2], nodata_lines=0, nodata_column=-1)
     cube[1:, 351:360, 1] = -9999.0                              # column 1 keeps exactly one valid row
     res = cmf.robust_mf(cube, library, to_numpy=True)
-    assert res.nuse[1] == 1 and res.status[1] == 2 and res.out[0, 1, 3] == 0.0
+    assert res.nuse[1] == 1 and res.status[1] == 0 and res.alphaidx[1] == 0 and np.isnan(res.out[0, 1, 3])
     o = O.robust_mf_oracle(cube[:, :, [0, 2, 3]], library)
     assert score_close(res.out[:, [0, 2, 3], 3], o["out"][..., 3]).all()
 

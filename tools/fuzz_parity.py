@@ -13,12 +13,17 @@ from oracle import cmf_oracle as O
 
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"      # windows of 97..200 bands: the batched-GEMM / blocked-Jacobi path
 lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
 t0 = time.time()
 for case in range(ncase):
     lines = int(rng.choice([37, 64, 100, 129, 257, 500, 777, 1024, 1500, 2049]))
     samples = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 75, 130]))
     p = int(rng.choice([8, 23, 40, 64, 69, 70, 71, 72, 72, 72, 83, 96]))
+    if WIDE:
+        p = int(rng.choice([97, 100, 112, 128, 129, 160, 200]))
+        samples = int(rng.choice([1, 3, 9]))
+        lines = int(rng.choice([100, 257, 500, 900]))
     a0 = int(rng.integers(1, 425 - p + 1))
     a0 = min(a0, 350) if p == 72 and rng.random() < 0.5 else a0
     active = (a0, a0 + p - 1)

@@ -213,8 +213,8 @@ def test_fcn_shift_and_stitch_matches_reference(fcn_gold, net):
     assert np.array_equal(sal == -9999, want == -9999)
     v = want != -9999
     np.testing.assert_allclose(sal[v], want[v], rtol=5e-3, atol=2e-6)
-    mid = v & (want > 1e-6) & (want < 1 - 1e-6)
-    assert mid.sum() > 200
+    mid = v & (want > 1e-3) & (want < 1 - 1e-3)      # a float32 probability closer to 0 or 1 no longer carries its logit
+    assert mid.sum() > 100
     assert np.abs(_logit(sal[mid]) - _logit(want[mid])).max() < 5e-3
 
 

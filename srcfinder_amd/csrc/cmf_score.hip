@@ -358,17 +358,18 @@ __device__ __forceinline__ void lds_bitonic_sort(float *a, int npow2, int tid) {
     }
   }
 }
-// numpy's method='nearest': round the virtual index (n-1) q half-to-even
-__device__ __forceinline__ int nearest_index(int n, double q) {
-  const double v = (double)(n - 1) * q;
-  const double f = floor(v), g = v - f;
-  int idx = (int)f;
-  if (g > 0.5 || (g == 0.5 && (idx & 1))) ++idx;
+// numpy's method='nearest' on a float32 array (numpy >= 2: NEP 50 keeps the percentile arithmetic in the array's dtype):
+// quantile = float32(q) / float32(100), virtual index = float32(n - 1) * quantile rounded to float32, then rint
+// (half to even).  In float64 the 5th percentile of 2451 values is index 123 (122.50000000000011), numpy takes 122.
+__device__ __forceinline__ int nearest_index(int n, float qpercent) {
+  const float quant = qpercent / 100.0f;
+  const float v = (float)(n - 1) * quant;
+  int idx = (int)rintf(v);
   return idx < 0 ? 0 : (idx >= n ? n - 1 : idx);
 }
 
 __global__ __launch_bounds__(PR_NT) void k_profile_robust(const double *__restrict__ img, int L, int S, int nb, int band,
-                                                           double nodata, double plo, double phi,
+                                                           double nodata, float plo, float phi,
                                                            double *__restrict__ prof) {
   extern __shared__ float vals[];   // [npow2]
   __shared__ int cnt;
@@ -423,8 +424,9 @@ extern "C" int sf_cmf_column_profile_robust(const double *img, int lines, int sa
   while (npow2 < lines) npow2 <<= 1;
   const size_t lds = (size_t)npow2 * sizeof(float);
   if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_profile_robust), lds)) return rc;
-  // the reference's percentile arguments are computed in float64: (1-p)*100 and p*100, then /100 inside numpy
-  const double plo = ((1.0 - p) * 100.0) / 100.0, phi = (p * 100.0) / 100.0;
+  // the reference's percentile arguments are computed in float64, (1-p)*100 and p*100 (srcfinder_util.py:652-653);
+  // numpy divides them by 100 in the array's float32
+  const float plo = (float)((1.0 - p) * 100.0), phi = (float)(p * 100.0);
   hipLaunchKernelGGL(k_profile_robust, dim3(samples), dim3(PR_NT), lds, (hipStream_t)stream, img, lines, samples, nbands, band,
                      nodata, plo, phi, profile);
   SF_LAUNCH_CHECK("k_profile_robust");

@@ -43,11 +43,14 @@ for case in range(ncase):
     abscf = lib.copy()
     if not np.any(abscf[active[0] - 1:active[1], 2]):
         abscf[active[0] - 1:active[1], 2] = -np.abs(np.sin(np.arange(p) / 3.0 + 1.0)) * 0.01
-    desc = "case %d: lines %d samples %d active %s refl %s" % (case, lines, samples, active, refl)
-    g = cmf.robust_mf(cube, abscf, active=active, reflectance=refl, metadata=True, to_numpy=True)
-    o = O.robust_mf_oracle(cube, abscf, active=active, reflectance=refl)
-    ok = np.array_equal(g.out[..., 3] == -9999.0, o["out"][..., 3] == -9999.0)
-    ok = ok and np.array_equal(g.out[..., :3], o["out"][..., :3], equal_nan=True)
+    nodata = float(rng.choice([-9999.0, -9999.0, -1.5, 0.0]))
+    rgb = tuple(int(v) for v in rng.integers(0, 425, size=3)) if rng.random() < 0.7 else ()
+    desc = "case %d: lines %d samples %d active %s refl %s nodata %g rgb %s" % (case, lines, samples, active, refl, nodata, rgb)
+    g = cmf.robust_mf(cube, abscf, active=active, reflectance=refl, metadata=True, to_numpy=True, nodata=nodata, rgb_bands=rgb)
+    o = O.robust_mf_oracle(cube, abscf, active=active, reflectance=refl, nodata=nodata, rgb_bands=rgb)
+    ok = g.out.shape == o["out"].shape and np.array_equal(g.out[..., -1] == nodata, o["out"][..., -1] == nodata)
+    ok = ok and np.array_equal(g.out[..., :-1], o["out"][..., :-1], equal_nan=True)
+    ok = ok and np.allclose(g.colstats, o["colstats"], rtol=1e-6, atol=1e-9 * max(np.nanmax(np.abs(o["colstats"])), 1e-300), equal_nan=True)
     ok = ok and np.array_equal(g.status, o["status"]) and np.array_equal(g.nuse, o["nuse"])
     so = o["status"] == 0
     ok = ok and np.array_equal(g.alphaidx[so], o["alphaidx"][so]) and np.array_equal(g.bgmeta, o["bgmeta"])
@@ -58,8 +61,8 @@ for case in range(ncase):
     for c in range(samples):
         if o["status"][c] != 0 or o["nuse"][c] <= p + 1:
             continue
-        v = o["out"][:, c, 3] != -9999.0
-        a, b = g.out[v, c, 3], o["out"][v, c, 3]
+        v = o["out"][:, c, -1] != nodata
+        a, b = g.out[v, c, -1], o["out"][v, c, -1]
         if a.size:
             e = np.abs(a - b) / (1e-4 * np.abs(b) + 1e-7 * max(np.abs(b).max(), 1e-300))
             worst = max(worst, float(e.max()))

@@ -810,3 +810,20 @@ def test_column_with_a_single_valid_row(torch_cuda, library):
     assert np.isnan(res.colstats[1, 2]) and np.isnan(o["colstats"][1, 2]) and res.colstats[0, 2] == 1
     ok = [0, 1, 3]
     assert score_close(res.out[:, ok, 3], o["out"][:, ok, 3]).all()
+
+
+def test_multimodal_and_wide_column_shards(torch_cuda, golden_dir, library):
+    """columns=(s0, s1) on the multimodal branch (injected labels, -r) and on a wide window: the shard's product equals
+    the same columns of the full run bit for bit (per-column arithmetic independent of the sharding)."""
+    g = np.load(os.path.join(golden_dir, "cmf_K3_reject.npz"))
+    cube = _bright_cube(g, library)
+    lab = np.abs(g["bgmeta"][:, :, 0].astype(np.int64))
+    full = cmf.robust_mf(cube, library, kmeans=3, reject=True, labels=lab, metadata=True, to_numpy=True)
+    part = cmf.robust_mf(cube, library, kmeans=3, reject=True, labels=lab, metadata=True, to_numpy=True, columns=(1, 4))
+    assert np.array_equal(part.out, full.out[:, 1:4], equal_nan=True) and np.array_equal(part.bgmeta, full.bgmeta[:, 1:4])
+    assert np.array_equal(part.alphaidx, full.alphaidx[1:4]) and np.array_equal(part.colstats, full.colstats[:, 1:4], equal_nan=True)
+    cube = make_cube_numpy(260, 7, seed=12, abscf_full=library[:, 2], nodata_column=3)
+    full = cmf.robust_mf(cube, library, reflectance=True, metadata=True, to_numpy=True)
+    part = cmf.robust_mf(cube, library, reflectance=True, metadata=True, to_numpy=True, columns=(2, 6))
+    assert np.array_equal(part.out, full.out[:, 2:6], equal_nan=True) and np.array_equal(part.bgmeta, full.bgmeta[:, 2:6])
+    assert np.array_equal(part.alphaidx, full.alphaidx[2:6])

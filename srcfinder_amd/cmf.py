@@ -255,8 +255,11 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
     over those rows.  If every cluster of a column is rejected none is (:330-332).
     full (-f, :354): the shrinkage target of every cluster is the covariance of the WHOLE column (numpy.cov removes the
     mean again, so the cluster mean subtracted at :354 drops out) -> sf_cmf_eigh_general instead of sf_cmf_eigh."""
-    if p > 96:
-        raise NotImplementedError("multimodal background needs an active window of <= 96 bands")
+    wide = p > 96                       # reflectance / full-band windows: statistics through sf_cmf_wide_stats
+    if p > 512:
+        raise NotImplementedError("active window of more than 512 bands")
+    if wide and full:
+        raise NotImplementedError("the full-column regulariser (-f) on a window of more than 96 bands")
     dev = cube.device
     ncols = s1 - s0
     ps = (p + 3) // 4 * 4
@@ -282,6 +285,10 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
 
     def stats(m, n_rows, n_loo, status, want_alpha=True):
         check(L.sf_cmf_column_mean(P(xt), 0, P(m), lines, p, ncols, P(n_rows), P(mu), P(ws), st), "sf_cmf_column_mean")
+        if wide:        # covariance + eigendecomposition + sweep in one call (the alpha index is a by-product)
+            check(L.sf_cmf_wide_stats(P(xt), 0, P(m), P(n_rows), P(n_loo), P(mu), P(alphas), nalpha, lines, p, ncols, P(S),
+                                      P(d), P(lam), P(evec), P(status), P(nll), P(aidx_k), P(ws), st), "sf_cmf_wide_stats")
+            return
         check(L.sf_cmf_covariance(P(xt), 0, P(m), P(n_rows), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
         if target is not None:
             check(L.sf_cmf_eigh_general(P(S), P(target), P(n_rows), p, ncols, P(r_tmp), P(l_tmp), P(d), P(lam), P(evec),

@@ -187,6 +187,8 @@ __global__ __launch_bounds__(KM_NT) void k_kmeans(const float *__restrict__ y, c
 }
 
 // rowmask_t[c][l] != 0: score the pixel with this cluster's filter and stamp (cluster, alpha index)
+// WGL: windows too wide for a [p][64] float64 LDS tile read the lane's filter vector from global memory (L1/L2 resident)
+template <bool WGL>
 __global__ __launch_bounds__(256) void k_score_cluster(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs,
                                                         int b0, int p, const double *__restrict__ filt,
                                                         const double *__restrict__ bias, const int32_t *__restrict__ status,
@@ -200,10 +202,13 @@ __global__ __launch_bounds__(256) void k_score_cluster(const float *__restrict__
   const int ncol = min(64, Cs - colbase);
   const bool colok = lane < ncol;
   const int col = colbase + (colok ? lane : ncol - 1);
-  for (int idx = tid; idx < 64 * p; idx += 256) {
-    const int cl = idx / p, b = idx - cl * p;
-    ws[b * 64 + cl] = (cl < ncol) ? filt[(size_t)(colbase + cl) * p + b] : 0.0;
+  if (!WGL) {
+    for (int idx = tid; idx < 64 * p; idx += 256) {
+      const int cl = idx / p, b = idx - cl * p;
+      ws[b * 64 + cl] = (cl < ncol) ? filt[(size_t)(colbase + cl) * p + b] : 0.0;
+    }
   }
+  const double *wg = filt + (size_t)col * p;
   const double mybias = bias[col];
   const int st = status[col], ai = alphaidx[col];
   __syncthreads();
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void k_score_cluster(const float *__restrict__
     if (!colok || st == 1 || !rowmask_t[(size_t)col * L + l]) continue;
     const float *xp = cube + ((size_t)l * B + b0) * C + s0 + col;
     double acc = 0.0;
-    for (int b = 0; b < p; ++b) acc = __builtin_fma((double)xp[(size_t)b * C], ws[b * 64 + lane], acc);
+    for (int b = 0; b < p; ++b) acc = __builtin_fma((double)xp[(size_t)b * C], WGL ? wg[b] : ws[b * 64 + lane], acc);
     const size_t pix = (size_t)l * oS + os0 + col;
     out[pix * ob + (ob - 1)] = (st == 2) ? 0.0 : (acc - mybias);   // singular C: the mode's rows get 0 (:373)
     if (bgmeta) {
@@ -276,16 +281,22 @@ int sf_cmf_score_cluster(const float *cube, int lines, int bands, int samples, i
                          int16_t *bgmeta, void *stream) {
   const int ncols = s1 - s0;
   if (!cube || !filt || !bias || !status || !alphaidx || !rowmask_t || !out || ncols < 1 || s0 < 0 || s1 > samples ||
-      b0 < 0 || b0 + p > bands || (out_bands != 1 && out_bands != 4) || (size_t)p * 64 * sizeof(double) > 100 * 1024) {
+      b0 < 0 || b0 + p > bands || (out_bands != 1 && out_bands != 4)) {
     sf_set_error("sf_cmf_score_cluster: bad argument");
     return -1;
   }
   const int lpw = 64;
   const size_t lds = (size_t)p * 64 * sizeof(double);
-  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_score_cluster), lds)) return rc;
-  hipLaunchKernelGGL(k_score_cluster, dim3(sf_cdiv(ncols, 64), sf_cdiv(lines, lpw)), dim3(256), lds, (hipStream_t)stream,
-                     cube, lines, bands, samples, s0, ncols, b0, p, filt, bias, status, alphaidx, rowmask_t, cluster, out,
-                     out_samples, out_s0, out_bands, bgmeta, lpw);
+  const dim3 grid(sf_cdiv(ncols, 64), sf_cdiv(lines, lpw));
+  if (lds > 100 * 1024) {
+    hipLaunchKernelGGL(k_score_cluster<true>, grid, dim3(256), 0, (hipStream_t)stream, cube, lines, bands, samples, s0, ncols,
+                       b0, p, filt, bias, status, alphaidx, rowmask_t, cluster, out, out_samples, out_s0, out_bands, bgmeta, lpw);
+  } else {
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_score_cluster<false>), lds)) return rc;
+    hipLaunchKernelGGL(k_score_cluster<false>, grid, dim3(256), lds, (hipStream_t)stream, cube, lines, bands, samples, s0,
+                       ncols, b0, p, filt, bias, status, alphaidx, rowmask_t, cluster, out, out_samples, out_s0, out_bands,
+                       bgmeta, lpw);
+  }
   SF_LAUNCH_CHECK("k_score_cluster");
   return 0;
 }

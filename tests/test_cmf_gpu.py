@@ -827,3 +827,28 @@ def test_multimodal_and_wide_column_shards(torch_cuda, golden_dir, library):
     part = cmf.robust_mf(cube, library, reflectance=True, metadata=True, to_numpy=True, columns=(2, 6))
     assert np.array_equal(part.out, full.out[:, 2:6], equal_nan=True) and np.array_equal(part.bgmeta, full.bgmeta[:, 2:6])
     assert np.array_equal(part.alphaidx, full.alphaidx[2:6])
+
+
+def test_multimodal_on_a_wide_window(torch_cuda, library):
+    """-R -k 2 (reflectance window 5..420, p = 416) with injected labels and with -r: the per-cluster statistics go through
+    sf_cmf_wide_stats (separate row count and n), the cluster score kernel reads its filter from global memory."""
+    cube = make_cube_numpy(1300, 3, seed=77, abscf_full=library[:, 2], nodata_column=-1, nodata_lines=2)
+    cube[500:900] *= np.float32(1.3)
+    lab = np.zeros((1300, 3), np.int64)
+    lab[500:900] = 1
+    lab[1250:, 1] = 2                                            # a 50-row cluster in column 1: rejected with -r
+    for kw in (dict(kmeans=2, labels=np.minimum(lab, 1)), dict(kmeans=3, labels=lab, reject=True)):
+        res = cmf.robust_mf(cube, library, reflectance=True, metadata=True, to_numpy=True, **kw)
+        with np.errstate(all="ignore"):
+            o = O.robust_mf_multimodal_oracle(cube, library, kw["labels"], reflectance=True, reject=kw.get("reject", False))
+        assert np.array_equal(res.out[..., 3] == -9999.0, o["out"][..., 3] == -9999.0)
+        assert np.array_equal(res.bgmeta, o["bgmeta"])
+        assert score_close(res.out[..., 3], o["out"][..., 3]).all()
+    with pytest.raises(NotImplementedError):
+        cmf.robust_mf(cube, library, reflectance=True, kmeans=2, labels=np.minimum(lab, 1), full=True)
+    a = cmf.robust_mf(cube, library, reflectance=True, kmeans=2, metadata=True, to_numpy=True, kmeans_seed=1)    # device k-means
+    b = cmf.robust_mf(cube, library, reflectance=True, kmeans=2, metadata=True, to_numpy=True, kmeans_seed=1)
+    assert np.array_equal(a.labels, b.labels) and np.array_equal(a.out, b.out)
+    found = a.labels[:, 0]
+    agree = np.mean(found[2:] == np.minimum(lab, 1)[2:, 0])
+    assert max(agree, 1 - agree) > 0.9                           # the brightened block is what it separates

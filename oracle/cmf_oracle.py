@@ -167,7 +167,7 @@ def active_window(gas: str = "ch4", reflectance: bool = False):
 
 def robust_mf_oracle(cube_bil: np.ndarray, library: np.ndarray, *, gas="ch4", reflectance=False,
                      rgb_bands=(60, 42, 24), nodata=-9999.0, active=None, columns=None,
-                     shrinkage=looshrinkage, return_nll=False):
+                     shrinkage=looshrinkage, return_nll=False, model="looshrinkage"):
     """Unimodal (k=1) column loop of cmf/robust_mf.py:297-397 on an in-memory BIL cube.
 
     cube_bil : [lines, bands, samples] (any float dtype; the reference reads float32)
@@ -209,12 +209,15 @@ def robust_mf_oracle(cube_bil: np.ndarray, library: np.ndarray, *, gas="ch4", re
             continue
         mu = np.mean(icol, axis=0)
         try:
-            c, aidx = shrinkage(icol - mu, alphas, nll, nuse)
-            alphaidx[col] = aidx
-            if return_nll:
-                nll_all[col] = nll
-            cinv = inv(c)
-            bgmeta[use, col, 1] = aidx
+            if model == "empirical":                       # -M empirical: the sample covariance itself (:350-351, :366-367)
+                cinv = inv(cov(icol - mu))
+            else:
+                c, aidx = shrinkage(icol - mu, alphas, nll, nuse)
+                alphaidx[col] = aidx
+                if return_nll:
+                    nll_all[col] = nll
+                cinv = inv(c)
+                bgmeta[use, col, 1] = aidx
         except sla.LinAlgError:
             out[use, col, -1] = 0
             status[col] = 2

@@ -168,9 +168,13 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
     kmeans = int(kmeans)
     if kmeans < 1 or kmeans > 8:
         raise ValueError("kmeans must be in 1..8")
-    if model != "looshrinkage":
-        raise NotImplementedError("only the looshrinkage model is built (the 'empirical' branch of the "
-                                  "reference hits a NameError, SURVEY.md D7)")
+    if model not in ("looshrinkage", "empirical"):
+        raise ValueError("model must be 'looshrinkage' or 'empirical'")
+    if model == "empirical":
+        if metadata:
+            raise NameError("name 'alphas' is not defined")       # what the reference does with -M empirical -m (:241-244 vs :275)
+        if kmeans > 1:
+            raise NotImplementedError("the empirical model on the multimodal branch")
     if nodata > 0:
         raise Exception("nodata value=%f > 0, values will not be masked" % nodata)       # robust_mf.py:232-234
     rgb_bands = tuple(int(b) for b in rgb_bands)
@@ -229,6 +233,15 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
         wsb = L.sf_cmf_workspace_bytes(lines, p, ncols, nalpha)
         ws = _Workspace.get(wsb, dev)
         r = rgb_bands if nb == 4 else (0, 0, 0)
+        if model == "empirical":
+            _empirical(torch, L, cube_bil, lines, bands, samples, s0, s1, a0, p, abscf, alphas, bool(reflectance), r,
+                       float(nodata), out_t, out_samples, out_s0, nb, alphaidx, nuse, status, colstats, ws)
+            res = CMFResult(out=out_t, bgmeta=None, colstats=colstats, alphaidx=alphaidx, nuse=nuse, status=status, nll=None,
+                            modelparms=model_parameters(reflectance, (a0, a1), modelname="empirical"))
+            if to_numpy:
+                for k in ("out", "colstats", "alphaidx", "nuse", "status"):
+                    setattr(res, k, getattr(res, k).cpu().numpy())
+            return res
         rc = L.sf_cmf_run(_ffi.ptr(cube_bil), lines, bands, samples, s0, s1, a0 - 1, p, _ffi.ptr(abscf),
                           _ffi.ptr(alphas), nalpha, int(bool(reflectance)), r[0], r[1], r[2], float(nodata),
                           _ffi.ptr(out_t), out_samples, out_s0, nb, _ffi.ptr(alphaidx), _ffi.ptr(nuse),
@@ -243,6 +256,35 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
             if v is not None:
                 setattr(res, k, v.cpu().numpy())
     return res
+
+
+def _empirical(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alphas, reflectance, rgb, nodata, out_t,
+               out_samples, out_s0, nb, alphaidx, nuse, status, colstats, ws):
+    """-M empirical (robust_mf.py:350-351, :366-367): C is the sample covariance itself -- the stage entry points without
+    stage 5; alpha index -1 makes stage 6 use alpha = 0, i.e. C = S."""
+    if p > 96:
+        raise NotImplementedError("the empirical model on a window of more than 96 bands")
+    dev = cube.device
+    ncols = s1 - s0
+    ps = (p + 3) // 4 * 4
+    P, st, check = _ffi.ptr, _ffi.stream_ptr(), _ffi.check
+    f64 = dict(dtype=torch.float64, device=dev)
+    xt = torch.empty((ncols, lines, ps), dtype=torch.float32, device=dev)
+    mask = torch.empty((ncols, lines), dtype=torch.uint8, device=dev)
+    mu, d, lam = (torch.empty((ncols, p), **f64) for _ in range(3))
+    S, evec = torch.empty((ncols, p, p), **f64), torch.empty((ncols, p, p), **f64)
+    filt, bias = torch.empty((ncols, p), **f64), torch.empty(ncols, **f64)
+    check(L.sf_cmf_extract_columns(P(cube), lines, bands, samples, s0, s1, a0 - 1, p, P(xt), P(mask), st), "sf_cmf_extract_columns")
+    check(L.sf_cmf_column_mean(P(xt), 0, P(mask), lines, p, ncols, P(nuse), P(mu), P(ws), st), "sf_cmf_column_mean")
+    check(L.sf_cmf_covariance(P(xt), 0, P(mask), P(nuse), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
+    check(L.sf_cmf_eigh(P(S), P(nuse), p, ncols, P(d), P(lam), P(evec), P(status), P(ws), st), "sf_cmf_eigh")
+    alphaidx.fill_(-1)
+    check(L.sf_cmf_filter(P(mu), P(d), P(lam), P(evec), P(alphas), P(alphaidx), P(abscf), int(reflectance), p, ncols,
+                          P(status), P(filt), P(bias), st), "sf_cmf_filter")
+    alphaidx.fill_(-1)                  # (a single-row column comes back with index 0: the empirical model has none)
+    check(L.sf_cmf_score(P(cube), lines, bands, samples, s0, s1, a0 - 1, p, P(filt), P(bias), P(status), P(alphaidx),
+                         P(nuse), rgb[0], rgb[1], rgb[2], nodata, P(out_t), out_samples, out_s0, nb, None, P(colstats),
+                         P(ws), st), "sf_cmf_score")
 
 
 def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alphas, nalpha, reflectance, rgb, nodata,

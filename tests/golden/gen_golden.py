@@ -68,7 +68,7 @@ def install_spectral_stub():
     sys.modules.update({"spectral": sp, "spectral.io": spio, "spectral.io.envi": envi})
 
 
-def run_reference_main(cube, extra_args=(), libpath=LIB_TXT, tag="in"):
+def run_reference_main(cube, extra_args=(), libpath=LIB_TXT, tag="in", metadata=True):
     """Execute the reference script on `cube` ([lines,bands,samples] f32). Returns dict of outputs."""
     lines, bands, samples = cube.shape
     IN, OUT = "/virtual/%s" % tag, "/virtual/%s_out" % tag
@@ -76,7 +76,7 @@ def run_reference_main(cube, extra_args=(), libpath=LIB_TXT, tag="in"):
     store[IN] = {"lines": lines, "samples": samples, "bands": bands, "interleave": "bil", "data type": 4,
                  "data ignore value": "-9999", "wavelength": ["0"] * bands}
     old_argv = sys.argv
-    sys.argv = ["robust_mf.py", "-m", *extra_args, IN, libpath, OUT]
+    sys.argv = ["robust_mf.py", *(["-m"] if metadata else []), *extra_args, IN, libpath, OUT]
     _map = builtins.map
     frame_globals = {}
     try:
@@ -95,7 +95,7 @@ def run_reference_main(cube, extra_args=(), libpath=LIB_TXT, tag="in"):
         sys.argv = old_argv
     assert frame_globals, "could not recover the column statistics from the reference frame"
     out = arrays[OUT]
-    bg = arrays[OUT + "_bgmeta"]
+    bg = arrays[OUT + "_bgmeta"] if metadata else np.zeros((lines, samples, 2), np.int16)
     return dict(out=out.copy(), bgmeta=bg.copy(),
                 colstats=np.stack([frame_globals["colnum"], frame_globals["colavg"], frame_globals["colstd"]]),
                 modelparms=str(store[OUT]["model parameters"]))

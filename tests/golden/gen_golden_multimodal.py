@@ -63,7 +63,23 @@ def main_reject_full():
                         versions=G.versions())
 
 
+def main_empirical():
+    """-M empirical (sample covariance, no shrinkage; cmf/robust_mf.py:350-351, :366-367) without -m: with -m the reference
+    dies on `alphas`."""
+    G.install_spectral_stub()
+    lib = np.float64(np.loadtxt(G.LIB_TXT))
+    lines, samples, seed = 600, 5, 557
+    cube = G.make_cube_numpy(lines, samples, seed=seed, abscf_full=lib[:, 2], nodata_column=2)
+    r = G.run_reference_main(cube, extra_args=("-M", "empirical"), tag="EMP", metadata=False)
+    print("empirical: score range", r["out"][..., 3][r["out"][..., 3] != -9999].min(), r["out"][..., 3].max(), r["modelparms"])
+    np.savez_compressed(os.path.join(HERE, "cmf_empirical.npz"), seed=seed, lines=lines, samples=samples, nodata_column=2,
+                        out=r["out"], colstats=r["colstats"], modelparms=np.array(r["modelparms"]), versions=G.versions())
+
+
 if __name__ == "__main__":
+    if "--empirical" in sys.argv:
+        main_empirical()
+        sys.exit(0)
     if "--reject-full" in sys.argv:
         main_reject_full()
         sys.exit(0)

@@ -852,3 +852,21 @@ def test_multimodal_on_a_wide_window(torch_cuda, library):
     found = a.labels[:, 0]
     agree = np.mean(found[2:] == np.minimum(lab, 1)[2:, 0])
     assert max(agree, 1 - agree) > 0.9                           # the brightened block is what it separates
+
+
+def test_empirical_model_golden(torch_cuda, golden_dir, library):
+    """-M empirical (C = the sample covariance, no shrinkage) against the golden of the real reference; with metadata the
+    reference dies on an undefined name and so does the mirror."""
+    g = np.load(os.path.join(golden_dir, "cmf_empirical.npz"))
+    cube = make_cube_numpy(int(g["lines"]), int(g["samples"]), seed=int(g["seed"]), abscf_full=library[:, 2],
+                           nodata_column=int(g["nodata_column"]))
+    res = cmf.robust_mf(cube, library, model="empirical", to_numpy=True)
+    ref = g["out"]
+    assert np.array_equal(res.out[..., 3] == -9999.0, ref[..., 3] == -9999.0)
+    assert np.array_equal(res.out[..., :3], ref[..., :3])
+    assert score_close(res.out[..., 3], ref[..., 3]).all()
+    ok = g["colstats"][0] > 0
+    np.testing.assert_allclose(res.colstats[:, ok], g["colstats"][:, ok], rtol=1e-6, atol=1e-9 * np.abs(ref[..., 3]).max())
+    assert res.modelparms == str(g["modelparms"]) and np.all(res.alphaidx == -1)
+    with pytest.raises(NameError):
+        cmf.robust_mf(cube, library, model="empirical", metadata=True)

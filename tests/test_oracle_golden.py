@@ -168,3 +168,13 @@ def test_multimodal_oracle_reproduces_reference_with_full_regulariser(golden_dir
     assert np.array_equal(o["out"], g["out"])
     assert np.array_equal(o["bgmeta"], g["bgmeta"])
     assert np.array_equal(o["colstats"], g["colstats"])
+
+
+def test_empirical_model_oracle_reproduces_reference(golden_dir, library):
+    """-M empirical golden from the real reference (no -m: with it the reference dies on `alphas`)."""
+    g = np.load(os.path.join(golden_dir, "cmf_empirical.npz"))
+    cube = make_cube_numpy(int(g["lines"]), int(g["samples"]), seed=int(g["seed"]), abscf_full=library[:, 2],
+                           nodata_column=int(g["nodata_column"]))
+    o = O.robust_mf_oracle(cube, library, model="empirical")
+    assert np.array_equal(o["out"], g["out"])
+    assert np.array_equal(o["colstats"], g["colstats"])

@@ -249,3 +249,19 @@ def test_fcn_command_line(fcn_gold, tmp_path):
     assert np.array_equal(got == -9999, want == -9999)
     v = want != -9999
     np.testing.assert_allclose(got[v], want[v], rtol=5e-3, atol=2e-6)
+
+
+def test_fcn_fp16_option_is_close_but_separate(fcn_gold):
+    """precision="fp16" on the FCN path (float16 activations / weights, fp32 accumulation, conv1 on the fp32 VALU): its own
+    tolerance -- the un-pooled logits are large, so the comparison is on the logit where float32 can resolve it."""
+    g = fcn_gold
+    net16 = cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024), precision="fp16")
+    sal = cnn.fcn_predict_flightline(g["plane"], "COVID_QC", net=net16, batch=16, to_numpy=True)
+    want = g["saliency"]
+    assert np.array_equal(sal == -9999, want == -9999)
+    v = want != -9999
+    mid = v & (want > 1e-3) & (want < 1 - 1e-3)
+    d = np.abs(_logit(sal[mid]) - _logit(want[mid]))
+    assert d.max() < 0.5 and np.median(d) < 0.05, (d.max(), np.median(d))
+    assert np.abs(sal[v] - want[v]).max() > 0                     # it really is a different arithmetic
+    assert np.mean((sal[v] > 0.5) == (want[v] > 0.5)) > 0.99      # same side of the decision threshold almost everywhere

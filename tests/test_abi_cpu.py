@@ -89,3 +89,25 @@ def test_model_parameter_string_matches_reference_run(golden_dir):
     assert str(g["modelparms"]) == cmf.model_parameters(False, (351, 422))
     g = np.load(os.path.join(golden_dir, "cmf_R_reflectance.npz"))
     assert str(g["modelparms"]) == cmf.model_parameters(True, (5, 420))
+
+
+def test_product_fails_loudly_without_library_or_gpu(monkeypatch, tmp_path):
+    """No CPU fallback: a missing libsrcfinder_amd.so raises from _ffi.lib(), and with no GPU visible the mirror raises
+    before any computation; nothing under srcfinder_amd/ imports the oracle."""
+    import numpy as np
+    import torch
+    from srcfinder_amd import cmf, cnn
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "libsrcfinder_amd.so"))
+    with pytest.raises(_ffi.SrcfinderError, match="no CPU fallback"):
+        _ffi.lib()
+    if not torch.cuda.is_available():
+        with pytest.raises(_ffi.SrcfinderError, match="no GPU visible"):
+            cmf.robust_mf(np.zeros((4, 425, 2), np.float32), np.zeros((425, 3)))
+        with pytest.raises(_ffi.SrcfinderError):
+            cnn.predict_flightline(np.zeros((3, 3), np.float32), weights={})
+    pkg = os.path.join(ROOT, "srcfinder_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn

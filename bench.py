@@ -137,6 +137,7 @@ def main():
     drain()
     L = _ffi.lib()
     barrier()
+    flush_c_stdio()                              # RCCL's version banner (C stdout, buffered) goes out now, not after the result
     L.sf_cmf_score_timing(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -195,12 +196,26 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cube, lib, lines, ncols, args.cpu_columns, res)
-        print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(line), flush=True)      # the last line of the job's output
 
 
 ACTIVE = None
+
+
+def flush_c_stdio():
+    """RCCL prints a version banner to the C stdout of every rank; left in the buffer it would be written at exit, AFTER
+    the JSON line.  Flush it early so that the result is the last line of the job's output."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 def cpu_baseline(cube, lib, lines, ncols, ncpu_cols, res):

@@ -924,8 +924,8 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
   const size_t ldsx = ((size_t)BJ_B * LDr + BJ_B) * sizeof(double);
   if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac_x), ldsx)) return rc;
   const int nsteps = (mblk > 1) ? mblk - 1 : 1;
-  for (int sweep = 0; sweep < 20; ++sweep) {       // converged matrices drop out by their flag; no host round trip
-    // (10-12 sweeps on flightline-like spectra; a matrix still rotating after 20 is redone by k_eigh_global, mode 2)
+  for (int sweep = 0; sweep < 16; ++sweep) {       // converged matrices drop out by their flag; no host round trip
+    // (10-12 sweeps on flightline-like spectra; a matrix still rotating after 16 is redone by k_eigh_global, mode 2)
     hipLaunchKernelGGL(k_blockjac, dim3(mblk / 2 > 0 ? mblk / 2 : 1, nb), dim3(BJ_NT), lds, st, gv, p2, LDr, nblk, mblk > 1 ? mblk : 2, 0,
                        cflag, done, rot);
     for (int s = 1; s < nsteps; ++s) {

@@ -11,69 +11,79 @@ from srcfinder_amd import cmf
 from srcfinder_amd.synth import make_cube_numpy
 from oracle import cmf_oracle as O
 
-ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"      # windows of 97..200 bands: the batched-GEMM / blocked-Jacobi path
 lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
-t0 = time.time()
-for case in range(ncase):
-    lines = int(rng.choice([37, 64, 100, 129, 257, 500, 777, 1024, 1500, 2049]))
-    samples = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 75, 130]))
-    p = int(rng.choice([8, 23, 40, 64, 69, 70, 71, 72, 72, 72, 83, 96]))
-    if WIDE:
-        p = int(rng.choice([97, 100, 112, 128, 129, 160, 200]))
-        samples = int(rng.choice([1, 3, 9]))
-        lines = int(rng.choice([100, 257, 500, 900]))
-    a0 = int(rng.integers(1, 425 - p + 1))
-    a0 = min(a0, 350) if p == 72 and rng.random() < 0.5 else a0
-    active = (a0, a0 + p - 1)
-    refl = bool(rng.random() < 0.2)
-    cube = make_cube_numpy(lines, samples, seed=int(rng.integers(1 << 30)), abscf_full=lib[:, 2],
-                           nodata_lines=int(rng.integers(0, 4)), nodata_column=int(rng.integers(-1, samples)))
-    # sprinkle invalid pixels inside the window; sometimes starve a column of rows or flatten a band
-    k = int(rng.integers(0, 12))
-    for _ in range(k):
-        l, s, b = int(rng.integers(lines)), int(rng.integers(samples)), int(rng.integers(active[0] - 1, active[1]))
-        cube[l, b, s] = rng.choice([np.nan, -1.0, np.inf, -9999.0])
-    if rng.random() < 0.25:
-        s = int(rng.integers(samples)); keep = int(rng.integers(1, p + 5))
-        cube[keep:, active[0] - 1, s] = -9999.0                       # fewer valid rows than bands (or about as many)
-    if rng.random() < 0.15:
-        s = int(rng.integers(samples)); cube[:, active[0] - 1 + int(rng.integers(p)), s] = np.float32(1.5)
-    abscf = lib.copy()
-    if not np.any(abscf[active[0] - 1:active[1], 2]):
-        abscf[active[0] - 1:active[1], 2] = -np.abs(np.sin(np.arange(p) / 3.0 + 1.0)) * 0.01
-    nodata = float(rng.choice([-9999.0, -9999.0, -1.5, 0.0]))
-    rgb = tuple(int(v) for v in rng.integers(0, 425, size=3)) if rng.random() < 0.7 else ()
-    desc = "case %d: lines %d samples %d active %s refl %s nodata %g rgb %s" % (case, lines, samples, active, refl, nodata, rgb)
-    g = cmf.robust_mf(cube, abscf, active=active, reflectance=refl, metadata=True, to_numpy=True, nodata=nodata, rgb_bands=rgb)
-    o = O.robust_mf_oracle(cube, abscf, active=active, reflectance=refl, nodata=nodata, rgb_bands=rgb)
-    ok = g.out.shape == o["out"].shape and np.array_equal(g.out[..., -1] == nodata, o["out"][..., -1] == nodata)
-    ok = ok and np.array_equal(g.out[..., :-1], o["out"][..., :-1], equal_nan=True)
-    wellposed = (o["nuse"] > p + 1) | (o["status"] != 0)          # (statistics of the scores: same exclusion as the scores below)
-    ok = ok and np.array_equal(g.colstats[0], o["colstats"][0]) and \
-        np.allclose(g.colstats[1:, wellposed], o["colstats"][1:, wellposed], rtol=1e-6,
-                    atol=1e-9 * max(np.nanmax(np.abs(o["colstats"])), 1e-300), equal_nan=True)
-    ok = ok and np.array_equal(g.status, o["status"]) and np.array_equal(g.nuse, o["nuse"])
-    so = o["status"] == 0
-    ok = ok and np.array_equal(g.alphaidx[so], o["alphaidx"][so]) and np.array_equal(g.bgmeta, o["bgmeta"])
-    # scores: 1e-4 relative (+ a floor on the column's scale).  Columns with no more valid rows than bands are left out of
-    # the score comparison: S is singular there, the selected alpha is the smallest one or none and C has a condition
-    # number > 1e10 -- the reference's own LU inverse is not reproducible to 1e-4 on such a matrix (indices still are).
-    worst = 0.0
-    for c in range(samples):
-        if o["status"][c] != 0 or o["nuse"][c] <= p + 1:
-            continue
-        v = o["out"][:, c, -1] != nodata
-        a, b = g.out[v, c, -1], o["out"][v, c, -1]
-        if a.size:
-            e = np.abs(a - b) / (1e-4 * np.abs(b) + 1e-7 * max(np.abs(b).max(), 1e-300))
-            worst = max(worst, float(e.max()))
-    ok = ok and worst <= 1.0
-    if not ok:
-        print("MISMATCH", desc)
-        print("  status", g.status, o["status"], "nuse", g.nuse, o["nuse"], "aidx", g.alphaidx, o["alphaidx"])
-        print("  worst score error / tolerance", worst)
-        sys.exit(1)
-    if case % 10 == 9: print("%d cases ok (%.0f s)" % (case + 1, time.time() - t0), flush=True)
-print("fuzz: %d cases, no mismatch" % ncase)
+
+
+def run(ncase=60, seed=0, WIDE=False, verbose=True):
+    """Returns the number of mismatching cases (stops at the first).  WIDE: windows of 97..200 bands (the batched-GEMM /
+    blocked-Jacobi path)."""
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    for case in range(ncase):
+        lines = int(rng.choice([37, 64, 100, 129, 257, 500, 777, 1024, 1500, 2049]))
+        samples = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 75, 130]))
+        p = int(rng.choice([8, 23, 40, 64, 69, 70, 71, 72, 72, 72, 83, 96]))
+        if WIDE:
+            p = int(rng.choice([97, 100, 112, 128, 129, 160, 200]))
+            samples = int(rng.choice([1, 3, 9]))
+            lines = int(rng.choice([100, 257, 500, 900]))
+        a0 = int(rng.integers(1, 425 - p + 1))
+        a0 = min(a0, 350) if p == 72 and rng.random() < 0.5 else a0
+        active = (a0, a0 + p - 1)
+        refl = bool(rng.random() < 0.2)
+        cube = make_cube_numpy(lines, samples, seed=int(rng.integers(1 << 30)), abscf_full=lib[:, 2],
+                               nodata_lines=int(rng.integers(0, 4)), nodata_column=int(rng.integers(-1, samples)))
+        # sprinkle invalid pixels inside the window; sometimes starve a column of rows or flatten a band
+        k = int(rng.integers(0, 12))
+        for _ in range(k):
+            l, s, b = int(rng.integers(lines)), int(rng.integers(samples)), int(rng.integers(active[0] - 1, active[1]))
+            cube[l, b, s] = rng.choice([np.nan, -1.0, np.inf, -9999.0])
+        if rng.random() < 0.25:
+            s = int(rng.integers(samples)); keep = int(rng.integers(1, p + 5))
+            cube[keep:, active[0] - 1, s] = -9999.0                       # fewer valid rows than bands (or about as many)
+        if rng.random() < 0.15:
+            s = int(rng.integers(samples)); cube[:, active[0] - 1 + int(rng.integers(p)), s] = np.float32(1.5)
+        abscf = lib.copy()
+        if not np.any(abscf[active[0] - 1:active[1], 2]):
+            abscf[active[0] - 1:active[1], 2] = -np.abs(np.sin(np.arange(p) / 3.0 + 1.0)) * 0.01
+        nodata = float(rng.choice([-9999.0, -9999.0, -1.5, 0.0]))
+        rgb = tuple(int(v) for v in rng.integers(0, 425, size=3)) if rng.random() < 0.7 else ()
+        desc = "case %d: lines %d samples %d active %s refl %s nodata %g rgb %s" % (case, lines, samples, active, refl, nodata, rgb)
+        g = cmf.robust_mf(cube, abscf, active=active, reflectance=refl, metadata=True, to_numpy=True, nodata=nodata, rgb_bands=rgb)
+        o = O.robust_mf_oracle(cube, abscf, active=active, reflectance=refl, nodata=nodata, rgb_bands=rgb)
+        ok = g.out.shape == o["out"].shape and np.array_equal(g.out[..., -1] == nodata, o["out"][..., -1] == nodata)
+        ok = ok and np.array_equal(g.out[..., :-1], o["out"][..., :-1], equal_nan=True)
+        wellposed = (o["nuse"] > p + 1) | (o["status"] != 0)          # (statistics of the scores: same exclusion as the scores below)
+        ok = ok and np.array_equal(g.colstats[0], o["colstats"][0]) and \
+            np.allclose(g.colstats[1:, wellposed], o["colstats"][1:, wellposed], rtol=1e-6,
+                        atol=1e-9 * max(np.nanmax(np.abs(o["colstats"])), 1e-300), equal_nan=True)
+        ok = ok and np.array_equal(g.status, o["status"]) and np.array_equal(g.nuse, o["nuse"])
+        so = o["status"] == 0
+        ok = ok and np.array_equal(g.alphaidx[so], o["alphaidx"][so]) and np.array_equal(g.bgmeta, o["bgmeta"])
+        # scores: 1e-4 relative (+ a floor on the column's scale).  Columns with no more valid rows than bands are left out of
+        # the score comparison: S is singular there, the selected alpha is the smallest one or none and C has a condition
+        # number > 1e10 -- the reference's own LU inverse is not reproducible to 1e-4 on such a matrix (indices still are).
+        worst = 0.0
+        for c in range(samples):
+            if o["status"][c] != 0 or o["nuse"][c] <= p + 1:
+                continue
+            v = o["out"][:, c, -1] != nodata
+            a, b = g.out[v, c, -1], o["out"][v, c, -1]
+            if a.size:
+                e = np.abs(a - b) / (1e-4 * np.abs(b) + 1e-7 * max(np.abs(b).max(), 1e-300))
+                worst = max(worst, float(e.max()))
+        ok = ok and worst <= 1.0
+        if not ok:
+            print("MISMATCH", desc)
+            print("  status", g.status, o["status"], "nuse", g.nuse, o["nuse"], "aidx", g.alphaidx, o["alphaidx"])
+            print("  worst score error / tolerance", worst)
+            return 1
+        if verbose and case % 10 == 9: print("%d cases ok (%.0f s)" % (case + 1, time.time() - t0), flush=True)
+    if verbose: print("fuzz: %d cases, no mismatch" % ncase)
+    return 0
+
+
+
+if __name__ == "__main__":
+    sys.exit(run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+                 len(sys.argv) > 3 and sys.argv[3] == "wide"))

@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--lines", type=int, default=LINES)
     ap.add_argument("--samples", type=int, default=SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-columns", type=int, default=8)
+    ap.add_argument("--cpu-columns", type=int, default=24)    # ~15-20 s of one host core
     ap.add_argument("--active", type=str, default="", help="a0,a1 (1-based inclusive) override of the active window, e.g. 1,425")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="flightlines in flight per GPU (srcfinder_amd.inflight); 0 = auto: 1 for >= 400 columns per "

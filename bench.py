@@ -35,11 +35,10 @@ def main():
     ap.add_argument("--lines", type=int, default=LINES)
     ap.add_argument("--samples", type=int, default=SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-columns", type=int, default=24)    # ~15-20 s of one host core
+    ap.add_argument("--cpu-columns", type=int, default=12)    # ~7 s of one host core (+ the all-cores sample)
     ap.add_argument("--active", type=str, default="", help="a0,a1 (1-based inclusive) override of the active window, e.g. 1,425")
     ap.add_argument("--in-flight", type=int, default=0,
-                    help="flightlines in flight per GPU (srcfinder_amd.inflight); 0 = auto: 1 for >= 400 columns per "
-                         "rank (the score kernel then runs alone and its HIP-event time is its isolated duration), else 3")
+                    help="flightlines in flight per GPU (srcfinder_amd.inflight); 0 = the default, 3 for every N")
     args = ap.parse_args()
 
     import torch
@@ -73,8 +72,6 @@ def main():
     if args.active:
         a0, a1 = (int(v) for v in args.active.split(","))
     p = a1 - a0 + 1
-    global ACTIVE
-    ACTIVE = (a0, a1)
 
     # synthetic flightline: each rank generates only its own column slice [lines, 425, ncols]
     cube = make_cube_torch(lines, ncols, seed=1234 + rank, abscf_full=lib[:, 2], device=dev,
@@ -86,89 +83,99 @@ def main():
     # stages (eigensolver, rank factorisation: one workgroup per column) run beside another's streaming stages; the
     # gather of flightline i (RCCL, its own stream) overlaps the compute of the following ones.  Every step is still
     # one complete pass over the whole flightline and all K of them finish inside the timed region.
+    # ONE depth policy for every N (default 3): the 1 / 2 / 4 / 8-GPU values are then measured the same way.  The same K
+    # steps are then repeated with ONE flightline in flight: that pass gives the latency of a single flightline
+    # ("one_in_flight") and the score kernel's isolated duration for the roofline (with several flightlines in flight
+    # its HIP-event time includes kernels of the other streams).
     from srcfinder_amd.inflight import FlightlinePipeline
-    depth = args.in_flight if args.in_flight > 0 else (1 if ncols >= 400 else 3)
-    pipe = FlightlinePipeline(depth, dev)
-    outs = [torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev) for _ in range(depth)]
-    pending = [None] * depth                     # per slot: (gather handle, event "the slot's product has been packed")
+    L = _ffi.lib()
     comm = torch.cuda.Stream(device=dev)         # packs and feeds the collective; never the stream submit() waits on
-    state = {"last": None}
-
-    def step():
-        slot = pipe.slot_of_next()
-        if pending[slot] is not None:
-            h, packed = pending[slot]
-            pipe.streams[slot].wait_event(packed)    # flightline i - depth's scores have left this slot's product buffer
-            with torch.cuda.stream(comm):
-                h.wait()                             # its image, assembled on rank 0
-            pending[slot] = None
-        t = pipe.submit(cube, lib, out=outs[slot], out_column0=0, active=(a0, a1))
-        if world > 1 or force_dist:
-            # the single RCCL gather of the score image: the float64 CMF band of every
-            # rank's block, 8 B/pixel; the RGB copy stays with the rank that read those columns
-            with torch.cuda.stream(comm):
-                t.wait(comm)                         # only the comm stream waits for the slot's compute
-                h = sd.gather_columns(outs[slot][..., 3], samples, dst=0, async_op=True)
-                packed = torch.cuda.Event()
-                packed.record(comm)
-            pending[slot] = (h, packed)
-        state["last"] = t
-        return t.result
-
-    def drain():
-        with torch.cuda.stream(comm):
-            for i in range(depth):
-                if pending[i] is not None:
-                    pending[i][0].wait()
-                    pending[i] = None
-        comm.synchronize()
-        pipe.synchronize()
 
     def barrier():
         if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(depth):                       # setup, not warmup: every slot allocates its scratch once
-        step()
-    drain()
-    for _ in range(args.warmup):
-        step()
-    drain()
-    L = _ffi.lib()
-    barrier()
-    flush_c_stdio()                              # RCCL's version banner (C stdout, buffered) goes out now, not after the result
-    L.sf_cmf_score_timing(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    t_enq = time.perf_counter() - t0             # host time to enqueue the K steps (diagnostic)
-    drain()                                      # every gather completes inside the timed region
-    barrier()
-    dt = time.perf_counter() - t0
-    tot_ms = _ffi.C.c_double(0.0)
-    nlaunch = _ffi.C.c_int(0)
-    L.sf_cmf_score_timing_read(_ffi.C.byref(tot_ms), _ffi.C.byref(nlaunch))
-    L.sf_cmf_score_timing(0)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    def timed_pass(depth):
+        pipe = FlightlinePipeline(depth, dev)
+        outs = [torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev) for _ in range(depth)]
+        pending = [None] * depth                 # per slot: (gather handle, event "the slot's product has been packed")
+        state = {}
+
+        def step():
+            slot = pipe.slot_of_next()
+            if pending[slot] is not None:
+                h, packed = pending[slot]
+                pipe.streams[slot].wait_event(packed)    # flightline i - depth's scores have left this slot's product buffer
+                with torch.cuda.stream(comm):
+                    h.wait()                             # its image, assembled on rank 0
+                pending[slot] = None
+            t = pipe.submit(cube, lib, out=outs[slot], out_column0=0, active=(a0, a1))
+            if world > 1 or force_dist:
+                # the single RCCL gather of the score image: the float64 CMF band of every
+                # rank's block, 8 B/pixel; the RGB copy stays with the rank that read those columns
+                with torch.cuda.stream(comm):
+                    t.wait(comm)                         # only the comm stream waits for the slot's compute
+                    h = sd.gather_columns(outs[slot][..., 3], samples, dst=0, async_op=True)
+                    packed = torch.cuda.Event()
+                    packed.record(comm)
+                pending[slot] = (h, packed)
+            state["res"] = t.result
+
+        def drain():
+            with torch.cuda.stream(comm):
+                for i in range(depth):
+                    if pending[i] is not None:
+                        pending[i][0].wait()
+                        pending[i] = None
+            comm.synchronize()
+            pipe.synchronize()
+
+        for _ in range(depth):                   # setup, not warmup: every slot allocates its scratch once
+            step()
+        drain()
+        for _ in range(args.warmup):
+            step()
+        drain()
+        barrier()
+        flush_c_stdio()                          # RCCL's version banner (C stdout, buffered) goes out now, not after the result
+        L.sf_cmf_score_timing(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        t_enq = time.perf_counter() - t0         # host time to enqueue the K steps (diagnostic)
+        drain()                                  # every gather completes inside the timed region
+        barrier()
+        dt = time.perf_counter() - t0
+        tot_ms = _ffi.C.c_double(0.0)
+        nlaunch = _ffi.C.c_int(0)
+        L.sf_cmf_score_timing_read(_ffi.C.byref(tot_ms), _ffi.C.byref(nlaunch))
+        L.sf_cmf_score_timing(0)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        res = state["res"]
+        pipe.close()
+        return {"dt": float(tmax.item()), "t_enq": t_enq, "score_ms": tot_ms.value / max(nlaunch.value, 1),
+                "launches": nlaunch.value, "res": res, "outs": outs}
+
+    depth = args.in_flight if args.in_flight > 0 else 3
+    main = timed_pass(depth)
+    solo = main if depth == 1 else timed_pass(1)
+    res = solo["res"]
 
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        mpix = lines * samples / (dt / args.steps) / 1e6
-        score_ms = tot_ms.value / max(nlaunch.value, 1)
-        # algorithmic bytes of the score kernel per launch: every active value once
-        # (4p B), the three RGB values (12 B), one 32-byte BIP record [R,G,B,CMF] float64 per pixel
-        bytes_per_pixel = 4 * p + 12 + 32
-        alg_bytes = bytes_per_pixel * lines * ncols
+        ms_per_step = main["dt"] / args.steps * 1e3
+        mpix = lines * samples / (main["dt"] / args.steps) / 1e6
+        score_ms = solo["score_ms"]
+        npix = lines * ncols
+        # algorithmic bytes of the score kernel = every active value once (4p B) + one float64 score
+        # (8 B) per pixel; every pixel counts (a NODATA row has to be read to be recognised and its record is written).
+        # The kernel also copies the three RGB bands into the 32-byte BIP record (12 B read + 24 B written per pixel):
+        # that is real traffic of this fused launch but NOT part of §8(d)'s figure -- reported as `frac_with_fused_rgb`.
+        alg_bytes = (4 * p + 8) * npix
         achieved = alg_bytes / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.isfile(pmc) and (lines, samples, p, world) == (LINES, SAMPLES, 72, 1):
-            # HBM bytes per k_score launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see file)
-            traffic = json.load(open(pmc))["kernels"]["k_score"]["hbm_bytes_per_launch"]
+        fused_bytes = (4 * p + 12 + 32) * npix
         line = {
             "metric": "CMF Mpixels/s on 598x20000x425 cube",
             "value": round(mpix, 3), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
@@ -178,24 +185,25 @@ def main():
                                    "window %d..%d (p=%d%s), 201-point LOO shrinkage sweep, unimodal"
                                    % (samples, lines, BANDS, a0, a1, p, ", CH4 radiance" if (a0, a1) == (351, 422) else ""),
                        "parallelism": "columns sharded over %d rank(s), one RCCL gather" % world,
-                       "in_flight": "%d flightlines in flight per GPU (one HIP stream each)" % depth,
-                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+                       "in_flight": "%d flightlines in flight per GPU (one HIP stream each); the same depth for every N"
+                                    % depth,
+                       "host_enqueue_ms_per_step": round(main["t_enq"] / args.steps * 1e3, 3),
+                       "one_in_flight": {"ms_per_step": round(solo["dt"] / args.steps * 1e3, 3),
+                                         "value": round(lines * samples / (solo["dt"] / args.steps) / 1e6, 3),
+                                         "note": "the same K steps with ONE flightline in flight (latency of a flightline)"},
                        "output": "float64 BIP [lines, samples, (R,G,B,CMF)]"},
-            "roofline": {"bound": "hbm", "kernel": "k_score<true>", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_score_rows<RGB>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "bytes_per_pixel": bytes_per_pixel,
-                         # the same launch priced with SURVEY.md §8(d)'s score-only figure (4p + 8 B/pixel), i.e. not
-                         # counting the RGB bands this kernel also reads and the 24 B of them it writes per pixel
-                         "frac_score_only_4p_plus_8": round((4 * p + 8) * lines * ncols / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                         "traffic": None, "bytes_per_pixel": 4 * p + 8,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac_with_fused_rgb": round(fused_bytes / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                          if score_ms > 0 else 0.0,
-                         "avg_launch_ms": round(score_ms, 4), "launches": nlaunch.value,
-                         "measured": ("the kernel alone on the device (one flightline in flight)" if depth == 1 else
-                                      "in situ: kernels of the %d other flightlines in flight share the device, so this is "
-                                      "a lower bound of the kernel's own rate (run --in-flight 1 for the isolated number)"
-                                      % (depth - 1))},
+                         "avg_launch_ms": round(score_ms, 4), "launches": solo["launches"],
+                         "measured": "HIP events on the launch stream around the kernel alone, one flightline in flight"},
         }
+        line["roofline"].update(pmc_traffic(lines, samples, p, world))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cube, lib, lines, ncols, args.cpu_columns, res)
+            line["cpu_baseline"] = cpu_baseline(cube, lib, lines, ncols, args.cpu_columns, res, (a0, a1))
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -204,7 +212,32 @@ def main():
         print(json.dumps(line), flush=True)      # the last line of the job's output
 
 
-ACTIVE = None
+def kernel_source_sha():
+    """sha256 (16 hex) of the score kernel's source: a PMC record is only quoted for the code it was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("cmf_score.hip", "cmf_common.h"):
+        h.update(open(os.path.join(ROOT, "srcfinder_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(lines, samples, p, world):
+    """HBM bytes per launch of the score kernel from the PMC passes of tools/pmc_traffic.sh (FETCH_SIZE x2 + WRITE_SIZE,
+    separate rocprofv3 --pmc runs of this very command).  Counters cannot be read from inside the run, so the figure
+    comes from the committed record -- and ONLY when that record was taken from the kernel source that is being run
+    (same sha) on the same geometry; otherwise `traffic` stays null."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.isfile(path) or (lines, samples, p, world) != (LINES, SAMPLES, 72, 1):
+        return {}
+    rec = json.load(open(path))
+    if rec.get("kernel_source_sha") != kernel_source_sha():
+        return {"traffic_note": "profiles/r02_pmc_traffic.json was taken from a different kernel source: not quoted"}
+    k = rec["kernels"].get("k_score_rows")
+    if not k:
+        return {}
+    return {"traffic": k["hbm_bytes_per_launch"],
+            "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this command at the same kernel "
+                              "source, sha %s; not measured by this run)" % rec["kernel_source_sha"]}
 
 
 def flush_c_stdio():
@@ -218,28 +251,79 @@ def flush_c_stdio():
         pass
 
 
-def cpu_baseline(cube, lib, lines, ncols, ncpu_cols, res):
-    """The oracle (faithful numpy restatement of cmf/robust_mf.py, 201x det+inv+GEMM per column) timed on ONE
-    host core over a bounded sample of the same cube: `ncpu_cols` evenly spaced columns, all lines."""
+def _cpu_columns(job):
+    """Worker of the all-cores baseline (a spawned process: numpy + the oracle only, never torch / HIP)."""
+    sub, lib72 = job
     from oracle import cmf_oracle as O
-    cols = [int(round(i * (ncols - 1) / max(ncpu_cols - 1, 1))) for i in range(ncpu_cols)]
-    cols = sorted(set(c for c in cols if c != ncols // 3))        # skip the all-NODATA column (no work)
-    host = cube[:, :, cols].cpu().numpy()
     t0 = time.perf_counter()
-    o = O.robust_mf_oracle(host, lib, active=ACTIVE)
-    t = time.perf_counter() - t0
-    # parity spot check of the timed sample against the GPU result of the same columns
-    got = res.out[:, cols, 3].cpu().numpy()
-    ref = o["out"][..., 3]
-    nod = ref == -9999.0
-    ok = bool(np.array_equal(got == -9999.0, nod)) and bool(
-        np.all(np.abs(got[~nod] - ref[~nod]) <= 1e-4 * np.abs(ref[~nod]) + 1e-9 * np.abs(ref[~nod]).max()))
-    so = o["status"] == 0
-    aidx_ok = bool(np.array_equal(res.alphaidx.cpu().numpy()[cols][so], o["alphaidx"][so]))
-    return {"value": round(lines * len(cols) / t / 1e6, 5), "unit": "Mpixel/s", "cores": 1, "kind": "port",
-            "sample": "%d evenly spaced columns x %d lines of the benchmark cube, %.1f s, OMP_NUM_THREADS=1"
-                      % (len(cols), lines, t),
-            "parity_on_sample": ok and aidx_ok}
+    o = O.robust_mf_oracle(sub, lib72, active=(1, sub.shape[1]), rgb_bands=(0, 0, 0))
+    return o["out"][..., 3], o["alphaidx"], o["status"], time.perf_counter() - t0
+
+
+def cpu_baseline(cube, lib, lines, ncols, ncpu_cols, res, active):
+    """The oracle (faithful numpy restatement of cmf/robust_mf.py, 201x det+inv+GEMM per column) timed on the host of
+    the GPU box over bounded samples of the same cube:
+      * ONE core: `ncpu_cols` evenly spaced columns, all lines, in this process;
+      * ALL cores: one spawned process per core (OMP_NUM_THREADS=1 each), two columns per core (at most 128 columns);
+        wall time from the first submission to the last result (process start-up is outside: the pool is warm).
+    Only the active window of the sampled columns travels to the workers."""
+    import multiprocessing as mp
+    a0, a1 = active
+    libw = np.ascontiguousarray(np.asarray(lib, np.float64)[a0 - 1:a1])
+
+    def sample(n):
+        cols = [int(round(i * (ncols - 1) / max(n - 1, 1))) for i in range(n)]
+        return sorted(set(c for c in cols if c != ncols // 3))       # skip the all-NODATA column (no work)
+
+    def fetch(cols):
+        idx = torch_index(cols, cube.device)
+        return np.ascontiguousarray(cube[:, a0 - 1:a1, :].index_select(2, idx).cpu().numpy())
+
+    def parity(cols, score, aidx, status):
+        got = res.out[:, cols, 3].cpu().numpy()
+        nod = score == -9999.0
+        ok = bool(np.array_equal(got == -9999.0, nod)) and bool(
+            np.all(np.abs(got[~nod] - score[~nod]) <= 1e-4 * np.abs(score[~nod]) + 1e-9 * np.abs(score[~nod]).max()))
+        so = status == 0
+        return ok and bool(np.array_equal(res.alphaidx.cpu().numpy()[cols][so], aidx[so]))
+
+    # ---- one core
+    cols1 = sample(ncpu_cols)
+    sc, ai, stt, t1 = _cpu_columns((fetch(cols1), libw))
+    one = {"value": round(lines * len(cols1) / t1 / 1e6, 5), "unit": "Mpixel/s", "cores": 1,
+           "sample": "%d evenly spaced columns x %d lines of the benchmark cube, %.1f s" % (len(cols1), lines, t1),
+           "parity_on_sample": parity(cols1, sc, ai, stt)}
+    # ---- all cores
+    cores = os.cpu_count() or 1
+    colsn = sample(min(2 * cores, 128, ncols - 1))
+    sub = fetch(colsn)
+    chunks = [list(range(i, len(colsn), cores)) for i in range(min(cores, len(colsn)))]
+    ctx = mp.get_context("spawn")                # never fork a process that has initialised HIP
+    with ctx.Pool(len(chunks)) as pool:
+        pool.map(_warm, range(len(chunks)))      # imports done before the clock starts
+        t0 = time.perf_counter()
+        outs = pool.map(_cpu_columns, [(np.ascontiguousarray(sub[:, :, ch]), libw) for ch in chunks])
+        tn = time.perf_counter() - t0
+    score = np.empty((lines, len(colsn)))
+    aidx = np.empty(len(colsn), np.int64)
+    status = np.empty(len(colsn), np.int32)
+    for ch, (s_, a_, st_, _t) in zip(chunks, outs):
+        score[:, ch], aidx[ch], status[ch] = s_, a_, st_
+    return {"value": round(lines * len(colsn) / tn / 1e6, 5), "unit": "Mpixel/s", "cores": cores, "kind": "port",
+            "sample": "%d evenly spaced columns x %d lines of the benchmark cube over %d processes (one per host core, "
+                      "OMP_NUM_THREADS=1), %.1f s wall" % (len(colsn), lines, len(chunks), tn),
+            "parity_on_sample": parity(colsn, score, aidx, status),
+            "one_core": one}
+
+
+def _warm(_):
+    from oracle import cmf_oracle  # noqa: F401
+    return 0
+
+
+def torch_index(cols, device):
+    import torch
+    return torch.as_tensor(cols, dtype=torch.long, device=device)
 
 
 if __name__ == "__main__":

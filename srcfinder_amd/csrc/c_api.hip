@@ -1,6 +1,6 @@
 // C ABI of libsrcfinder_amd.so (declared in include/srcfinder_amd.h): argument checks, workspace carving,
-// stage sequencing.  No device allocation, no synchronisation, no global mutable state except the
-// thread-local error string and the optional score-kernel timing list.
+// stage sequencing.  No device allocation, no synchronisation, no process-wide mutable state: the error string, the
+// optional score-kernel timing list and the tuning knobs of sf_debug_set are all per calling thread.
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -8,16 +8,9 @@
 
 #include "cmf_common.h"
 
-extern int g_score_variant, g_score_lpw, g_score_xcd;
-extern int g_wide_eigh_variant;   // cmf_wide.hip  // cmf_score.hip
-extern int g_sweep_variant;                            // cmf_loocv.hip
-extern int g_cov_variant;                              // cmf_cov.hip
-extern int g_extract_variant;                          // cmf_extract.hip
-extern int g_eigh_lpp;                                 // cmf_eigh.hip
-extern int g_sweep4r_waves;                            // cmf_loocv4.hip
-
 namespace {
 thread_local char g_err[512] = "";
+thread_local SfTune g_tune;
 
 struct TimedLaunch {
   hipEvent_t a, b;
@@ -91,12 +84,12 @@ int timed_score(const float *cube, int lines, int bands, int samples, int s0, in
   if (timed) {
     SF_HIP(hipEventCreate(&tl.a));
     SF_HIP(hipEventCreate(&tl.b));
-    SF_HIP(hipEventRecord(tl.a, st));
   }
   int rc = sf_launch_score(cube, lines, bands, samples, s0, ncols, b0, p, filt, bias, status, alphaidx, rgb0, rgb1, rgb2,
-                           nodata, out, out_samples, out_s0, out_bands, bgmeta, scratch, colstats != nullptr, st);
+                           nodata, out, out_samples, out_s0, out_bands, bgmeta, scratch, colstats != nullptr, st,
+                           timed ? tl.a : nullptr, timed ? tl.b : nullptr);
   if (timed) {
-    SF_HIP(hipEventRecord(tl.b, st));
+    if (rc) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); return rc; }
     if (!g_timed) g_timed = new std::vector<TimedLaunch>();
     g_timed->push_back(tl);
   }
@@ -105,6 +98,8 @@ int timed_score(const float *cube, int lines, int bands, int samples, int s0, in
   return rc;
 }
 }  // namespace
+
+SfTune &sf_tune() { return g_tune; }
 
 void sf_set_error(const char *fmt, ...) {
   va_list ap;
@@ -280,15 +275,18 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
 
 int sf_debug_set(int key, int value) {
   switch (key) {
-    case 1: g_score_variant = value; return 0;
-    case 2: g_score_lpw = value; return 0;
-    case 3: g_score_xcd = value; return 0;
-    case 4: g_sweep_variant = value; return 0;
-    case 5: g_cov_variant = value; return 0;
-    case 6: g_extract_variant = value; return 0;
-    case 7: g_eigh_lpp = value; return 0;
-    case 8: g_sweep4r_waves = value; return 0;
-    case 10: g_wide_eigh_variant = value; return 0;
+    case 1: sf_tune().score_variant = value; return 0;
+    case 2: sf_tune().score_lpw = value; return 0;
+    case 3: sf_tune().score_xcd = value; return 0;
+    case 4: sf_tune().sweep_variant = value; return 0;
+    case 5: sf_tune().cov_variant = value; return 0;
+    case 6: sf_tune().extract_variant = value; return 0;
+    case 7: sf_tune().eigh_lpp = value; return 0;
+    case 8: sf_tune().sweep4r_waves = value; return 0;
+    case 10: sf_tune().wide_eigh_variant = value; return 0;
+    case 11: sf_tune().score_bg = value; return 0;
+    case 12: sf_tune().score_wgs = value; return 0;
+    case 13: sf_tune().score_exp = value; return 0;
     default: sf_set_error("sf_debug_set: unknown key %d", key); return -1;
   }
 }

@@ -25,6 +25,25 @@ int sf_fail_hip(hipError_t e, const char *what);
 // remembered per (device, function) so the driver is asked only when the size grows).  Thread safe.  c_api.hip
 int sf_lds_attr(const void *fn, size_t bytes);
 
+// Tuning / experiment knobs (sf_debug_set): a per-THREAD context, zero-initialised = the built-in choices.  The library
+// holds no process-wide mutable state: a thread that flips a knob (tools/tune_*.py, the kernel-variant tests) changes
+// only the launches it issues itself.
+struct SfTune {
+  int score_variant = 0;      // key 1: score kernel form (cmf_score.hip)
+  int score_lpw = 0;          // key 2: lines per workgroup of the column-block score kernel
+  int score_xcd = 1;          // key 3: XCD-aware block map of the column-block score kernel
+  int sweep_variant = 0;      // key 4: 1 = force the 16x16x4 sweep, 2 = full-rank 4x4x4 sweep only
+  int cov_variant = 0;        // key 5: 1 = force the 16x16x4 covariance, 3 = two waves per SIMD
+  int extract_variant = 0;    // key 6: 1 = never the flat (narrow-cube) kernel, 2 = the unpipelined blocked kernel
+  int eigh_lpp = 0;           // key 7: lanes per column pair of the Jacobi eigensolver
+  int sweep4r_waves = 8;      // key 8: waves per workgroup of the rank-factored sweep
+  int wide_eigh_variant = 0;  // key 10: 1 = the single-workgroup eigensolver for every wide matrix
+  int score_bg = 0;           // key 11: bands per LDS filter tile of the row score kernel (0 = built-in)
+  int score_wgs = 0;          // key 12: workgroups per CU the row score kernel is sized for (0 = occupancy query)
+  int score_exp = 0;          // key 13: timing experiments of the row score kernel (only with -DSF_SCORE_EXPERIMENTS)
+};
+SfTune &sf_tune();   // c_api.hip (thread_local)
+
 static inline int sf_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t sf_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -80,55 +99,46 @@ static inline SfGeom sf_geom(int lines, int p, int ncols, int nalpha) {
   return g;
 }
 
-// split counts (deterministic functions of the geometry so that results do not depend on the GPU)
+// split counts.  Every one is a function of the number of LINES only (the ncols argument is deliberately unused):
+// the split boundaries fix the order in which a column's float64 sums (masked column sums, covariance, NLL terms,
+// score statistics) are accumulated, and a column must come out bit-identical whether it is processed as part of the
+// full 598-column flightline or of a 74-column shard on one of 8 GPUs (tests/test_cmf_gpu.py:
+// test_shard_of_a_full_width_run_is_bit_identical).  The values are chosen for the standard widths 598 / 299 / 150 / 75.
 static inline int sf_extract_lines_per_wg(int lines, int ncols) {
   // <= 500 line chunks (measured: 250 -> 2.05 ms, 500 -> 1.91 ms, 1000 -> 1.97 ms + a slower mean kernel): every
   // chunk leaves a partial-sum record per column that the mean kernel reads back.
-  // Deliberately independent of the number of columns: the chunk boundaries fix the order in which a column's
-  // masked sum is accumulated, and that must not depend on how the columns are sharded over ranks.
   (void)ncols;
   int lpw = sf_cdiv(lines, 500);
   lpw = (lpw + 3) / 4 * 4;
   return lpw < 4 ? 4 : lpw;
 }
 static inline int sf_colsum_chunks(int lines, int ncols) {
-  int want = sf_cdiv(2048, ncols);
-  int maxc = sf_cdiv(lines, 256);
-  int c = want < maxc ? want : maxc;
-  return c < 1 ? 1 : c;
+  (void)ncols;
+  const int maxc = sf_cdiv(lines, 256);
+  return maxc < 4 ? (maxc < 1 ? 1 : maxc) : 4;
 }
 static inline int sf_syrk_splits(int lines, int ncols) {
-  // many more workgroups than resident slots (7 per CU) so the last partial round costs < 1/8
-  int want = sf_cdiv(16384, ncols);
-  int maxc = sf_cdiv(lines, 512);
-  int c = want < maxc ? want : maxc;
-  return c < 1 ? 1 : c;
+  // the 16x16x4 covariance (windows other than the production one): 7 workgroups per CU are resident, so 598 columns
+  // x 28 splits are ~9 rounds with a short last one
+  (void)ncols;
+  const int maxc = sf_cdiv(lines, 512);
+  return maxc < 28 ? (maxc < 1 ? 1 : maxc) : 28;
 }
 static inline int sf_sweep_splits(int lines, int ncols) {
-  // The sweep runs ONE workgroup per CU (LDS-bound) and all workgroups take the same time, so the launch
-  // proceeds in rounds of 256: pick the row split whose last round is fullest (598 columns x 3 splits
-  // would leave 2 workgroups alone in an 8th round; x 5 fills 11.7 of 12).
-  int maxs = sf_cdiv(lines, 1024);
-  if (maxs > 24) maxs = 24;
-  if (maxs < 1) maxs = 1;
-  int best = 1;
-  double best_cost = 1e300;
-  for (int ns = 1; ns <= maxs; ++ns) {
-    const long wgs = (long)ncols * ns;
-    const long rounds = (wgs + 255) / 256;
-    const double cost = (double)rounds / ns * (1.0 + 0.004 * ns);  // mild preference for fewer prologues
-    if (cost < best_cost * 0.999) { best_cost = cost; best = ns; }
-  }
-  return best;
+  // The 4x4x4 sweep and covariance run ONE workgroup per CU (LDS- / register-bound) and all workgroups take the same
+  // time, so a launch proceeds in rounds of 256 workgroups.  2048-row splits: at 20000 lines 598 / 299 / 150 / 75
+  // columns x 10 splits are 23.4 / 11.7 / 5.9 / 2.9 rounds -- the last round is nearly full for every standard shard
+  // width (4096-row splits cost the same at 598 columns but leave a 75-column shard 1.5 rounds of 2: +33 %).
+  (void)ncols;
+  int ns = sf_cdiv(lines, 2048);
+  if (ns > 24) ns = 24;
+  return ns < 1 ? 1 : ns;
 }
 static inline int sf_score_lines_per_wg(int lines, int ncols) {
-  // 32-line chunks (one 8-line batch per wave: the workgroup has no line loop at all) measured best on the full
-  // flightline (tools/tune_score.py: 0.81 ms against 0.86 ms for 64 lines, many short workgroups beat fewer long
-  // ones); keep at least ~1 round of 1024 workgroups on small shards
-  int colblocks = sf_cdiv(ncols, 64);
-  int lpw = 32;
-  while (lpw > 16 && (long)colblocks * sf_cdiv(lines, lpw) < 1024) lpw -= 16;
-  return lpw;
+  // the column-block score kernel (the row kernel has its own fixed 8-line granularity): 32-line chunks -- one 8-line
+  // batch per wave, no line loop at all -- measured best on the full flightline (tools/tune_score.py)
+  (void)ncols;
+  return lines >= 2048 ? 32 : 16;
 }
 
 // ---- stage launchers (each in its own .hip) -------------------------------------------------------
@@ -167,7 +177,8 @@ size_t sf_score_scratch_bytes(int lines, int ncols);
 int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
                     const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,
                     int rgb0, int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0,
-                    int out_bands, int16_t *bgmeta, void *scratch, int want_stats, hipStream_t st);
+                    int out_bands, int16_t *bgmeta, void *scratch, int want_stats, hipStream_t st,
+                    hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);   // events bracket the score kernel alone
 int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0, int ncols, int p, const int32_t *nuse,
                        const int32_t *status, double nodata, double *colstats, hipStream_t st);
 // cmf_loocv4.hip: the production-window sweep (p in 69..72, 201-point grid) on the 4x4x4 fp64 MFMA

@@ -164,7 +164,6 @@ int launch_cov_nt(const void *xt, int xt_f64, const uint8_t *mask_t, const int32
 
 }  // namespace
 
-int g_cov_variant = 0;  // sf_debug_set key 5: 1 = force the 16x16x4 kernels
 
 size_t sf_cov_scratch_bytes(const SfGeom &g) {
   const int nsplit = sf_syrk_splits(g.lines, g.ncols);
@@ -175,7 +174,7 @@ size_t sf_cov_scratch_bytes(const SfGeom &g) {
 
 int sf_launch_cov(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu,
                   const SfGeom &g, double *cov, void *scratch, hipStream_t st) {
-  if (!xt_f64 && g_cov_variant != 1 && g.s4 == SF_SW4_NJ)   // production window: p in 69..72
+  if (!xt_f64 && sf_tune().cov_variant != 1 && g.s4 == SF_SW4_NJ)   // production window: p in 69..72
     return sf_launch_cov4((const float *)xt, mask_t, nuse, mu, g, cov, scratch, st);
   switch (g.nt) {
     case 1: return launch_cov_nt<1>(xt, xt_f64, mask_t, nuse, mu, g, cov, scratch, st);

@@ -263,15 +263,14 @@ int sf_launch_cov4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
   int rows = sf_cdiv(g.lines, nsplit);
   rows = (rows + 127) / 128 * 128;   // whole prefetch rings: 4 waves x 16 rows x depth 2
   double *part = reinterpret_cast<double *>(scratch);
-  extern int g_cov_variant;
 #ifdef SF_SWEEP_EXPERIMENTS
-  if (g_cov_variant == 11)
+  if (sf_tune().cov_variant == 11)
     hipLaunchKernelGGL(k_syrk4<1>, dim3(g.ncols, nsplit), dim3(256), 0, st, xt, mask_t, mu, g.lines, g.p, rows, part);
-  else if (g_cov_variant == 12)
+  else if (sf_tune().cov_variant == 12)
     hipLaunchKernelGGL(k_syrk4<2>, dim3(g.ncols, nsplit), dim3(256), 0, st, xt, mask_t, mu, g.lines, g.p, rows, part);
   else
 #endif
-  if (g_cov_variant == 3) {   // two waves per SIMD, each half of the tiles: measured slower (1.62 vs 1.45 ms), kept as an option
+  if (sf_tune().cov_variant == 3) {   // two waves per SIMD, each half of the tiles: measured slower (1.62 vs 1.45 ms), kept as an option
     hipLaunchKernelGGL(k_syrk4d, dim3(g.ncols, nsplit), dim3(512), 0, st, xt, mask_t, mu, g.lines, g.p, rows, part);
   } else
   hipLaunchKernelGGL(k_syrk4<0>, dim3(g.ncols, nsplit), dim3(256), 0, st, xt, mask_t, mu, g.lines, g.p, rows, part);

@@ -337,7 +337,6 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
 
 }  // namespace
 
-int g_eigh_lpp = 0;  // sf_debug_set key 7: force 4 or 8 lanes per column pair (0 = built-in choice)
 
 size_t sf_eigh_scratch_bytes(const SfGeom &g) {
   const int p2 = g.p + (g.p & 1);
@@ -361,7 +360,7 @@ static int launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, 
   // Lanes per column pair: 8 is the measured optimum (tools/probe_eigh.py, one 72x72 matrix: 8 lanes 0.65 ms,
   // 4 lanes -- 3 waves, one per SIMD, twice the rows per lane -- 0.78 ms, 16 lanes -- 9 waves -- 0.77 ms).
   // The other two stay reachable through sf_debug_set(7, .) for the production sizes.
-  const int lpp = (g_eigh_lpp == 4 || g_eigh_lpp == 8 || g_eigh_lpp == 16) ? g_eigh_lpp : 8;
+  const int lpp = (sf_tune().eigh_lpp == 4 || sf_tune().eigh_lpp == 8 || sf_tune().eigh_lpp == 16) ? sf_tune().eigh_lpp : 8;
   const bool lpp4 = lpp == 4 && (p2 == 72 || p2 == 84);
   const bool lpp16 = lpp == 16 && (p2 == 72 || p2 == 84);
   int LD = p2;

@@ -482,7 +482,6 @@ __global__ __launch_bounds__(XF_NT) void k_extract_flat(const float *__restrict_
 
 }  // namespace
 
-int g_extract_variant = 0;  // sf_debug_set key 6: 1 = never use the flat (narrow-cube) kernel, 2 = the unpipelined blocked kernel
 
 static int extract_chunks(int lines, int ncols, int *lpw_out) {
   const int lpw = sf_extract_lines_per_wg(lines, ncols);
@@ -505,7 +504,7 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
   const int nchunk = extract_chunks(lines, ncols, &lpw);
   // a compact narrow cube (a rank's shard): the flat kernel, if a tile of at least one line fits
   if (s0 == 0 && ncols == samples && p <= XT_PBMAX && (size_t)p * ncols <= XF_NT * (size_t)XF_MAXSUM &&
-      ncols <= 256 && g_extract_variant != 1) {
+      ncols <= 256 && sf_tune().extract_variant != 1) {
     int tl = (XF_NT * XF_MAXLD) / (p * ncols);
     if (tl > 4) tl = 4;
     const size_t ldsf = ((size_t)XF_NT * (((size_t)tl * p * ncols + XF_NT - 1) / XF_NT) + (size_t)tl * ncols) * sizeof(float);
@@ -516,7 +515,7 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
     return 0;
   }
   const int ncb = sf_cdiv(ncols, 64);
-  if (fuse && g_extract_variant != 2 && p == 72) {     // the production window: software-pipelined kernel
+  if (fuse && sf_tune().extract_variant != 2 && p == 72) {     // the production window: software-pipelined kernel
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_pipe<TL, 72>), maxlds)) return rc;
     hipLaunchKernelGGL((k_extract_pipe<TL, 72>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), lds, st, cube, lines, bands, samples,
                        s0, ncols, b0, PS, xt, mask_t, lpw, cs, ncb, nchunk, sum_part, cnt_part);

@@ -413,7 +413,6 @@ int launch_nll(const double *part, int nsplit, const int32_t *nuse, const double
 
 }  // namespace
 
-int g_sweep_variant = 0;  // sf_debug_set key 4: 0 = built-in choice, 1 = force the 16x16x4 kernels, 2 = full-rank 4x4x4 sweep only
 
 int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
                          const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
@@ -422,7 +421,7 @@ int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, co
 }
 
 static bool sweep4_ok(const SfGeom &g, int xt_f64) {
-  return !xt_f64 && g_sweep_variant != 1 && g.nu == SF_SW4_NM && g.s4 == SF_SW4_NJ;
+  return !xt_f64 && sf_tune().sweep_variant != 1 && g.nu == SF_SW4_NM && g.s4 == SF_SW4_NJ;
 }
 
 size_t sf_wfrag_elems(const SfGeom &g) {
@@ -452,7 +451,7 @@ int sf_launch_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int
     if (int rcw = sf_launch_wfrag4(evec, d, g, wstride, wfrag, st)) return rcw;
     void *lr = reinterpret_cast<char *>(part) + sf_align((size_t)g.ncols * nsplit * 2 * g.nu * 16 * sizeof(double));
     int rc4 = sf_launch_sweep4((const float *)xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part,
-                               g_sweep_variant, g_sweep_variant == 2 ? nullptr : lr, st);
+                               sf_tune().sweep_variant, sf_tune().sweep_variant == 2 ? nullptr : lr, st);
     if (rc4) return rc4;
     return launch_nll(part, nsplit, nuse, d, lam, status, alphas, g, 1, nll, alphaidx, st);
   }

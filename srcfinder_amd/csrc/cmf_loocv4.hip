@@ -6,8 +6,6 @@
 #include "cmf_common.h"
 #include <type_traits>
 
-int g_sweep4r_waves = 8;   // sf_debug_set key 8: waves per workgroup of the rank-factored sweep (8 = two waves per SIMD
-                           // sharing one copy of the LDS tables: -9 %; needs every operand in arch VGPRs, see VG)
 
 namespace {
 
@@ -708,7 +706,7 @@ int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
   int rows = sf_cdiv(g.lines, nsplit);
   rows = (rows + 127) / 128 * 128;
 #define SW4R_ARGS xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part
-  if (g_sweep4r_waves == 4)
+  if (sf_tune().sweep4r_waves == 4)
     hipLaunchKernelGGL((k_sweep4r<0, 4, NK1>), dim3(g.ncols, nsplit), dim3(256), sw4r_lds(NK1), st, SW4R_ARGS);
   else
     hipLaunchKernelGGL((k_sweep4r<0, 8, NK1>), dim3(g.ncols, nsplit), dim3(512), sw4r_lds(NK1), st, SW4R_ARGS);

@@ -887,12 +887,11 @@ int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, co
                          const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
                          hipStream_t st);
 
-int g_wide_eigh_variant = 0;   // sf_debug_set(10, 1): the single-workgroup k_eigh_global for every matrix
 
 // eigendecomposition of a batch of nb correlation matrices (columns c0 .. c0+nb-1)
 static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int c0, int nb, double *d, double *lam, double *evec,
                      int32_t *status, double *gv, int32_t *cflag, int32_t *done, int32_t *rot, hipStream_t st) {
-  if (g_wide_eigh_variant == 1) {
+  if (sf_tune().wide_eigh_variant == 1) {
     hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 0, cflag);
     SF_LAUNCH_CHECK("k_eigh_global");
     return 0;

@@ -32,28 +32,27 @@ class GatherHandle:
         return _assemble(self.recv, *self.meta)
 
 
-def _assemble(recv, shape, cols_last, samples, world, as_int16):
+def _assemble(recv, shape, axis, samples, world, as_int16):
     import torch
     if recv is None:
         return None
     # one pass: every rank's [ncols_r, ...] block is written straight into its column range of the final layout
-    if cols_last:
-        full = torch.empty((int(np.prod(shape[:-1])) if len(shape) > 1 else 1, samples), dtype=recv[0].dtype, device=recv[0].device)
-        for r in range(world):
-            a, b = shard_columns(samples, world, r)
-            full[:, a:b].copy_(recv[r][:b - a].transpose(0, 1))
-        full = full.reshape(tuple(shape[:-1]) + (samples,))
-    else:
-        full = torch.empty((shape[0], samples) + tuple(shape[2:]), dtype=recv[0].dtype, device=recv[0].device)
-        for r in range(world):
-            a, b = shard_columns(samples, world, r)
-            full[:, a:b].copy_(recv[r][:b - a].transpose(0, 1))
+    full_shape = list(shape)
+    full_shape[axis] = samples
+    full = torch.empty(full_shape, dtype=recv[0].dtype, device=recv[0].device)
+    for r in range(world):
+        a, b = shard_columns(samples, world, r)
+        full.narrow(axis, a, b - a).copy_(recv[r][:b - a].movedim(0, axis))
     return full.view(torch.int16) if as_int16 else full
 
 
-def gather_columns(block, samples: int, *, group=None, dst: int = 0, async_op: bool = False):
-    """Gather per-rank column blocks ``[lines, ncols_r, ...]`` (or ``[..., ncols_r]`` 2-D stats with columns
-    LAST when ``block.dim() == 2`` or 1) into the full array on ``dst``; other ranks get ``None``.
+def gather_columns(block, samples: int, *, axis=None, group=None, dst: int = 0, async_op: bool = False):
+    """Gather per-rank column blocks into the full array on ``dst``; other ranks get ``None``.
+
+    ``axis`` is the axis of ``block`` that runs over this rank's columns.  Default: 1 for arrays of two or more
+    dimensions (``[lines, ncols_r, ...]`` products, ``[3, ncols_r]`` column statistics), 0 for vectors; per-column
+    records whose FIRST axis is the column (``alphaidx`` / ``status`` ``[ncols_r, k]`` of a multimodal run) must pass
+    ``axis=0`` -- nothing is inferred from the shape beyond that default.
 
     Blocks are padded to the largest shard so a single fixed-size gather suffices.  With ``async_op`` a
     :class:`GatherHandle` is returned instead and the collective overlaps whatever the caller enqueues next
@@ -63,28 +62,38 @@ def gather_columns(block, samples: int, *, group=None, dst: int = 0, async_op: b
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if axis is None:
+        axis = 1 if block.dim() >= 2 else 0
+    axis = axis % block.dim()
     as_int16 = block.dtype == torch.int16
     if as_int16:                        # not a collective dtype everywhere (gloo): ship the bytes
+        if axis == block.dim() - 1:
+            raise ValueError("int16 blocks are shipped as bytes: the column axis must not be the last one")
         block = block.contiguous().view(torch.uint8)
-    cols_last = block.dim() <= 2
-    if cols_last:
-        x = block.reshape(-1, block.shape[-1]).transpose(0, 1)                          # -> [ncols, ...]
-    else:
-        x = block.transpose(0, 1)                                                       # [ncols, lines, ...]
+    a, b = shard_columns(samples, world, rank)
+    if block.shape[axis] != b - a:
+        raise ValueError("rank %d holds columns [%d, %d) but the block has %d along axis %d"
+                         % (rank, a, b, block.shape[axis], axis))
+    x = block.movedim(axis, 0)                                                           # -> [ncols_r, ...]
     maxc = max(b - a for a, b in (shard_columns(samples, world, r) for r in range(world)))
     send = torch.zeros((maxc,) + tuple(x.shape[1:]), dtype=block.dtype, device=block.device)
     send[:x.shape[0]].copy_(x)
     recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     work = dist.gather(send, recv, dst=dst, group=group, async_op=async_op)
-    h = GatherHandle(work if async_op else None, send, recv, (tuple(block.shape), cols_last, samples, world, as_int16))
+    h = GatherHandle(work if async_op else None, send, recv, (tuple(block.shape), axis, samples, world, as_int16))
     return h if async_op else h.wait()
+
+
+# which axis of each robust_mf() result runs over the columns (multimodal runs return alphaidx / status as [ncols, k])
+_COLUMN_AXIS = {"out": 1, "bgmeta": 1, "labels": 1, "colstats": 1, "alphaidx": 0, "nuse": 0, "status": 0, "nll": 0}
 
 
 def robust_mf_sharded(cube_shard, library, samples: int, *, group=None, dst: int = 0, compute=None, **kw):
     """Run the matched filter on this rank's column slice ``cube_shard`` [lines, bands, ncols_r] and gather.
 
     Returns on ``dst`` a dict with the full ``out`` [lines, samples, nb], ``alphaidx``, ``nuse``, ``status``
-    [samples], ``colstats`` [3, samples] (and ``bgmeta`` when requested); ``None`` elsewhere.
+    [samples] ([samples, k] for alphaidx / status of a multimodal run), ``colstats`` [3, samples] (and ``bgmeta``,
+    ``labels`` [lines, samples], ``nll`` when the run produced them); ``None`` elsewhere.
     ``compute`` defaults to :func:`srcfinder_amd.cmf.robust_mf`; tests inject a CPU stand-in to exercise the
     sharding and the collective without a GPU.
     """
@@ -92,11 +101,11 @@ def robust_mf_sharded(cube_shard, library, samples: int, *, group=None, dst: int
         from .cmf import robust_mf as compute
     res = compute(cube_shard, library, **kw)
     fields = {}
-    for name in ("out", "alphaidx", "nuse", "status", "colstats", "bgmeta"):
+    for name, axis in _COLUMN_AXIS.items():
         v = getattr(res, name, None) if not isinstance(res, dict) else res.get(name)
         if v is None:
             continue
-        fields[name] = gather_columns(v, samples, group=group, dst=dst)
+        fields[name] = gather_columns(v, samples, axis=axis, group=group, dst=dst)
     import torch.distributed as dist
     return fields if dist.get_rank(group) == dst else None
 

@@ -389,6 +389,141 @@ def test_full_size_properties(torch_cuda, library):
     assert np.array_equal(r1.alphaidx.cpu().numpy()[cols][so], o["alphaidx"][so])
 
 
+@pytest.fixture(scope="module")
+def full_flightline(torch_cuda, library):
+    """BASELINE.json config 2 at FULL size: 598 samples x 20000 lines x 425 bands float32 BIL (20.3 GB, generated on
+    the device exactly as bench.py does) and its product.  ~26 GB of HBM with the workspace."""
+    torch = torch_cuda
+    from srcfinder_amd.synth import make_cube_torch
+    lines, samples = 20000, 598
+    cube = make_cube_torch(lines, samples, seed=1234, abscf_full=library[:, 2], device="cuda", nodata_column=samples // 3)
+    res = cmf.robust_mf(cube, library, metadata=True)
+    torch.cuda.synchronize()
+    yield cube, res
+    del cube, res
+    torch.cuda.empty_cache()
+
+
+def test_full_flightline_598x20000x425(torch_cuda, library, full_flightline):
+    """The headline configuration itself: validity == NODATA placement exactly, idempotent re-run bit-identical,
+    sum of a column's scores ~ 0, and 9 evenly spaced columns plus the all-NODATA column against the faithful oracle
+    (alpha index and valid-row sets exact, scores 1e-4 relative)."""
+    torch = torch_cuda
+    cube, r1 = full_flightline
+    lines, _, samples = cube.shape
+    r2 = cmf.robust_mf(cube, library, metadata=True)
+    assert torch.equal(r1.out, r2.out) and torch.equal(r1.alphaidx, r2.alphaidx) and torch.equal(r1.bgmeta, r2.bgmeta)
+    assert torch.equal(r1.colstats, r2.colstats)
+    del r2
+    valid = torch.ones((lines, samples), dtype=torch.bool, device=cube.device)
+    for b in range(350, 422):                                   # band by band: no 3.4 GB temporary
+        x = cube[:, b, :]
+        valid &= (x >= 0) & torch.isfinite(x)
+    assert torch.equal(r1.out[..., 3] != -9999.0, valid)
+    assert torch.equal(r1.nuse.long(), valid.sum(dim=0))
+    assert torch.equal(r1.bgmeta[..., 1] != 0, valid & (r1.status == 0)[None, :] & (r1.alphaidx != 0)[None, :])
+    st = r1.status.cpu().numpy()
+    assert st[samples // 3] == 1 and (st == 0).sum() == samples - 1
+    cs = r1.colstats.cpu().numpy()
+    okc = st == 0
+    assert np.all(np.abs(cs[1][okc]) <= 1e-7 * cs[2][okc])
+    # RGB copy: bands 60, 42, 24 as float64 for every line of a processed column; 0 for the skipped column
+    for k, b in enumerate((60, 42, 24)):
+        want = cube[:, b, :].double()
+        want[:, samples // 3] = 0.0
+        assert torch.equal(r1.out[..., k], want)
+    cols = sorted(set([int(round(i * (samples - 1) / 8)) for i in range(9)] + [samples // 3]))
+    host = cube[:, :, cols].cpu().numpy()
+    o = O.robust_mf_oracle(host, library)
+    got = r1.out[:, cols, :].cpu().numpy()
+    nod = o["out"][..., 3] == -9999.0
+    assert np.array_equal(got[..., 3] == -9999.0, nod)
+    assert score_close(got[..., 3][~nod], o["out"][..., 3][~nod]).all()
+    so = o["status"] == 0
+    assert np.array_equal(st[cols], o["status"])
+    assert np.array_equal(r1.alphaidx.cpu().numpy()[cols][so], o["alphaidx"][so])
+    assert np.array_equal(r1.nuse.cpu().numpy()[cols], o["nuse"])
+    assert np.array_equal(r1.bgmeta[:, cols, :].cpu().numpy(), o["bgmeta"])
+
+
+def test_full_flightline_shard_is_bit_identical(torch_cuda, library, full_flightline):
+    """What one rank of 8 does with the same flightline: a COMPACT 75-column cube (its own allocation, flat extract
+    kernel, three flightlines in flight on three streams) must reproduce columns 224..298 of the single-GPU product
+    bit for bit -- every float64 sum is accumulated in an order that depends on the number of lines only
+    (cmf_common.h, split counts) -- and so must the column range of the full cube processed in place."""
+    torch = torch_cuda
+    from srcfinder_amd.dist import shard_columns
+    from srcfinder_amd.inflight import FlightlinePipeline
+    cube, full = full_flightline
+    samples = cube.shape[2]
+    s0, s1 = shard_columns(samples, 8, 3)
+    assert (s0, s1) == (224, 299)
+    shard = cube[:, :, s0:s1].contiguous()
+    with FlightlinePipeline(3, cube.device) as pipe:
+        tickets = [pipe.submit(shard, library, metadata=True) for _ in range(4)]
+        results = [t.synchronize() for t in tickets]
+    inplace = cmf.robust_mf(cube, library, metadata=True, columns=(s0, s1))
+    for r in results + [inplace]:
+        assert torch.equal(r.out, full.out[:, s0:s1])
+        assert torch.equal(r.bgmeta, full.bgmeta[:, s0:s1])
+        assert torch.equal(r.alphaidx, full.alphaidx[s0:s1]) and torch.equal(r.nuse, full.nuse[s0:s1])
+        assert torch.equal(r.status, full.status[s0:s1])
+        assert torch.equal(r.colstats, full.colstats[:, s0:s1])
+
+
+def test_shard_of_a_full_width_run_is_bit_identical(torch_cuda, library):
+    """the same claim on a mid-size cube whose geometry exercises more than one row split of the covariance
+    and the sweep (4500 lines -> 3 splits), for an odd-width shard at an odd offset, the CO2 window (16x16x4 kernels)
+    and with the NLL curves compared too."""
+    torch = torch_cuda
+    from srcfinder_amd.synth import make_cube_torch
+    cube = make_cube_torch(4500, 300, seed=99, abscf_full=library[:, 2], device="cuda", nodata_column=40)
+    for kw in ({}, {"gas": "co2"}):
+        full = cmf.robust_mf(cube, library, metadata=True, return_nll=True, **kw)
+        for s0, s1 in ((37, 112), (0, 1), (150, 300)):
+            a = cmf.robust_mf(cube[:, :, s0:s1].contiguous(), library, metadata=True, return_nll=True, **kw)
+            b = cmf.robust_mf(cube, library, metadata=True, return_nll=True, columns=(s0, s1), **kw)
+            for r in (a, b):
+                assert torch.equal(r.out, full.out[:, s0:s1]) and torch.equal(r.bgmeta, full.bgmeta[:, s0:s1])
+                assert torch.equal(r.alphaidx, full.alphaidx[s0:s1]) and torch.equal(r.nuse, full.nuse[s0:s1])
+                assert torch.equal(r.colstats, full.colstats[:, s0:s1])
+                assert torch.equal(r.nll.view(torch.int64), full.nll[s0:s1].view(torch.int64))
+
+
+def test_score_kernels_agree_bit_for_bit(torch_cuda, library):
+    """The row score kernel (production) and the column-block kernel of round 1 accumulate a pixel's dot product in the
+    same order: identical products and statistics on ragged geometries (odd widths and offsets, a single-column tail
+    pair, line counts that are not multiples of the 8-line batch), with and without RGB, plain and non-temporal loads."""
+    torch = torch_cuda
+    L = _ffi.lib()
+    rng = np.random.default_rng(11)
+    for lines, samples, cols in ((97, 70, None), (203, 151, (37, 112)), (164, 9, (2, 9)), (133, 1000, None), (141, 5, (1, 3))):
+        cube = make_cube_numpy(lines, samples, seed=int(rng.integers(1 << 30)), abscf_full=library[:, 2], nodata_lines=2)
+        cube[5, 360, min(3, samples - 1)] = -0.0            # -0.0 is a VALID value for the reference (not < 0)
+        cube[6, 361, min(2, samples - 1)] = np.inf
+        cube[7, 362, samples - 1] = -np.inf
+        t = torch.as_tensor(cube).cuda()
+        for rgb in ((60, 42, 24), ()):
+            outs = []
+            for variant in (100, 0, 21, 22, 30):
+                try:
+                    L.sf_debug_set(1, variant)
+                    outs.append(cmf.robust_mf(t, library, metadata=True, columns=cols, rgb_bands=rgb))
+                finally:
+                    L.sf_debug_set(1, 0)
+            for r in outs[1:]:
+                assert torch.equal(r.out, outs[0].out) and torch.equal(r.bgmeta, outs[0].bgmeta)
+                np.testing.assert_allclose(r.colstats.cpu().numpy(), outs[0].colstats.cpu().numpy(), rtol=1e-12, equal_nan=True)
+        c0, c1 = (0, samples) if cols is None else cols
+        pick = list(range(c0, c1, max(1, (c1 - c0) // 12)))          # a dozen columns through the oracle
+        ref = O.robust_mf_oracle(cube, library, columns=pick)
+        got = outs[1].out.cpu().numpy()[:, [c - c0 for c in pick], -1]
+        want = ref["out"][:, pick, -1]
+        nod = want == -9999.0
+        assert np.array_equal(got == -9999.0, nod)
+        assert score_close(got[~nod], want[~nod]).all()
+
+
 def test_column_profile_and_systematics(torch_cuda, library):
     """N2: triage column profile of the product on the GPU against the numpy restatement (parity unpinned: the
     reference function cannot run here), and the rolling-median flag rule on a planted column."""

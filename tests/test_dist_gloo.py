@@ -65,6 +65,62 @@ def test_sharded_gather_matches_single_run(world, samples):
     assert q.get(timeout=5) is True
 
 
+def _mm_worker(rank, world, port, q):
+    """Multimodal-shaped results (alphaidx / status [ncols, k], labels [lines, ncols], nll [ncols, k, A]) through
+    robust_mf_sharded with uneven shards: the column axis of every field is explicit (a [10, 2] status
+    block used to be gathered along the wrong axis)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    from srcfinder_amd import dist as sd
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lines, samples, k, A = 12, 11, 2, 5
+    rng = np.random.default_rng(5)
+    full = {"out": rng.normal(size=(lines, samples, 4)),
+            "bgmeta": rng.integers(-3, 200, size=(lines, samples, 2)).astype(np.int16),
+            "labels": rng.integers(0, 3, size=(lines, samples)).astype(np.uint8),
+            "colstats": rng.normal(size=(3, samples)),
+            "alphaidx": rng.integers(-2, 200, size=(samples, k)).astype(np.int32),
+            "status": rng.integers(0, 3, size=(samples, k)).astype(np.int32),
+            "nuse": rng.integers(0, lines, size=samples).astype(np.int32),
+            "nll": rng.normal(size=(samples, k, A))}
+    s0, s1 = sd.shard_columns(samples, world, rank)
+
+    def compute(shard, library, **kw):
+        return {name: torch.as_tensor(np.ascontiguousarray(np.take(v, np.arange(s0, s1), axis=sd._COLUMN_AXIS[name])))
+                for name, v in full.items()}
+
+    got = sd.robust_mf_sharded(None, None, samples, compute=compute)
+    # a block whose column axis disagrees with the rank's shard is refused, not silently mis-assembled
+    try:
+        sd.gather_columns(torch.zeros(s1 - s0 + 1, k), samples, axis=0)
+        raised = False
+    except ValueError:
+        raised = True
+    if rank == 0:
+        ok = raised and all(np.array_equal(got[name].numpy(), v) for name, v in full.items())
+        q.put(bool(ok))
+    else:
+        assert got is None and raised
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gather_of_multimodal_fields(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() + world) % 2000
+    procs = [ctx.Process(target=_mm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_shard_columns_cover_everything():
     from srcfinder_amd.dist import shard_columns
     for world in (1, 2, 4, 8):

@@ -3,7 +3,9 @@
 
 FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md, HBM section; re-calibrated in round 1 on a 4 GiB streaming read:
 the counter reports 2,097,165 KB).  Counter units are KB (1024 B... the calibration fixes the scale: 1 unit = 1 KiB)."""
-import csv, glob, json, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def load(d, name):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
@@ -20,6 +22,10 @@ fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (tools/pmc_traffic.sh)",
        "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section; calibrated in round 1: a 4 GiB streaming read at 4/8/16 B per lane reports 2,097,165 KB; WRITE_SIZE exact on a 4 GiB copy)",
        "workload": "598x20000x425, p=72", "kernels": {}}
+_h = hashlib.sha256()
+for _f in ("cmf_score.hip", "cmf_common.h"):        # bench.py quotes this record only for the same score-kernel source
+    _h.update(open(os.path.join(ROOT, "srcfinder_amd", "csrc", _f), "rb").read())
+out["kernel_source_sha"] = _h.hexdigest()[:16]
 for k in sorted(set(fetch) | set(write)):
     f = sum(fetch.get(k, [0])) / max(len(fetch.get(k, [])), 1)
     w = sum(write.get(k, [0])) / max(len(write.get(k, [])), 1)

@@ -1,14 +1,23 @@
 #!/usr/bin/env python3
-"""A/B the score kernel's launch shape on a full-size cube (interleaved rounds in ONE process)."""
-import os, sys, itertools
+"""A/B the score kernel on a full-size cube (interleaved rounds in ONE process).
+
+    python tools/tune_score.py [samples] [quick]
+
+Configurations are (variant, bands per LDS tile, workgroups per CU, line groups): sf_debug_set keys 1, 11, 12, 2.
+variant 0 / 20..22 = the row kernel (8 lines x 2 / 2 / 4 / 1 bands per load batch, non-temporal loads), 30..32 the same
+with plain loads, 100 = the round-1 column-block kernel.  Every configuration must reproduce the column-block
+kernel's product bit for bit (same FMA order)."""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from srcfinder_amd import _ffi, cmf
+from srcfinder_amd import _ffi
 from srcfinder_amd.synth import make_cube_torch
 
-lines, samples, p = 20000, 598, 72
+samples = int(sys.argv[1]) if len(sys.argv) > 1 else 598
+quick = len(sys.argv) > 2
+lines, p = 20000, 72
 lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
 cube = make_cube_torch(lines, samples, seed=1, abscf_full=lib[:, 2])
 L = _ffi.lib()
@@ -20,27 +29,55 @@ status = torch.zeros(samples, dtype=torch.int32, device=dev)
 aidx = torch.full((samples,), 130, dtype=torch.int32, device=dev)
 nuse = torch.full((samples,), lines, dtype=torch.int32, device=dev)
 out = torch.empty((lines, samples, 4), dtype=torch.float64, device=dev)
-ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+colstats = torch.empty((3, samples), dtype=torch.float64, device=dev)
+ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 P = _ffi.ptr
+
 
 def run():
     _ffi.check(L.sf_cmf_score(P(cube), lines, 425, samples, 0, samples, 350, p, P(filt), P(bias), P(status), P(aidx), P(nuse),
-                              60, 42, 24, -9999.0, P(out), samples, 0, 4, None, None, P(ws), _ffi.stream_ptr()), "score")
+                              60, 42, 24, -9999.0, P(out), samples, 0, 4, None, P(colstats), P(ws), _ffi.stream_ptr()), "score")
 
-cfgs = []
-for variant, lpw, xcd in itertools.product([0], [16, 24, 32, 40, 48, 64, 80], [1]):
-    cfgs.append((variant, lpw, xcd))
+
+def setcfg(c):
+    L.sf_debug_set(1, c[0]); L.sf_debug_set(11, c[1]); L.sf_debug_set(12, c[2]); L.sf_debug_set(2, c[3])
+    L.sf_debug_set(13, c[4] if len(c) > 4 else 0)
+
+
+cfgs = [(100, 0, 0, 0), (0, 0, 0, 0)]
+if not quick:
+    for v in (20, 21, 22, 30):
+        for bg in (4, 8, 16, 72):
+            if v in (21,) and bg % 8:
+                continue
+            if bg * ((samples + 1) // 2 * 2) * 8 > 160 * 1024:
+                continue
+            for wgs in (0, 2):
+                cfgs.append((v, bg, wgs, 0))
+if os.environ.get("SF_SCORE_EXP"):     # library built with EXTRA=-DSF_SCORE_EXPERIMENTS: where does the time go?
+    cfgs = [(100, 0, 0, 0)] + [(v, 8, w, 0, e) for v in (22,) for w in (0,) for e in (0, 1, 8, 16, 24)]
+cfgs = list(dict.fromkeys(cfgs))
+setcfg((100, 0, 0, 0)); run(); torch.cuda.synchronize(); ref = out.clone(); refcs = colstats.clone()
 res = {c: [] for c in cfgs}
+bad = set()
 for rnd in range(4):
     for c in cfgs:
-        L.sf_debug_set(1, c[0]); L.sf_debug_set(2, c[1]); L.sf_debug_set(3, c[2])
-        run(); torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); run(); b.record(); torch.cuda.synchronize()
-        res[c].append(a.elapsed_time(b))
-names = {0: "8x4", 1: "2x16", 3: "4x4", 4: "2x8", 5: "8x8", 6: "4x8", 7: "8x4/128", 8: "4x8/128", 9: "4x4/128"}
-L.sf_debug_set(1, 0); L.sf_debug_set(2, 0); run(); torch.cuda.synchronize(); ref = out.clone()
-for v in (7, 8, 9):
-    L.sf_debug_set(1, v); out.zero_(); run(); torch.cuda.synchronize(); print("variant", v, "bit-identical to default:", bool(torch.equal(out, ref)))
+        setcfg(c)
+        try:
+            if rnd == 0:
+                out.zero_(); run(); torch.cuda.synchronize()
+                if not torch.equal(out, ref):
+                    bad.add(c)
+                if c[0] != 100 and not torch.allclose(colstats, refcs, rtol=1e-9, atol=0, equal_nan=True):
+                    bad.add(c)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); run(); run(); b.record(); torch.cuda.synchronize()
+            res[c].append(a.elapsed_time(b) / 2)     # includes the tiny transpose + colstats kernels
+        except _ffi.SrcfinderError as e:
+            res[c].append(float("nan")); bad.add(c); print("cfg", c, "failed:", e)
+setcfg((0, 0, 0, 0))
 for c in sorted(cfgs, key=lambda c: np.median(res[c])):
-    print("LPIxUB %-5s lpw %4d xcd %d : median %.3f ms min %.3f  -> %.0f GB/s" % (names[c[0]], c[1], c[2], np.median(res[c]), min(res[c]), 332 * lines * samples / np.median(res[c]) / 1e6))
+    med = np.median(res[c])
+    print("variant %3d BG %2d wgs/CU %d G %d exp %d : median %.3f ms min %.3f  -> %.0f GB/s (332 B/px), frac(4p+8) %.3f %s"
+          % (c[0], c[1], c[2], c[3], c[4] if len(c) > 4 else 0, med, min(res[c]), 332 * lines * samples / med / 1e6,
+             296 * lines * samples / (med * 1e-3) / 8e12, "MISMATCH" if c in bad else "bit-identical"))

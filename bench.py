@@ -192,7 +192,7 @@ def main():
                                          "value": round(lines * samples / (solo["dt"] / args.steps) / 1e6, 3),
                                          "note": "the same K steps with ONE flightline in flight (latency of a flightline)"},
                        "output": "float64 BIP [lines, samples, (R,G,B,CMF)]"},
-            "roofline": {"bound": "hbm", "kernel": "k_score_rows<RGB>", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_score<RGB> (64-sample blocks, staged stores)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": None, "bytes_per_pixel": 4 * p + 8,
                          "algorithmic_bytes_per_launch": alg_bytes,
@@ -293,9 +293,9 @@ def cpu_baseline(cube, lib, lines, ncols, ncpu_cols, res, active):
     one = {"value": round(lines * len(cols1) / t1 / 1e6, 5), "unit": "Mpixel/s", "cores": 1,
            "sample": "%d evenly spaced columns x %d lines of the benchmark cube, %.1f s" % (len(cols1), lines, t1),
            "parity_on_sample": parity(cols1, sc, ai, stt)}
-    # ---- all cores
-    cores = os.cpu_count() or 1
-    colsn = sample(min(2 * cores, 128, ncols - 1))
+    # ---- all cores this process may use (affinity mask and cgroup CPU quota: the GPU boxes are containers)
+    cores = usable_cores()
+    colsn = sample(min(max(2 * cores, 16), 128, ncols - 1))
     sub = fetch(colsn)
     chunks = [list(range(i, len(colsn), cores)) for i in range(min(cores, len(colsn)))]
     ctx = mp.get_context("spawn")                # never fork a process that has initialised HIP
@@ -310,10 +310,29 @@ def cpu_baseline(cube, lib, lines, ncols, ncpu_cols, res, active):
     for ch, (s_, a_, st_, _t) in zip(chunks, outs):
         score[:, ch], aidx[ch], status[ch] = s_, a_, st_
     return {"value": round(lines * len(colsn) / tn / 1e6, 5), "unit": "Mpixel/s", "cores": cores, "kind": "port",
-            "sample": "%d evenly spaced columns x %d lines of the benchmark cube over %d processes (one per host core, "
-                      "OMP_NUM_THREADS=1), %.1f s wall" % (len(colsn), lines, len(chunks), tn),
+            "sample": "%d evenly spaced columns x %d lines of the benchmark cube over %d processes (one per usable host "
+                      "core: os.cpu_count() = %d, affinity / cgroup quota = %d; OMP_NUM_THREADS=1), %.1f s wall"
+                      % (len(colsn), lines, len(chunks), os.cpu_count() or 1, cores, tn),
             "parity_on_sample": parity(colsn, score, aidx, status),
             "one_core": one}
+
+
+def usable_cores():
+    """CPUs this process can actually run on: the affinity mask, capped by the cgroup CPU quota (v2 cpu.max, v1 cfs)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
 
 
 def _warm(_):

@@ -171,11 +171,57 @@ int sf_debug_lowrank(const double *lam, const int32_t *nuse, const int32_t *stat
  * sf_cmf_score_timing_read() synchronises those events, returns the summed kernel time and the
  * number of launches since the last enable, and clears the list. */
 int sf_cmf_score_timing(int enable);
-/* Tuning knobs for experiments (tools/tune_score.py); defaults are the shipped choices.  key 1: score kernel
- * (lines, bands)-per-batch variant, 2: lines per workgroup, 3: XCD-aware block map on/off. */
+/* Tuning knobs for experiments (tools/tune_*.py; the keys are listed at struct SfTune in csrc/cmf_common.h); the
+ * defaults are the shipped choices.  The knobs are PER CALLING THREAD: the library holds no process-wide mutable state. */
 int sf_debug_set(int key, int value);
 int sf_cmf_score_timing_read(double *total_ms, int *launches);
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Spectrometer masks on the resident cube (spectrometer_masks/masks_sds.py) and the image primitives they share with
+ * the saliency -> detections step (salience_predictions.py): binary dilations, 8-connected component labelling.
+ * Masks are uint8 [lines][samples] (0 / 1) device arrays owned by the caller.
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* Per-pixel rules over the BIL cube (masks_sds.py:133-232, :330): sat = any band of [sat_b0, sat_b1) > sat_thr;
+ * cloud = x[cloud_b0] > cloud_thr and the slope cloud_b0 -> cloud_b1 is negative (dwl = wavelength[cloud_b1] -
+ * wavelength[cloud_b0]; the second slope of :222 never enters the result, :230); spec = sat and x[vis_band] > vis_thr;
+ * dark = x[dark_band] < dark_thr and not <= -9999; grow = sat and x[grow_band] < vis_thr (:314); border = x[0] == -9999. */
+int sf_masks_pixel(const float *cube, int lines, int bands, int samples, int sat_b0, int sat_b1, float sat_thr, int cloud_b0,
+                   int cloud_b1, float cloud_thr, float dwl, int vis_band, float vis_thr, int dark_band, float dark_thr,
+                   int grow_band, uint8_t *sat, uint8_t *cloud, uint8_t *spec, uint8_t *dark, uint8_t *grow,
+                   uint8_t *border, void *stream);
+/* `iterations` passes of the 4-neighbour binary dilation, in place (tmp: a second H x W buffer) -- dilate_mask,
+ * masks_sds.py:252-273 (skimage.morphology.binary_dilation's default structuring element, background border). */
+int sf_image_dilate_cross(uint8_t *mask, uint8_t *tmp, int H, int W, int iterations, void *stream);
+/* Binary dilation by skimage.morphology.disk(radius) = {x^2 + y^2 <= r^2} (masks_sds.py:280, :317). */
+size_t sf_image_dilate_disk_scratch_bytes(int H, int W, int radius);
+int sf_image_dilate_disk(const uint8_t *src, uint8_t *dst, int H, int W, int radius, void *scratch, void *stream);
+/* 8-connected (skimage connectivity=2) component labelling: labels[H][W] int32, 0 = background, components numbered
+ * 1..n in raster order of their first pixels (measure.label, masks_sds.py:309; srcfinder_util.imlabel,
+ * salience_predictions.py:61); area (optional): pixels per id, area_cap >= n + 1 entries; *ncomp_dev = n. */
+size_t sf_image_label8_scratch_bytes(int H, int W);
+int sf_image_label8(const uint8_t *mask, int H, int W, int32_t *labels, int32_t *area, int area_cap, int32_t *ncomp_dev,
+                    void *scratch, void *stream);
+/* Clear the pixels of `sel` that lie in components of fewer than minarea pixels (region.area >= mingrowarea, :310). */
+int sf_image_filter_small_components(const int32_t *labels, const int32_t *area, int minarea, uint8_t *sel, int H, int W,
+                                     void *stream);
+/* Product assembly (:336-341): out[lines][samples][4] int16 = cloud, specular, flare (2 where flare_buffer, 1 where sat
+ * and not specular; flare_buffer NULL = no grow radius: 0), dark; all four -9999 where border. */
+int sf_masks_compose(const uint8_t *cloud, const uint8_t *spec, const uint8_t *sat, const uint8_t *flare_buffer,
+                     const uint8_t *dark, const uint8_t *border, int lines, int samples, int16_t *out, void *stream);
+
+/* Saliency map -> detections, the region loop of salience_predictions.py:66-108 (salience2detections).  labels[H][W]:
+ * 1..nregions from sf_image_label8 of (salience > threshold, :60-61); sal[H][W] float32; cmf[H][W][cmf_nb] float64
+ * product, CMF in band cmf_band; nodata[H][W] uint8 (RGB band 0 == -9999, :45).  Per region, over pmsk = (label == id)
+ * & ~nodata for the saliency and pmsk & (cmf > cmfthr) for the CMF: max, min, median, MAD (median of |x - median|),
+ * truncated centre of mass of the pixels holding the maximum (:81-103).  bbox: scratch (nregions + 1) * 4 int32.
+ * rec[nregions + 1][20] float64, row id: [0..3] bounding slices (row start, row stop, col start, col stop),
+ * [4..10] saliency max, min, median, MAD, max row, max col, n; [11..17] the same for the CMF; [18] status (1 = the
+ * region has more pixels than the LDS-resident sort holds: 32768 saliency / 16384 CMF values). */
+int sf_detect_region_stats(const int32_t *labels, int H, int W, int nregions, const float *sal, const double *cmf,
+                           int cmf_nb, int cmf_band, const uint8_t *nodata, double cmfthr, int32_t *bbox, double *rec,
+                           void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * CNN tile scorer (cnn/cnn_pred_pipeline.py + cnn/archs/googlenet1.py, eval graph).  Activations are NHWC

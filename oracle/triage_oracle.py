@@ -1,8 +1,10 @@
 """TEST INFRASTRUCTURE -- numpy restatement of the column profile of ``triage/cmf_profile.py:110-140``.
 
-PARITY UNPINNED: the reference function reads its inputs through ``srcfinder_util.openimgmm`` (GDAL / spectral, absent
-here) and cannot be executed in this container, so there is no golden from the real code; this file follows the
-listing line by line instead (float32 cast :112, validity + positivity mask :113-114, nan-statistics :128-131)."""
+Pinned: ``tests/golden/triage_profile.npz`` holds the two CSV tables (plain and ``--robust``) that the REAL script wrote
+for a seeded synthetic product -- ``cmf_profile.py`` executed unmodified with the real ``srcfinder_util`` (its file
+reader replaced by an in-memory product, the absent third-party imports stubbed; ``tests/golden/gen_golden_triage.py``).
+``tests/test_oracle_golden.py::test_triage_profile_golden`` checks this restatement against them bit for bit.
+Follows the listing line by line: float32 cast :112, validity + positivity mask :113-114, nan-statistics :124-131."""
 import warnings
 
 import numpy as np

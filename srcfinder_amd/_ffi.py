@@ -55,6 +55,16 @@ SIGNATURES = {
     "sf_debug_lowrank": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "sf_cmf_column_profile_robust": (i32, [vp, i32, i32, i32, i32, f64, f64, vp, vp]),
     "sf_cmf_column_profile": (i32, [vp, i32, i32, i32, i32, f64, vp, vp, vp]),
+    "sf_masks_pixel": (i32, [vp, i32, i32, i32, i32, i32, f32, i32, i32, f32, f32, i32, f32, i32, f32, i32,
+                             vp, vp, vp, vp, vp, vp, vp]),
+    "sf_image_dilate_cross": (i32, [vp, vp, i32, i32, i32, vp]),
+    "sf_image_dilate_disk_scratch_bytes": (sz, [i32, i32, i32]),
+    "sf_image_dilate_disk": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "sf_image_label8_scratch_bytes": (sz, [i32, i32]),
+    "sf_image_label8": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, vp]),
+    "sf_image_filter_small_components": (i32, [vp, vp, i32, vp, i32, i32, vp]),
+    "sf_masks_compose": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    "sf_detect_region_stats": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, f64, vp, vp, vp]),
     "sf_cmf_score_timing": (i32, [i32]),
     "sf_debug_set": (i32, [i32, i32]),
     "sf_cmf_score_timing_read": (i32, [C.POINTER(f64), C.POINTER(i32)]),

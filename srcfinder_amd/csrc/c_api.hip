@@ -284,7 +284,6 @@ int sf_debug_set(int key, int value) {
     case 7: sf_tune().eigh_lpp = value; return 0;
     case 8: sf_tune().sweep4r_waves = value; return 0;
     case 10: sf_tune().wide_eigh_variant = value; return 0;
-    case 11: sf_tune().score_bg = value; return 0;
     case 12: sf_tune().score_wgs = value; return 0;
     case 13: sf_tune().score_exp = value; return 0;
     default: sf_set_error("sf_debug_set: unknown key %d", key); return -1;

@@ -29,7 +29,7 @@ int sf_lds_attr(const void *fn, size_t bytes);
 // holds no process-wide mutable state: a thread that flips a knob (tools/tune_*.py, the kernel-variant tests) changes
 // only the launches it issues itself.
 struct SfTune {
-  int score_variant = 0;      // key 1: score kernel form (cmf_score.hip)
+  int score_variant = 0;      // key 1: score kernel form (cmf_score.hip): 100 = round 1, 10 / 11 = k_score_blk2 plain / nt
   int score_lpw = 0;          // key 2: lines per workgroup of the column-block score kernel
   int score_xcd = 1;          // key 3: XCD-aware block map of the column-block score kernel
   int sweep_variant = 0;      // key 4: 1 = force the 16x16x4 sweep, 2 = full-rank 4x4x4 sweep only
@@ -38,9 +38,8 @@ struct SfTune {
   int eigh_lpp = 0;           // key 7: lanes per column pair of the Jacobi eigensolver
   int sweep4r_waves = 8;      // key 8: waves per workgroup of the rank-factored sweep
   int wide_eigh_variant = 0;  // key 10: 1 = the single-workgroup eigensolver for every wide matrix
-  int score_bg = 0;           // key 11: bands per LDS filter tile of the row score kernel (0 = built-in)
-  int score_wgs = 0;          // key 12: workgroups per CU the row score kernel is sized for (0 = occupancy query)
-  int score_exp = 0;          // key 13: timing experiments of the row score kernel (only with -DSF_SCORE_EXPERIMENTS)
+  int score_wgs = 0;          // key 12: workgroups per CU k_score_blk2 is sized for (0 = occupancy query)
+  int score_exp = 0;          // key 13: timing experiments of k_score_blk2 (only with -DSF_SCORE_EXPERIMENTS)
 };
 SfTune &sf_tune();   // c_api.hip (thread_local)
 

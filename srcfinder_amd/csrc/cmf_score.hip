@@ -6,19 +6,21 @@
 // and the three RGB bands are copied next to the score so each pixel's 32-byte BIP record
 // [R, G, B, CMF] (float64) is written once, whole.
 //
-// Two kernels:
-//  * k_score_rows (the production kernel): a workgroup owns WHOLE rows.  In BIL the active window of one line is ONE
-//    contiguous run of p x samples floats, so a workgroup that takes all the columns of a line streams it with 8-byte
-//    loads (a lane owns two adjacent samples, 512 contiguous bytes per wave instruction) and shares no 128-byte line
-//    with any other workgroup; the loads are non-temporal (every value is used once: tools/microbench/readbw.hip
-//    measures 7.0 TB/s for nt reads of workgroup-contiguous runs against 6.2 plain and 4.9 for 256-byte pieces at
-//    arbitrary offsets, the round-1 layout).  The filter vectors of all the columns do not fit LDS (598 x 72 x 8 B =
-//    344 KB), so the bands are walked in groups: the group's [BG][samples] float64 tile is staged in LDS, every lane
-//    keeps the partial dot products of its 2 columns x LPI lines in registers across the groups, and the cube loads
-//    of the next group are already in flight while the tile is swapped (LDS-only barriers).
-//  * k_score (round 1; kept for shards wider than 1024 columns or of a single column, and as the A/B reference):
-//    lane = sample, 64-sample column blocks, the block's filter vectors in LDS as [band][64].
-// Both accumulate a pixel's dot product in band order with one float64 FMA per band: bit-identical results.
+// k_score (production): lane = sample, 64-sample column blocks (256 contiguous bytes per wave instruction), the
+// block's 64 filter vectors resident in LDS as [band][64] for the workgroup's lifetime, four workgroups = 16 waves per
+// CU with 64 loads each in flight (256 KB per CU), XCD-aware block order.  Round 2 added the staged stores: a wave's
+// 64 records of a line (2 KB of contiguous output) pass through 1 KB of LDS and leave as 1 KB contiguous store
+// instructions instead of 16-byte pieces at a 32-byte stride (-0 .. -3 % per launch, never slower).
+// k_score_blk2 (sf_debug_set(1, 10); measured alternative): 128-sample blocks, a lane owns two adjacent samples.
+//
+// What round 2 measured about this kernel (profiles/r02_score_kernel_experiments.md; tools/microbench/readbw*.hip,
+// tools/tune_score.py with -DSF_SCORE_EXPERIMENTS): the launch is NOT limited by its load geometry.  With the stores
+// switched off every form -- 64-sample blocks, 128-sample blocks with 8-byte loads, whole rows per workgroup with LDS
+// filter tiles or with the filter streamed from L2 -- reads the window at 5.4-6.0 TB/s (0.60-0.70 ms); the 0.38 GB of
+// product stores then add 0.17-0.19 ms whatever their form (16-byte pieces or 1 KB runs, the product's layout or one
+// contiguous run per wave, plain / nt / sc1 / sc0 sc1, issued before or after the next batch's loads): 0.45 ms per GB
+// written beside a saturated read stream, twice what a plain copy pays.  The fused RGB copy is 3/4 of those bytes.
+// All forms accumulate a pixel's dot product in band order with one float64 FMA per band: bit-identical results.
 // Algorithmic bytes per pixel: 4p (cube) + 8 (score) [+ 12 read + 24 written when RGB is fused].  2p flops per
 // pixel -> HBM-bound by a wide margin.
 #include "cmf_common.h"
@@ -65,7 +67,7 @@ __device__ __forceinline__ void score_fma(const float (&x)[SC_LPI][SC_UB], const
 // CW: 64-column blocks per workgroup.  With CW = 2 the two halves of a 128-column block read ADJACENT 256-byte row
 // segments at the same time from the same CU, so the 128-byte lines straddling their boundary are fetched once
 // (the row stride, 2392 B, is not a multiple of the line size: every segment starts mid-line).
-template <bool RGB, int SC_LPI, int SC_UB, bool WGL, int CW = 1>
+template <bool RGB, int SC_LPI, int SC_UB, bool WGL, int CW = 1, bool STG = false>
 __global__ __launch_bounds__(256 * CW) void k_score(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs,
                                                 int b0, int p, const double *__restrict__ filt,
                                                 const double *__restrict__ bias, const int32_t *__restrict__ status,
@@ -140,6 +142,39 @@ __global__ __launch_bounds__(256 * CW) void k_score(const float *__restrict__ cu
         rgbv[j][2] = (pl + (size_t)rgb2 * C)[lanec];
       }
     }
+    if (RGB && STG) {
+      // staged stores: the wave's 64 records [R, G, B, CMF] of a line are 2 KB of contiguous output; they pass through a
+      // 1 KB LDS block of the wave (sred, free until the statistics at the end) in two halves and leave as 1 KB
+      // contiguous store instructions instead of 16-byte pieces at a 32-byte stride
+      typedef double d2v_t __attribute__((ext_vector_type(2)));
+      d2v_t *stg = reinterpret_cast<d2v_t *>(&sred[wv][0][0]);
+#pragma unroll
+      for (int j = 0; j < SC_LPI; ++j) {
+        if (j >= nl) break;
+        const bool v = ok[j];
+        const double sc = v ? ((st == 2) ? 0.0 : (acc[j] - mybias)) : nodata;
+        if (v && colok) { s1 += sc; s2 += sc * sc; }
+        const bool cp = st != 1;
+        const d2v_t ra = {cp ? (double)rgbv[j][0] : 0.0, cp ? (double)rgbv[j][1] : 0.0};
+        const d2v_t rb = {cp ? (double)rgbv[j][2] : 0.0, sc};
+        d2v_t *orow = reinterpret_cast<d2v_t *>(out + ((size_t)(l + j) * oS + os0 + colbase) * 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if ((lane >> 5) == h) {
+            const int s = lane & 31, sw = (s >> 3) & 1;
+            stg[2 * s + (0 ^ sw)] = ra;
+            stg[2 * s + (1 ^ sw)] = rb;
+          }
+          const int s = lane >> 1;
+          const d2v_t val = stg[2 * s + ((lane & 1) ^ ((s >> 3) & 1))];
+          if (32 * h + s < ncol) orow[(size_t)(32 * h + s) * 2 + (lane & 1)] = val;
+        }
+        if (bgmeta && colok) {
+          const uint32_t m = (v && st == 0) ? ((uint32_t)(uint16_t)(int16_t)ai << 16) : 0u;
+          reinterpret_cast<uint32_t *>(bgmeta)[(size_t)(l + j) * oS + os0 + col] = m;
+        }
+      }
+    } else
 #pragma unroll
     for (int j = 0; j < SC_LPI; ++j) {
       if (j < nl && colok) {
@@ -182,18 +217,16 @@ __global__ __launch_bounds__(256 * CW) void k_score(const float *__restrict__ cu
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_score_rows
+// helpers of k_score_blk2
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f2a_t __attribute__((ext_vector_type(2)));
-
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 typedef double sc_d2_t __attribute__((ext_vector_type(2)));
-constexpr int SC_TL = 8;   // 16-byte pieces of an LDS filter tile per thread (tiles are swapped through registers)
-__device__ __forceinline__ void sc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Cube loads are raw buffer loads: one descriptor per LPI-line batch (base = the batch's first line at the shard's
-// first sample; the range ends with the last line of the cube, reads past it return 0), the lane's byte offset in a
+// first sample; the range ends with the batch's last line, reads past it return 0), the lane's byte offset in a
 // VGPR and the (line, band) offset in an SGPR -- no 64-bit VALU address arithmetic and no per-line pointer registers.
-typedef unsigned u2_t __attribute__((ext_vector_type(2)));
 template <bool NT>
 __device__ __forceinline__ f2a_t sc_ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   const u2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, NT ? 2 : 0);   // aux 2 = nt
@@ -208,66 +241,83 @@ __device__ __forceinline__ f2a_t sc_ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned vo
 __device__ __forceinline__ uint32_t sc_vkey(float x) { return __float_as_uint(x + 0.0f); }
 constexpr uint32_t SC_VKEY_MAX = 0x7F7FFFFFu;
 
-// Thread layout: `wpg` waves cover the columns of one line group (lane t of the group owns samples 2t, 2t+1), G line
-// groups per workgroup, each taking LPI consecutive lines of a batch of G*LPI lines; a workgroup walks a contiguous,
-// balanced range of batches (every workgroup the same number +-1, all resident at once: no tail round).
-// wT: the filter transposed and zero padded, [ngrp*BG][ldw] float64 (k_filt_transpose); tile g = rows g*BG.. of it.
-// stat_part: [ceil(L/LPI)][Cs][2] sums of the written scores per LPI-line batch -- a granularity that does not depend
-// on the workgroup shape, so the column statistics are bit-identical however the columns are sharded.
-template <bool RGB, int LPI, int UB, bool NT>
-__global__ __launch_bounds__(512, 3) void k_score_rows(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs,
-                                                     int b0, int p, const double *__restrict__ wT, int ldw, int BG,
-                                                     int ngrp, const double *__restrict__ bias,
-                                                     const int32_t *__restrict__ status,
-                                                     const int32_t *__restrict__ alphaidx, int rgb0, int rgb1, int rgb2,
-                                                     double nodata, double *__restrict__ out, int oS, int os0,
-                                                     int16_t *__restrict__ bgmeta, double *__restrict__ stat_part,
-                                                     int wpg, int G, int nwb, int expf) {
-  extern __shared__ __attribute__((aligned(16))) double tile[];   // [BG][ldw]
-#ifndef SF_SCORE_EXPERIMENTS
-  expf = 0;   // timing experiments (tools/tune_score.py, wrong results): 1 = no stores, 2 = no tile swaps, 4 = no arithmetic
+// ---------------------------------------------------------------------------------------------------------------
+// k_score_blk2: 128-sample column blocks, two samples per lane (a measured alternative, not the default)
+// ---------------------------------------------------------------------------------------------------------------
+// Measured on the benchmark cube, loads only (tools/microbench/readbw2.hip, 598 x 20000 x 425, bands 350..421, every
+// form with >= 256 KB in flight per CU): 64-sample blocks with 4-byte loads 5.3 TB/s, 128-sample blocks with 8-byte
+// loads 6.0, 256-sample blocks with 16-byte loads 6.0, whole rows 6.0 -- and 7.0 for one contiguous run, which a
+// strided window of a BIL cube is not.  What a form needs is (a) wide enough pieces and (b) bytes in flight, i.e.
+// registers: whole rows per workgroup (git history: e35b16f) put the filter of ALL columns on the path (344 KB: LDS
+// tiles with barriers, or L2 reads through registers) and lose (b); column blocks keep the block's filter resident in LDS for
+// the workgroup's lifetime, with no barrier after the prologue.  So: 128-sample blocks, a lane owns two adjacent
+// samples (8-byte loads, 512 contiguous bytes per wave instruction), [p][128] float64 filter tile (73.7 KB at p = 72:
+// two workgroups = 8 waves per CU), 8 lines x 4 bands x 2 batches = 64 loads = 32 KB in flight per wave.
+// A workgroup is persistent: one column block, a balanced contiguous range of 8-line batches dealt to its 4 waves;
+// the grid is sized to be resident at once and all column blocks of a line range sit on one XCD (sf_xcd_map), so
+// the 128-byte lines that straddle block boundaries are fetched by neighbours on the same L2 at about the same time.
+// Validity is one running unsigned maximum per pixel (sc_vkey), the wave's records leave through a 2 KB LDS staging
+// block as 1 KB contiguous stores, the statistics partials are per 8-line batch (independent of the launch shape).
+constexpr int SB_LPI = 8, SB_UB = 4, SB_CB = 128;
+static_assert(SB_UB >= 3, "the RGB rows reuse a load buffer");
+// one 16-byte piece of the product.  mode (timing experiments only): 1 = nt, 2 = sc1 (write-through), 3 = sc0 sc1
+__device__ __forceinline__ void sc_store16(sc_d2_t *p, sc_d2_t v, int mode) {
+#ifdef SF_SCORE_EXPERIMENTS
+  if (mode == 1) { __builtin_nontemporal_store(v, p); return; }
+  if (mode == 2) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); return; }
+  if (mode == 3) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); return; }
 #endif
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform on purpose: row pointers stay scalar
-  const int grp = wave / wpg, wv = wave - grp * wpg, traw = wv * 64 + lane;
-  const int T = (Cs + 1) >> 1;
-  const bool active = traw < T;
-  const int t = active ? traw : T - 1;
-  const int c0 = min(2 * t, Cs - 2);           // the pair (c0, c0+1) is always inside the shard (Cs >= 2)
-  const bool own0 = active && c0 == 2 * t;     // odd Cs: the last lane re-reads column Cs-2 and owns only Cs-1
-  const bool own1 = active;
-  const double bias0 = bias[c0], bias1 = bias[c0 + 1];
-  const int st0 = status[c0], st1 = status[c0 + 1];
-  const int ai0 = alphaidx[c0], ai1 = alphaidx[c0 + 1];
+  (void)mode;
+  *p = v;
+}
+static size_t sb_lds_bytes(int p) { return ((size_t)(p + 2 * SB_UB - 1) / (2 * SB_UB) * (2 * SB_UB) * SB_CB + 4 * 256) * sizeof(double); }
+template <bool RGB, bool NT>
+__global__ __launch_bounds__(256, 2) void k_score_blk2(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs,
+                                                        int b0, int p, const double *__restrict__ filt,
+                                                        const double *__restrict__ bias,
+                                                        const int32_t *__restrict__ status,
+                                                        const int32_t *__restrict__ alphaidx, int rgb0, int rgb1,
+                                                        int rgb2, double nodata, double *__restrict__ out, int oS,
+                                                        int os0, int16_t *__restrict__ bgmeta,
+                                                        double *__restrict__ stat_part, int ncb, int nk, int nbatch,
+                                                        int expf) {
+#ifndef SF_SCORE_EXPERIMENTS
+  expf = 0;
+#endif
+  constexpr int LPI = SB_LPI, UB = SB_UB;
+  extern __shared__ __attribute__((aligned(16))) double tile[];      // [pr][128] filter tile, then 4 x 2 KB staging
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int cbi, kk;
+  if (!sf_xcd_map(blockIdx.x, ncb, nk, cbi, kk)) return;
+  const int colbase = cbi * SB_CB, ncol = min(SB_CB, Cs - colbase);
+  // the lane's pair: local columns 2 lane, 2 lane + 1.  A pair (half) past the block's last column is never written;
+  // its loads stay inside the batch's buffer range (or return 0 past it) and its tile weights are 0.
+  const int lc0 = 2 * lane;
+  const bool own0 = lc0 < ncol, own1 = lc0 + 1 < ncol;
+  const int c0 = colbase + lc0;
+  const int pr = (p + 2 * UB - 1) / (2 * UB) * (2 * UB);      // tile rows: the window padded to whole load batches
+  for (int idx = tid; idx < pr * SB_CB; idx += 256) {
+    const int cl = idx / pr, b = idx - cl * pr;
+    tile[b * SB_CB + cl] = (cl < ncol && b < p) ? filt[(size_t)(colbase + cl) * p + b] : 0.0;
+  }
+  const int c0c = min(c0, Cs - 1), c1c = min(c0 + 1, Cs - 1);
+  const double bias0 = bias[c0c], bias1 = bias[c1c];
+  const int st0 = status[c0c], st1 = status[c1c];
+  const int ai0 = alphaidx[c0c], ai1 = alphaidx[c1c];
   const size_t lstride = (size_t)B * C;
   const unsigned lstride4 = (unsigned)lstride * 4u, C4 = (unsigned)C * 4u;
-  const unsigned coff = (unsigned)c0 * 4u;
-  const double *w0p = tile + c0;
-  sc_d2_t *stg = reinterpret_cast<sc_d2_t *>(tile + (size_t)BG * ldw) + 256 * wave;   // this wave's 4 KB staging block
-  const int nb = ngrp * BG;                    // padded band count (tile rows past p hold zeros)
-  const int tile2 = BG * ldw / 2;              // double2 elements per tile (ldw is even)
+  const unsigned coff = (unsigned)lc0 * 4u;
+  const double *wp = tile + lc0;
+  sc_d2_t *stg = reinterpret_cast<sc_d2_t *>(tile + (size_t)pr * SB_CB) + 128 * wave;   // 2 KB per wave
+  __syncthreads();
 
-  const int wb_beg = (int)((long)blockIdx.x * nwb / gridDim.x), wb_end = (int)((long)(blockIdx.x + 1) * nwb / gridDim.x);
-  sc_d2_t tl[SC_TL];                           // the next tile, in flight / parked in registers (ngrp > 1)
-  auto tile_fetch = [&](int g) {
-    const sc_d2_t *src = reinterpret_cast<const sc_d2_t *>(wT) + (size_t)g * tile2;
-#pragma unroll
-    for (int u = 0; u < SC_TL; ++u) {
-      const int i = tid + u * nthr;
-      tl[u] = src[min(i, tile2 - 1)];
-    }
+  const int bat_beg = (int)((long)kk * nbatch / nk), bat_end = (int)((long)(kk + 1) * nbatch / nk);
+  auto batch_rsrc = [&](int sbx) {   // from the batch's first line at the block's first sample to the end of its last line
+    const int lx = sbx * LPI, nlx = min(LPI, L - lx);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cube + (size_t)lx * lstride + (size_t)s0 + colbase), 0,
+                                             (unsigned)nlx * lstride4 - (unsigned)(s0 + colbase) * 4u, 0x00020000);
   };
-  if (ngrp > 1 && wb_beg < wb_end) tile_fetch(0);
-
-  // descriptor of one LPI-line batch; a batch past the last line gets an empty range
-  auto batch_rsrc = [&](int sbx) {
-    const int lx = sbx * LPI;
-    const bool lv = lx < L;
-    const int nlx = lv ? min(LPI, L - lx) : 0;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cube + (size_t)s0 + (size_t)min(lx, L - 1) * lstride), 0,
-                                             lv ? (unsigned)nlx * lstride4 - (unsigned)s0 * 4u : 0u, 0x00020000);
-  };
-  f2a_t xa[LPI][UB], xb[LPI][UB];
   auto load = [&](f2a_t (&x)[LPI][UB], __amdgpu_buffer_rsrc_t rs, int bs) {
 #pragma unroll
     for (int bb = 0; bb < UB; ++bb) {
@@ -276,24 +326,28 @@ __global__ __launch_bounds__(512, 3) void k_score_rows(const float *__restrict__
       for (int j = 0; j < LPI; ++j) x[j][bb] = sc_ld2<NT>(rs, coff, boff + (unsigned)j * lstride4);
     }
   };
-  // The loads run one band batch ahead of the arithmetic, across the tile swaps.  The epilogue of a line batch (RGB
-  // read, record assembly, stores) issues no cube loads, and the tile barriers keep the waves of a workgroup in step:
-  // the launch is sized so that two or three workgroups share a CU and one's epilogue runs under the others' streaming.
-  for (int wb = wb_beg; wb < wb_end; ++wb) {
-    const int sb = wb * G + grp;               // this group's LPI-line batch
+  int sb = bat_beg + wave;
+  if (sb >= bat_end) return;
+  __amdgpu_buffer_rsrc_t rsrc = batch_rsrc(sb);
+  f2a_t xa[LPI][UB], xb[LPI][UB];
+  load(xa, rsrc, 0);
+
+  // One line batch.  On entry P holds the batch's first band batch (in flight); on exit Q holds the NEXT line batch's
+  // first band batch: it is issued BEFORE this batch's epilogue, because vmcnt retires in order -- loads issued after
+  // the epilogue's 32 stores could not be consumed until every one of those stores had been acknowledged (~10 us
+  // behind the CU's queue), and the wave's stream would stand still that long once per batch.
+  auto batch = [&](f2a_t (&P)[LPI][UB], f2a_t (&Q)[LPI][UB]) -> bool {
     const int l0 = sb * LPI;
-    const bool live = l0 < L;                  // (a trailing group without lines still joins the barriers)
-    const __amdgpu_buffer_rsrc_t rsrc = batch_rsrc(sb);
-    if (live) load(xa, rsrc, 0);
+    const int nl = min(LPI, L - l0);
     double acc[LPI][2];
     uint32_t vk[LPI][2];
 #pragma unroll
     for (int j = 0; j < LPI; ++j) { acc[j][0] = acc[j][1] = 0.0; vk[j][0] = vk[j][1] = 0u; }
-
-    auto fma = [&](const f2a_t (&x)[LPI][UB], int row) {
+    auto fma = [&](const f2a_t (&x)[LPI][UB], int bs) {
+      if (expf & 4) { acc[0][0] += (double)x[0][0].x + (double)x[LPI - 1][UB - 1].y; return; }
 #pragma unroll
       for (int bb = 0; bb < UB; ++bb) {
-        const double w0 = w0p[(size_t)(row + bb) * ldw], w1 = w0p[(size_t)(row + bb) * ldw + 1];
+        const double w0 = wp[(size_t)(bs + bb) * SB_CB], w1 = wp[(size_t)(bs + bb) * SB_CB + 1];   // rows >= p are zero
 #pragma unroll
         for (int j = 0; j < LPI; ++j) {
           vk[j][0] = max(vk[j][0], sc_vkey(x[j][bb].x));
@@ -303,111 +357,100 @@ __global__ __launch_bounds__(512, 3) void k_score_rows(const float *__restrict__
         }
       }
     };
-    for (int g = 0; g < ngrp; ++g) {
-      if (ngrp > 1 && !((expf & 2) && (g > 0 || wb > wb_beg))) {
-        // the tile of this group was fetched into registers one group ago (L2 hits, a full round trip that the
-        // previous group's arithmetic covered): swap it in between two LDS-only barriers
-        sc_lds_barrier();                      // every wave is done with the previous tile
+    for (int bc = 0; bc < pr; bc += 2 * UB) {
+      load(Q, rsrc, bc + UB);
+      fma(P, bc);
+      if (bc + 2 * UB < pr) {
+        load(P, rsrc, bc + 2 * UB);
+      } else if (RGB) {
+        // the last band batch is in flight and P is free: the three RGB rows of the batch's lines (whole-row pieces
+        // again) queue up right behind it, in P's registers
 #pragma unroll
-        for (int u = 0; u < SC_TL; ++u) {
-          const int i = tid + u * nthr;
-          if (i < tile2) reinterpret_cast<sc_d2_t *>(tile)[i] = tl[u];
-        }
-        sc_lds_barrier();
-        if (g + 1 < ngrp || wb + 1 < wb_end) tile_fetch(g + 1 < ngrp ? g + 1 : 0);
-      } else if (wb == wb_beg) {               // a window that fits one tile is staged once per workgroup
-        const double2 *src = reinterpret_cast<const double2 *>(wT);
-        for (int i = tid; i < tile2; i += nthr) reinterpret_cast<double2 *>(tile)[i] = src[i];
-        sc_lds_barrier();
-      }
-      if (live) {
-        for (int k = 0; k < BG; k += 2 * UB) {  // BG is a multiple of 2 UB
-          const int bs = g * BG + k;
-          load(xb, rsrc, bs + UB);
-          if (!(expf & 4)) fma(xa, k);
-          else acc[0][0] += (double)xa[0][0].x + (double)xa[LPI - 1][UB - 1].y;
-          if (bs + 2 * UB < nb) load(xa, rsrc, bs + 2 * UB);
-          if (!(expf & 4)) fma(xb, k + UB);
-          else acc[0][1] += (double)xb[0][0].x + (double)xb[LPI - 1][UB - 1].y;
+        for (int j = 0; j < LPI; ++j) {
+          P[j][0] = sc_ld2<NT>(rsrc, coff, (unsigned)rgb0 * C4 + (unsigned)j * lstride4);
+          P[j][1] = sc_ld2<NT>(rsrc, coff, (unsigned)rgb1 * C4 + (unsigned)j * lstride4);
+          P[j][2] = sc_ld2<NT>(rsrc, coff, (unsigned)rgb2 * C4 + (unsigned)j * lstride4);
         }
       }
+      fma(Q, bc + UB);
     }
-    if (!live) continue;
-
-    double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
-    if ((expf & 1) && acc[0][0] != 1.2345e300) continue;
-    // epilogue in two halves of LPI/2 lines: the RGB rows of a half (whole rows again, 3 x LPI/2 loads) are read right
-    // before its records are assembled -- half the registers of reading them all at once
-#pragma unroll
-    for (int jh = 0; jh < LPI; jh += LPI / 2) {
-    f2a_t rgbv[LPI / 2][3];
-    if (RGB && (expf & 16)) {
-#pragma unroll
-      for (int jj = 0; jj < LPI / 2; ++jj) rgbv[jj][0] = rgbv[jj][1] = rgbv[jj][2] = f2a_t{1.f, 2.f};
-    } else if (RGB) {
-#pragma unroll
-      for (int jj = 0; jj < LPI / 2; ++jj) {
-        rgbv[jj][0] = sc_ld2<NT>(rsrc, coff, (unsigned)rgb0 * C4 + (unsigned)(jh + jj) * lstride4);
-        rgbv[jj][1] = sc_ld2<NT>(rsrc, coff, (unsigned)rgb1 * C4 + (unsigned)(jh + jj) * lstride4);
-        rgbv[jj][2] = sc_ld2<NT>(rsrc, coff, (unsigned)rgb2 * C4 + (unsigned)(jh + jj) * lstride4);
-      }
+    const int sbn = sb + 4;
+    const bool more = sbn < bat_end;
+    if (more) {
+      rsrc = batch_rsrc(sbn);
+      load(Q, rsrc, 0);
     }
+    if (!((expf & 1) && acc[0][0] != 1.2345e300)) {
+      double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+      {
+        const f2a_t (&rgbv)[LPI][UB] = P;
 #pragma unroll
-    for (int jj = 0; jj < LPI / 2; ++jj) {
-      const int j = jh + jj;
-      if (l0 + j < L) {
-        // status 2 (singular C): filt = bias = 0 -> the valid rows get exactly 0 (robust_mf.py:373)
-        const bool ok0 = vk[j][0] <= SC_VKEY_MAX, ok1 = vk[j][1] <= SC_VKEY_MAX;
-        const double sc0 = ok0 ? ((st0 == 2) ? 0.0 : (acc[j][0] - bias0)) : nodata;
-        const double sc1 = ok1 ? ((st1 == 2) ? 0.0 : (acc[j][1] - bias1)) : nodata;
-        if (ok0) { s1[0] += sc0; s2[0] += sc0 * sc0; }
-        if (ok1) { s1[1] += sc1; s2[1] += sc1 * sc1; }
-        const size_t pix = (size_t)(l0 + j) * oS + os0 + c0;
-        if (RGB) {
-          // The wave's 128 pixel records [R, G, B, CMF] of this line are 4 KB of contiguous output.  A lane holds the two
-          // 32-byte records of its pixels; stored from there, every 16-byte store instruction would scatter 16-byte pieces
-          // at a 64-byte stride (measured: the stores then cost 0.17 ms of a 0.82 ms launch).  The records go through a
-          // 4 KB LDS staging block of the wave instead and leave as four instructions of 1 KB contiguous bytes each.
-          // Staging layout: 16-byte piece m of lane s at index 4 s + (m ^ ((s >> 2) & 3)) -- conflict-free both ways.
-          // columns without a valid row are skipped before the RGB copy (:303-304)
-          const bool cp0 = st0 != 1, cp1 = st1 != 1;
-          sc_d2_t r0a = {cp0 ? (double)rgbv[jj][0].x : 0.0, cp0 ? (double)rgbv[jj][1].x : 0.0};
-          sc_d2_t r0b = {cp0 ? (double)rgbv[jj][2].x : 0.0, sc0};
-          const sc_d2_t r1a = {cp1 ? (double)rgbv[jj][0].y : 0.0, cp1 ? (double)rgbv[jj][1].y : 0.0};
-          const sc_d2_t r1b = {cp1 ? (double)rgbv[jj][2].y : 0.0, sc1};
-          if (!own0) { r0a = r1a; r0b = r1b; }   // odd shard width: the last lane holds (Cs-2, Cs-1) and owns only Cs-1
-          const int sw = (lane >> 2) & 3;
-          stg[4 * lane + (0 ^ sw)] = r0a;
-          stg[4 * lane + (1 ^ sw)] = r0b;
-          stg[4 * lane + (2 ^ sw)] = r1a;
-          stg[4 * lane + (3 ^ sw)] = r1b;
-          sc_d2_t *orow = reinterpret_cast<sc_d2_t *>(out + ((size_t)(l0 + j) * oS + os0) * 4);
+        for (int jj = 0; jj < LPI; ++jj) {
+          const int j = jj;
+          if (j >= nl) break;                                   // (wave-uniform)
+          // status 2 (singular C): filt = bias = 0 -> the valid rows get exactly 0 (robust_mf.py:373)
+          const bool ok0 = vk[j][0] <= SC_VKEY_MAX, ok1 = vk[j][1] <= SC_VKEY_MAX;
+          const double sc0 = ok0 ? ((st0 == 2) ? 0.0 : (acc[j][0] - bias0)) : nodata;
+          const double sc1 = ok1 ? ((st1 == 2) ? 0.0 : (acc[j][1] - bias1)) : nodata;
+          if (ok0) { s1[0] += sc0; s2[0] += sc0 * sc0; }
+          if (ok1) { s1[1] += sc1; s2[1] += sc1 * sc1; }
+          const size_t pix = (size_t)(l0 + j) * oS + os0 + c0;
+          if (expf & 8) continue;
+          if (RGB) {
+            // the wave's 128 records [R, G, B, CMF] of this line are 4 KB of contiguous output; they pass through the wave's
+            // 2 KB staging block in two halves (32 lanes each) and leave as 1 KB contiguous store instructions.
+            // Layout: 16-byte piece m of lane s' at 4 s' + (m ^ ((s' >> 2) & 3)) -- conflict-free both ways.
+            // columns without a valid row are skipped before the RGB copy (:303-304)
+            const bool cp0 = st0 != 1, cp1 = st1 != 1;
+            const sc_d2_t r0a = {cp0 ? (double)rgbv[jj][0].x : 0.0, cp0 ? (double)rgbv[jj][1].x : 0.0};
+            const sc_d2_t r0b = {cp0 ? (double)rgbv[jj][2].x : 0.0, sc0};
+            const sc_d2_t r1a = {cp1 ? (double)rgbv[jj][0].y : 0.0, cp1 ? (double)rgbv[jj][1].y : 0.0};
+            const sc_d2_t r1b = {cp1 ? (double)rgbv[jj][2].y : 0.0, sc1};
+            sc_d2_t *orow = reinterpret_cast<sc_d2_t *>(out + ((size_t)(l0 + j) * oS + os0 + colbase) * 4);
+            if (expf & 32)   // (experiment: the same bytes, but each wave's batch as ONE contiguous 32 KB run)
+              orow = reinterpret_cast<sc_d2_t *>(out) + (((size_t)sb * ncb + cbi) * LPI + j) * 256;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int P = 64 * k + lane;                    // 16-byte piece of the wave's 4 KB run
-            const int s = P >> 2;
-            const sc_d2_t v = stg[4 * s + ((P & 3) ^ ((s >> 2) & 3))];
-            const int col = 128 * wv + (P >> 1);
-            if (col < Cs && !((expf & 8) && v.x != 1.2345e300)) orow[(size_t)col * 2 + (P & 1)] = v;
+            for (int h = 0; h < 2; ++h) {
+              if ((lane >> 5) == h) {
+                const int s = lane & 31, sw = (s >> 2) & 3;
+                stg[4 * s + (0 ^ sw)] = r0a;
+                stg[4 * s + (1 ^ sw)] = r0b;
+                stg[4 * s + (2 ^ sw)] = r1a;
+                stg[4 * s + (3 ^ sw)] = r1b;
+              }
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
+                const int P = 64 * k + lane;                    // 16-byte piece of this half's 2 KB
+                const int s = P >> 2;
+                const sc_d2_t v = stg[4 * s + ((P & 3) ^ ((s >> 2) & 3))];
+                const int lcol = 64 * h + (P >> 1);
+                if (lcol < ncol && !((expf & 64) && v.x != 1.2345e300)) sc_store16(orow + (size_t)lcol * 2 + (P & 1), v, expf >> 8);
+              }
+            }
+          } else {
+            if (own0) out[pix] = sc0;
+            if (own1) out[pix + 1] = sc1;
           }
-        } else {
-          if (own0) out[pix] = sc0;
-          if (own1) out[pix + 1] = sc1;
-        }
-        if (bgmeta) {
-          // int16 pair (cluster id = 0, alpha index); written only on valid rows of solved columns (:365)
-          uint32_t *bm = reinterpret_cast<uint32_t *>(bgmeta) + pix;
-          if (own0) bm[0] = (ok0 && st0 == 0) ? ((uint32_t)(uint16_t)(int16_t)ai0 << 16) : 0u;
-          if (own1) bm[1] = (ok1 && st1 == 0) ? ((uint32_t)(uint16_t)(int16_t)ai1 << 16) : 0u;
+          if (bgmeta) {
+            // int16 pair (cluster id = 0, alpha index); written only on valid rows of solved columns (:365)
+            uint32_t *bm = reinterpret_cast<uint32_t *>(bgmeta) + pix;
+            if (own0) bm[0] = (ok0 && st0 == 0) ? ((uint32_t)(uint16_t)(int16_t)ai0 << 16) : 0u;
+            if (own1) bm[1] = (ok1 && st1 == 0) ? ((uint32_t)(uint16_t)(int16_t)ai1 << 16) : 0u;
+          }
         }
       }
+      if (stat_part) {
+        double2 *o = reinterpret_cast<double2 *>(stat_part) + (size_t)sb * Cs + c0;
+        if (own0) o[0] = make_double2(s1[0], s2[0]);
+        if (own1) o[1] = make_double2(s1[1], s2[1]);
+      }
     }
-    }
-    if (stat_part) {
-      double2 *o = reinterpret_cast<double2 *>(stat_part) + (size_t)sb * Cs + c0;
-      if (own0) o[0] = make_double2(s1[0], s2[0]);
-      if (own1) o[1] = make_double2(s1[1], s2[1]);
-    }
+    sb = sbn;
+    return more;
+  };
+  for (;;) {
+    if (!batch(xa, xb)) break;
+    if (!batch(xb, xa)) break;
   }
 }
 
@@ -515,20 +558,20 @@ __global__ void k_filt_transpose(const double *__restrict__ filt, int Cs, int p,
   wT[i] = (c < Cs && b < p) ? filt[(size_t)c * p + b] : 0.0;
 }
 
-template <bool RGB, int LPI, int UB, bool WGL = false, int CW = 1>
+template <bool RGB, int LPI, int UB, bool WGL = false, int CW = 1, bool STG = false>
 int launch_score_t(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
                    const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx, int rgb0,
                    int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0, int16_t *bgmeta,
                    double *stat_part, int lpw, hipStream_t st, hipEvent_t ea, hipEvent_t eb, const double *wT = nullptr,
                    int ldw = 0) {
   const size_t lds = WGL ? 0 : (size_t)CW * p * 64 * sizeof(double);
-  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_score<RGB, LPI, UB, WGL, CW>), lds)) return rc;
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_score<RGB, LPI, UB, WGL, CW, STG>), lds)) return rc;
   const int nchunk = sf_cdiv(lines, lpw);
   const int ncb = sf_cdiv(ncols, 64 * CW);
   const int xcd = sf_tune().score_xcd;
   const int nblk = xcd ? sf_xcd_grid(ncb, nchunk) : ncb * nchunk;
   if (ea) SF_HIP(hipEventRecord(ea, st));
-  hipLaunchKernelGGL((k_score<RGB, LPI, UB, WGL, CW>), dim3(nblk), dim3(256 * CW), lds, st, cube, lines, bands, samples, s0, ncols, b0,
+  hipLaunchKernelGGL((k_score<RGB, LPI, UB, WGL, CW, STG>), dim3(nblk), dim3(256 * CW), lds, st, cube, lines, bands, samples, s0, ncols, b0,
                      p, filt, bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, out_samples, out_s0, bgmeta, stat_part,
                      lpw, ncb, nchunk, xcd, wT, ldw);
   SF_LAUNCH_CHECK("k_score");
@@ -539,16 +582,15 @@ int launch_score_t(const float *cube, int lines, int bands, int samples, int s0,
 // ---- launch plan: which kernel scores a shard, and with which line granularity of the statistics partials --------
 // A function of the geometry and the calling thread's tuning knobs only (sf_launch_colstats must agree with it).
 namespace {
-constexpr int SR_LPI = 8;            // lines per lane of the row kernel = granularity of its statistics partials
 struct ScorePlan {
-  bool rows;                         // k_score_rows (else the column-block kernel k_score)
+  int kernel;                        // 0: k_score_blk2, 2: k_score (production)
   int lpw;                           // lines per statistics partial
 };
-ScorePlan score_plan(int lines, int ncols) {
+ScorePlan score_plan(int lines, int ncols, int p) {
   const int v = sf_tune().score_variant;
   ScorePlan pl;
-  pl.rows = (v == 0 || (v >= 20 && v < 60)) && ncols >= 2 && ncols <= 1024;
-  pl.lpw = pl.rows ? SR_LPI : (sf_tune().score_lpw > 0 ? sf_tune().score_lpw : sf_score_lines_per_wg(lines, ncols));
+  pl.kernel = ((v == 10 || v == 11) && sb_lds_bytes(p) <= 160 * 1024) ? 0 : 2;
+  pl.lpw = pl.kernel == 0 ? SB_LPI : (sf_tune().score_lpw > 0 ? sf_tune().score_lpw : sf_score_lines_per_wg(lines, ncols));
   return pl;
 }
 
@@ -572,84 +614,52 @@ int resident_wgs(const void *fn, int nthr, size_t lds, int *out) {
   return 0;
 }
 
-template <bool RGB, int LPI, int UB, bool NT>
-int launch_rows_t(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p, const double *wT,
-                  int ldw, int BG, int ngrp, const double *bias, const int32_t *status, const int32_t *alphaidx, int rgb0,
-                  int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0, int16_t *bgmeta,
-                  double *stat_part, int wpg, int G, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
-  static_assert(LPI == SR_LPI, "the statistics partials are per SR_LPI lines");
-  const void *fn = reinterpret_cast<const void *>(k_score_rows<RGB, LPI, UB, NT>);
-  const int nthr = 64 * wpg * G;
-  const size_t lds = (size_t)BG * ldw * sizeof(double) + (RGB ? (size_t)(nthr / 64) * 4096 : 0);   // tile + staging
-  if (int rc = sf_lds_attr(fn, lds)) return rc;
-  const int nwb = sf_cdiv(lines, G * LPI);
-  int slots = 0;
-  if (int rc = resident_wgs(fn, nthr, lds, &slots)) return rc;
-  if (sf_tune().score_wgs > 0) slots = sf_tune().score_wgs * 256;
-  const int k = sf_cdiv(nwb, slots);           // batches per workgroup: every workgroup resident, all the same length
-  const int nwg = sf_cdiv(nwb, k);
-  if (ea) SF_HIP(hipEventRecord(ea, st));
-  hipLaunchKernelGGL((k_score_rows<RGB, LPI, UB, NT>), dim3(nwg), dim3(nthr), lds, st, cube, lines, bands, samples, s0,
-                     ncols, b0, p, wT, ldw, BG, ngrp, bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, out_samples,
-                     out_s0, bgmeta, stat_part, wpg, G, nwb, sf_tune().score_exp);
-  SF_LAUNCH_CHECK("k_score_rows");
-  if (eb) SF_HIP(hipEventRecord(eb, st));
-  return 0;
-}
 }  // namespace
 
-int sf_score_lpw(int lines, int ncols) { return score_plan(lines, ncols).lpw; }
+int sf_score_lpw(int lines, int ncols, int p) { return score_plan(lines, ncols, p).lpw; }
 
 #define SC_ARGS cube, lines, bands, samples, s0, ncols, b0, p, filt, bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, \
                 out_samples, out_s0, bgmeta, stat_part, lpw, st, ea, eb
-#define SR_ARGS cube, lines, bands, samples, s0, ncols, b0, p, wT, ldw, BG, ngrp, bias, status, alphaidx, rgb0, rgb1, rgb2, \
-                nodata, out, out_samples, out_s0, bgmeta, stat_part, wpg, G, st, ea, eb
 int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
                     const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,
                     int rgb0, int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0,
                     int out_bands, int16_t *bgmeta, void *scratch, int want_stats, hipStream_t st, hipEvent_t ea,
                     hipEvent_t eb) {
-  const ScorePlan pl = score_plan(lines, ncols);
+  const ScorePlan pl = score_plan(lines, ncols, p);
   const int lpw = pl.lpw;
   double *stat_part = (scratch && want_stats) ? reinterpret_cast<double *>(scratch) : nullptr;
   double *wT = scratch ? reinterpret_cast<double *>(reinterpret_cast<char *>(scratch) + score_stat_bytes(lines, ncols)) : nullptr;
   const bool rgb = out_bands == 4;
-  if (pl.rows) {
-    if (!scratch) { sf_set_error("score kernel: scratch is required (sf_score_scratch_bytes)"); return -1; }
-    const int v = sf_tune().score_variant;
-    const int form = (v >= 20) ? (v - 20) % 10 : 0;        // bands per load batch (x 8 lines): 0 -> 2, 1 -> 4, 2 -> 1
-    const bool nt = !(v >= 30 && v < 40);                  // 30..39: plain (temporal) loads
-    const int UB = form == 1 ? 4 : (form == 2 ? 1 : 2);
-    const int T = (ncols + 1) / 2, wpg = sf_cdiv(T, 64);
-    int G = 8 / wpg;                                        // <= 512 threads per workgroup
-    if (G > 4) G = 4;
-    if (sf_tune().score_lpw > 0 && sf_tune().score_lpw <= G) G = sf_tune().score_lpw;   // (experiments: key 2 = line groups)
-    const int ldw = (ncols + 1) / 2 * 2;
-    // bands per LDS tile: a multiple of 2 UB, the tile within ~48 KB so that three workgroups share a CU's LDS
-    int BG = sf_tune().score_bg > 0 ? sf_tune().score_bg : (int)((size_t)48 * 1024 / ((size_t)ldw * sizeof(double)));
-    BG = BG / (2 * UB) * (2 * UB);
-    if (BG < 2 * UB) BG = 2 * UB;
-    const int pmax = sf_cdiv(p, 2 * UB) * 2 * UB;
-    if (BG > pmax) BG = pmax;
-    if (BG < pmax) {   // several tiles per batch: a tile is swapped through SC_TL 16-byte registers per thread
-      const int cap = (int)((size_t)SC_TL * 64 * wpg * G * 2 / ldw) / (2 * UB) * (2 * UB);
-      if (cap < 2 * UB) { sf_set_error("score kernel: shard of %d columns too wide for the tile swap", ncols); return -2; }
-      if (BG > cap) BG = cap;
-    }
-    const int ngrp = sf_cdiv(p, BG);
-    if (ngrp * BG > SC_WT_ROWS) { sf_set_error("score kernel: window of %d bands too wide", p); return -2; }
-    if ((size_t)BG * ldw * sizeof(double) + (size_t)wpg * G * 4096 > 160 * 1024) {
-      sf_set_error("score kernel: a tile of %d bands x %d columns does not fit the LDS", BG, ldw);
-      return -2;
-    }
-    hipLaunchKernelGGL(k_filt_transpose, dim3(sf_cdiv(ngrp * BG * ldw, 256)), dim3(256), 0, st, filt, ncols, p, ldw, ngrp * BG, wT);
-    SF_LAUNCH_CHECK("k_filt_transpose");
-#define SR_DISPATCH(RGBV, NTV)                                                \
-    (UB == 4 ? launch_rows_t<RGBV, SR_LPI, 4, NTV>(SR_ARGS)                                \
-             : (UB == 1 ? launch_rows_t<RGBV, SR_LPI, 1, NTV>(SR_ARGS) : launch_rows_t<RGBV, SR_LPI, 2, NTV>(SR_ARGS)))
-    if (rgb) return nt ? SR_DISPATCH(true, true) : SR_DISPATCH(true, false);
-    return nt ? SR_DISPATCH(false, true) : SR_DISPATCH(false, false);
-#undef SR_DISPATCH
+  if (pl.kernel == 0 && (size_t)bands * samples * 4 * SB_LPI >= ((size_t)1 << 32)) {
+    sf_set_error("score kernel: %d lines of %d x %d values exceed a buffer descriptor", SB_LPI, bands, samples);
+    return -2;
+  }
+  if (pl.kernel == 0) {
+    const size_t lds = sb_lds_bytes(p);
+    const bool nt = sf_tune().score_variant == 11;            // (experiment: non-temporal loads)
+    const void *fn = rgb ? (nt ? (const void *)k_score_blk2<true, true> : (const void *)k_score_blk2<true, false>)
+                         : (nt ? (const void *)k_score_blk2<false, true> : (const void *)k_score_blk2<false, false>);
+    if (int rc = sf_lds_attr(fn, lds)) return rc;
+    int slots = 0;
+    if (int rc = resident_wgs(fn, 256, lds, &slots)) return rc;
+    if (sf_tune().score_wgs > 0) slots = sf_tune().score_wgs * 256;
+    const int ncb = sf_cdiv(ncols, SB_CB), nbatch = sf_cdiv(lines, SB_LPI);
+    int nk = slots / (8 * ncb) * 8;                           // every workgroup resident, whole XCD rounds
+    if (nk < 8) nk = 8;
+    if (nk > sf_cdiv(nbatch, 4)) nk = sf_cdiv(nbatch, 4);     // at least one batch per wave
+    if (nk < 1) nk = 1;
+    const int grid = sf_xcd_grid(ncb, nk);
+    if (ea) SF_HIP(hipEventRecord(ea, st));
+#define SB_LAUNCH(RGBV, NTV)                                                                                          \
+    hipLaunchKernelGGL((k_score_blk2<RGBV, NTV>), dim3(grid), dim3(256), lds, st, cube, lines, bands, samples, s0, ncols,  \
+                       b0, p, filt, bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, out_samples, out_s0, bgmeta,     \
+                       stat_part, ncb, nk, nbatch, sf_tune().score_exp)
+    if (rgb) { if (nt) SB_LAUNCH(true, true); else SB_LAUNCH(true, false); }
+    else { if (nt) SB_LAUNCH(false, true); else SB_LAUNCH(false, false); }
+#undef SB_LAUNCH
+    SF_LAUNCH_CHECK("k_score_blk2");
+    if (eb) SF_HIP(hipEventRecord(eb, st));
+    return 0;
   }
   // ---- column-block kernel (round 1)
   if ((size_t)p * 64 * sizeof(double) > 100 * 1024) {  // wide window: filter from a transposed global copy
@@ -670,16 +680,16 @@ int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0
     case 7: return launch_score_t<true, 8, 4, false, 2>(SC_ARGS);
     case 8: return launch_score_t<true, 4, 8, false, 2>(SC_ARGS);
     case 9: return launch_score_t<true, 4, 4, false, 2>(SC_ARGS);
-    default: return launch_score_t<true, 8, 4>(SC_ARGS);  // the round-1 choice (tools/tune_score.py)
+    case 100: return launch_score_t<true, 8, 4>(SC_ARGS);                    // round 1: 16-byte pieces stored by the lanes
+    default: return launch_score_t<true, 8, 4, false, 1, true>(SC_ARGS);     // 8 lines x 4 bands per batch, staged stores
   }
 }
 #undef SC_ARGS
-#undef SR_ARGS
 
 int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0, int ncols, int p, const int32_t *nuse,
                        const int32_t *status, double nodata, double *colstats, hipStream_t st) {
-  (void)samples; (void)s0; (void)p;
-  const int lpw = sf_score_lpw(lines, ncols);
+  (void)samples; (void)s0;
+  const int lpw = sf_score_lpw(lines, ncols, p);
   const int nchunk = sf_cdiv(lines, lpw);
   hipLaunchKernelGGL(k_colstats, dim3(sf_cdiv(ncols, 64)), dim3(1024), 0, st,
                      reinterpret_cast<const double *>(stat_scratch), nchunk, ncols, nuse, status, nodata, colstats);

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Golden vectors for saliency map -> detections, produced by EXECUTING the reference.
+
+Only runs in the development container (needs /root/reference).  ``salience_predictions.py`` is run unmodified as
+``__main__`` (its ``salience2detections`` reads a global of the script body) with the real ``srcfinder_util``
+(``extrema``, ``findobj``, ``sl2latlon`` / ``sl2xy``, ``mapinfo``; the UTM -> lat/lon conversion itself is a third-party
+module that is absent: its stand-in returns the map coordinates it is given); stand-ins: the file reader (``openimgmm`` hands over
+in-memory arrays), and the third-party functions this image lacks, by their published definitions --
+``skimage.measure.label`` (connectivity 2 -> scipy.ndimage.label with the 3 x 3 structure, same raster numbering) and
+``statsmodels.robust.scale.mad`` (``median(|a - center|) / c``).  The table the script builds (one row per region) is
+captured where it is assembled (``DataFrame.from_records``); the figures it draws per region go to a scratch directory.
+
+    python tests/golden/gen_golden_detections.py
+"""
+import os
+import runpy
+import sys
+import tempfile
+import types
+import warnings
+
+import numpy as np
+import scipy.ndimage as ndi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+LINES, SAMPLES, SEED = 180, 90, 77
+MAPINFO = ["UTM", "1", "1", "367000.0", "3790000.0", "3.3", "3.3", "11", "North", "WGS-84", "units=Meters"]
+
+
+def scene(lines=LINES, samples=SAMPLES, seed=SEED):
+    """(saliency [lines, samples, 1] float32, product [lines, samples, 4] float64): a dozen blobs of saliency above 0.5
+    (touching diagonally, plateaus with several maxima, one on the NODATA border), CMF enhancements under most of them."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:lines, 0:samples]
+    sal = rng.uniform(0.0, 0.3, (lines, samples))
+    cmf = rng.normal(40.0, 120.0, (lines, samples))
+    for k in range(12):
+        cy, cx = rng.integers(6, lines - 6), rng.integers(6, samples - 6)
+        ry, rx = rng.uniform(1.5, 7), rng.uniform(1.5, 6)
+        blob = np.exp(-(((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2))
+        sal = np.maximum(sal, 0.98 * blob)
+        cmf += (300 + 900 * rng.random()) * blob * (rng.random((lines, samples)) * 0.5 + 0.75)
+    sal[40:44, 20:24] = 0.875                       # a plateau: four-by-four pixels share the maximum
+    sal[44, 24] = sal[45, 25] = 0.7                 # joined to the plateau only diagonally
+    cmf[40:44, 20:24] = 777.0
+    sal = np.round(sal.astype(np.float32), 3)       # ties
+    img = np.empty((lines, samples, 4))
+    img[..., :3] = rng.uniform(0.5, 12, (lines, samples, 3))
+    img[..., 3] = cmf
+    img[:5, :, :3] = -9999.0                        # NODATA border (RGB band 0 == -9999)
+    img[:5, :, 3] = -9999.0
+    sal[3:8, 50:56] = 0.9                           # a region that straddles the border
+    cmf2 = img[..., 3]
+    cmf2[5:8, 50:56] = 650.0
+    return sal[..., None], img
+
+
+def _stub(name, **a):
+    m = types.ModuleType(name)
+    m.__dict__.update(a)
+    sys.modules[name] = m
+    return m
+
+
+def run_reference(sal, img, prob_thr=0.5, ppmm_thr=250.0):
+    for name in ("gdal", "rasterio", "geopandas", "spectral", "spectral.io", "skimage", "statsmodels", "statsmodels.robust"):
+        _stub(name)
+    _stub("osgeo", gdal=sys.modules["gdal"])
+    sys.modules["gdal"].gdalconst = sys.modules["gdal"].ogr = sys.modules["gdal"].osr = None
+    _stub("spectral.io.envi", open=lambda *a, **k: None)
+    sys.modules["spectral"].SpyFile = type("SpyFile", (), {})
+    # UTM -> lat/lon is a third-party module (absent): the stand-in passes the map coordinates through, so the table's
+    # "lat" / "lon" columns hold what the reference's own sl2xy computed and handed to the conversion (as arrays)
+    _stub("LatLongUTMconversion", UTMtoLL=lambda datum, e, n, zone: (np.atleast_1d(np.float64(e)), np.atleast_1d(np.float64(n))),
+          LLtoUTM=None)
+    sys.modules["skimage"].__path__ = []
+    _stub("skimage.morphology", disk=lambda r, **k: np.ones((2 * r + 1, 2 * r + 1), bool))
+    _stub("skimage.measure", label=lambda a, connectivity=None, **k: ndi.label(a, structure=ndi.generate_binary_structure(a.ndim, connectivity or a.ndim))[0])
+    _stub("statsmodels.robust.scale", mad=lambda a, c=0.6745, axis=0, center=np.median: np.median(np.abs(a - (center(a) if callable(center) else center)), axis=axis) / c)
+    sys.path.insert(0, REF)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import srcfinder_util as U
+    SpyFile = sys.modules["spectral"].SpyFile
+
+    class Img(SpyFile):
+        metadata = {"map info": list(MAPINFO)}
+    arrays = {"sal_img": sal, "ang20200101t000000_cmf_v1_img": img}
+    U.openimgmm = lambda f, **k: (Img(), arrays[os.path.basename(f)])
+    captured = []
+    import pandas as pd
+    orig = pd.DataFrame.from_records
+
+    def spy(*a, **k):
+        df = orig(*a, **k)
+        captured.append(df)
+        return df
+    pd.DataFrame.from_records = staticmethod(spy)
+    out = tempfile.mkdtemp()
+    old = sys.argv
+    sys.argv = ["salience_predictions.py", "--prob_thr", str(prob_thr), "--ppmm_thr", str(ppmm_thr), "--outdir", out,
+                "sal_img", "ang20200101t000000_cmf_v1_img"]
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            runpy.run_path(os.path.join(REF, "salience_predictions.py"), run_name="__main__")
+    except (SystemExit, AttributeError, ImportError, ModuleNotFoundError) as e:   # the .xlsx writer (pandas >= 2) after the table is built
+        print("script stopped after the table:", type(e).__name__, e)
+    finally:
+        sys.argv = old
+        pd.DataFrame.from_records = orig
+    return captured[0]
+
+
+def main():
+    sal, img = scene()
+    df = run_reference(sal, img)
+    cols = [c for c in df.columns if c not in ("detid", "lid")]
+    table = df[cols].to_numpy(dtype=np.float64)
+    import scipy
+    np.savez_compressed(os.path.join(HERE, "detections_golden.npz"), lines=LINES, samples=SAMPLES, seed=SEED,
+                        prob_thr=0.5, ppmm_thr=250.0, columns=np.array(cols), table=table, detid=np.array(df["detid"], dtype=str),
+                        mapinfo=np.array(MAPINFO), versions=np.array(["numpy " + np.__version__, "scipy " + scipy.__version__]))
+    print(df.to_string())
+
+
+if __name__ == "__main__":
+    main()

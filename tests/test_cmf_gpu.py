@@ -491,9 +491,10 @@ def test_shard_of_a_full_width_run_is_bit_identical(torch_cuda, library):
 
 
 def test_score_kernels_agree_bit_for_bit(torch_cuda, library):
-    """The row score kernel (production) and the column-block kernel of round 1 accumulate a pixel's dot product in the
-    same order: identical products and statistics on ragged geometries (odd widths and offsets, a single-column tail
-    pair, line counts that are not multiples of the 8-line batch), with and without RGB, plain and non-temporal loads."""
+    """Every form of the score kernel (round 1's lane-stored records = 100, the production kernel with staged stores = 0,
+    the 128-sample-block kernel with plain / non-temporal buffer loads = 10 / 11) accumulates a pixel's dot product in the
+    same order: identical products on ragged geometries (odd widths and offsets, 1- and 2-column shards, line counts
+    that are not multiples of the 8-line batch, -0.0 / +-inf values), with and without RGB."""
     torch = torch_cuda
     L = _ffi.lib()
     rng = np.random.default_rng(11)
@@ -505,7 +506,7 @@ def test_score_kernels_agree_bit_for_bit(torch_cuda, library):
         t = torch.as_tensor(cube).cuda()
         for rgb in ((60, 42, 24), ()):
             outs = []
-            for variant in (100, 0, 21, 22, 30):
+            for variant in (100, 0, 10, 11):
                 try:
                     L.sf_debug_set(1, variant)
                     outs.append(cmf.robust_mf(t, library, metadata=True, columns=cols, rgb_bands=rgb))
@@ -525,8 +526,8 @@ def test_score_kernels_agree_bit_for_bit(torch_cuda, library):
 
 
 def test_column_profile_and_systematics(torch_cuda, library):
-    """N2: triage column profile of the product on the GPU against the numpy restatement (parity unpinned: the
-    reference function cannot run here), and the rolling-median flag rule on a planted column."""
+    """N2: triage column profile of a real product of the pipeline on the GPU against the numpy restatement (itself
+    pinned by test_triage_profile_golden), and the rolling-median flag rule on a planted column."""
     from oracle import triage_oracle as TO
     from srcfinder_amd import triage
     cube = make_cube_numpy(300, 70, seed=71, abscf_full=library[:, 2], nodata_column=11)
@@ -545,6 +546,28 @@ def test_column_profile_and_systematics(torch_cuda, library):
     avg[40] += 50 * np.nanstd(avg)                       # a planted systematic column
     coldiff, sigma, counts = triage.systematics_flags(avg)
     assert sigma > 0 and counts[2] >= 1 and np.nanargmax(coldiff) == 40
+
+
+def test_column_profile_against_reference_golden(torch_cuda, golden_dir):
+    """N2 pinned: sf_cmf_column_profile / _robust on the GPU against the CSV tables the real triage/cmf_profile.py wrote
+    (tests/golden/triage_profile.npz).  Counts and order statistics (median of float32 values, MAD, 'nearest'
+    percentiles, min, max) exact; mean / std to the rounding of numpy's float32 reductions."""
+    import importlib.util
+    from srcfinder_amd import triage
+    spec = importlib.util.spec_from_file_location("gen_golden_triage", os.path.join(golden_dir, "gen_golden_triage.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    g = np.load(os.path.join(golden_dir, "triage_profile.npz"))
+    img = gen.product(int(g["lines"]), int(g["samples"]), int(g["seed"]))
+    prof = triage.column_profile(img).T
+    want = g["plain"]
+    assert np.array_equal(prof[:, 0], want[:, 0])
+    assert np.array_equal(np.isnan(prof), np.isnan(want))
+    f = ~np.isnan(want[:, 1])
+    assert np.array_equal(np.float32(prof[f][:, 3:]), np.float32(want[f][:, 3:]))   # min, max (the CSV has 16 digits)
+    np.testing.assert_allclose(prof[f][:, 1:3], want[f][:, 1:3], rtol=2e-5, atol=1e-4)
+    rob = triage.column_profile(img, robust=True).T
+    assert np.array_equal(np.float32(rob), np.float32(g["robust"]), equal_nan=True)
 
 
 def test_narrow_cube_extract_is_bit_identical(torch_cuda, library):

@@ -178,3 +178,21 @@ def test_empirical_model_oracle_reproduces_reference(golden_dir, library):
     o = O.robust_mf_oracle(cube, library, model="empirical")
     assert np.array_equal(o["out"], g["out"])
     assert np.array_equal(o["colstats"], g["colstats"])
+
+
+def test_triage_profile_golden(golden_dir):
+    """N2: the column-profile restatement against the CSV tables written by the real triage/cmf_profile.py
+    (tests/golden/gen_golden_triage.py) -- bit for bit, NaN placement included."""
+    import importlib.util
+    from oracle import triage_oracle as TO
+    spec = importlib.util.spec_from_file_location("gen_golden_triage", os.path.join(golden_dir, "gen_golden_triage.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    g = np.load(os.path.join(golden_dir, "triage_profile.npz"))
+    img = gen.product(int(g["lines"]), int(g["samples"]), int(g["seed"]))
+    plain = TO.column_profile(img[..., 3]).T
+    rob = TO.column_profile_robust(img[..., 3]).T
+    # the statistics are float32 values; the CSV carries them with pandas' 16 significant digits -> compare as float32
+    assert np.array_equal(np.float32(plain), np.float32(g["plain"]), equal_nan=True)
+    assert np.array_equal(np.float32(rob), np.float32(g["robust"]), equal_nan=True)
+    assert np.isnan(g["plain"][7, 1]) and g["plain"][11, 0] == 1 and g["plain"][13, 0] == 0

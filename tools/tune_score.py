@@ -3,10 +3,10 @@
 
     python tools/tune_score.py [samples] [quick]
 
-Configurations are (variant, bands per LDS tile, workgroups per CU, line groups): sf_debug_set keys 1, 11, 12, 2.
-variant 0 / 20..22 = the row kernel (8 lines x 2 / 2 / 4 / 1 bands per load batch, non-temporal loads), 30..32 the same
-with plain loads, 100 = the round-1 column-block kernel.  Every configuration must reproduce the column-block
-kernel's product bit for bit (same FMA order)."""
+Configurations are (variant, -, workgroups per CU, -[, experiment bits]): sf_debug_set keys 1, 12, 13.
+variant 0 = the production kernel (64-sample blocks, staged stores), 100 = round 1 (records stored by the lanes),
+10 / 11 = k_score_blk2 (128-sample blocks, two samples per lane) with plain / non-temporal loads.  Every configuration
+must reproduce round 1's product bit for bit (same FMA order)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -40,22 +40,15 @@ def run():
 
 
 def setcfg(c):
-    L.sf_debug_set(1, c[0]); L.sf_debug_set(11, c[1]); L.sf_debug_set(12, c[2]); L.sf_debug_set(2, c[3])
+    L.sf_debug_set(1, c[0]); L.sf_debug_set(12, c[2])
     L.sf_debug_set(13, c[4] if len(c) > 4 else 0)
 
 
-cfgs = [(100, 0, 0, 0), (0, 0, 0, 0)]
-if not quick:
-    for v in (20, 21, 22, 30):
-        for bg in (4, 8, 16, 72):
-            if v in (21,) and bg % 8:
-                continue
-            if bg * ((samples + 1) // 2 * 2) * 8 > 160 * 1024:
-                continue
-            for wgs in (0, 2):
-                cfgs.append((v, bg, wgs, 0))
-if os.environ.get("SF_SCORE_EXP"):     # library built with EXTRA=-DSF_SCORE_EXPERIMENTS: where does the time go?
-    cfgs = [(100, 0, 0, 0)] + [(v, 8, w, 0, e) for v in (22,) for w in (0,) for e in (0, 1, 8, 16, 24)]
+cfgs = [(100, 0, 0, 0), (0, 0, 0, 0), (10, 0, 0, 0), (11, 0, 0, 0)]
+if os.environ.get("SF_SCORE_EXP"):     # library built with EXTRA=-DSF_SCORE_EXPERIMENTS: where does k_score_blk2's time go?
+    # exp bits: 1 no epilogue, 4 no arithmetic, 8 no record assembly / stores, 32 one contiguous run per wave,
+    #           64 staging but no global stores, 256 / 512 / 768 nt / sc1 / sc0 sc1 stores
+    cfgs += [(10, 0, 0, 0, e) for e in (1, 4, 8, 32, 64, 256, 512, 768)]
 cfgs = list(dict.fromkeys(cfgs))
 setcfg((100, 0, 0, 0)); run(); torch.cuda.synchronize(); ref = out.clone(); refcs = colstats.clone()
 res = {c: [] for c in cfgs}

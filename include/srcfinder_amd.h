@@ -177,6 +177,14 @@ int sf_debug_set(int key, int value);
 int sf_cmf_score_timing_read(double *total_ms, int *launches);
 
 
+/* scipy.linalg.det / inv as the reference wraps them (cmf/robust_mf.py:72-76, :86-90) for a batch of n x n float64
+ * matrices (row-major, device): LU with partial pivoting.  det = the running product of the pivots in index order (a
+ * prefix that reaches inf or 0 stays there: what log(det) and the det == 0 test of looshrinkage see, :111-113), 0 for
+ * an exactly singular matrix.  inv: info[b] > 0 = exactly singular (scipy raises LinAlgError; the column loop catches
+ * it, :371).  work: batch * n * n doubles; piv: batch * n int32. */
+int sf_linalg_det(const double *A, int n, int batch, double *work, double *det, void *stream);
+int sf_linalg_inv(const double *A, int n, int batch, double *work, int32_t *piv, double *Ainv, int32_t *info, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Spectrometer masks on the resident cube (spectrometer_masks/masks_sds.py) and the image primitives they share with
  * the saliency -> detections step (salience_predictions.py): binary dilations, 8-connected component labelling.

@@ -64,6 +64,8 @@ SIGNATURES = {
     "sf_image_label8": (i32, [vp, i32, i32, vp, vp, i32, vp, vp, vp]),
     "sf_image_filter_small_components": (i32, [vp, vp, i32, vp, i32, i32, vp]),
     "sf_masks_compose": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    "sf_linalg_det": (i32, [vp, i32, i32, vp, vp, vp]),
+    "sf_linalg_inv": (i32, [vp, i32, i32, vp, vp, vp, vp, vp]),
     "sf_detect_region_stats": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, f64, vp, vp, vp]),
     "sf_cmf_score_timing": (i32, [i32]),
     "sf_debug_set": (i32, [i32, i32]),

@@ -3,7 +3,7 @@
 Mirrors the interface of the reference's ``cmf/robust_mf.py``:
 
 * ``looshrinkage(I_zm, alphas, nll, n, I_reg=[]) -> (C, mindex)``   (robust_mf.py:92-136; fills ``nll``)
-* ``cov(A, **kw)``                                                  (robust_mf.py:52-70)
+* ``cov(A, **kw)``, ``inv``, ``det``, ``eig``                        (robust_mf.py:52-90)
 * ``robust_mf(cube_bil, library, ...)`` -- the body of the reference's ``__main__`` column loop
   (robust_mf.py:185-397), which has no callable form upstream; keyword names follow the CLI flags
   (robust_mf.py:142-166).
@@ -475,6 +475,108 @@ def cov(A, **kwargs):
     if ddof != 1:
         S = S * ((n - 1.0) / (n - float(ddof)))
     return S
+
+
+def _square(A, what):
+    torch = _torch()
+    if isinstance(A, torch.Tensor):
+        A = A.detach().cpu().numpy()
+    a = np.ascontiguousarray(A, dtype=np.float64)
+    if a.ndim != 2 or a.shape[0] != a.shape[1]:
+        raise ValueError("expected square matrix")
+    if a.shape[0] > 1024:
+        raise NotImplementedError("%s(): more than 1024 rows" % what)
+    return a
+
+
+def _lapack_kwargs(kwargs, allowed):
+    """The reference's wrappers forward **kwargs to scipy.linalg after setting overwrite_a / check_finite (:72-90);
+    those two have no effect here (the input is copied to the device, nothing is checked), anything else is refused."""
+    for k in list(kwargs):
+        if k in ("overwrite_a", "check_finite") or k in allowed:
+            continue
+        raise TypeError("unsupported scipy.linalg keyword: %s" % k)
+
+
+def inv(A, **kwargs):
+    """``scipy.linalg.inv(A, overwrite_a=False, check_finite=False)`` (robust_mf.py:72-76) on the GPU: LU with partial
+    pivoting + triangular solves in float64; an exactly singular matrix raises ``numpy.linalg.LinAlgError`` like LAPACK's
+    ``info > 0`` (the column loop catches it and writes zeros, :371-374)."""
+    torch = _torch()
+    _lapack_kwargs(kwargs, ())
+    a = _square(A, "inv")
+    n = a.shape[0]
+    L = _ffi.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ad = torch.as_tensor(a, device=dev)
+    work, out = torch.empty_like(ad), torch.empty_like(ad)
+    piv = torch.empty(n, dtype=torch.int32, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    _ffi.check(L.sf_linalg_inv(_ffi.ptr(ad), n, 1, _ffi.ptr(work), _ffi.ptr(piv), _ffi.ptr(out), _ffi.ptr(info),
+                               _ffi.stream_ptr()), "sf_linalg_inv")
+    if int(info.item()) > 0:
+        raise np.linalg.LinAlgError("singular matrix")
+    return out.cpu().numpy()
+
+
+def det(A, **kwargs):
+    """``scipy.linalg.det(A, overwrite_a=False, check_finite=False)`` (robust_mf.py:86-90) on the GPU: the running
+    product of the LU pivots in index order -- once a prefix has reached inf or 0 it stays there, which is what decides
+    ``log(det)`` and the ``det == 0`` test of looshrinkage (:111-113); 0.0 for an exactly singular matrix."""
+    torch = _torch()
+    _lapack_kwargs(kwargs, ())
+    a = _square(A, "det")
+    n = a.shape[0]
+    L = _ffi.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ad = torch.as_tensor(a, device=dev)
+    work = torch.empty_like(ad)
+    out = torch.empty(1, dtype=torch.float64, device=dev)
+    _ffi.check(L.sf_linalg_det(_ffi.ptr(ad), n, 1, _ffi.ptr(work), _ffi.ptr(out), _ffi.stream_ptr()), "sf_linalg_det")
+    return np.float64(out.item())
+
+
+def eig(A, **kwargs):
+    """``scipy.linalg.eig(A, left=False, right=True)`` (robust_mf.py:78-84) for the one use the reference makes of it:
+    the eigendecomposition of a covariance matrix (:312).  Returns ``(w, vr)`` with complex128 ``w`` (imaginary parts 0)
+    and unit-norm eigenvectors in the columns of ``vr``; the ORDER of the pairs is the eigensolver's (LAPACK's geev does
+    not sort either -- the reference takes "the first six").  Symmetric matrices of up to 96 rows
+    (one-sided Jacobi on the GPU); anything else is refused."""
+    torch = _torch()
+    _lapack_kwargs(kwargs, ("left", "right"))
+    if kwargs.get("left", False) or not kwargs.get("right", True):
+        raise NotImplementedError("eig(): only left=False, right=True")
+    a = _square(A, "eig")
+    n = a.shape[0]
+    if n > 96:
+        raise NotImplementedError("eig(): more than 96 rows")
+    if not np.allclose(a, a.T, rtol=1e-12, atol=1e-12 * np.abs(a).max()):
+        raise NotImplementedError("eig(): nonsymmetric matrix")
+    a = (a + a.T) * 0.5
+    # shift to positive definite: the solver factorises its input (the eigenvectors do not change)
+    shift = 0.0
+    gersh = float(np.min(np.diag(a) - (np.abs(a).sum(1) - np.abs(np.diag(a)))))
+    if gersh <= 0:
+        shift = -gersh + 1e-3 * max(np.abs(a).max(), 1e-300)
+    L = _ffi.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    f64 = dict(dtype=torch.float64, device=dev)
+    S = torch.as_tensor((a + shift * np.eye(n))[None], device=dev)
+    T = torch.eye(n, **f64)[None].contiguous()
+    nrows = torch.tensor([n + 2], dtype=torch.int32, device=dev)
+    d, lam = torch.empty((1, n), **f64), torch.empty((1, n), **f64)
+    evec, r_tmp, l_tmp = (torch.empty((1, n, n), **f64) for _ in range(3))
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _Workspace.get(L.sf_cmf_workspace_bytes(n + 2, n, 1, 1), dev)
+    _ffi.check(L.sf_cmf_eigh_general(_ffi.ptr(S), _ffi.ptr(T), _ffi.ptr(nrows), n, 1, _ffi.ptr(r_tmp), _ffi.ptr(l_tmp),
+                                     _ffi.ptr(d), _ffi.ptr(lam), _ffi.ptr(evec), _ffi.ptr(status), _ffi.ptr(ws),
+                                     _ffi.stream_ptr()), "sf_cmf_eigh_general")
+    if int(status.item()) != 0:
+        raise np.linalg.LinAlgError("eig(): the eigensolver did not converge (status %d)" % int(status.item()))
+    w = lam[0].cpu().numpy() - shift
+    v = evec[0].cpu().numpy().T.copy()                     # rows -> columns
+    v /= np.linalg.norm(v, axis=0, keepdims=True)
+    return w.astype(np.complex128), v
 
 
 def looshrinkage(I_zm, alphas, nll, n, I_reg=[]):

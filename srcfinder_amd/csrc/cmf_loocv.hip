@@ -261,7 +261,8 @@ __global__ __launch_bounds__(1024) void k_nll(const double *__restrict__ part, i
                                               const double *__restrict__ d, const double *__restrict__ lam,
                                               const int32_t *__restrict__ status, const double *__restrict__ alphas,
                                               int nalpha, int p, int NA16, int rq_scaled,
-                                              double *__restrict__ nll_out, int32_t *__restrict__ alphaidx) {
+                                              double *__restrict__ nll_out, int32_t *__restrict__ alphaidx,
+                                              double *__restrict__ rest_out) {
   extern __shared__ double tbl[];   // TBL: [nalpha][p] log(n beta_i lam_j + alpha_i), then [p] log(100 d_j)
   __shared__ double snll[SF_NALPHA_MAX];
   __shared__ double slogd;
@@ -328,6 +329,8 @@ __global__ __launch_bounds__(1024) void k_nll(const double *__restrict__ part, i
         const double dt = exp(ld);
         ld = (dt > 0.0) ? log(dt) : -inf;
       }
+      // everything but the determinant term: the exact-determinant pass of the wide windows (linalg.hip) adds its own
+      if (rest_out) rest_out[(size_t)c * nalpha + i] = 0.5 * ((double)p * 1.8378770664093453) + 1.0 / (2.0 * n) * (lsum + rsum);
       if (ld < -745.2) {
         v = inf;  // det underflowed to 0 -> the reference skips this alpha (robust_mf.py:112-113)
       } else {
@@ -397,15 +400,16 @@ int launch_sweep(const XT *xt, const uint8_t *mask_t, const int32_t *nuse, const
 #undef SW_ARGS
 
 int launch_nll(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam, const int32_t *status,
-               const double *alphas, const SfGeom &g, int rq_scaled, double *nll, int32_t *alphaidx, hipStream_t st) {
+               const double *alphas, const SfGeom &g, int rq_scaled, double *nll, int32_t *alphaidx, hipStream_t st,
+               double *rest = nullptr) {
   const size_t lds = ((size_t)g.nalpha * g.p + g.p) * sizeof(double);
   if (lds <= 150 * 1024 && g.ncols <= 256) {   // one 116 KB workgroup per CU: only worth it when the launch is a single round
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_nll<true>), lds)) return rc;
     hipLaunchKernelGGL(k_nll<true>, dim3(g.ncols), dim3(1024), lds, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha,
-                       g.p, g.nu * 16, rq_scaled, nll, alphaidx);
+                       g.p, g.nu * 16, rq_scaled, nll, alphaidx, rest);
   } else {
     hipLaunchKernelGGL(k_nll<false>, dim3(g.ncols), dim3(256), 0, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha,
-                       g.p, g.nu * 16, rq_scaled, nll, alphaidx);
+                       g.p, g.nu * 16, rq_scaled, nll, alphaidx, rest);
   }
   SF_LAUNCH_CHECK("k_nll");
   return 0;
@@ -416,8 +420,8 @@ int launch_nll(const double *part, int nsplit, const int32_t *nuse, const double
 
 int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
                          const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
-                         hipStream_t st) {
-  return launch_nll(part, nsplit, nuse, d, lam, status, alphas, g, 0, nll, alphaidx, st);
+                         hipStream_t st, double *rest) {
+  return launch_nll(part, nsplit, nuse, d, lam, status, alphas, g, 0, nll, alphaidx, st, rest);
 }
 
 static bool sweep4_ok(const SfGeom &g, int xt_f64) {

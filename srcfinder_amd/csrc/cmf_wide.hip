@@ -873,19 +873,21 @@ int sf_wide_batch(const SfGeom &g) {
   return (int)b;
 }
 static int wide_nll_splits(const SfGeom &g) { return sf_cdiv(g.lines, 512) > 64 ? 64 : sf_cdiv(g.lines, 512); }
+// Exact determinants (linalg.hip): every grid point while that is cheap (the function-level looshrinkage(): one
+// column, 201 factorisations side by side on 256 CUs), else the 24 grid points on the finite side of each crossing of
+// the float64 range (the prefix products of p <= 512 pivots were never seen to run further ahead of the total than 16
+// grid points, tests/test_cmf_gpu.py::test_looshrinkage_function_512_band_golden).
+int sf_exact_det_window(const SfGeom &g) { return ((size_t)g.ncols * g.nalpha <= 2048) ? 0 : 24; }
 size_t sf_wide_scratch_bytes(const SfGeom &g) {
   return (size_t)sf_wide_batch(g) * wide_col_bytes(g) +
-         sf_align((size_t)g.ncols * wide_nll_splits(g) * 2 * g.nu * 16 * sizeof(double));
+         sf_align((size_t)g.ncols * wide_nll_splits(g) * 2 * g.nu * 16 * sizeof(double)) +
+         sf_align((size_t)g.ncols * g.nalpha * sizeof(double)) + sf_exact_det_scratch_bytes(g, sf_exact_det_window(g));
 }
 
 // stages 3-5 (covariance, eigendecomposition, LOO sweep + argmin) for windows too wide for the fused kernels
 int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const int32_t *nloo,
                          const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
                          double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st);
-
-int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
-                         const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
-                         hipStream_t st);
 
 
 // eigendecomposition of a batch of nb correlation matrices (columns c0 .. c0+nb-1)
@@ -997,5 +999,11 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
                        c0, nsplit, part);
     SF_LAUNCH_CHECK("k_nllrows");
   }
-  return sf_launch_nll_finish(part, nsplit, nloo, d, lam, status, alphas, g, nll, alphaidx, st);
+  double *rest = reinterpret_cast<double *>(reinterpret_cast<char *>(part) +
+                                            sf_align((size_t)g.ncols * nsplit * 2 * g.nu * 16 * sizeof(double)));
+  void *det_scratch = reinterpret_cast<char *>(rest) + sf_align((size_t)g.ncols * g.nalpha * sizeof(double));
+  if (int rc = sf_launch_nll_finish(part, nsplit, nloo, d, lam, status, alphas, g, nll, alphaidx, st, rest)) return rc;
+  // det() over/underflow exactly as scipy's running LU product has it (robust_mf.py:111-113), where the total
+  // log-determinant cannot decide
+  return sf_launch_exact_det(cov, nloo, status, alphas, g, sf_exact_det_window(g), rest, nll, alphaidx, det_scratch, st);
 }

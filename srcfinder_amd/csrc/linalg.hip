@@ -1,0 +1,280 @@
+// Small dense linear algebra with the reference's LAPACK semantics: batched LU with partial pivoting in float64.
+//
+//  * det / inv of the Python surface (cmf/robust_mf.py:72-90: scipy.linalg.det / inv, check_finite=False);
+//  * the EXACT over/underflow behaviour of the determinants inside looshrinkage (:111-113).  scipy's det is getrf
+//    followed by the running product of the LU diagonal in index order: once a prefix of that product has reached inf
+//    it stays inf (log -> inf: the alpha can never win), once it has reached 0 it stays 0 (the alpha is skipped) --
+//    whatever the value of the full determinant.  The restated sweep (one eigendecomposition per column) knows the
+//    TOTAL log-determinant only, which classifies an alpha wrongly when a prefix leaves the float64 range and the total
+//    does not (1-2 grid points at p = 425, up to 16 at p = 512: SURVEY.md §7.3 item 3).  For windows wider than 96 bands
+//    the grid points in question are factorised for real: G = n beta S' + alpha diag(S') (S' the covariance of the
+//    data scaled by 100, :94-110), partial-pivot LU, running product.
+// One workgroup per matrix, the matrix in global memory (a 425 x 425 float64 matrix is 1.4 MB: L2-resident), right-
+// looking elimination.  Latency-bound (~2 ms per 425 x 425 matrix), used where it is the only exact way.
+#include "cmf_common.h"
+
+namespace {
+
+constexpr int LU_NT = 1024;
+
+// A[n][n] row-major, overwritten by L \ U (unit lower).  piv[k] = row swapped with k.  Returns through shared state:
+// first zero pivot (LAPACK info, 0 = none), number of swaps.  det (optional): the running product of U's diagonal in
+// index order with the sign of the permutation applied at the end (scipy: find_det_from_lu; 0 when info > 0).
+__device__ void lu_factor(double *A, int n, int *piv, double *det_out, int *info_out, int tid) {
+  __shared__ double sval[LU_NT / 64];
+  __shared__ int sidx[LU_NT / 64];
+  __shared__ int s_p;
+  __shared__ double s_piv;
+  int info = 0, nswap = 0;
+  double det = 1.0;
+  for (int k = 0; k < n; ++k) {
+    // ---- pivot: first row of max |A[i][k]|, i >= k (idamax)
+    double best = -1.0;
+    int bi = 0x7fffffff;
+    for (int i = k + tid; i < n; i += LU_NT) {
+      const double v = fabs(A[(size_t)i * n + k]);
+      if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { sval[tid >> 6] = best; sidx[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      double b = sval[0];
+      int p = sidx[0];
+      for (int w = 1; w < LU_NT / 64; ++w)
+        if (sval[w] > b || (sval[w] == b && sidx[w] < p)) { b = sval[w]; p = sidx[w]; }
+      if (p == 0x7fffffff) p = k;                 // (a column of NaNs: idamax returns the first row)
+      s_p = p;
+      s_piv = A[(size_t)p * n + k];
+    }
+    __syncthreads();
+    const int p = s_p;
+    const double pv = s_piv;
+    if (piv && tid == 0) piv[k] = p;
+    if (p != k) {
+      ++nswap;
+      for (int j = tid; j < n; j += LU_NT) {
+        const double t = A[(size_t)k * n + j];
+        A[(size_t)k * n + j] = A[(size_t)p * n + j];
+        A[(size_t)p * n + j] = t;
+      }
+    }
+    det *= pv;
+    if (pv == 0.0) {
+      if (!info) info = k + 1;                    // dgetf2: record, skip the elimination of this column
+      __syncthreads();
+      continue;
+    }
+    __syncthreads();
+    const int m = n - k - 1;
+    for (int i = tid; i < m; i += LU_NT) A[(size_t)(k + 1 + i) * n + k] /= pv;
+    __syncthreads();
+    // ---- trailing update: A[i][j] -= l_i * u_j, i, j > k (64 columns x 16 rows per pass, coalesced along j)
+    for (int i = k + 1 + (tid >> 6); i < n; i += LU_NT / 64) {
+      const double li = A[(size_t)i * n + k];
+      for (int j = k + 1 + (tid & 63); j < n; j += 64) A[(size_t)i * n + j] -= li * A[(size_t)k * n + j];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (det_out) *det_out = info ? 0.0 : ((nswap & 1) ? -det : det);
+    if (info_out) *info_out = info;
+  }
+}
+
+__global__ __launch_bounds__(LU_NT) void k_lu_det(const double *__restrict__ A, int n, double *__restrict__ work,
+                                                  double *__restrict__ det, int32_t *__restrict__ info) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double *W = work + (size_t)b * n * n;
+  for (size_t e = tid; e < (size_t)n * n; e += LU_NT) W[e] = A[(size_t)b * n * n + e];
+  __syncthreads();
+  lu_factor(W, n, nullptr, det + b, info ? info + b : nullptr, tid);
+}
+
+// inverse from the factors: solve (P A) X = P I column by column (forward with unit L, backward with U)
+__global__ __launch_bounds__(LU_NT) void k_lu_inv(const double *__restrict__ A, int n, double *__restrict__ work,
+                                                  int32_t *__restrict__ pivs, double *__restrict__ Ainv,
+                                                  int32_t *__restrict__ info) {
+  __shared__ int s_info;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double *W = work + (size_t)b * n * n;
+  int *piv = pivs + (size_t)b * n;
+  for (size_t e = tid; e < (size_t)n * n; e += LU_NT) W[e] = A[(size_t)b * n * n + e];
+  __syncthreads();
+  lu_factor(W, n, piv, nullptr, &s_info, tid);
+  __syncthreads();
+  if (tid == 0 && info) info[b] = s_info;
+  if (s_info) return;                              // singular: scipy raises LinAlgError
+  double *X = Ainv + (size_t)b * n * n;
+  // X = P (identity rows permuted as the factorisation did)
+  for (size_t e = tid; e < (size_t)n * n; e += LU_NT) X[e] = ((e / n) == (e % n)) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    const int p = piv[k];
+    if (p != k)
+      for (int j = tid; j < n; j += LU_NT) {
+        const double t = X[(size_t)k * n + j];
+        X[(size_t)k * n + j] = X[(size_t)p * n + j];
+        X[(size_t)p * n + j] = t;
+      }
+    __syncthreads();
+  }
+  // forward: L Y = P, row by row (all right-hand sides j in parallel)
+  for (int i = 1; i < n; ++i) {
+    for (int j = tid; j < n; j += LU_NT) {
+      double s = X[(size_t)i * n + j];
+      for (int k = 0; k < i; ++k) s -= W[(size_t)i * n + k] * X[(size_t)k * n + j];
+      X[(size_t)i * n + j] = s;
+    }
+    __syncthreads();
+  }
+  // backward: U X = Y
+  for (int i = n - 1; i >= 0; --i) {
+    for (int j = tid; j < n; j += LU_NT) {
+      double s = X[(size_t)i * n + j];
+      for (int k = i + 1; k < n; ++k) s -= W[(size_t)i * n + k] * X[(size_t)k * n + j];
+      X[(size_t)i * n + j] = s / W[(size_t)i * n + i];
+    }
+    __syncthreads();
+  }
+}
+
+// ---- exact determinants of the shrinkage grid ---------------------------------------------------------------------
+// job list: (column, alpha index) pairs whose determinant is factorised for real
+//   full   every alpha of every column (function-level looshrinkage: one column)
+//   window the finite grid points within W points of one where the TOTAL log-determinant (rule (i)) has left the
+//          float64 range
+__global__ void k_det_jobs(const double *__restrict__ nll, const double *__restrict__ rest, const int32_t *__restrict__ status,
+                           int ncols, int nalpha, int window, int32_t *__restrict__ jobs, int32_t *__restrict__ njobs, int cap) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols || status[c] != 0) return;
+  auto push = [&](int i) {
+    const int k = atomicAdd(njobs, 1);
+    if (k < cap) jobs[k] = c * nalpha + i;
+  };
+  if (window <= 0) {
+    for (int i = 0; i < nalpha; ++i) push(i);
+    return;
+  }
+  // rest is finite wherever the sweep is; nll = +inf there means the TOTAL log-determinant left the float64 range
+  // (rule (i)).  A prefix of the pivot product can leave it a few grid points earlier: every grid point that is still
+  // finite and lies within `window` points of a lost one is factorised.
+  for (int i = 0; i < nalpha; ++i) {
+    const double v = nll[(size_t)c * nalpha + i];
+    if (v == __builtin_inf() || v != v) continue;
+    bool near = false;
+    for (int j = max(0, i - window); j <= min(nalpha - 1, i + window) && !near; ++j) {
+      const double vj = nll[(size_t)c * nalpha + j], rj = rest[(size_t)c * nalpha + j];
+      near = (vj == __builtin_inf()) && (rj == rj) && (rj != __builtin_inf());
+    }
+    if (near) push(i);
+  }
+}
+
+// G = n (beta S') + alpha T, S' = 1e4 S (the covariance of 100 x), T = diag S' (robust_mf.py:94-110), then LU
+__global__ __launch_bounds__(LU_NT) void k_det_grid(const double *__restrict__ cov, const int32_t *__restrict__ nloo,
+                                                    const double *__restrict__ alphas, int nalpha, int p,
+                                                    const int32_t *__restrict__ jobs, const int32_t *__restrict__ njobs,
+                                                    int job0, double *__restrict__ work, double *__restrict__ det) {
+  const int slot = blockIdx.x, tid = threadIdx.x;
+  const int jb = job0 + slot;
+  if (jb >= *njobs) return;
+  const int job = jobs[jb], c = job / nalpha, ai = job - c * nalpha;
+  const double n = (double)nloo[c], a = alphas[ai];
+  const double beta = (1.0 - a) / (n - 1.0);
+  const double *S = cov + (size_t)c * p * p;
+  double *G = work + (size_t)slot * p * p;
+  for (size_t e = tid; e < (size_t)p * p; e += LU_NT) {
+    const int i = (int)(e / p), j = (int)(e % p);
+    const double s = S[e] * 1e4;
+    double gij = n * (beta * s);
+    if (i == j) gij += a * s;
+    G[e] = gij;
+  }
+  __syncthreads();
+  lu_factor(G, p, nullptr, det + jb, nullptr, tid);
+}
+
+// nll[job] = 0.5 log(det) + rest, +inf where det == 0 (the reference skips the alpha, :112-113); then numpy.argmin
+__global__ void k_det_apply(const int32_t *__restrict__ jobs, const int32_t *__restrict__ njobs, const double *__restrict__ det,
+                            const double *__restrict__ rest, double *__restrict__ nll, int cap) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= *njobs || k >= cap) return;
+  const int job = jobs[k];
+  const double dt = det[k];
+  nll[job] = (dt == 0.0) ? __builtin_inf() : 0.5 * log(dt) + rest[job];
+}
+__global__ void k_argmin_nan_first(const double *__restrict__ nll, const int32_t *__restrict__ status, int ncols, int nalpha,
+                                   int32_t *__restrict__ alphaidx) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols || status[c] != 0) return;
+  int idx = -1;
+  double best = __builtin_inf();
+  for (int i = 0; i < nalpha; ++i) {
+    const double v = nll[(size_t)c * nalpha + i];
+    if (v != v) { idx = i; break; }
+    if (v < best) { best = v; idx = i; }
+  }
+  alphaidx[c] = idx;
+}
+
+}  // namespace
+
+constexpr int DET_SLOTS = 512;   // matrices factorised per launch (two rounds of 256 CUs)
+size_t sf_exact_det_scratch_bytes(const SfGeom &g, int window) {
+  const size_t maxjobs = window <= 0 ? (size_t)g.ncols * g.nalpha : (size_t)g.ncols * 2 * window;
+  const size_t slots = maxjobs < DET_SLOTS ? maxjobs : DET_SLOTS;
+  return sf_align(slots * g.p * g.p * sizeof(double)) + sf_align(maxjobs * sizeof(int32_t)) + sf_align(maxjobs * sizeof(double)) +
+         sf_align(sizeof(int32_t));
+}
+// window <= 0: every grid point; else the `window` points on the safe side of each range crossing (see k_det_jobs)
+int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *status, const double *alphas, const SfGeom &g,
+                        int window, const double *rest, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st) {
+  const size_t maxjobs = window <= 0 ? (size_t)g.ncols * g.nalpha : (size_t)g.ncols * 2 * window;
+  const size_t slots = maxjobs < DET_SLOTS ? maxjobs : DET_SLOTS;
+  char *p = reinterpret_cast<char *>(scratch);
+  double *work = reinterpret_cast<double *>(p); p += sf_align(slots * g.p * g.p * sizeof(double));
+  int32_t *jobs = reinterpret_cast<int32_t *>(p); p += sf_align(maxjobs * sizeof(int32_t));
+  double *det = reinterpret_cast<double *>(p); p += sf_align(maxjobs * sizeof(double));
+  int32_t *njobs = reinterpret_cast<int32_t *>(p);
+  SF_HIP(hipMemsetAsync(njobs, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_det_jobs, dim3(sf_cdiv(g.ncols, 128)), dim3(128), 0, st, nll, rest, status, g.ncols, g.nalpha, window, jobs,
+                     njobs, (int)maxjobs);
+  SF_LAUNCH_CHECK("k_det_jobs");
+  for (size_t j0 = 0; j0 < maxjobs; j0 += slots) {
+    hipLaunchKernelGGL(k_det_grid, dim3((unsigned)slots), dim3(LU_NT), 0, st, cov, nloo, alphas, g.nalpha, g.p, jobs, njobs, (int)j0,
+                       work, det);
+    SF_LAUNCH_CHECK("k_det_grid");
+  }
+  hipLaunchKernelGGL(k_det_apply, dim3(sf_cdiv((int)maxjobs, 256)), dim3(256), 0, st, jobs, njobs, det, rest, nll, (int)maxjobs);
+  SF_LAUNCH_CHECK("k_det_apply");
+  hipLaunchKernelGGL(k_argmin_nan_first, dim3(sf_cdiv(g.ncols, 128)), dim3(128), 0, st, nll, status, g.ncols, g.nalpha, alphaidx);
+  SF_LAUNCH_CHECK("k_argmin_nan_first");
+  return 0;
+}
+
+extern "C" {
+
+/* scipy.linalg.det semantics (cmf/robust_mf.py:86-90) for a batch of n x n float64 matrices: LU with partial pivoting,
+ * the running product of the diagonal in index order (prefixes that reach inf or 0 stay there), 0 for an exactly
+ * singular matrix.  work: batch * n * n doubles. */
+int sf_linalg_det(const double *A, int n, int batch, double *work, double *det, void *stream) {
+  if (!A || !work || !det || n < 1 || batch < 1) { sf_set_error("sf_linalg_det: bad argument"); return -1; }
+  hipLaunchKernelGGL(k_lu_det, dim3(batch), dim3(LU_NT), 0, (hipStream_t)stream, A, n, work, det, nullptr);
+  SF_LAUNCH_CHECK("k_lu_det");
+  return 0;
+}
+/* scipy.linalg.inv semantics (cmf/robust_mf.py:72-76): LU with partial pivoting + solves; info[b] > 0 = exactly
+ * singular (the reference catches LinAlgError, :371).  work: batch * n * n doubles, piv: batch * n int32. */
+int sf_linalg_inv(const double *A, int n, int batch, double *work, int32_t *piv, double *Ainv, int32_t *info, void *stream) {
+  if (!A || !work || !piv || !Ainv || !info || n < 1 || batch < 1) { sf_set_error("sf_linalg_inv: bad argument"); return -1; }
+  hipLaunchKernelGGL(k_lu_inv, dim3(batch), dim3(LU_NT), 0, (hipStream_t)stream, A, n, work, piv, Ainv, info);
+  SF_LAUNCH_CHECK("k_lu_inv");
+  return 0;
+}
+
+}  // extern "C"

@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--lines", type=int, default=LINES)
     ap.add_argument("--samples", type=int, default=SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cnn", action="store_true", help="skip the CNN tile-scorer section of the line (BASELINE configs 4/5)")
+    ap.add_argument("--cnn-tiles", type=int, default=8192)
+    ap.add_argument("--cnn-batch", type=int, default=512)
     ap.add_argument("--cpu-columns", type=int, default=12)    # ~7 s of one host core (+ the all-cores sample)
     ap.add_argument("--active", type=str, default="", help="a0,a1 (1-based inclusive) override of the active window, e.g. 1,425")
     ap.add_argument("--in-flight", type=int, default=0,
@@ -204,12 +207,68 @@ def main():
         line["roofline"].update(pmc_traffic(lines, samples, p, world))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cube, lib, lines, ncols, args.cpu_columns, res, (a0, a1))
+        if world == 1 and not args.no_cnn:
+            # the second half of the path (BASELINE.json configs 4 / 5): the per-pixel GoogLeNet tile scorer on the CMF plane
+            # this run produced -- its own metric (tiles/s) and its own roofline (fp32 MFMA), inside the same line
+            line["cnn"] = cnn_section(res, args.cnn_tiles, args.cnn_batch, not args.no_cpu_baseline)
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     flush_c_stdio()
     if rank == 0:
         print(json.dumps(line), flush=True)      # the last line of the job's output
+
+
+def cnn_section(res, ntiles, batch, with_cpu):
+    """CNN tile scorer (cnn/cnn_pred_pipeline.py:159-189): `ntiles` 256 x 256 windows of the CMF band of the product,
+    fp32 (the parity path), seeded synthetic weights of the reference's GoogLeNet (no checkpoint ships with it).
+    3.706 GFLOP per window (1.853 GMAC) against the fp32 MFMA peak of the guide (157.3 TFLOP/s).
+    CPU baseline: the torch-CPU restatement (oracle/cnn_oracle.py) on all usable cores, a bounded sample of windows."""
+    import torch
+    from srcfinder_amd import cnn
+    from srcfinder_amd.cnn_weights import synthetic_state_dict
+    sd = synthetic_state_dict(2024)
+    net = cnn.GoogLeNetHIP(sd)
+    W = res.out.shape[1]
+    rows = max(1, (ntiles + W - 1) // W)
+    r0 = min(4000, max(0, res.out.shape[0] - rows))
+    plane = res.out[r0:r0 + rows, :, 3].to(torch.float32).contiguous()            # a strip of the flightline
+    ds = cnn.FlightlineConvolve(plane, "COVID_QC", device=net.device)
+    out = torch.zeros(rows * W, dtype=torch.float32, device=net.device)
+    ntiles = min(ntiles, rows * W)
+
+    def run():
+        for t0 in range(0, ntiles, batch):
+            net.forward_tiles(ds.x, W, t0, min(batch, ntiles - t0), plane=ds.plane, out=out)
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tf = ntiles * 3.706e9 / dt / 1e12
+    sec = {"metric": "CNN tiles/s (GoogLeNet, one 256x256 window per pixel)", "value": round(ntiles / dt, 1), "unit": "tiles/s",
+           "dtype": "f32", "data": "synthetic weights (seeded), CMF plane of this run", "tiles": ntiles, "batch": batch,
+           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": round(tf / 157.3, 4), "flop_per_tile": 3.706e9,
+                        "note": "all kernels of a forward pass (implicit-GEMM conv on v_mfma_f32_32x32x2_f32, pools, head)"}}
+    if with_cpu:
+        from oracle import cnn_oracle as O
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        n = 64
+        pl = plane.cpu().numpy()
+        O.predict_plane(pl, sd, *cnn.MODEL_NORM["COVID_QC"], batch=16, indices=range(16))     # warm-up
+        t0 = time.perf_counter()
+        ref = O.predict_plane(pl, sd, *cnn.MODEL_NORM["COVID_QC"], batch=16, indices=range(n))
+        t = time.perf_counter() - t0
+        got = out[:n].cpu().numpy()
+        v = ref != -9999
+        ok = bool(np.array_equal(got == -9999, ~v)) and bool(np.allclose(got[v], ref[v], rtol=2e-4, atol=1e-7))
+        sec["cpu_baseline"] = {"value": round(n / t, 2), "unit": "tiles/s", "cores": cores, "kind": "port",
+                               "sample": "%d windows, torch CPU (%d threads), %.1f s" % (n, cores, t), "parity_on_sample": ok}
+    return sec
 
 
 def kernel_source_sha():
@@ -232,7 +291,7 @@ def pmc_traffic(lines, samples, p, world):
     rec = json.load(open(path))
     if rec.get("kernel_source_sha") != kernel_source_sha():
         return {"traffic_note": "profiles/r02_pmc_traffic.json was taken from a different kernel source: not quoted"}
-    k = rec["kernels"].get("k_score_rows")
+    k = rec["kernels"].get("k_score")
     if not k:
         return {}
     return {"traffic": k["hbm_bytes_per_launch"],

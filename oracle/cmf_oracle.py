@@ -244,7 +244,7 @@ def robust_mf_oracle(cube_bil: np.ndarray, library: np.ndarray, *, gas="ch4", re
 
 def robust_mf_multimodal_oracle(cube_bil: np.ndarray, library: np.ndarray, labels: np.ndarray, *, gas="ch4",
                                 reflectance=False, rgb_bands=(60, 42, 24), nodata=-9999.0, active=None,
-                                shrinkage=looshrinkage, reject=False, full=False):
+                                shrinkage=looshrinkage, reject=False, full=False, model="looshrinkage"):
     """Multimodal (k > 1) column loop of cmf/robust_mf.py:297-397 with the cluster labels INJECTED
     (labels[lines, samples], ids >= 0; what the reference's unseeded MiniBatchKMeans chose, :312-313, as stored
     in its bgmeta image, :327).  Per cluster of a column (:336-386): its own mean, looshrinkage with n = the
@@ -294,11 +294,15 @@ def robust_mf_multimodal_oracle(cube_bil: np.ndarray, library: np.ndarray, label
             mu = np.mean(icol_ki, axis=0)
             icol_reg = icol - mu if full else []                                   # :354
             try:
-                # n = nuse of the column (:355)
-                c, aidx = shrinkage(icol_ki - mu, alphas, nll, nuse, icol_reg) if full else shrinkage(icol_ki - mu, alphas, nll, nuse)
-                alphaidx[col, abs(ki)] = aidx
-                cinv = inv(c)
-                bgmeta[use[kmask], col, 1] = aidx
+                if model == "empirical":                                           # :350-351, :366-367
+                    cinv = inv(cov(icol_ki - mu))
+                    alphaidx[col, abs(ki)] = -1
+                else:
+                    # n = nuse of the column (:355)
+                    c, aidx = shrinkage(icol_ki - mu, alphas, nll, nuse, icol_reg) if full else shrinkage(icol_ki - mu, alphas, nll, nuse)
+                    alphaidx[col, abs(ki)] = aidx
+                    cinv = inv(c)
+                    bgmeta[use[kmask], col, 1] = aidx
             except sla.LinAlgError:
                 out[use[kmask], col, -1] = 0
                 status[col, abs(ki)] = 2

@@ -43,14 +43,20 @@ def main(argv=None):
         print("[ERR] CUDA not found, exiting.")            # there is no CPU path here (reference: -g -1 runs on CPU)
         return 1
     from . import cnn, envi
-    device = torch.device("cuda:%d" % (args.gpus[0] if args.gpus[0] >= 0 else 0))
+    if any(g < 0 for g in args.gpus):
+        print("[ERR] -g -1 (CPU) is not available: srcfinder_amd has no CPU path, exiting.")
+        return 1
+    if max(args.gpus) >= torch.cuda.device_count():
+        print("[ERR] -g %s: only %d GPU(s) visible, exiting." % (" ".join(map(str, args.gpus)), torch.cuda.device_count()))
+        return 1
     sd = torch.load(weightpath, map_location="cpu")
-    net = cnn.GoogLeNetHIP(sd, device=device)
     mm, meta = envi.open_memmap(args.flightline)
     bil = envi.to_bil(mm, meta)
     plane = np.ascontiguousarray(bil[:, args.band - 1, :], dtype=np.float32)
     print("[STEP] MODEL PREDICTION")
-    sal = cnn.predict_flightline(plane, args.model, net=net, batch=args.batch * max(1, len(args.gpus)), to_numpy=True)
+    # -g 0 1 2 3: every listed GPU scores its own block of rows with the per-GPU batch size (the reference multiplies
+    # the batch by the GPU count for DataParallel to split again, cnn_pred_pipeline.py:170)
+    sal = cnn.predict_flightline(plane, args.model, weights=sd, batch=args.batch, gpus=list(args.gpus), to_numpy=True)
     print("[STEP] RESULT EXPORT")
     outpath = op.join(args.output, f"{Path(args.flightline).stem}_saliency.img")
     print("[INFO] Saving to", outpath)

@@ -134,6 +134,9 @@ def _device_const(arr, dev):
     t = _CONSTS.get(key)
     if t is None:
         if len(_CONSTS) > 64:
+            # other streams' kernels (flightlines in flight, inflight.py) may still read cached tables: nothing is
+            # released before the whole device has drained
+            torch.cuda.synchronize(dev)
             _CONSTS.clear()
         t = torch.as_tensor(arr, device=dev)
         torch.cuda.current_stream(dev).synchronize()      # usable from any stream from now on
@@ -173,8 +176,6 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
     if model == "empirical":
         if metadata:
             raise NameError("name 'alphas' is not defined")       # what the reference does with -M empirical -m (:241-244 vs :275)
-        if kmeans > 1:
-            raise NotImplementedError("the empirical model on the multimodal branch")
     if nodata > 0:
         raise Exception("nodata value=%f > 0, values will not be masked" % nodata)       # robust_mf.py:232-234
     rgb_bands = tuple(int(b) for b in rgb_bands)
@@ -221,9 +222,9 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
             res = _multimodal(torch, L, cube_bil, lines, bands, samples, s0, s1, a0, p, abscf, alphas, nalpha,
                               bool(reflectance), r, float(nodata), out_t, out_samples, out_s0, nb, bgmeta, kmeans,
                               int(pcadim), labels, int(kmeans_seed), int(kmeans_iters), bool(reject), bool(full),
-                              int((a1 - a0) * 1.2), bool(return_nll))                   # bgminsamp, robust_mf.py:200
-            res.modelparms = model_parameters(reflectance, (a0, a1), bgmodes=kmeans, pcadim=int(pcadim), reject=reject,
-                                              regfull=full)
+                              int((a1 - a0) * 1.2), bool(return_nll), model == "empirical")   # bgminsamp, robust_mf.py:200
+            res.modelparms = model_parameters(reflectance, (a0, a1), modelname=model, bgmodes=kmeans, pcadim=int(pcadim),
+                                              reject=reject, regfull=full)
             if to_numpy:
                 for k in ("out", "bgmeta", "colstats", "alphaidx", "nuse", "status", "labels", "nll"):
                     v = getattr(res, k)
@@ -262,8 +263,8 @@ def _empirical(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alph
                out_samples, out_s0, nb, alphaidx, nuse, status, colstats, ws):
     """-M empirical (robust_mf.py:350-351, :366-367): C is the sample covariance itself -- the stage entry points without
     stage 5; alpha index -1 makes stage 6 use alpha = 0, i.e. C = S."""
-    if p > 96:
-        raise NotImplementedError("the empirical model on a window of more than 96 bands")
+    if p > 512:
+        raise NotImplementedError("active window of more than 512 bands")
     dev = cube.device
     ncols = s1 - s0
     ps = (p + 3) // 4 * 4
@@ -276,8 +277,14 @@ def _empirical(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alph
     filt, bias = torch.empty((ncols, p), **f64), torch.empty(ncols, **f64)
     check(L.sf_cmf_extract_columns(P(cube), lines, bands, samples, s0, s1, a0 - 1, p, P(xt), P(mask), st), "sf_cmf_extract_columns")
     check(L.sf_cmf_column_mean(P(xt), 0, P(mask), lines, p, ncols, P(nuse), P(mu), P(ws), st), "sf_cmf_column_mean")
-    check(L.sf_cmf_covariance(P(xt), 0, P(mask), P(nuse), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
-    check(L.sf_cmf_eigh(P(S), P(nuse), p, ncols, P(d), P(lam), P(evec), P(status), P(ws), st), "sf_cmf_eigh")
+    if p > 96:      # wide window (-R: 5..420): covariance + eigendecomposition by the batched-GEMM path (its sweep is unused)
+        nalpha = alphas.numel()
+        nll = torch.empty((ncols, nalpha), **f64)
+        check(L.sf_cmf_wide_stats(P(xt), 0, P(mask), P(nuse), P(nuse), P(mu), P(alphas), nalpha, lines, p, ncols, P(S), P(d),
+                                  P(lam), P(evec), P(status), P(nll), P(alphaidx), P(ws), st), "sf_cmf_wide_stats")
+    else:
+        check(L.sf_cmf_covariance(P(xt), 0, P(mask), P(nuse), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
+        check(L.sf_cmf_eigh(P(S), P(nuse), p, ncols, P(d), P(lam), P(evec), P(status), P(ws), st), "sf_cmf_eigh")
     alphaidx.fill_(-1)
     check(L.sf_cmf_filter(P(mu), P(d), P(lam), P(evec), P(alphas), P(alphaidx), P(abscf), int(reflectance), p, ncols,
                           P(status), P(filt), P(bias), st), "sf_cmf_filter")
@@ -289,7 +296,7 @@ def _empirical(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alph
 
 def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alphas, nalpha, reflectance, rgb, nodata,
                 out_t, out_samples, out_s0, nb, bgmeta, k, pcadim, labels, seed, iters, reject=False, full=False,
-                bgminsamp=85, return_nll=False):
+                bgminsamp=85, return_nll=False, empirical=False):
     """Multimodal column loop (robust_mf.py:306-386): stage entry points of the C ABI, once per cluster with the row
     mask  valid & (label == ki);  stage 5 gets the COLUMN's valid-row count as n (:355-356).
     reject (-r, :317-341): clusters of fewer than bgminsamp rows (never label 0: -0 == 0, :323) are relabelled -l in the
@@ -300,6 +307,8 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
     wide = p > 96                       # reflectance / full-band windows: statistics through sf_cmf_wide_stats
     if p > 512:
         raise NotImplementedError("active window of more than 512 bands")
+    if empirical:                       # -M empirical: C = the cluster's sample covariance (:350-351); -f has no effect on it
+        full, return_nll = False, False
     if wide and full:
         raise NotImplementedError("the full-column regulariser (-f) on a window of more than 96 bands")
     dev = cube.device
@@ -387,9 +396,13 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
         mask_k = (labels_valid == ki).to(torch.uint8)
         if reject:
             mask_k = torch.where(rej[:, ki, None], keep, mask_k)
-        stats(mask_k, nuse_k, nuse_col, status_k)
+        stats(mask_k, nuse_k, nuse_col, status_k, want_alpha=not empirical)
+        if empirical:
+            aidx_k.fill_(-1)            # alpha index -1 makes stage 6 use alpha = 0: C = S (:366-367)
         check(L.sf_cmf_filter(P(mu), P(d), P(lam), P(evec), P(alphas), P(aidx_k), P(abscf), int(reflectance), p, ncols,
                               P(status_k), P(filt), P(bias), st), "sf_cmf_filter")
+        if empirical:
+            aidx_k.fill_(-1)            # (a single-row cluster comes back with index 0: the empirical model has none)
         check(L.sf_cmf_score_cluster(P(cube), lines, bands, samples, s0, s1, a0 - 1, p, P(filt), P(bias), P(status_k),
                                      P(aidx_k), P(mask_k), -32768 if reject else ki, P(out_t), out_samples, out_s0, nb,
                                      P(bgmeta), st),

@@ -300,8 +300,26 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
     model   : a name of MODEL_NORM or a (mean, std) pair
     weights : a GoogLeNet ``state_dict`` (name -> tensor/ndarray)
     rows    : optional (r0, r1) image rows to score (multi-GPU row sharding); other rows are left at 0
+    gpus    : device indices (the script's ``-g 0 1 2 3``, which wraps the model in ``DataParallel`` and re-scatters
+              every batch, cnn_pred_pipeline.py:113-116).  Here every listed GPU gets its own copy of the weights and
+              of the 69 MB padded plane and scores a contiguous block of image rows from its own host thread; the
+              blocks are copied to the first device once.  A negative index (the reference's CPU run) is refused.
     """
     torch = _torch()
+    if gpus is not None and len(gpus) > 0:
+        gpus = [int(g) for g in gpus]
+        if any(g < 0 for g in gpus):
+            raise _ffi.SrcfinderError("gpus=%r: srcfinder_amd has no CPU path (the reference's -g -1)" % (gpus,))
+        if any(g >= torch.cuda.device_count() for g in gpus):
+            raise _ffi.SrcfinderError("gpus=%r: only %d device(s) visible" % (gpus, torch.cuda.device_count()))
+        if len(gpus) > 1:
+            if net is not None or rows is not None:
+                raise ValueError("gpus=[...] builds one network per device: do not pass net= or rows=")
+            return _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision)
+        if net is None:
+            if weights is None:
+                raise ValueError("weights (a GoogLeNet state_dict) are required")
+            net = GoogLeNetHIP(weights, device=torch.device("cuda", gpus[0]), precision=precision)
     if net is None:
         if weights is None:
             raise ValueError("weights (a GoogLeNet state_dict) are required")      # the script exits 1 (:93-95)
@@ -315,6 +333,40 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
         n = min(batch, i1 - t0)
         net.forward_tiles(ds.x, W, t0, n, plane=ds.plane, out=out)
     out = out.view(H, W)
+    return out.cpu().numpy() if to_numpy else out
+
+
+def _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision):
+    """Row blocks of the saliency map on several GPUs of one process (one host thread per device)."""
+    import threading
+    torch = _torch()
+    if weights is None:
+        raise ValueError("weights (a GoogLeNet state_dict) are required")
+    plane = cmf2d.detach().cpu().numpy() if torch.is_tensor(cmf2d) else np.asarray(cmf2d, dtype=np.float32)
+    H = plane.shape[0]
+    n = len(gpus)
+    parts, errs = [None] * n, [None] * n
+
+    def work(i):
+        try:
+            dev = torch.device("cuda", gpus[i])
+            with torch.cuda.device(dev):
+                net = GoogLeNetHIP(weights, device=dev, precision=precision)
+                r0, r1 = i * H // n, (i + 1) * H // n
+                sal = predict_flightline(plane, model, net=net, batch=batch, rows=(r0, r1))
+                parts[i] = sal[r0:r1].to(torch.device("cuda", gpus[0]), non_blocking=False)
+        except Exception as e:                                  # surfaced in the caller's thread
+            errs[i] = e
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errs:
+        if e is not None:
+            raise e
+    out = torch.cat(parts, 0)
     return out.cpu().numpy() if to_numpy else out
 
 

@@ -95,7 +95,7 @@ def create_image(path, meta, dtype, interleave="bip"):
     m["data type"] = DTYPE_TO_ENVI[np.dtype(dtype).str[1:]]
     m["interleave"] = interleave
     m["byte order"] = 0
-    m.setdefault("header offset", 0)
+    m["header offset"] = 0          # the data is written at the start of the file, whatever the input's header said
     m.setdefault("file type", "ENVI Standard")
     L, S, B = int(m["lines"]), int(m["samples"]), int(m["bands"])
     shape = {"bil": (L, B, S), "bip": (L, S, B), "bsq": (B, L, S)}[interleave]

@@ -24,9 +24,16 @@ class Ticket:
         self.result, self.event, self.slot = result, event, slot
 
     def wait(self, stream=None):
-        """Make ``stream`` (default: the current stream) wait for this flightline -- no host synchronisation."""
+        """Make ``stream`` (default: the current stream) wait for this flightline -- no host synchronisation.  The result
+        tensors were allocated on the slot's stream: they are marked as in use by the waiting stream, so the caching
+        allocator does not hand their memory to the slot's next flightline while the consumer still reads them."""
         import torch
-        (stream or torch.cuda.current_stream()).wait_event(self.event)
+        stream = stream or torch.cuda.current_stream()
+        stream.wait_event(self.event)
+        for name in ("out", "bgmeta", "colstats", "alphaidx", "nuse", "status", "nll", "labels"):
+            t = getattr(self.result, name, None)
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)
         return self.result
 
     def synchronize(self):

@@ -76,7 +76,39 @@ def main_empirical():
                         out=r["out"], colstats=r["colstats"], modelparms=np.array(r["modelparms"]), versions=G.versions())
 
 
+def main_empirical_more():
+    """-M empirical on the other two branches: multimodal (-k 2) and the wide reflectance window (-R, p = 416).
+    The reference cannot save its labels with -M empirical (-m dies on `alphas`), but the clustering happens before the
+    model is fitted and consumes numpy's global RNG identically: the SAME seed with -k 2 -m (looshrinkage) gives the
+    labels of the -M empirical -k 2 run (checked here: the two runs' NODATA patterns and cluster-dependent scores are
+    reproduced by the oracle with those labels)."""
+    G.install_spectral_stub()
+    lib = np.float64(np.loadtxt(G.LIB_TXT))
+    lines, samples, seed = 1400, 4, 558
+    cube = G.make_cube_numpy(lines, samples, seed=seed, abscf_full=lib[:, 2], nodata_column=1)
+    cube[500:1000] *= np.float32(1.35)
+    np.random.seed(21)
+    ra = G.run_reference_main(cube, extra_args=("-k", "2"), tag="EK2A")                 # labels (bgmeta band 0)
+    np.random.seed(21)
+    rb = G.run_reference_main(cube, extra_args=("-k", "2", "-M", "empirical"), tag="EK2B", metadata=False)
+    np.savez_compressed(os.path.join(HERE, "cmf_empirical_K2.npz"), seed=seed, lines=lines, samples=samples, nodata_column=1,
+                        bright=np.array([500, 1000, 1.35]), labels=ra["bgmeta"][:, :, 0], out=rb["out"], colstats=rb["colstats"],
+                        modelparms=np.array(rb["modelparms"]), versions=G.versions())
+    print("empirical -k 2:", rb["modelparms"], "cluster sizes", [(int((ra["bgmeta"][:, c, 0] == 0).sum()), int((ra["bgmeta"][:, c, 0] == 1).sum())) for c in range(samples)])
+    lines, samples, seed = 900, 3, 559
+    cube = G.make_cube_numpy(lines, samples, seed=seed, abscf_full=lib[:, 2], nodata_column=2)
+    cube = np.float32(np.clip(cube, -1e9, None) * (cube > 0) * 0.08 + cube * (cube <= 0))   # reflectance-like magnitudes
+    rc = G.run_reference_main(cube, extra_args=("-R", "-M", "empirical"), tag="ER", metadata=False)
+    np.savez_compressed(os.path.join(HERE, "cmf_empirical_R.npz"), seed=seed, lines=lines, samples=samples, nodata_column=2,
+                        scale=0.08, out=rc["out"], colstats=rc["colstats"], modelparms=np.array(rc["modelparms"]),
+                        versions=G.versions())
+    print("empirical -R:", rc["modelparms"])
+
+
 if __name__ == "__main__":
+    if "--empirical-more" in sys.argv:
+        main_empirical_more()
+        sys.exit(0)
     if "--empirical" in sys.argv:
         main_empirical()
         sys.exit(0)

@@ -1063,3 +1063,30 @@ def test_empirical_model_golden(torch_cuda, golden_dir, library):
     assert res.modelparms == str(g["modelparms"]) and np.all(res.alphaidx == -1)
     with pytest.raises(NameError):
         cmf.robust_mf(cube, library, model="empirical", metadata=True)
+
+
+def test_empirical_model_on_the_multimodal_and_wide_branches(torch_cuda, golden_dir, library):
+    """-M empirical -k 2 (labels injected) and -M empirical -R (p = 416) against goldens of the real reference."""
+    g = np.load(os.path.join(golden_dir, "cmf_empirical_K2.npz"))
+    cube = make_cube_numpy(int(g["lines"]), int(g["samples"]), seed=int(g["seed"]), abscf_full=library[:, 2],
+                           nodata_column=int(g["nodata_column"]))
+    b0, b1, f = g["bright"]
+    cube[int(b0):int(b1)] *= np.float32(f)
+    res = cmf.robust_mf(cube, library, model="empirical", kmeans=2, labels=g["labels"], to_numpy=True)
+    ref = g["out"]
+    assert np.array_equal(res.out[..., 3] == -9999.0, ref[..., 3] == -9999.0) and np.array_equal(res.out[..., :3], ref[..., :3])
+    assert score_close(res.out[..., 3], ref[..., 3]).all()
+    assert res.modelparms == str(g["modelparms"]) and np.all(res.alphaidx[res.status == 0] == -1)
+    ok = g["colstats"][0] > 0
+    np.testing.assert_allclose(res.colstats[:, ok], g["colstats"][:, ok], rtol=1e-6, atol=1e-9 * np.abs(ref[..., 3]).max())
+    with pytest.raises(NameError):
+        cmf.robust_mf(cube, library, model="empirical", kmeans=2, labels=g["labels"], metadata=True)
+    g = np.load(os.path.join(golden_dir, "cmf_empirical_R.npz"))
+    cube = make_cube_numpy(int(g["lines"]), int(g["samples"]), seed=int(g["seed"]), abscf_full=library[:, 2],
+                           nodata_column=int(g["nodata_column"]))
+    cube = np.float32(np.clip(cube, -1e9, None) * (cube > 0) * 0.08 + cube * (cube <= 0))
+    res = cmf.robust_mf(cube, library, model="empirical", reflectance=True, to_numpy=True)
+    ref = g["out"]
+    assert np.array_equal(res.out[..., 3] == -9999.0, ref[..., 3] == -9999.0)
+    assert score_close(res.out[..., 3], ref[..., 3]).all()
+    assert res.modelparms == str(g["modelparms"])

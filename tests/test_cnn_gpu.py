@@ -91,6 +91,25 @@ def test_batch_split_and_row_shard_invariance(gold, net):
     np.testing.assert_allclose(a.reshape(-1)[[0, 50, 116]].cpu().numpy(), o, rtol=1e-4, atol=1e-7)
 
 
+def test_gpu_list_scores_row_blocks_from_threads(gold, net):
+    """``gpus=[...]`` (the script's ``-g 0 1 ...``, cnn_pred_pipeline.py:113-116): one network and one host thread per
+    listed device, contiguous row blocks, assembled once.  On a one-GPU box the list [0, 0, 0] drives the same code with
+    three threads on one device: bit-identical to the single call.  A negative index (the reference's CPU run) raises."""
+    import torch
+    from srcfinder_amd import _ffi
+    plane = synthetic_plane(10, 13, seed=5)
+    a = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=64)
+    sd = synthetic_state_dict(seed=2024)
+    b = cnn.predict_flightline(plane, (MEAN, STD), weights=sd, batch=16, gpus=[0, 0, 0])
+    assert torch.equal(a, b)
+    c = cnn.predict_flightline(plane, (MEAN, STD), weights=sd, batch=64, gpus=[0])
+    assert torch.equal(a, c)
+    with pytest.raises(_ffi.SrcfinderError):
+        cnn.predict_flightline(plane, (MEAN, STD), weights=sd, gpus=[-1])
+    with pytest.raises(_ffi.SrcfinderError):
+        cnn.predict_flightline(plane, (MEAN, STD), weights=sd, gpus=[0, 97])
+
+
 def test_cmf_into_cnn_end_to_end(net, library):
     """BASELINE config 4 in miniature: cube -> HIP CMF -> HIP CNN, against oracle CMF -> oracle CNN."""
     import torch

@@ -196,3 +196,22 @@ def test_triage_profile_golden(golden_dir):
     assert np.array_equal(np.float32(plain), np.float32(g["plain"]), equal_nan=True)
     assert np.array_equal(np.float32(rob), np.float32(g["robust"]), equal_nan=True)
     assert np.isnan(g["plain"][7, 1]) and g["plain"][11, 0] == 1 and g["plain"][13, 0] == 0
+
+
+def test_empirical_multimodal_and_wide_goldens(golden_dir, library):
+    """-M empirical on the multimodal branch (labels of the same-seed -k 2 -m run, see gen_golden_multimodal.py) and on
+    the wide reflectance window: the oracle reproduces the real reference's products bit for bit."""
+    from srcfinder_amd.synth import make_cube_numpy
+    g = np.load(os.path.join(golden_dir, "cmf_empirical_K2.npz"))
+    cube = make_cube_numpy(int(g["lines"]), int(g["samples"]), seed=int(g["seed"]), abscf_full=library[:, 2],
+                           nodata_column=int(g["nodata_column"]))
+    b0, b1, f = g["bright"]
+    cube[int(b0):int(b1)] *= np.float32(f)
+    o = O.robust_mf_multimodal_oracle(cube, library, g["labels"], model="empirical")
+    assert np.array_equal(o["out"], g["out"])
+    g = np.load(os.path.join(golden_dir, "cmf_empirical_R.npz"))
+    cube = make_cube_numpy(int(g["lines"]), int(g["samples"]), seed=int(g["seed"]), abscf_full=library[:, 2],
+                           nodata_column=int(g["nodata_column"]))
+    cube = np.float32(np.clip(cube, -1e9, None) * (cube > 0) * 0.08 + cube * (cube <= 0))
+    o = O.robust_mf_oracle(cube, library, reflectance=True, model="empirical")
+    assert np.array_equal(o["out"], g["out"])

@@ -7,6 +7,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_$tag -o p -- python3 $root/bench.py "$@" > $root/gpurun_out/prof_$tag.log 2>&1
 cd $root
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
-python3 tools/kstats.py $f > gpurun_out/${tag}_kstats.txt
+t=$(find gpurun_out/prof_$tag -name "*kernel_trace.csv" | head -1)
+steps=5; prev=""; for a in "$@"; do if [ "$prev" = "--steps" ]; then steps=$a; fi; prev=$a; done
+python3 tools/kstats.py $f $t $steps > gpurun_out/${tag}_kstats.txt
 tail -1 gpurun_out/prof_$tag.log | cut -c1-160
 cat gpurun_out/${tag}_kstats.txt

@@ -247,6 +247,10 @@ int sf_cnn_prepare_plane(const float *plane, int H, int W, float vmin, float vma
  * -> out[ntiles][128][128][64].  w = [64][49], bias = [64]. */
 int sf_cnn_conv1(const float *padded, int Hp, int Wp, int W, long long tile0, int ntiles, const float *w,
                  const float *bias, float *out, void *stream);
+/* The same fused with maxpool1 = MaxPool2d(3, stride 2, ceil_mode) (googlenet1.py:61): out[ntiles][64][64][64]; the
+ * 128 x 128 x 64 conv1 activation (4 MB per tile) never leaves the CU (implicit GEMM on the fp32 matrix cores). */
+int sf_cnn_conv1_pool(const float *padded, int Hp, int Wp, int W, long long tile0, int ntiles, const float *w,
+                      const float *bias, float *out, void *stream);
 
 /* nn.MaxPool2d(ksize, stride, pad, ceil_mode=True) (googlenet1.py:61,:64,:68,:75,:213); Ho/Wo are the caller's
  * ceil-mode output sizes; edge windows are clipped to the input. */

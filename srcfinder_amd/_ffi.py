@@ -35,6 +35,7 @@ SIGNATURES = {
                          vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "sf_cnn_prepare_plane": (i32, [vp, i32, i32, f32, f32, f32, f32, i32, vp, vp]),
     "sf_cnn_conv1": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp, vp]),
+    "sf_cnn_conv1_pool": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp, vp]),
     "sf_cnn_maxpool": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "sf_cnn_conv": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, i32, i32, vp]),
     "sf_cnn_conv_split3": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, i32, vp, i32, i32,

@@ -229,9 +229,10 @@ class GoogLeNetHIP(object):
         self._conv(pooled, name + ".branch4.1", y, c1 + c3 + c5)
         return y
 
-    def _trunk(self, a1, taps=None):
-        """maxpool1 .. inception5b on the conv1 activations a1 [N, H, W, 64] (googlenet1.py:61-86)."""
-        x = self._pool(a1, "pool1", 3, 2, 0)
+    def _trunk(self, a1, taps=None, pooled=False):
+        """maxpool1 .. inception5b on the conv1 activations a1 [N, H, W, 64] (googlenet1.py:61-86); with ``pooled`` a1 is
+        already the output of maxpool1 (the fused conv1 + pool kernel of the tile scorer)."""
+        x = a1 if pooled else self._pool(a1, "pool1", 3, 2, 0)
         a3 = self._buf("conv2", x.shape)
         self._conv(x, "conv2", a3, 0)
         a4 = self._buf("conv3", tuple(x.shape[:3]) + (192,))
@@ -276,11 +277,18 @@ class GoogLeNetHIP(object):
         Hp, Wp = padded.shape[-2], padded.shape[-1]
         with torch.cuda.device(self.device):
             st = _ffi.stream_ptr()
-            a1 = self._buf("conv1", (ntiles, 128, 128, 64))
             w, b = self.w["conv1"]
-            _ffi.check(getattr(L, "sf_cnn_conv1" + self.sfx)(_ffi.ptr(padded), Hp, Wp, width, C.c_longlong(tile0), ntiles,
-                                                             _ffi.ptr(w), _ffi.ptr(b), _ffi.ptr(a1), st), "sf_cnn_conv1")
-            x = self._trunk(a1, taps)
+            if taps is None and not self.half and getattr(self, "fuse_conv1", True):
+                # production: conv1 and maxpool1 in one kernel, the 4 MB-per-tile conv1 activation never reaches HBM
+                a1 = self._buf("pool1", (ntiles, 64, 64, 64))
+                _ffi.check(L.sf_cnn_conv1_pool(_ffi.ptr(padded), Hp, Wp, width, C.c_longlong(tile0), ntiles, _ffi.ptr(w),
+                                               _ffi.ptr(b), _ffi.ptr(a1), st), "sf_cnn_conv1_pool")
+                x = self._trunk(a1, None, pooled=True)
+            else:
+                a1 = self._buf("conv1", (ntiles, 128, 128, 64))
+                _ffi.check(getattr(L, "sf_cnn_conv1" + self.sfx)(_ffi.ptr(padded), Hp, Wp, width, C.c_longlong(tile0), ntiles,
+                                                                 _ffi.ptr(w), _ffi.ptr(b), _ffi.ptr(a1), st), "sf_cnn_conv1")
+                x = self._trunk(a1, taps)
             if taps is not None:
                 taps["conv1"] = a1.clone()
             N, H, W, Cc = x.shape

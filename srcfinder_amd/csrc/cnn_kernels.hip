@@ -77,6 +77,104 @@ __global__ __launch_bounds__(256) void k_conv1(const float *__restrict__ padded,
   }
 }
 
+// ---- conv1 + maxpool1 fused: 7x7 stride 2 pad 3 (1 -> 64) + BN + ReLU, then 3x3 stride 2 ceil-mode max pool ----------
+// (googlenet1.py:60-61).  conv1's 128 x 128 x 64 activation of a tile is 4 MB that the pool reads back at once and
+// nothing else ever does: written and read for every tile it is 8 of the ~25 MB a tile moves through HBM.  Here a
+// workgroup produces an 8 x 8 block of POOLED pixels: it stages the 39 x 39 input patch, evaluates the 17 x 17 conv
+// outputs the block's windows cover as one implicit GEMM on the matrix cores (M = 289 pixels in 10 blocks of 32,
+// N = 64 channels, K = 49 taps padded to 50; A is gathered from the patch in LDS, lane by lane), keeps them in LDS and
+// pools from there.  Only the 64 x 64 x 64 pooled activation (1 MB per tile) leaves the CU.
+constexpr int CP_PT = 8, CP_CR = 2 * CP_PT + 1, CP_NPX = CP_CR * CP_CR;   // pooled tile, conv rows/cols, conv pixels
+constexpr int CP_PATCH = 2 * (CP_CR - 1) + 7;                             // 39
+constexpr int CP_LDP = CP_PATCH + 1, CP_LDB = 64 + 1, CP_LDC = 36, CP_KP = 50, CP_MB = (CP_NPX + 31) / 32;   // 10 blocks
+// 61 KB: two workgroups per CU (the channels go in two halves of 32 through one [289][36] conv tile), so one's patch
+// load / pooling runs under the other's matrix phase
+static size_t cp_lds_bytes() { return ((size_t)CP_PATCH * CP_LDP + CP_KP * CP_LDB + (size_t)CP_NPX * CP_LDC + 64) * sizeof(float); }
+__global__ __launch_bounds__(256, 2) void k_conv1_pool(const float *__restrict__ padded, int Wp, int Wimg, long long tile0,
+                                                        const float *__restrict__ w /*[64][49]*/, const float *__restrict__ bias,
+                                                        float *__restrict__ out /*[n][64][64][64]*/) {
+  extern __shared__ __attribute__((aligned(16))) float cp_lds[];
+  float *patch = cp_lds;                                   // [39][40]
+  float *Bs = patch + CP_PATCH * CP_LDP;                   // [50][65]  Bs[k][co], rows 49.. zero
+  float *convt = Bs + CP_KP * CP_LDB;                      // [289][36] relu(conv + bias) of one channel half
+  float *bs = convt + CP_NPX * CP_LDC;                     // [64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.y;
+  const long long tile = tile0 + t;
+  const int trow = (int)(tile / Wimg), tcol = (int)(tile % Wimg);
+  const int py0 = (blockIdx.x >> 3) * CP_PT, px0 = (blockIdx.x & 7) * CP_PT;     // pooled block origin
+  const int cy0 = 2 * py0, cx0 = 2 * px0;                                         // conv block origin
+  for (int i = tid; i < CP_KP * 64; i += 256) {
+    const int k = i / 64, co = i % 64;
+    Bs[k * CP_LDB + co] = (k < 49) ? w[co * 49 + k] : 0.f;
+  }
+  if (tid < 64) bs[tid] = bias[tid];
+  for (int i = tid; i < CP_PATCH * CP_PATCH; i += 256) {
+    const int py = i / CP_PATCH, px = i % CP_PATCH;
+    const int iy = 2 * cy0 - 3 + py, ix = 2 * cx0 - 3 + px;                      // tile-local input coordinates
+    float v = 0.f;                                                               // the tile is its own image: zero outside
+    if (iy >= 0 && iy < 256 && ix >= 0 && ix < 256) v = padded[(size_t)(trow + iy) * Wp + tcol + ix];
+    patch[py * CP_LDP + px] = v;
+  }
+  __syncthreads();
+  const int l31 = lane & 31, kh = lane >> 5;
+  constexpr int NBW = (CP_MB + 3) / 4;
+  int abase[NBW];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    const int m = min(32 * (wave + 4 * j) + l31, CP_NPX - 1);                     // rows past 289: duplicates, never stored
+    abase[j] = (2 * (m / CP_CR)) * CP_LDP + 2 * (m % CP_CR);
+  }
+  for (int h = 0; h < 2; ++h) {                                                   // channel half
+    // ---- implicit GEMM: wave w takes the M blocks w, w + 4, w + 8 (the last two waves two blocks)
+    f16_t acc[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll 5
+    for (int kk = 0; kk < CP_KP / 2; ++kk) {
+      const int k = 2 * kk + kh, kc = min(k, 48);                                 // tap 49 is padding: weight row is zero
+      const int koff = (kc / 7) * CP_LDP + (kc % 7);
+      const float b = Bs[k * CP_LDB + 32 * h + l31];
+#pragma unroll
+      for (int j = 0; j < NBW; ++j)
+        if (wave + 4 * j < CP_MB)                                                 // (wave-uniform)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(patch[abase[j] + koff], b, acc[j], 0, 0, 0);
+    }
+    // acc[.][r] = D[row = (r&3) + 8(r>>2) + 4(lane>>5)][col = lane&31]
+    const float bb = bs[32 * h + l31];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      if (wave + 4 * j < CP_MB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = 32 * (wave + 4 * j) + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (m < CP_NPX) convt[m * CP_LDC + l31] = fmaxf(acc[j][r] + bb, 0.f);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 3x3 stride-2 max pool, windows clipped to the 128 x 128 conv image (ceil_mode: the last window is partial)
+    for (int i = tid; i < CP_PT * CP_PT * 8; i += 256) {
+      const int c4 = i & 7, pp = i >> 3, py = pp / CP_PT, px = pp % CP_PT;
+      float4 m = make_float4(-3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        if (cy0 + 2 * py + dy > 127) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          if (cx0 + 2 * px + dx > 127) continue;
+          const float4 v = *reinterpret_cast<const float4 *>(convt + ((2 * py + dy) * CP_CR + 2 * px + dx) * CP_LDC + 4 * c4);
+          m = make_float4(fmaxf(m.x, v.x), fmaxf(m.y, v.y), fmaxf(m.z, v.z), fmaxf(m.w, v.w));
+        }
+      }
+      *reinterpret_cast<float4 *>(out + (((size_t)t * 64 + py0 + py) * 64 + px0 + px) * 64 + 32 * h + 4 * c4) = m;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- max pool, NHWC, window clipped to the input (ceil_mode edge windows are partial) ------------------------------
 // (googlenet1.py:61,:64,:68,:75 and the stride-1 pool of the inception branch4 :213)
 // Each thread produces PR vertically adjacent outputs of one (n, ox, channel quad): the 3-wide row maxima of the
@@ -317,6 +415,20 @@ int sf_cnn_conv1(const float *padded, int Hp, int Wp, int W, long long tile0, in
   }
   hipLaunchKernelGGL(k_conv1, dim3(64, ntiles), dim3(256), 0, (hipStream_t)stream, padded, Wp, W, tile0, w, bias, out);
   SF_LAUNCH_CHECK("k_conv1");
+  return 0;
+}
+
+int sf_cnn_conv1_pool(const float *padded, int Hp, int Wp, int W, long long tile0, int ntiles, const float *w,
+                      const float *bias, float *out, void *stream) {
+  if (!padded || !w || !bias || !out || ntiles < 1 || W < 1 || Wp != W + 255 || tile0 < 0 ||
+      (tile0 + ntiles + W - 1) / W > Hp - 255) {
+    sf_set_error("sf_cnn_conv1_pool: bad argument");
+    return -1;
+  }
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_conv1_pool), cp_lds_bytes())) return rc;
+  hipLaunchKernelGGL(k_conv1_pool, dim3(64, ntiles), dim3(256), cp_lds_bytes(), (hipStream_t)stream, padded, Wp, W, tile0, w,
+                     bias, out);
+  SF_LAUNCH_CHECK("k_conv1_pool");
   return 0;
 }
 

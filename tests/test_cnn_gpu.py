@@ -91,6 +91,34 @@ def test_batch_split_and_row_shard_invariance(gold, net):
     np.testing.assert_allclose(a.reshape(-1)[[0, 50, 116]].cpu().numpy(), o, rtol=1e-4, atol=1e-7)
 
 
+def test_fused_conv1_pool_matches_the_two_kernels(net):
+    """The production tile scorer evaluates conv1 + maxpool1 in one kernel (implicit GEMM on the matrix cores, the conv1
+    activation stays in LDS); the two-kernel form (VALU conv1, then the pool) is what the activation taps use.  Same
+    values up to the order of the 49-term fp32 sums -- on interior tiles and on tiles that hang over every image border."""
+    import ctypes as C
+    import torch
+    from srcfinder_amd import _ffi
+    L = _ffi.lib()
+    plane = synthetic_plane(7, 9, seed=11)
+    ds = cnn.FlightlineConvolve(plane, (MEAN, STD), device=net.device)
+    Hp, Wp = ds.x.shape[-2], ds.x.shape[-1]
+    w, b = net.w["conv1"]
+    n = 7 * 9
+    a1 = torch.empty((n, 128, 128, 64), dtype=torch.float32, device=net.device)
+    p_ref = torch.empty((n, 64, 64, 64), dtype=torch.float32, device=net.device)
+    p_fused = torch.full((n, 64, 64, 64), float("nan"), dtype=torch.float32, device=net.device)
+    st = _ffi.stream_ptr()
+    _ffi.check(L.sf_cnn_conv1(_ffi.ptr(ds.x), Hp, Wp, 9, C.c_longlong(0), n, _ffi.ptr(w), _ffi.ptr(b), _ffi.ptr(a1), st), "conv1")
+    _ffi.check(L.sf_cnn_maxpool(_ffi.ptr(a1), n, 128, 128, 64, 3, 2, 0, _ffi.ptr(p_ref), 64, 64, st), "maxpool")
+    _ffi.check(L.sf_cnn_conv1_pool(_ffi.ptr(ds.x), Hp, Wp, 9, C.c_longlong(0), n, _ffi.ptr(w), _ffi.ptr(b), _ffi.ptr(p_fused), st),
+               "conv1_pool")
+    torch.cuda.synchronize()
+    assert torch.isfinite(p_fused).all()
+    scale = float(p_ref.abs().max())
+    assert float((p_fused - p_ref).abs().max()) <= 2e-6 * scale
+    assert float(p_ref.max()) > 0          # ReLU outputs: something is active
+
+
 def test_gpu_list_scores_row_blocks_from_threads(gold, net):
     """``gpus=[...]`` (the script's ``-g 0 1 ...``, cnn_pred_pipeline.py:113-116): one network and one host thread per
     listed device, contiguous row blocks, assembled once.  On a one-GPU box the list [0, 0, 0] drives the same code with

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--tiles", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true", help="conv1 and maxpool1 as two kernels (A/B of the fused kernel)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"])
     args = ap.parse_args()
     import torch
@@ -27,6 +28,7 @@ def main():
 
     sd = synthetic_state_dict(2024)
     net = cnn.GoogLeNetHIP(sd, precision=args.precision)
+    net.fuse_conv1 = not args.no_fuse
     w = 64
     h = (args.tiles + w - 1) // w
     plane = synthetic_plane(h, w, seed=5)

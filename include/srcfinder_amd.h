@@ -72,6 +72,15 @@ int sf_cmf_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const i
                       const double *mu, const double *alphas, int nalpha, int lines, int p, int ncols, double *cov, double *d,
                       double *lam, double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, void *stream);
 
+/* The same with a full shrinkage target[ncols][p][p] (multimodal -f on a wide window; looshrinkage(..., I_reg) with more
+ * than 96 bands -- robust_mf.py:99, :131, :354): blocked Cholesky of the target, R = L^-1 S L^-T by substitution,
+ * eigenpairs of R, outputs d = diag(L), evec_j = D (L^-T v_j) as sf_cmf_eigh_general returns them; the exact
+ * determinants are those of n beta S + alpha T.  status 2 when the target is not positive definite. */
+int sf_cmf_wide_stats_target(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nrows, const int32_t *nloo,
+                             const double *mu, const double *alphas, int nalpha, int lines, int p, int ncols,
+                             const double *target, double *cov, double *d, double *lam, double *evec, int32_t *status,
+                             double *nll, int32_t *alphaidx, void *scratch, void *stream);
+
 /* Stage 4, full shrinkage target (multimodal -f: T = cov(I_reg), robust_mf.py:99, :131, :354) -- the same restatement one
  * congruence further: target = L L^T (Cholesky), eigendecomposition of L^-1 S L^-T, and outputs d = diag(L),
  * evec_j = D (L^-T v_j) chosen so that stages 5-7 run unchanged (they only form D^-1 evec^T and 2 sum log d = log det T).
@@ -274,6 +283,18 @@ int sf_cnn_conv_split3(const float *in, int N, int H, int W, int Cin, int ld_in,
  * and the NODATA rule (:185-189): out[tile0 + t] = plane[tile0 + t] == nodata ? nodata : p.  plane may be NULL. */
 int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, const float *fcb, const float *plane,
                 long long tile0, float nodata, float *out, void *stream);
+
+/* The whole tile scorer in one call (cnn_pred_pipeline.py:159-189 around googlenet1.py's eval graph): scores the image
+ * rows [r0, r1) of the H x W plane -- one 256 x 256 window per pixel of the padded plane [H+255][W+255] from
+ * sf_cnn_prepare_plane -- in batches of `batch` windows and writes out[row * W + col] (float32; NODATA where plane is
+ * NODATA, plane may be NULL).  blob: the BatchNorm-folded float32 weights in ONE array of sf_cnn_blob_floats() values:
+ * for conv1, conv2, conv3, then per inception block {branch1|branch2.0|branch3.0 stacked, branch2.1, branch3.1,
+ * branch4.1}, then fc: weights [Cout][k*k][Cin] followed by the bias [Cout].  workspace >=
+ * sf_cnn_score_workspace_bytes(batch) (activations of one batch).  All launches are enqueued on `stream`. */
+size_t sf_cnn_blob_floats(void);
+size_t sf_cnn_score_workspace_bytes(int batch);
+int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int r0, int r1, const float *blob, float *out,
+                      int batch, void *workspace, size_t workspace_bytes, void *stream);
 
 /* FCN shift-and-stitch, the reference's approximate fast mode (cnn/fcn_pred_pipeline.py).
  * sf_cnn_fcn_prepare: ClampCH4 + Normalize of the plane, embedded at (top, left) = divmod(shift, scale) in a zero canvas

@@ -26,6 +26,8 @@ SIGNATURES = {
     "sf_cmf_covariance": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "sf_cmf_eigh": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
     "sf_cmf_wide_stats": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "sf_cmf_wide_stats_target": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                       vp]),
     "sf_cmf_eigh_general": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "sf_cmf_loocv": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "sf_cmf_filter": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
@@ -41,6 +43,9 @@ SIGNATURES = {
     "sf_cnn_conv_split3": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, i32, vp, i32, i32,
                                  vp, i32, i32, vp]),
     "sf_cnn_head": (i32, [vp, i32, i32, i32, vp, vp, vp, i64, f32, vp, vp]),
+    "sf_cnn_blob_floats": (sz, []),
+    "sf_cnn_score_workspace_bytes": (sz, [i32]),
+    "sf_cnn_score_rows": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, sz, vp]),
     "sf_cnn_fcn_prepare": (i32, [vp, i32, i32, f32, f32, f32, f32, i32, i32, i32, i32, i32, vp, vp]),
     "sf_cnn_conv1_image": (i32, [vp, i32, i32, i32, vp, vp, vp, i32, vp]),
     "sf_cnn_fcn_stitch": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, f32, vp, vp]),

@@ -309,8 +309,6 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
         raise NotImplementedError("active window of more than 512 bands")
     if empirical:                       # -M empirical: C = the cluster's sample covariance (:350-351); -f has no effect on it
         full, return_nll = False, False
-    if wide and full:
-        raise NotImplementedError("the full-column regulariser (-f) on a window of more than 96 bands")
     dev = cube.device
     ncols = s1 - s0
     ps = (p + 3) // 4 * 4
@@ -337,8 +335,13 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
     def stats(m, n_rows, n_loo, status, want_alpha=True):
         check(L.sf_cmf_column_mean(P(xt), 0, P(m), lines, p, ncols, P(n_rows), P(mu), P(ws), st), "sf_cmf_column_mean")
         if wide:        # covariance + eigendecomposition + sweep in one call (the alpha index is a by-product)
-            check(L.sf_cmf_wide_stats(P(xt), 0, P(m), P(n_rows), P(n_loo), P(mu), P(alphas), nalpha, lines, p, ncols, P(S),
-                                      P(d), P(lam), P(evec), P(status), P(nll), P(aidx_k), P(ws), st), "sf_cmf_wide_stats")
+            if target is not None:
+                check(L.sf_cmf_wide_stats_target(P(xt), 0, P(m), P(n_rows), P(n_loo), P(mu), P(alphas), nalpha, lines, p, ncols,
+                                                 P(target), P(S), P(d), P(lam), P(evec), P(status), P(nll), P(aidx_k), P(ws),
+                                                 st), "sf_cmf_wide_stats_target")
+            else:
+                check(L.sf_cmf_wide_stats(P(xt), 0, P(m), P(n_rows), P(n_loo), P(mu), P(alphas), nalpha, lines, p, ncols, P(S),
+                                          P(d), P(lam), P(evec), P(status), P(nll), P(aidx_k), P(ws), st), "sf_cmf_wide_stats")
             return
         check(L.sf_cmf_covariance(P(xt), 0, P(m), P(n_rows), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
         if target is not None:
@@ -365,10 +368,14 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
             raise ValueError("labels must be cluster ids in 0..%d" % (k - 1))
         labels_t = lab.to(dev)[:, s0:s1].t().contiguous().to(torch.uint8)
         check(L.sf_cmf_column_mean(P(xt), 0, P(mask), lines, p, ncols, P(nuse_col), P(mu), P(ws), st), "sf_cmf_column_mean")
-        if full:
+        if full and wide:           # (the wide route has no covariance-only entry: the whole-column statistics once)
+            stats(mask, nuse_col, nuse_col, status_k, want_alpha=False)
+        elif full:
             check(L.sf_cmf_covariance(P(xt), 0, P(mask), P(nuse_col), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
     if full:                        # S holds the whole column's covariance at this point on both routes
-        target, r_tmp, l_tmp = S.clone(), torch.empty_like(S), torch.empty_like(S)
+        target = S.clone()
+        if not wide:
+            r_tmp, l_tmp = torch.empty_like(S), torch.empty_like(S)
     # ---- the product starts as: NODATA on invalid rows, 0 on valid ones, RGB copied (a zero filter through stage 7)
     status0 = (nuse_col == 0).to(torch.int32)                           # 1 = column without a valid row: skipped (:303-304)
     zero_idx = torch.zeros(ncols, **i32)
@@ -437,7 +444,7 @@ def _upload_rows(a):
     return xt, mask, n, p
 
 
-def _wide_stats(torch, L, xt, mask, nrows, nloo, mu, alphas, rows, p, S, ws, nll=None, aidx=None):
+def _wide_stats(torch, L, xt, mask, nrows, nloo, mu, alphas, rows, p, S, ws, nll=None, aidx=None, target=None):
     """sf_cmf_wide_stats on ONE float64 matrix (function-level entries with more than 96 bands)."""
     dev = xt.device
     f64 = dict(dtype=torch.float64, device=dev)
@@ -447,6 +454,12 @@ def _wide_stats(torch, L, xt, mask, nrows, nloo, mu, alphas, rows, p, S, ws, nll
     status = torch.empty(1, dtype=torch.int32, device=dev)
     nll = torch.empty((1, nalpha), **f64) if nll is None else nll
     aidx = torch.empty(1, dtype=torch.int32, device=dev) if aidx is None else aidx
+    if target is not None:
+        _ffi.check(L.sf_cmf_wide_stats_target(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nrows), _ffi.ptr(nloo), _ffi.ptr(mu),
+                                              _ffi.ptr(alphas), nalpha, rows, p, 1, _ffi.ptr(target), _ffi.ptr(S), _ffi.ptr(d),
+                                              _ffi.ptr(lam), _ffi.ptr(evec), _ffi.ptr(status), _ffi.ptr(nll), _ffi.ptr(aidx),
+                                              _ffi.ptr(ws), _ffi.stream_ptr()), "sf_cmf_wide_stats_target")
+        return nll, aidx
     _ffi.check(L.sf_cmf_wide_stats(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nrows), _ffi.ptr(nloo), _ffi.ptr(mu),
                                    _ffi.ptr(alphas), nalpha, rows, p, 1, _ffi.ptr(S), _ffi.ptr(d), _ffi.ptr(lam),
                                    _ffi.ptr(evec), _ffi.ptr(status), _ffi.ptr(nll), _ffi.ptr(aidx), _ffi.ptr(ws),
@@ -606,8 +619,6 @@ def looshrinkage(I_zm, alphas, nll, n, I_reg=[]):
     xt, mask, rows, p = _upload_rows(I_zm)
     if p > 512:
         raise NotImplementedError("looshrinkage(): more than 512 bands")
-    if p > 96 and len(I_reg) != 0:
-        raise NotImplementedError("looshrinkage(): a full shrinkage target with more than 96 bands")
     L = _ffi.lib()
     dev = xt.device
     nalpha = len(alphas_np)
@@ -625,21 +636,22 @@ def looshrinkage(I_zm, alphas, nll, n, I_reg=[]):
     aidx = torch.empty(1, dtype=torch.int32, device=dev)
     al = torch.as_tensor(alphas_np, device=dev)
     st = _ffi.stream_ptr()
-    if p > 96:      # wide window (e.g. the reference's own -R run, p = 416; full-band p = 425): batched-GEMM path
-        _wide_stats(torch, L, xt, mask, nrows, nloo, mu, al, rows, p, S, ws, nll_d, aidx)
-        nll[:] = nll_d[0].cpu().numpy()
-        mindex = int(aidx.item())
-        alpha = float(alphas_np[mindex]) if mindex >= 0 else 0.0
-        S = S[0].cpu().numpy()
-        return (1.0 - alpha) * S + alpha * np.diag(np.diag(S)), mindex
-    _ffi.check(L.sf_cmf_covariance(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nrows), _ffi.ptr(mu), rows, p, 1,
-                                   _ffi.ptr(S), _ffi.ptr(ws), st), "sf_cmf_covariance")
-    T_np = None
+    T_np = T_d = None
     if len(I_reg) != 0:
         T_np = cov(I_reg)
         if T_np.shape != (p, p):
             raise ValueError("I_reg must have the same number of columns as I_zm")
         T_d = torch.as_tensor(np.ascontiguousarray(T_np[None]), device=dev)
+    if p > 96:      # wide window (e.g. the reference's own -R run, p = 416; full-band p = 425): batched-GEMM path
+        _wide_stats(torch, L, xt, mask, nrows, nloo, mu, al, rows, p, S, ws, nll_d, aidx, target=T_d)
+        nll[:] = nll_d[0].cpu().numpy()
+        mindex = int(aidx.item())
+        alpha = float(alphas_np[mindex]) if mindex >= 0 else 0.0
+        S = S[0].cpu().numpy()
+        return (1.0 - alpha) * S + alpha * (np.diag(np.diag(S)) if T_np is None else T_np), mindex
+    _ffi.check(L.sf_cmf_covariance(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nrows), _ffi.ptr(mu), rows, p, 1,
+                                   _ffi.ptr(S), _ffi.ptr(ws), st), "sf_cmf_covariance")
+    if T_d is not None:
         r_tmp, l_tmp = torch.empty_like(S), torch.empty_like(S)
         _ffi.check(L.sf_cmf_eigh_general(_ffi.ptr(S), _ffi.ptr(T_d), _ffi.ptr(nrows), p, 1, _ffi.ptr(r_tmp), _ffi.ptr(l_tmp),
                                          _ffi.ptr(d), _ffi.ptr(lam), _ffi.ptr(evec), _ffi.ptr(status), _ffi.ptr(ws), st),

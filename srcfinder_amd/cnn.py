@@ -181,6 +181,24 @@ class GoogLeNetHIP(object):
             raise ValueError("fc.weight must be [2, 1024]")
         return self
 
+    def packed_blob(self):
+        """The folded float32 weights as the ONE array ``sf_cnn_score_rows`` takes (layout: include/srcfinder_amd.h)."""
+        torch = _torch()
+        if self.half:
+            raise ValueError("the C driver scores in fp32")
+        if getattr(self, "_blob", None) is None:
+            parts = []
+            for name in ("conv1", "conv2", "conv3"):
+                parts += [self.w[name][0].reshape(-1), self.w[name][1]]
+            for spec in INCEPTION:
+                for sfx in (".head3", ".branch2.1", ".branch3.1", ".branch4.1"):
+                    w, b = self.w[spec[0] + sfx]
+                    parts += [w.reshape(-1), b]
+            parts += [self.fcw.reshape(-1), self.fcb]
+            self._blob = torch.cat([p.to(torch.float32) for p in parts]).contiguous()
+            assert self._blob.numel() == _ffi.lib().sf_cnn_blob_floats()
+        return self._blob
+
     # -- buffers ---------------------------------------------------------------------------------------------
     def _buf(self, key, shape):
         torch = _torch()
@@ -336,10 +354,20 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
     H, W = ds.inshape[1], ds.inshape[2]
     out = torch.zeros(H * W, dtype=torch.float32, device=net.device)
     r0, r1 = (0, H) if rows is None else rows
-    i0, i1 = r0 * W, r1 * W
-    for t0 in range(i0, i1, batch):
-        n = min(batch, i1 - t0)
-        net.forward_tiles(ds.x, W, t0, n, plane=ds.plane, out=out)
+    if not net.half and getattr(net, "c_driver", True):
+        # the C-side driver sequences the whole graph for the row range: one library call
+        L = _ffi.lib()
+        with torch.cuda.device(net.device):
+            wsb = L.sf_cnn_score_workspace_bytes(int(batch))
+            ws = net._buf("c_driver_ws", ((wsb + 3) // 4,))
+            _ffi.check(L.sf_cnn_score_rows(_ffi.ptr(ds.x), _ffi.ptr(ds.plane), H, W, int(r0), int(r1), _ffi.ptr(net.packed_blob()),
+                                           _ffi.ptr(out), int(batch), _ffi.ptr(ws), C.c_size_t(ws.numel() * 4), _ffi.stream_ptr()),
+                       "sf_cnn_score_rows")
+    else:
+        i0, i1 = r0 * W, r1 * W
+        for t0 in range(i0, i1, batch):
+            n = min(batch, i1 - t0)
+            net.forward_tiles(ds.x, W, t0, n, plane=ds.plane, out=out)
     out = out.view(H, W)
     return out.cpu().numpy() if to_numpy else out
 

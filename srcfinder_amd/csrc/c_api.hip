@@ -189,6 +189,20 @@ int sf_cmf_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const i
                               status, nll, alphaidx, scratch, (hipStream_t)stream);
 }
 
+int sf_cmf_wide_stats_target(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nrows, const int32_t *nloo,
+                             const double *mu, const double *alphas, int nalpha, int lines, int p, int ncols,
+                             const double *target, double *cov, double *d, double *lam, double *evec, int32_t *status,
+                             double *nll, int32_t *alphaidx, void *scratch, void *stream) {
+  if (!xt || !mask_t || !nrows || !mu || !alphas || !target || !cov || !d || !lam || !evec || !status || !nll || !alphaidx ||
+      !scratch) {
+    sf_set_error("null pointer");
+    return -1;
+  }
+  if (lines < 1 || p < 1 || ncols < 1 || nalpha < 1) { sf_set_error("sf_cmf_wide_stats_target: bad geometry"); return -1; }
+  return sf_launch_wide_stats(xt, xt_f64, mask_t, nrows, nloo, mu, alphas, sf_geom(lines, p, ncols, nalpha), cov, d, lam, evec,
+                              status, nll, alphaidx, scratch, (hipStream_t)stream, target);
+}
+
 int sf_cmf_filter(const double *mu, const double *d, const double *lam, const double *evec, const double *alphas,
                   int32_t *alphaidx, const double *abscf, int reflectance, int p, int ncols, int32_t *status,
                   double *filt, double *bias, void *stream) {

@@ -168,7 +168,8 @@ int sf_launch_filter(const double *mu, const double *d, const double *lam, const
 size_t sf_wide_scratch_bytes(const SfGeom &g);
 int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const int32_t *nloo,
                          const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
-                         double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st);
+                         double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st,
+                         const double *target = nullptr);   // target [ncols][p][p]: full shrinkage target (-f), else diag(S)
 int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
                          const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
                          hipStream_t st, double *rest = nullptr);   // rest: the NLL without its determinant term
@@ -177,7 +178,8 @@ int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, co
 size_t sf_exact_det_scratch_bytes(const SfGeom &g, int window);
 int sf_exact_det_window(const SfGeom &g);   // cmf_wide.hip: the policy (0 = every grid point)
 int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *status, const double *alphas, const SfGeom &g,
-                        int window, const double *rest, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st);
+                        int window, const double *rest, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st,
+                        const double *target = nullptr);
 size_t sf_score_scratch_bytes(int lines, int ncols);
 int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
                     const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx,

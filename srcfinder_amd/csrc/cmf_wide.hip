@@ -246,7 +246,9 @@ __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ 
                                                        int p2, int c0, double *__restrict__ d_out,
                                                        double *__restrict__ lam_out, double *__restrict__ evec_out,
                                                        int32_t *__restrict__ status, double *__restrict__ gscratch,
-                                                       int mode, int32_t *__restrict__ cflag) {
+                                                       int mode, int32_t *__restrict__ cflag, int unit) {
+  // unit: `cov` holds the batch's already whitened matrices (full shrinkage target, k_wg_* below): matrix blockIdx.x,
+  // no diagonal scaling, d is not written.
   // mode 0: the whole decomposition here.  mode 1: status, d and the Cholesky factor only (G = L left in gscratch for
   // the blocked Jacobi below; cflag = 0 ok, 1 not positive definite -> mode 2, 2 nothing to do).  mode 2: the whole
   // decomposition, only for the matrices mode 1 flagged 1 (Jacobi on R with V accumulated alongside).
@@ -255,14 +257,14 @@ __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ 
   __shared__ int flag[2];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int c = c0 + blockIdx.x;
-  const double *S = cov + (size_t)c * p * p;
+  const double *S = cov + (size_t)(unit ? (int)blockIdx.x : c) * p * p;
   double *G = gscratch + (size_t)blockIdx.x * 2 * p2 * p2;  // [p2][p2] column-major
   double *V = G + (size_t)p2 * p2;
   const int n = nuse[c];
   const int LD = p2;
   if (mode == 2 && cflag[blockIdx.x] != 1) return;
   if (tid < 2) flag[tid] = 0;
-  for (int i = tid; i < p2; i += nthr) dv[i] = (i < p) ? sqrt(S[(size_t)i * p + i]) : 0.0;
+  for (int i = tid; i < p2; i += nthr) dv[i] = (i < p) ? (unit ? 1.0 : sqrt(S[(size_t)i * p + i])) : 0.0;
   __syncthreads();
   for (int i = tid; i < p; i += nthr) {
     const double v = dv[i];
@@ -274,11 +276,11 @@ __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ 
   else if (n == 1) st = 3;   // one valid row: numpy.cov (ddof 1) is NaN, every NLL is NaN, argmin = 0, C and the score are NaN
   else if (flag[0]) st = 2;
   if (tid == 0) status[c] = st;
-  for (int i = tid; i < p; i += nthr) d_out[(size_t)c * p + i] = dv[i];
+  if (!unit) for (int i = tid; i < p; i += nthr) d_out[(size_t)c * p + i] = dv[i];
   if (st != 0) {
     for (int i = tid; i < p; i += nthr) lam_out[(size_t)c * p + i] = 0.0;
     for (int i = tid; i < p * p; i += nthr) evec_out[(size_t)c * p * p + i] = ((i / p) == (i % p)) ? 1.0 : 0.0;
-    if (mode == 1 && tid == 0) cflag[blockIdx.x] = 2;
+    if ((mode == 1 || mode == 3) && tid == 0) cflag[blockIdx.x] = 2;
     return;
   }
   auto load_R = [&]() {
@@ -842,6 +844,121 @@ __global__ __launch_bounds__(512) void k_blockjac_finish(const double *__restric
   }
 }
 
+// ---- full shrinkage target on a wide window (-f, robust_mf.py:354; looshrinkage's T = cov(I_reg), :99, :131) ---------
+// cmf_general.hip has the algebra and the 96-band version with everything in LDS.  Here the matrices stay in global
+// memory (L2-resident, 1.4 MB each at p = 425):  T = L L^T by the blocked Cholesky above,  R = L^-1 S L^-T  by two
+// forward substitutions with one thread per right-hand side (the right-hand sides are the ROWS of the row-major buffer,
+// so a wave reads 64 consecutive doubles per step and the L entry is wave-uniform),  eigenpairs of R by the blocked
+// Jacobi in `unit` mode,  evec_j <- D L^-T v_j  by one backward substitution, d = diag(L).
+__global__ void k_wg_load(const double *__restrict__ target, const int32_t *__restrict__ nuse, int p, int p2, int c0,
+                          double *__restrict__ gscratch, int32_t *__restrict__ cflag) {
+  const int mtx = blockIdx.y, c = c0 + mtx;
+  const double *T = target + (size_t)c * p * p;
+  double *G = gscratch + (size_t)mtx * 2 * p2 * p2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p2 * p2; i += gridDim.x * blockDim.x) {
+    const int col = i / p2, row = i - col * p2;
+    G[i] = (col < p && row < p) ? T[(size_t)row * p + col] : 0.0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) cflag[mtx] = nuse[c] > 0 ? 0 : 2;
+}
+// Lc[k*p + i] = L[i][k] (column-major), B = S, d = diag(L); a target that is not positive definite makes every G_a
+// singular together with S (fewer rows than bands): L = B = I, d = 1 and tflag = 1 marks the column for k_wg_back_out
+__global__ void k_wg_prep(const double *__restrict__ gscratch, const int32_t *__restrict__ cflag, const double *__restrict__ cov,
+                          int p, int p2, int c0, double *__restrict__ Lc, double *__restrict__ B, double *__restrict__ d_out,
+                          int32_t *__restrict__ tflag) {
+  const int mtx = blockIdx.y, c = c0 + mtx;
+  const double *G = gscratch + (size_t)mtx * 2 * p2 * p2, *S = cov + (size_t)c * p * p;
+  double *Lm = Lc + (size_t)mtx * p * p, *Bm = B + (size_t)mtx * p * p;
+  const int flag = cflag[mtx];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p * p; i += gridDim.x * blockDim.x) {
+    const int a = i / p, b = i - a * p;
+    if (flag == 0) {
+      Lm[i] = G[(size_t)a * p2 + b];      // column a, row b (upper part zeroed by k_chol_clean)
+      Bm[i] = S[i];
+    } else {
+      Lm[i] = Bm[i] = (a == b) ? 1.0 : 0.0;
+    }
+    if (a == b) d_out[(size_t)c * p + a] = (flag == 0) ? G[(size_t)a * p2 + a] : 1.0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) tflag[mtx] = flag;
+}
+// B <- L^-1 B (UPPER = false) or L^-T B (true), column t of B by thread t; B row-major [p][p]
+template <bool UPPER>
+__global__ __launch_bounds__(64) void k_wg_solve(const double *__restrict__ Lc, double *__restrict__ B, int p) {
+  const int mtx = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= p) return;
+  const double *Lm = Lc + (size_t)mtx * p * p;
+  double *Bm = B + (size_t)mtx * p * p + t;
+  if (!UPPER) {
+    for (int i = 0; i < p; ++i) {         // x_i = (b_i - sum_{k < i} L[i][k] x_k) / L[i][i]
+      double a0 = Bm[(size_t)i * p], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int k = 0;
+      for (; k + 4 <= i; k += 4) {
+        a0 = __builtin_fma(-Lm[(size_t)k * p + i], Bm[(size_t)k * p], a0);
+        a1 = __builtin_fma(-Lm[(size_t)(k + 1) * p + i], Bm[(size_t)(k + 1) * p], a1);
+        a2 = __builtin_fma(-Lm[(size_t)(k + 2) * p + i], Bm[(size_t)(k + 2) * p], a2);
+        a3 = __builtin_fma(-Lm[(size_t)(k + 3) * p + i], Bm[(size_t)(k + 3) * p], a3);
+      }
+      for (; k < i; ++k) a0 = __builtin_fma(-Lm[(size_t)k * p + i], Bm[(size_t)k * p], a0);
+      Bm[(size_t)i * p] = ((a0 + a1) + (a2 + a3)) / Lm[(size_t)i * p + i];
+    }
+  } else {
+    for (int i = p - 1; i >= 0; --i) {    // w_i = (v_i - sum_{k > i} L[k][i] w_k) / L[i][i]
+      double a0 = Bm[(size_t)i * p], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      const double *Li = Lm + (size_t)i * p;
+      int k = i + 1;
+      for (; k + 4 <= p; k += 4) {
+        a0 = __builtin_fma(-Li[k], Bm[(size_t)k * p], a0);
+        a1 = __builtin_fma(-Li[k + 1], Bm[(size_t)(k + 1) * p], a1);
+        a2 = __builtin_fma(-Li[k + 2], Bm[(size_t)(k + 2) * p], a2);
+        a3 = __builtin_fma(-Li[k + 3], Bm[(size_t)(k + 3) * p], a3);
+      }
+      for (; k < p; ++k) a0 = __builtin_fma(-Li[k], Bm[(size_t)k * p], a0);
+      Bm[(size_t)i * p] = ((a0 + a1) + (a2 + a3)) / Li[i];
+    }
+  }
+}
+// in place: B <- B^T (sym = 0) or (B + B^T) / 2 (sym = 1)
+__global__ void k_wg_transpose(double *__restrict__ B, int p, int sym) {
+  double *Bm = B + (size_t)blockIdx.y * p * p;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p * p; i += gridDim.x * blockDim.x) {
+    const int a = i / p, b = i - a * p;
+    if (b >= a) continue;
+    const double x = Bm[(size_t)a * p + b], y = Bm[(size_t)b * p + a];
+    Bm[(size_t)a * p + b] = sym ? 0.5 * (x + y) : y;
+    Bm[(size_t)b * p + a] = sym ? 0.5 * (x + y) : x;
+  }
+}
+// B[b][j] = evec[c][j][b]: the eigenvectors as the right-hand sides of L^T w = v
+__global__ void k_wg_back_in(const double *__restrict__ evec, int p, int c0, double *__restrict__ B) {
+  const int mtx = blockIdx.y, c = c0 + mtx;
+  const double *ev = evec + (size_t)c * p * p;
+  double *Bm = B + (size_t)mtx * p * p;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p * p; i += gridDim.x * blockDim.x) {
+    const int b = i / p, j = i - b * p;
+    Bm[i] = ev[(size_t)j * p + b];
+  }
+}
+// evec[c][j][b] = d_b w_j[b];  status 2 (and lam = 0) where the Cholesky of the target failed
+__global__ void k_wg_back_out(const double *__restrict__ B, int p, int c0, const double *__restrict__ d, double *__restrict__ evec,
+                              double *__restrict__ lam, int32_t *__restrict__ status, const int32_t *__restrict__ tflag) {
+  const int mtx = blockIdx.y, c = c0 + mtx;
+  if (tflag[mtx] == 1) {
+    if (blockIdx.x == 0) {
+      if (threadIdx.x == 0 && status[c] == 0) status[c] = 2;
+      for (int i = threadIdx.x; i < p; i += blockDim.x) lam[(size_t)c * p + i] = 0.0;
+    }
+    return;
+  }
+  if (status[c] != 0) return;
+  const double *Bm = B + (size_t)mtx * p * p, *dc = d + (size_t)c * p;
+  double *ev = evec + (size_t)c * p * p;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p * p; i += gridDim.x * blockDim.x) {
+    const int j = i / p, b = i - j * p;
+    ev[i] = Bm[(size_t)b * p + j] * dc[b];
+  }
+}
+
 }  // namespace
 
 // scratch per column of a batch: X~ + Z (L x p each), r (L x NA16), W (p x p), C (p x NA16), G|V (2 p2^2)
@@ -878,43 +995,46 @@ static int wide_nll_splits(const SfGeom &g) { return sf_cdiv(g.lines, 512) > 64 
 // the float64 range (the prefix products of p <= 512 pivots were never seen to run further ahead of the total than 16
 // grid points, tests/test_cmf_gpu.py::test_looshrinkage_function_512_band_golden).
 int sf_exact_det_window(const SfGeom &g) { return ((size_t)g.ncols * g.nalpha <= 2048) ? 0 : 24; }
+// the full-target route's extra per batch column: L, B (p^2 each) and a flag word
+static size_t wide_target_bytes(const SfGeom &g) {
+  return sf_align((size_t)sf_wide_batch(g) * (2 * (size_t)g.p * g.p * sizeof(double) + sizeof(int32_t)));
+}
 size_t sf_wide_scratch_bytes(const SfGeom &g) {
-  return (size_t)sf_wide_batch(g) * wide_col_bytes(g) +
+  return (size_t)sf_wide_batch(g) * wide_col_bytes(g) + wide_target_bytes(g) +
          sf_align((size_t)g.ncols * wide_nll_splits(g) * 2 * g.nu * 16 * sizeof(double)) +
          sf_align((size_t)g.ncols * g.nalpha * sizeof(double)) + sf_exact_det_scratch_bytes(g, sf_exact_det_window(g));
 }
 
-// stages 3-5 (covariance, eigendecomposition, LOO sweep + argmin) for windows too wide for the fused kernels
-int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const int32_t *nloo,
-                         const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
-                         double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st);
-
+// blocked Cholesky of the nb matrices in gv whose flag is 0 (flag -> 1 where a pivot is not positive)
+static int wide_chol(double *gv, int p, int p2, int nb, int32_t *cflag, hipStream_t st) {
+  const size_t plds = (size_t)CH_B * p * sizeof(double);
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_chol_panel), plds)) return rc;
+  const int npan = sf_cdiv(p, CH_B);
+  for (int kb = 0; kb < npan; ++kb) {
+    hipLaunchKernelGGL(k_chol_panel, dim3(nb), dim3(256), plds, st, gv, p, p2, kb, cflag);
+    const int rem = p - (kb + 1) * CH_B;
+    if (rem > 0) {
+      const int nt = sf_cdiv(rem, 64);
+      hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt, nb), dim3(256), 0, st, gv, p, p2, kb, cflag);
+    }
+  }
+  hipLaunchKernelGGL(k_chol_clean, dim3(64, nb), dim3(256), 0, st, gv, p, p2, cflag);
+  SF_LAUNCH_CHECK("k_chol");
+  return 0;
+}
 
 // eigendecomposition of a batch of nb correlation matrices (columns c0 .. c0+nb-1)
+// (unit: `cov` = the batch's nb whitened matrices, no diagonal scaling, d untouched -- the full-target route)
 static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int c0, int nb, double *d, double *lam, double *evec,
-                     int32_t *status, double *gv, int32_t *cflag, int32_t *done, int32_t *rot, hipStream_t st) {
+                     int32_t *status, double *gv, int32_t *cflag, int32_t *done, int32_t *rot, hipStream_t st, int unit = 0) {
   if (sf_tune().wide_eigh_variant == 1) {
-    hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 0, cflag);
+    hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 0, cflag, unit);
     SF_LAUNCH_CHECK("k_eigh_global");
     return 0;
   }
-  hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 3, cflag);
+  hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 3, cflag, unit);
   SF_LAUNCH_CHECK("k_eigh_global(prep)");
-  {
-    const size_t plds = (size_t)CH_B * p * sizeof(double);
-    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_chol_panel), plds)) return rc;
-    const int npan = sf_cdiv(p, CH_B);
-    for (int kb = 0; kb < npan; ++kb) {
-      hipLaunchKernelGGL(k_chol_panel, dim3(nb), dim3(256), plds, st, gv, p, p2, kb, cflag);
-      const int rem = p - (kb + 1) * CH_B;
-      if (rem > 0) {
-        const int nt = sf_cdiv(rem, 64);
-        hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt, nb), dim3(256), 0, st, gv, p, p2, kb, cflag);
-      }
-    }
-    hipLaunchKernelGGL(k_chol_clean, dim3(64, nb), dim3(256), 0, st, gv, p, p2, cflag);
-    SF_LAUNCH_CHECK("k_chol");
-  }
+  if (int rc = wide_chol(gv, p, p2, nb, cflag, st)) return rc;
   SF_HIP(hipMemsetAsync(done, 0, (size_t)nb * sizeof(int32_t), st));
   SF_HIP(hipMemsetAsync(rot, 0, (size_t)nb * sizeof(int32_t), st));
   const int nblk = sf_cdiv(p2, BJ_B), mblk = nblk + (nblk & 1);
@@ -938,14 +1058,15 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
   hipLaunchKernelGGL(k_blockjac_leftover, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, cflag, done);
   hipLaunchKernelGGL(k_blockjac_finish, dim3(nb), dim3(512), 0, st, gv, p, p2, c0, cflag, lam, evec);
   SF_LAUNCH_CHECK("k_blockjac_finish");
-  hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 2, cflag);
+  hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 2, cflag, unit);
   SF_LAUNCH_CHECK("k_eigh_global(fallback)");
   return 0;
 }
 
 int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const int32_t *nloo,
                          const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
-                         double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st) {
+                         double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st,
+                         const double *target) {
   if (g.p > 512 || g.nalpha > SF_NALPHA_MAX) {
     sf_set_error("wide statistics path supports up to 512 bands and %d alphas", SF_NALPHA_MAX);
     return -2;
@@ -957,7 +1078,7 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
   const int rows = sf_cdiv(L, nsplit);
   const size_t per = wide_col_bytes(g);
   char *base = reinterpret_cast<char *>(scratch);
-  double *part = reinterpret_cast<double *>(base + (size_t)bc * per);
+  double *part = reinterpret_cast<double *>(base + (size_t)bc * per + wide_target_bytes(g));
   // batch-strided views (column c of the batch at base + c*per would break the GEMM batch stride, so each
   // array is laid out contiguously over the batch instead)
   double *xc = reinterpret_cast<double *>(base);
@@ -967,6 +1088,9 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
   double *Cm = W + (size_t)bc * p * p;
   double *gv = Cm + (size_t)bc * p * NA16;
   int32_t *flags = reinterpret_cast<int32_t *>(gv + (size_t)bc * 2 * p2 * p2);   // cflag | done | rot, bc each
+  double *Lc = reinterpret_cast<double *>(base + (size_t)bc * per);              // full-target route only
+  double *Bw = Lc + (size_t)bc * p * p;
+  int32_t *tflag = reinterpret_cast<int32_t *>(Bw + (size_t)bc * p * p);
   for (int c0 = 0; c0 < g.ncols; c0 += bc) {
     const int nb = (g.ncols - c0 < bc) ? g.ncols - c0 : bc;
     // nuse: the rows the covariance is made of (ddof 1); nloo: the n of beta and of 1/(2n) (robust_mf.py:109, :116) --
@@ -984,7 +1108,24 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
     SF_LAUNCH_CHECK("k_dgemm(syrk)");
     hipLaunchKernelGGL(k_scale_cov, dim3(64, nb), dim3(256), 0, st, cov, nuse, p, c0);
     SF_LAUNCH_CHECK("k_scale_cov");
-    if (int rc = wide_eigh(cov, nuse, p, p2, c0, nb, d, lam, evec, status, gv, flags, flags + bc, flags + 2 * bc, st)) return rc;
+    if (!target) {
+      if (int rc = wide_eigh(cov, nuse, p, p2, c0, nb, d, lam, evec, status, gv, flags, flags + bc, flags + 2 * bc, st)) return rc;
+    } else {
+      hipLaunchKernelGGL(k_wg_load, dim3(64, nb), dim3(256), 0, st, target, nuse, p, p2, c0, gv, flags);
+      SF_LAUNCH_CHECK("k_wg_load");
+      if (int rc = wide_chol(gv, p, p2, nb, flags, st)) return rc;
+      hipLaunchKernelGGL(k_wg_prep, dim3(64, nb), dim3(256), 0, st, gv, flags, cov, p, p2, c0, Lc, Bw, d, tflag);
+      hipLaunchKernelGGL(k_wg_solve<false>, dim3(sf_cdiv(p, 64), nb), dim3(64), 0, st, Lc, Bw, p);
+      hipLaunchKernelGGL(k_wg_transpose, dim3(64, nb), dim3(256), 0, st, Bw, p, 0);
+      hipLaunchKernelGGL(k_wg_solve<false>, dim3(sf_cdiv(p, 64), nb), dim3(64), 0, st, Lc, Bw, p);
+      hipLaunchKernelGGL(k_wg_transpose, dim3(64, nb), dim3(256), 0, st, Bw, p, 1);
+      SF_LAUNCH_CHECK("k_wg_whiten");
+      if (int rc = wide_eigh(Bw, nuse, p, p2, c0, nb, d, lam, evec, status, gv, flags, flags + bc, flags + 2 * bc, st, 1)) return rc;
+      hipLaunchKernelGGL(k_wg_back_in, dim3(64, nb), dim3(256), 0, st, evec, p, c0, Bw);
+      hipLaunchKernelGGL(k_wg_solve<true>, dim3(sf_cdiv(p, 64), nb), dim3(64), 0, st, Lc, Bw, p);
+      hipLaunchKernelGGL(k_wg_back_out, dim3(64, nb), dim3(256), 0, st, Bw, p, c0, d, evec, lam, status, tflag);
+      SF_LAUNCH_CHECK("k_wg_back");
+    }
     hipLaunchKernelGGL(k_wmat, dim3(64, nb), dim3(256), 0, st, evec, d, p, c0, W);
     SF_LAUNCH_CHECK("k_wmat");
     hipLaunchKernelGGL(k_cmat, dim3(64, nb), dim3(256), 0, st, lam, nloo, status, alphas, g.nalpha, NA16, p, c0, Cm);
@@ -1005,5 +1146,5 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
   if (int rc = sf_launch_nll_finish(part, nsplit, nloo, d, lam, status, alphas, g, nll, alphaidx, st, rest)) return rc;
   // det() over/underflow exactly as scipy's running LU product has it (robust_mf.py:111-113), where the total
   // log-determinant cannot decide
-  return sf_launch_exact_det(cov, nloo, status, alphas, g, sf_exact_det_window(g), rest, nll, alphaidx, det_scratch, st);
+  return sf_launch_exact_det(cov, nloo, status, alphas, g, sf_exact_det_window(g), rest, nll, alphaidx, det_scratch, st, target);
 }

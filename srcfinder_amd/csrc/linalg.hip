@@ -179,7 +179,8 @@ __global__ void k_det_jobs(const double *__restrict__ nll, const double *__restr
 __global__ __launch_bounds__(LU_NT) void k_det_grid(const double *__restrict__ cov, const int32_t *__restrict__ nloo,
                                                     const double *__restrict__ alphas, int nalpha, int p,
                                                     const int32_t *__restrict__ jobs, const int32_t *__restrict__ njobs,
-                                                    int job0, double *__restrict__ work, double *__restrict__ det) {
+                                                    int job0, double *__restrict__ work, double *__restrict__ det,
+                                                    const double *__restrict__ target) {
   const int slot = blockIdx.x, tid = threadIdx.x;
   const int jb = job0 + slot;
   if (jb >= *njobs) return;
@@ -187,12 +188,14 @@ __global__ __launch_bounds__(LU_NT) void k_det_grid(const double *__restrict__ c
   const double n = (double)nloo[c], a = alphas[ai];
   const double beta = (1.0 - a) / (n - 1.0);
   const double *S = cov + (size_t)c * p * p;
+  const double *T = target ? target + (size_t)c * p * p : nullptr;   // full shrinkage target (:99), else diag(S)
   double *G = work + (size_t)slot * p * p;
   for (size_t e = tid; e < (size_t)p * p; e += LU_NT) {
     const int i = (int)(e / p), j = (int)(e % p);
     const double s = S[e] * 1e4;
     double gij = n * (beta * s);
-    if (i == j) gij += a * s;
+    if (T) gij += a * (T[e] * 1e4);
+    else if (i == j) gij += a * s;
     G[e] = gij;
   }
   __syncthreads();
@@ -233,7 +236,8 @@ size_t sf_exact_det_scratch_bytes(const SfGeom &g, int window) {
 }
 // window <= 0: every grid point; else the `window` points on the safe side of each range crossing (see k_det_jobs)
 int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *status, const double *alphas, const SfGeom &g,
-                        int window, const double *rest, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st) {
+                        int window, const double *rest, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st,
+                        const double *target) {
   const size_t maxjobs = window <= 0 ? (size_t)g.ncols * g.nalpha : (size_t)g.ncols * 2 * window;
   const size_t slots = maxjobs < DET_SLOTS ? maxjobs : DET_SLOTS;
   char *p = reinterpret_cast<char *>(scratch);
@@ -247,7 +251,7 @@ int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *s
   SF_LAUNCH_CHECK("k_det_jobs");
   for (size_t j0 = 0; j0 < maxjobs; j0 += slots) {
     hipLaunchKernelGGL(k_det_grid, dim3((unsigned)slots), dim3(LU_NT), 0, st, cov, nloo, alphas, g.nalpha, g.p, jobs, njobs, (int)j0,
-                       work, det);
+                       work, det, target);
     SF_LAUNCH_CHECK("k_det_grid");
   }
   hipLaunchKernelGGL(k_det_apply, dim3(sf_cdiv((int)maxjobs, 256)), dim3(256), 0, st, jobs, njobs, det, rest, nll, (int)maxjobs);

@@ -105,7 +105,28 @@ def main_empirical_more():
     print("empirical -R:", rc["modelparms"])
 
 
+def main_full_wide():
+    """-R -k 2 -f: the full-column regulariser on the reflectance window (p = 416) -- looshrinkage(..., I_reg) with a
+    416 x 416 target (cmf/robust_mf.py:99, :131, :354)."""
+    G.install_spectral_stub()
+    lib = np.float64(np.loadtxt(G.LIB_TXT))
+    lines, samples, seed = 1000, 3, 560
+    cube = G.make_cube_numpy(lines, samples, seed=seed, abscf_full=lib[:, 2], active=(5, 420), nodata_column=1)
+    cube[400:750] *= np.float32(1.3)
+    np.random.seed(31)
+    r = G.run_reference_main(cube, extra_args=("-R", "-k", "2", "-f"), tag="RK2F")
+    lab = r["bgmeta"][:, :, 0]
+    print("-R -k 2 -f cluster sizes:", [(int((lab[:, c] == 0).sum()), int((lab[:, c] == 1).sum())) for c in range(samples)],
+          "alpha idx:", np.unique(r["bgmeta"][:, :, 1]), r["modelparms"])
+    np.savez_compressed(os.path.join(HERE, "cmf_R_K2_full.npz"), seed=seed, lines=lines, samples=samples, nodata_column=1,
+                        bright=np.array([[400, 750, 1.3]]), out=r["out"], bgmeta=r["bgmeta"], colstats=r["colstats"],
+                        modelparms=np.array(r["modelparms"]), versions=G.versions())
+
+
 if __name__ == "__main__":
+    if "--full-wide" in sys.argv:
+        main_full_wide()
+        sys.exit(0)
     if "--empirical-more" in sys.argv:
         main_empirical_more()
         sys.exit(0)

@@ -693,6 +693,52 @@ def test_looshrinkage_function_with_full_target(torch_cuda):
     np.testing.assert_allclose(c_g, c_o, rtol=1e-10, atol=1e-12 * np.abs(c_o).max())
 
 
+def test_full_regulariser_on_a_wide_window(torch_cuda, golden_dir, library):
+    """-R -k 2 -f (p = 416): looshrinkage with a 416 x 416 target -- blocked Cholesky of the target, substitution
+    whitening, unit-mode block Jacobi (sf_cmf_wide_stats_target) -- against the golden of the real reference, then
+    against the oracle with a cluster of fewer rows than bands (S singular, T not) and with -r."""
+    g = np.load(os.path.join(golden_dir, "cmf_R_K2_full.npz"))
+    cube = make_cube_numpy(int(g["lines"]), int(g["samples"]), seed=int(g["seed"]), abscf_full=library[:, 2],
+                           active=(5, 420), nodata_column=int(g["nodata_column"]))
+    for b0, b1, f in g["bright"]:
+        cube[int(b0):int(b1)] *= np.float32(f)
+    lab = g["bgmeta"][:, :, 0].astype(np.int64)
+    res = cmf.robust_mf(cube, library, reflectance=True, kmeans=2, full=True, labels=lab, metadata=True, to_numpy=True)
+    _check_multimodal(res, g["out"], g["bgmeta"], g["colstats"])
+    assert res.modelparms == str(g["modelparms"])
+    cube = make_cube_numpy(700, 2, seed=78, abscf_full=library[:, 2], active=(5, 420), nodata_lines=1)
+    cube[300:500] *= np.float32(1.25)
+    lab = np.zeros((700, 2), np.int64)
+    lab[300:500] = 1                                             # 200 rows < 416 bands
+    lab[650:, 1] = 2
+    for kw in (dict(kmeans=2, labels=np.minimum(lab, 1)), dict(kmeans=3, labels=lab, reject=True)):
+        res = cmf.robust_mf(cube, library, reflectance=True, full=True, metadata=True, to_numpy=True, **kw)
+        with np.errstate(all="ignore"):
+            o = O.robust_mf_multimodal_oracle(cube, library, kw["labels"], reflectance=True, full=True,
+                                              reject=kw.get("reject", False))
+        _check_multimodal(res, o["out"], o["bgmeta"], o["colstats"])
+
+
+def test_looshrinkage_function_with_full_target_wide(torch_cuda):
+    """looshrinkage(I_zm, alphas, nll, n, I_reg) with 425 bands and a non-empty I_reg: index, NLL curve (finite pattern
+    included: the determinants leave the float64 range at both ends of the grid) and final covariance as the oracle."""
+    from srcfinder_amd.synth import synth_columns
+    for scale in (1.0, 30.0):
+        x = synth_columns(1200, 425, 322) * scale
+        sub = x[100:700] - x[100:700].mean(0)
+        reg = x - x[100:700].mean(0)
+        al = cmf.alpha_grid()
+        nll_o, nll_g = np.zeros(len(al)), np.zeros(len(al))
+        with np.errstate(all="ignore"):
+            c_o, i_o = O.looshrinkage(sub, al, nll_o, 1200, reg)
+        c_g, i_g = cmf.looshrinkage(sub, al, nll_g, 1200, reg)
+        assert i_g == i_o
+        fin = np.isfinite(nll_o)
+        assert np.array_equal(np.isfinite(nll_g), fin)
+        np.testing.assert_allclose(nll_g[fin], nll_o[fin], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(c_g, c_o, rtol=1e-10, atol=1e-12 * np.abs(c_o).max())
+
+
 def test_multimodal_device_kmeans(torch_cuda, golden_dir, library):
     """Device k-means: deterministic (same seed -> same labels), finds the planted bright region the reference's
     MiniBatchKMeans found (>= 90 % agreement up to a permutation), and the pipeline downstream of ITS labels matches
@@ -1037,8 +1083,6 @@ def test_multimodal_on_a_wide_window(torch_cuda, library):
         assert np.array_equal(res.out[..., 3] == -9999.0, o["out"][..., 3] == -9999.0)
         assert np.array_equal(res.bgmeta, o["bgmeta"])
         assert score_close(res.out[..., 3], o["out"][..., 3]).all()
-    with pytest.raises(NotImplementedError):
-        cmf.robust_mf(cube, library, reflectance=True, kmeans=2, labels=np.minimum(lab, 1), full=True)
     a = cmf.robust_mf(cube, library, reflectance=True, kmeans=2, metadata=True, to_numpy=True, kmeans_seed=1)    # device k-means
     b = cmf.robust_mf(cube, library, reflectance=True, kmeans=2, metadata=True, to_numpy=True, kmeans_seed=1)
     assert np.array_equal(a.labels, b.labels) and np.array_equal(a.out, b.out)

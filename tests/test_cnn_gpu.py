@@ -119,6 +119,26 @@ def test_fused_conv1_pool_matches_the_two_kernels(net):
     assert float(p_ref.max()) > 0          # ReLU outputs: something is active
 
 
+def test_c_driver_equals_the_python_sequenced_graph(gold):
+    """sf_cnn_score_rows (the whole graph for a row range in one C call, weights as one packed blob) against the same
+    kernels sequenced from Python (forward_tiles): bit-identical saliency maps, row ranges and ragged last batches."""
+    import torch
+    from srcfinder_amd import _ffi
+    net = cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024))
+    plane = synthetic_plane(11, 7, seed=9)
+    plane[2, 3] = -9999.0
+    a = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=13)            # C driver (default)
+    net.c_driver = False
+    b = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=13)
+    net.c_driver = True
+    assert torch.equal(a, b) and float(a[2, 3]) == -9999.0
+    c = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=64, rows=(3, 8))
+    assert torch.equal(c[3:8], a[3:8]) and float(c[:3].abs().sum()) == 0.0
+    L = _ffi.lib()
+    assert net.packed_blob().numel() == L.sf_cnn_blob_floats() and L.sf_cnn_score_workspace_bytes(13) > 0
+    assert L.sf_cnn_score_rows(None, None, 4, 4, 0, 4, None, None, 8, None, 0, None) == -1      # argument errors, no launch
+
+
 def test_gpu_list_scores_row_blocks_from_threads(gold, net):
     """``gpus=[...]`` (the script's ``-g 0 1 ...``, cnn_pred_pipeline.py:113-116): one network and one host thread per
     listed device, contiguous row blocks, assembled once.  On a one-GPU box the list [0, 0, 0] drives the same code with

@@ -170,6 +170,20 @@ def test_multimodal_oracle_reproduces_reference_with_full_regulariser(golden_dir
     assert np.array_equal(o["colstats"], g["colstats"])
 
 
+def test_multimodal_oracle_reproduces_reference_with_full_regulariser_on_the_reflectance_window(golden_dir, library):
+    """-R -k 2 -f golden from the real reference (p = 416, a 332-row cluster: S singular, the 416 x 416 target not)."""
+    g = np.load(os.path.join(golden_dir, "cmf_R_K2_full.npz"))
+    cube = make_cube_numpy(int(g["lines"]), int(g["samples"]), seed=int(g["seed"]), abscf_full=library[:, 2],
+                           active=(5, 420), nodata_column=int(g["nodata_column"]))
+    for b0, b1, f in g["bright"]:
+        cube[int(b0):int(b1)] *= np.float32(f)
+    with np.errstate(all="ignore"):
+        o = O.robust_mf_multimodal_oracle(cube, library, g["bgmeta"][:, :, 0].astype(np.int64), reflectance=True, full=True)
+    assert np.array_equal(o["out"], g["out"])
+    assert np.array_equal(o["bgmeta"], g["bgmeta"])
+    assert np.array_equal(o["colstats"], g["colstats"])
+
+
 def test_empirical_model_oracle_reproduces_reference(golden_dir, library):
     """-M empirical golden from the real reference (no -m: with it the reference dies on `alphas`)."""
     g = np.load(os.path.join(golden_dir, "cmf_empirical.npz"))

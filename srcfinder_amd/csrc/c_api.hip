@@ -300,6 +300,7 @@ int sf_debug_set(int key, int value) {
     case 10: sf_tune().wide_eigh_variant = value; return 0;
     case 12: sf_tune().score_wgs = value; return 0;
     case 13: sf_tune().score_exp = value; return 0;
+    case 14: sf_tune().lu_variant = value; return 0;
     default: sf_set_error("sf_debug_set: unknown key %d", key); return -1;
   }
 }

@@ -90,6 +90,9 @@ constexpr int CP_LDP = CP_PATCH + 1, CP_LDB = 64 + 1, CP_LDC = 36, CP_KP = 50, C
 // 61 KB: two workgroups per CU (the channels go in two halves of 32 through one [289][36] conv tile), so one's patch
 // load / pooling runs under the other's matrix phase
 static size_t cp_lds_bytes() { return ((size_t)CP_PATCH * CP_LDP + CP_KP * CP_LDB + (size_t)CP_NPX * CP_LDC + 64) * sizeof(float); }
+// EXP: timing experiments of tools/microbench/conv1pool.hip (0 in production): 1 no weight gather, 2 no patch load,
+// 4 no matrix loop, 8 no conv-tile store, 16 no pooling reads, 32 no global store
+template <int EXP>
 __global__ __launch_bounds__(256, 2) void k_conv1_pool(const float *__restrict__ padded, int Wp, int Wimg, long long tile0,
                                                         const float *__restrict__ w /*[64][49]*/, const float *__restrict__ bias,
                                                         float *__restrict__ out /*[n][64][64][64]*/) {
@@ -106,14 +109,14 @@ __global__ __launch_bounds__(256, 2) void k_conv1_pool(const float *__restrict__
   const int cy0 = 2 * py0, cx0 = 2 * px0;                                         // conv block origin
   for (int i = tid; i < CP_KP * 64; i += 256) {
     const int k = i / 64, co = i % 64;
-    Bs[k * CP_LDB + co] = (k < 49) ? w[co * 49 + k] : 0.f;
+    Bs[k * CP_LDB + co] = (k < 49 && !(EXP & 1)) ? w[co * 49 + k] : 0.f;
   }
   if (tid < 64) bs[tid] = bias[tid];
   for (int i = tid; i < CP_PATCH * CP_PATCH; i += 256) {
     const int py = i / CP_PATCH, px = i % CP_PATCH;
     const int iy = 2 * cy0 - 3 + py, ix = 2 * cx0 - 3 + px;                      // tile-local input coordinates
     float v = 0.f;                                                               // the tile is its own image: zero outside
-    if (iy >= 0 && iy < 256 && ix >= 0 && ix < 256) v = padded[(size_t)(trow + iy) * Wp + tcol + ix];
+    if (iy >= 0 && iy < 256 && ix >= 0 && ix < 256 && !(EXP & 2)) v = padded[(size_t)(trow + iy) * Wp + tcol + ix];
     patch[py * CP_LDP + px] = v;
   }
   __syncthreads();
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1_pool(const float *__restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll 5
-    for (int kk = 0; kk < CP_KP / 2; ++kk) {
+    for (int kk = 0; kk < ((EXP & 4) ? 1 : CP_KP / 2); ++kk) {
       const int k = 2 * kk + kh, kc = min(k, 48);                                 // tap 49 is padding: weight row is zero
       const int koff = (kc / 7) * CP_LDP + (kc % 7);
       const float b = Bs[k * CP_LDB + 32 * h + l31];
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1_pool(const float *__restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = 32 * (wave + 4 * j) + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          if (m < CP_NPX) convt[m * CP_LDC + l31] = fmaxf(acc[j][r] + bb, 0.f);
+          if (m < CP_NPX && (!(EXP & 8) || r == 0)) convt[m * CP_LDC + l31] = fmaxf(acc[j][r] + bb, 0.f);
         }
       }
     }
@@ -160,16 +163,17 @@ __global__ __launch_bounds__(256, 2) void k_conv1_pool(const float *__restrict__
       const int c4 = i & 7, pp = i >> 3, py = pp / CP_PT, px = pp % CP_PT;
       float4 m = make_float4(-3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f);
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
+      for (int dy = 0; dy < ((EXP & 16) ? 1 : 3); ++dy) {
         if (cy0 + 2 * py + dy > 127) continue;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
+        for (int dx = 0; dx < ((EXP & 16) ? 1 : 3); ++dx) {
           if (cx0 + 2 * px + dx > 127) continue;
           const float4 v = *reinterpret_cast<const float4 *>(convt + ((2 * py + dy) * CP_CR + 2 * px + dx) * CP_LDC + 4 * c4);
           m = make_float4(fmaxf(m.x, v.x), fmaxf(m.y, v.y), fmaxf(m.z, v.z), fmaxf(m.w, v.w));
         }
       }
-      *reinterpret_cast<float4 *>(out + (((size_t)t * 64 + py0 + py) * 64 + px0 + px) * 64 + 32 * h + 4 * c4) = m;
+      if (!(EXP & 32) || m.x == 123.456f)
+        *reinterpret_cast<float4 *>(out + (((size_t)t * 64 + py0 + py) * 64 + px0 + px) * 64 + 32 * h + 4 * c4) = m;
     }
     __syncthreads();
   }
@@ -425,8 +429,8 @@ int sf_cnn_conv1_pool(const float *padded, int Hp, int Wp, int W, long long tile
     sf_set_error("sf_cnn_conv1_pool: bad argument");
     return -1;
   }
-  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_conv1_pool), cp_lds_bytes())) return rc;
-  hipLaunchKernelGGL(k_conv1_pool, dim3(64, ntiles), dim3(256), cp_lds_bytes(), (hipStream_t)stream, padded, Wp, W, tile0, w,
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_conv1_pool<0>), cp_lds_bytes())) return rc;
+  hipLaunchKernelGGL(k_conv1_pool<0>, dim3(64, ntiles), dim3(256), cp_lds_bytes(), (hipStream_t)stream, padded, Wp, W, tile0, w,
                      bias, out);
   SF_LAUNCH_CHECK("k_conv1_pool");
   return 0;

@@ -928,6 +928,32 @@ def test_linalg_wrappers_follow_scipy(torch_cuda):
         cmf.inv(np.zeros((4, 4)))
 
 
+def test_blocked_lu_determinant(torch_cuda):
+    """The blocked determinant kernel (panel of 16 columns in LDS, one column of the trailing part per thread) against
+    scipy and against the unblocked kernel: sizes around the panel and thread-count boundaries, rows that need pivoting
+    in every column, prefix over/underflow in the middle of a panel, a zero pivot column."""
+    from srcfinder_amd import _ffi
+    rng = np.random.default_rng(77)
+    mats = [rng.normal(size=(n, n)) for n in (3, 15, 16, 17, 31, 33, 100, 257, 425, 512, 600)]
+    mats.append(np.cov(rng.normal(size=(900, 425)).T) * 50.0)                  # SPD, the production shape
+    m = rng.normal(size=(40, 40)); m[:, 7] = 0.0; mats.append(m)               # zero column: info > 0 -> 0.0
+    mats.append(np.diag(np.r_[np.full(20, 1e30), np.full(20, 1e-30)]) + 1e-40 * rng.normal(size=(40, 40)))   # prefix -> inf
+    mats.append(np.diag(np.r_[np.full(20, 1e-30), np.full(20, 1e30)]) + 1e-40 * rng.normal(size=(40, 40)))   # prefix -> 0
+    for a in mats:
+        ref = O.det(a)
+        got = cmf.det(a)
+        _ffi.lib().sf_debug_set(14, 1)
+        try:
+            old = cmf.det(a)
+        finally:
+            _ffi.lib().sf_debug_set(14, 0)
+        if np.isfinite(ref) and ref != 0.0:
+            np.testing.assert_allclose(got, ref, rtol=1e-9)
+            np.testing.assert_allclose(old, ref, rtol=1e-9)
+        else:
+            assert got == ref and old == ref, (a.shape, got, old, ref)
+
+
 def test_exact_determinant_window_on_the_flightline_path(torch_cuda, library):
     """The column loop at p = 425 (full-band window) takes the windowed exact-determinant pass (the grid points within
     24 of a lost one): the finite / inf pattern of every column's NLL curve equals the faithful oracle's."""

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-launch view of ONE batch of the CNN tile scorer from a rocprofv3 kernel trace (csv): the launches between the last
+k_conv1_pool / k_conv1 and the following k_head, in order, with grid and duration.
+   python tools/cnn_layers.py <kernel_trace.csv>"""
+import csv
+import sys
+
+
+def main(path):
+    rows = []
+    for r in csv.DictReader(open(path)):
+        n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
+        if n.startswith("k_"):
+            rows.append((int(r["Start_Timestamp"]), n, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                         r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Grid_Size_Y", ""), r.get("Workgroup_Size_X", "")))
+    rows.sort()
+    starts = [i for i, r in enumerate(rows) if r[1].startswith("k_conv1")]
+    i0 = starts[-1]
+    i1 = next(i for i in range(i0, len(rows)) if rows[i][1] == "k_head")
+    tot = sum(r[2] for r in rows[i0:i1 + 1])
+    print("%-28s %10s %8s %9s %6s" % ("kernel", "grid_x", "grid_y", "us", "share"))
+    for r in rows[i0:i1 + 1]:
+        print("%-28s %10s %8s %9.1f %5.1f%%" % (r[1][:28], r[3], r[4], r[2], 100 * r[2] / tot))
+    print("batch total %.1f us (kernel time, %.1f us wall first start to last end)" %
+          (tot, (rows[i1][0] - rows[i0][0]) / 1e3 + rows[i1][2]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -12,6 +12,7 @@
 // One workgroup per matrix, the matrix in global memory (a 425 x 425 float64 matrix is 1.4 MB: L2-resident), right-
 // looking elimination.  Latency-bound (~2 ms per 425 x 425 matrix), used where it is the only exact way.
 #include "cmf_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -297,6 +298,77 @@ __global__ void k_det_jobs(const double *__restrict__ nll, const double *__restr
   }
 }
 
+// The windowed rule in rounds ("deepening"): the grid points whose pivot product leaves the range although the total does
+// not sit next to the crossing -- one grid step moves log det by up to p log(10^0.05) (49 at p = 425), the excess of the
+// largest prefix over the total changes slowly with alpha.  So the finite points are factorised in groups of `group`,
+// walking away from each crossing: round r takes the next `group` points of every side that is still open; a side closes
+// when a whole group came back unchanged (or when the walk has covered `window` points or met the other side).  On the
+// benchmark flightline this factorises ~8 points per column instead of 48.  Columns whose lost points are not a run at
+// the start and / or a run at the end of the grid take the plain window rule in round 0.
+// state[c] = { next candidate of the low side (ascending), of the high side (descending), low side open, high side open }
+__global__ void k_det_round(const double *__restrict__ nll, const double *__restrict__ rest, const int32_t *__restrict__ status,
+                            int ncols, int nalpha, int window, int group, int round, int32_t *__restrict__ jobs,
+                            int32_t *__restrict__ njobs, int cap, int32_t *__restrict__ state) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols || status[c] != 0) return;
+  const double *v = nll + (size_t)c * nalpha, *rs = rest + (size_t)c * nalpha;
+  const double inf = __builtin_inf();
+  auto push = [&](int i) {
+    const int k = atomicAdd(njobs, 1);
+    if (k < cap) jobs[k] = c * nalpha + i;
+  };
+  auto lost = [&](int i) { return v[i] == inf && rs[i] == rs[i] && rs[i] != inf; };
+  auto finite = [&](int i) { return v[i] == v[i] && v[i] != inf && v[i] != -inf; };
+  int32_t *s = state + 4 * (size_t)c;
+  if (round == 0) {
+    int lo = 0;
+    while (lo < nalpha && lost(lo)) ++lo;
+    int hi = nalpha;
+    while (hi > lo && lost(hi - 1)) --hi;
+    bool interior = false;
+    for (int i = lo; i < hi; ++i) interior = interior || lost(i);
+    if (interior) {
+      for (int i = 0; i < nalpha; ++i) {
+        if (!finite(i)) continue;
+        bool near = false;
+        for (int j = max(0, i - window); j <= min(nalpha - 1, i + window) && !near; ++j) near = lost(j);
+        if (near) push(i);
+      }
+      s[0] = s[1] = s[2] = s[3] = 0;
+      return;
+    }
+    s[0] = lo;
+    s[1] = hi - 1;
+    s[2] = lo > 0;
+    s[3] = hi < nalpha;
+  } else {
+    if (s[2]) {                                    // the low side's last group: s[0]-group .. s[0]-1
+      bool changed = false;
+      for (int i = max(0, s[0] - group); i < s[0]; ++i) changed = changed || !finite(i);
+      if (!changed) s[2] = 0;
+    }
+    if (s[3]) {
+      bool changed = false;
+      for (int i = s[1] + 1; i <= min(nalpha - 1, s[1] + group); ++i) changed = changed || !finite(i);
+      if (!changed) s[3] = 0;
+    }
+  }
+  if (s[2])
+    for (int k = 0; k < group; ++k) {
+      const int i = s[0];
+      if (i > s[1]) { s[2] = 0; break; }
+      s[0] = i + 1;
+      if (finite(i)) push(i);
+    }
+  if (s[3])
+    for (int k = 0; k < group; ++k) {
+      const int i = s[1];
+      if (i < s[0]) { s[3] = 0; break; }
+      s[1] = i - 1;
+      if (finite(i)) push(i);
+    }
+}
+
 // G = n (beta S') + alpha T, S' = 1e4 S (the covariance of 100 x), T = diag S' (robust_mf.py:94-110), then LU
 __global__ __launch_bounds__(LU_NT) void k_det_grid(const double *__restrict__ cov, const int32_t *__restrict__ nloo,
                                                     const double *__restrict__ alphas, int nalpha, int p,
@@ -378,11 +450,12 @@ __global__ void k_argmin_nan_first(const double *__restrict__ nll, const int32_t
 }  // namespace
 
 constexpr int DET_SLOTS = 512;   // matrices factorised per launch (two rounds of 256 CUs)
+constexpr int DET_GROUP = 4;     // grid points per side and round of the deepening rule (k_det_round)
 size_t sf_exact_det_scratch_bytes(const SfGeom &g, int window) {
   const size_t maxjobs = window <= 0 ? (size_t)g.ncols * g.nalpha : (size_t)g.ncols * 2 * window;
   const size_t slots = maxjobs < DET_SLOTS ? maxjobs : DET_SLOTS;
   return sf_align(slots * g.p * g.p * sizeof(double)) + sf_align(maxjobs * sizeof(int32_t)) + sf_align(maxjobs * sizeof(double)) +
-         sf_align(sizeof(int32_t));
+         sf_align(sizeof(int32_t)) + sf_align((size_t)g.ncols * 4 * sizeof(int32_t));
 }
 // window <= 0: every grid point; else the `window` points on the safe side of each range crossing (see k_det_jobs)
 int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *status, const double *alphas, const SfGeom &g,
@@ -394,25 +467,37 @@ int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *s
   double *work = reinterpret_cast<double *>(p); p += sf_align(slots * g.p * g.p * sizeof(double));
   int32_t *jobs = reinterpret_cast<int32_t *>(p); p += sf_align(maxjobs * sizeof(int32_t));
   double *det = reinterpret_cast<double *>(p); p += sf_align(maxjobs * sizeof(double));
-  int32_t *njobs = reinterpret_cast<int32_t *>(p);
-  SF_HIP(hipMemsetAsync(njobs, 0, sizeof(int32_t), st));
-  hipLaunchKernelGGL(k_det_jobs, dim3(sf_cdiv(g.ncols, 128)), dim3(128), 0, st, nll, rest, status, g.ncols, g.nalpha, window, jobs,
-                     njobs, (int)maxjobs);
-  SF_LAUNCH_CHECK("k_det_jobs");
+  int32_t *njobs = reinterpret_cast<int32_t *>(p); p += sf_align(sizeof(int32_t));
+  int32_t *state = reinterpret_cast<int32_t *>(p);
   const bool blocked = lb_fits(g.p) && sf_tune().lu_variant == 0;
   if (blocked)
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_det_grid_blocked), lb_lds_bytes(g.p))) return rc;
-  for (size_t j0 = 0; j0 < maxjobs; j0 += slots) {
-    if (blocked)
-      hipLaunchKernelGGL(k_det_grid_blocked, dim3((unsigned)slots), dim3(LB_NT), lb_lds_bytes(g.p), st, cov, nloo, alphas, g.nalpha,
-                         g.p, jobs, njobs, (int)j0, work, det, target);
+  // window > 0: rounds of DET_GROUP points per open side (k_det_round); det_variant 1 = the plain window rule in one round
+  const bool rounds = window > 0 && sf_tune().det_variant == 0;
+  const int nrounds = rounds ? sf_cdiv(window, DET_GROUP) : 1;
+  for (int r = 0; r < nrounds; ++r) {
+    // round 0 may hold a plain-window column's 2 x window points, later rounds at most 2 x DET_GROUP per column
+    const size_t cap = (r == 0) ? maxjobs : std::min(maxjobs, (size_t)g.ncols * 2 * DET_GROUP);
+    SF_HIP(hipMemsetAsync(njobs, 0, sizeof(int32_t), st));
+    if (rounds)
+      hipLaunchKernelGGL(k_det_round, dim3(sf_cdiv(g.ncols, 128)), dim3(128), 0, st, nll, rest, status, g.ncols, g.nalpha, window,
+                         DET_GROUP, r, jobs, njobs, (int)maxjobs, state);
     else
-      hipLaunchKernelGGL(k_det_grid, dim3((unsigned)slots), dim3(LU_NT), 0, st, cov, nloo, alphas, g.nalpha, g.p, jobs, njobs, (int)j0,
-                         work, det, target);
-    SF_LAUNCH_CHECK("k_det_grid");
+      hipLaunchKernelGGL(k_det_jobs, dim3(sf_cdiv(g.ncols, 128)), dim3(128), 0, st, nll, rest, status, g.ncols, g.nalpha, window, jobs,
+                         njobs, (int)maxjobs);
+    SF_LAUNCH_CHECK("k_det_jobs");
+    for (size_t j0 = 0; j0 < cap; j0 += slots) {
+      if (blocked)
+        hipLaunchKernelGGL(k_det_grid_blocked, dim3((unsigned)slots), dim3(LB_NT), lb_lds_bytes(g.p), st, cov, nloo, alphas,
+                           g.nalpha, g.p, jobs, njobs, (int)j0, work, det, target);
+      else
+        hipLaunchKernelGGL(k_det_grid, dim3((unsigned)slots), dim3(LU_NT), 0, st, cov, nloo, alphas, g.nalpha, g.p, jobs, njobs,
+                           (int)j0, work, det, target);
+      SF_LAUNCH_CHECK("k_det_grid");
+    }
+    hipLaunchKernelGGL(k_det_apply, dim3(sf_cdiv((int)cap, 256)), dim3(256), 0, st, jobs, njobs, det, rest, nll, (int)cap);
+    SF_LAUNCH_CHECK("k_det_apply");
   }
-  hipLaunchKernelGGL(k_det_apply, dim3(sf_cdiv((int)maxjobs, 256)), dim3(256), 0, st, jobs, njobs, det, rest, nll, (int)maxjobs);
-  SF_LAUNCH_CHECK("k_det_apply");
   hipLaunchKernelGGL(k_argmin_nan_first, dim3(sf_cdiv(g.ncols, 128)), dim3(128), 0, st, nll, status, g.ncols, g.nalpha, alphaidx);
   SF_LAUNCH_CHECK("k_argmin_nan_first");
   return 0;

@@ -966,6 +966,16 @@ def test_exact_determinant_window_on_the_flightline_path(torch_cuda, library):
     assert (~np.isfinite(o["nll"][ok])).sum() > 100              # the case does overflow
     f = np.isfinite(o["nll"]) & ok[:, None]
     np.testing.assert_allclose(res.nll[f], o["nll"][f], rtol=1e-8)
+    # the rounds of four points per crossing (default) and the plain 24-point window in one round: the same curves
+    from srcfinder_amd import _ffi
+    _ffi.lib().sf_debug_set(15, 1)
+    try:
+        plain = cmf.robust_mf(cube, library, active=(1, 425), return_nll=True, to_numpy=True)
+    finally:
+        _ffi.lib().sf_debug_set(15, 0)
+    assert np.array_equal(plain.alphaidx, res.alphaidx)
+    assert np.array_equal(np.isfinite(plain.nll), np.isfinite(res.nll))
+    np.testing.assert_allclose(plain.nll[f], res.nll[f], rtol=1e-12)
 
 
 def test_cli_multimodal_flags_reach_the_device_path(torch_cuda, tmp_path, library):

@@ -179,6 +179,114 @@ __global__ __launch_bounds__(256, 2) void k_conv1_pool(const float *__restrict__
   }
 }
 
+// ---- conv1 + maxpool1, second form: 16 x 16 pooled pixels per workgroup, pooling by LDS atomics --------------------
+// k_conv1_pool spends more time around its matrix phase than in it (tools/microbench/conv1pool.hip: of 1.80 ms per
+// 512 tiles the matrix loop is 0.9, writing the conv tile to LDS 0.27, reading it back for the pool 0.43, the prologue
+// 0.17), at two workgroups per CU because the [289][36] conv tile takes 42 of its 61 KB.  Here the rows of the implicit
+// GEMM are ordered by 2 x 2 QUADS of conv pixels: a lane's four consecutive accumulator rows are one quad, and a 3 x 3
+// stride-2 pooling window is exactly quad (qy, qx) + the left column of quad (qy, qx+1) + the top row of quad (qy+1, qx)
+// + the top-left pixel of quad (qy+1, qx+1).  So every lane reduces its quad to four numbers in registers and merges
+// them into the POOLED tile with four LDS integer-max atomics (the values are >= 0 after ReLU: their bit patterns order
+// like integers, and a tile of zeros is the identity) -- no conv tile, no read-back.  A workgroup of 8 waves produces
+// 16 x 16 pooled pixels from 17 x 17 quads (the 17th row / column only through its top row / left column): 37 M-blocks
+// instead of 4 x 10, 13 % above the 128 x 128 conv pixels a tile has, where the 8 x 8 form computes 25 % more and waits
+// for its slowest wave's third block.  LDS: patch 73 x 74, weights [50][65], pooled [256][32] = 67 KB, two workgroups
+// (16 waves) per CU.
+constexpr int C2_PT = 16, C2_Q = C2_PT + 1, C2_NQ = C2_Q * C2_Q, C2_MB = (C2_NQ + 7) / 8;   // 289 quads, 37 blocks
+constexpr int C2_PATCH = 4 * C2_Q + 5, C2_LDP = C2_PATCH + 1;                               // 73 input rows / cols
+constexpr int C2_NT = 512, C2_NW = C2_NT / 64, C2_PASS = 3;
+static size_t c2_lds_bytes() { return ((size_t)C2_PATCH * C2_LDP + CP_KP * CP_LDB + (size_t)C2_PT * C2_PT * 32 + 64) * sizeof(float); }
+template <int EXP>
+__global__ __launch_bounds__(C2_NT, 2) void k_conv1_pool16(const float *__restrict__ padded, int Wp, int Wimg, long long tile0,
+                                                            const float *__restrict__ w /*[64][49]*/,
+                                                            const float *__restrict__ bias,
+                                                            float *__restrict__ out /*[n][64][64][64]*/) {
+  extern __shared__ __attribute__((aligned(16))) float cp_lds[];
+  float *patch = cp_lds;                                   // [73][74]
+  float *Bs = patch + C2_PATCH * C2_LDP;                   // [50][65]  Bs[k][co], row 49 zero
+  int *pooled = reinterpret_cast<int *>(Bs + CP_KP * CP_LDB);   // [16][16][32] bit patterns of non-negative floats
+  float *bs = reinterpret_cast<float *>(pooled + C2_PT * C2_PT * 32);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.y;
+  const long long tile = tile0 + t;
+  const int trow = (int)(tile / Wimg), tcol = (int)(tile % Wimg);
+  const int py0 = (blockIdx.x >> 2) * C2_PT, px0 = (blockIdx.x & 3) * C2_PT;      // pooled block origin
+  const int cy0 = 2 * py0, cx0 = 2 * px0;                                         // conv block origin
+  for (int i = tid; i < CP_KP * 64; i += C2_NT) {
+    const int k = i / 64, co = i % 64;
+    Bs[k * CP_LDB + co] = (k < 49) ? w[co * 49 + k] : 0.f;
+  }
+  if (tid < 64) bs[tid] = bias[tid];
+  for (int i = tid; i < C2_PATCH * C2_PATCH; i += C2_NT) {
+    const int py = i / C2_PATCH, px = i % C2_PATCH;
+    const int iy = 2 * cy0 - 3 + py, ix = 2 * cx0 - 3 + px;                      // tile-local input coordinates
+    float v = 0.f;                                                               // the tile is its own image: zero outside
+    if (iy >= 0 && iy < 256 && ix >= 0 && ix < 256) v = padded[(size_t)(trow + iy) * Wp + tcol + ix];
+    patch[py * C2_LDP + px] = v;
+  }
+  const int l31 = lane & 31, kh = lane >> 5;
+  for (int h = 0; h < 2; ++h) {                                                   // channel half
+    for (int i = tid; i < C2_PT * C2_PT * 32; i += C2_NT) pooled[i] = 0;
+    __syncthreads();                                                              // (also: patch and weights are in LDS)
+    const float bb = bs[32 * h + l31];
+    for (int b0 = wave; b0 < C2_MB; b0 += C2_NW * C2_PASS) {                      // blocks b0, b0 + 8, b0 + 16 of this pass
+      int abase[C2_PASS];
+#pragma unroll
+      for (int j = 0; j < C2_PASS; ++j) {
+        const int m = 32 * (b0 + C2_NW * j) + l31;
+        const int q = min(m >> 2, C2_NQ - 1), wq = m & 3;
+        abase[j] = (2 * (2 * (q / C2_Q) + (wq >> 1))) * C2_LDP + 2 * (2 * (q % C2_Q) + (wq & 1));
+      }
+      f16_t acc[C2_PASS];
+#pragma unroll
+      for (int j = 0; j < C2_PASS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll 5
+      for (int kk = 0; kk < ((EXP & 4) ? 1 : CP_KP / 2); ++kk) {
+        const int k = 2 * kk + kh, kc = min(k, 48);                               // tap 49 is padding: weight row is zero
+        const int koff = (kc / 7) * C2_LDP + (kc % 7);
+        const float b = Bs[k * CP_LDB + 32 * h + l31];
+#pragma unroll
+        for (int j = 0; j < C2_PASS; ++j)
+          if (b0 + C2_NW * j < C2_MB)                                             // (wave-uniform)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(patch[abase[j] + koff], b, acc[j], 0, 0, 0);
+      }
+      // acc[.][r]: row (r&3) + 8(r>>2) + 4 kh of the block = pixel r&3 of quad 2(r>>2) + kh, channel l31
+#pragma unroll
+      for (int j = 0; j < C2_PASS; ++j) {
+        if (b0 + C2_NW * j >= C2_MB) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int q = 8 * (b0 + C2_NW * j) + 2 * g + kh;
+          if (q >= C2_NQ || (EXP & 8)) continue;
+          const int qy = q / C2_Q, qx = q % C2_Q;
+          const bool y0 = cy0 + 2 * qy <= 127, y1 = cy0 + 2 * qy + 1 <= 127;       // conv pixels past the 128 x 128 image
+          const bool x0 = cx0 + 2 * qx <= 127, x1 = cx0 + 2 * qx + 1 <= 127;       // do not exist (ceil_mode windows are clipped)
+          const float v00 = (y0 && x0) ? fmaxf(acc[j][4 * g + 0] + bb, 0.f) : 0.f;
+          const float v01 = (y0 && x1) ? fmaxf(acc[j][4 * g + 1] + bb, 0.f) : 0.f;
+          const float v10 = (y1 && x0) ? fmaxf(acc[j][4 * g + 2] + bb, 0.f) : 0.f;
+          const float v11 = (y1 && x1) ? fmaxf(acc[j][4 * g + 3] + bb, 0.f) : 0.f;
+          const float top = fmaxf(v00, v01), left = fmaxf(v00, v10), all = fmaxf(fmaxf(top, v10), v11);
+          int *pq = pooled + (qy * C2_PT + qx) * 32 + l31;
+          if (qy < C2_PT && qx < C2_PT) atomicMax(pq, __float_as_int(all));
+          if (qy < C2_PT && qx >= 1) atomicMax(pq - 32, __float_as_int(left));
+          if (qy >= 1 && qx < C2_PT) atomicMax(pq - C2_PT * 32, __float_as_int(top));
+          if (qy >= 1 && qx >= 1) atomicMax(pq - C2_PT * 32 - 32, __float_as_int(v00));
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < C2_PT * C2_PT * 8; i += C2_NT) {
+      const int c4 = i & 7, pp = i >> 3, py = pp / C2_PT, px = pp % C2_PT;
+      const float4 m = *reinterpret_cast<const float4 *>(pooled + pp * 32 + 4 * c4);
+      if (!(EXP & 32) || m.x == 123.456f)
+        *reinterpret_cast<float4 *>(out + (((size_t)t * 64 + py0 + py) * 64 + px0 + px) * 64 + 32 * h + 4 * c4) = m;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- max pool, NHWC, window clipped to the input (ceil_mode edge windows are partial) ------------------------------
 // (googlenet1.py:61,:64,:68,:75 and the stride-1 pool of the inception branch4 :213)
 // Each thread produces PR vertically adjacent outputs of one (n, ox, channel quad): the 3-wide row maxima of the
@@ -429,9 +537,15 @@ int sf_cnn_conv1_pool(const float *padded, int Hp, int Wp, int W, long long tile
     sf_set_error("sf_cnn_conv1_pool: bad argument");
     return -1;
   }
-  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_conv1_pool<0>), cp_lds_bytes())) return rc;
-  hipLaunchKernelGGL(k_conv1_pool<0>, dim3(64, ntiles), dim3(256), cp_lds_bytes(), (hipStream_t)stream, padded, Wp, W, tile0, w,
-                     bias, out);
+  if (sf_tune().cnn_variant == 1) {                  // the 8 x 8 form with the conv tile in LDS
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_conv1_pool<0>), cp_lds_bytes())) return rc;
+    hipLaunchKernelGGL(k_conv1_pool<0>, dim3(64, ntiles), dim3(256), cp_lds_bytes(), (hipStream_t)stream, padded, Wp, W, tile0, w,
+                       bias, out);
+  } else {
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_conv1_pool16<0>), c2_lds_bytes())) return rc;
+    hipLaunchKernelGGL(k_conv1_pool16<0>, dim3(16, ntiles), dim3(C2_NT), c2_lds_bytes(), (hipStream_t)stream, padded, Wp, W, tile0,
+                       w, bias, out);
+  }
   SF_LAUNCH_CHECK("k_conv1_pool");
   return 0;
 }

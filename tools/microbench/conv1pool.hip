@@ -23,6 +23,23 @@ float run(const float *padded, int Wp, int W, int ntiles, const float *w, const 
   return ms / 3;
 }
 
+template <int EXP>
+float run16(const float *padded, int Wp, int W, int ntiles, const float *w, const float *b, float *out) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv1_pool16<EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c2_lds_bytes());
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(k_conv1_pool16<EXP>, dim3(16, ntiles), dim3(C2_NT), c2_lds_bytes(), 0, padded, Wp, W, 0ll, w, b, out);
+  (void)hipEventRecord(e0);
+  for (int r = 0; r < 3; ++r)
+    hipLaunchKernelGGL(k_conv1_pool16<EXP>, dim3(16, ntiles), dim3(C2_NT), c2_lds_bytes(), 0, padded, Wp, W, 0ll, w, b, out);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  printf("16x16 form, EXP %2d: %8.1f us\n", EXP, ms / 3 * 1e3f);
+  return ms / 3;
+}
+
 int main() {
   const int W = 64, H = 8, ntiles = W * H, Wp = W + 255, Hp = H + 255;
   float *padded, *w, *b, *out;
@@ -47,5 +64,10 @@ int main() {
   run<56>(padded, Wp, W, ntiles, w, b, out);
   run<60>(padded, Wp, W, ntiles, w, b, out);
   run<63>(padded, Wp, W, ntiles, w, b, out);
+  run16<0>(padded, Wp, W, ntiles, w, b, out);
+  run16<4>(padded, Wp, W, ntiles, w, b, out);
+  run16<8>(padded, Wp, W, ntiles, w, b, out);
+  run16<32>(padded, Wp, W, ntiles, w, b, out);
+  run16<44>(padded, Wp, W, ntiles, w, b, out);
   return 0;
 }

@@ -303,6 +303,7 @@ int sf_debug_set(int key, int value) {
     case 14: sf_tune().lu_variant = value; return 0;
     case 15: sf_tune().det_variant = value; return 0;
     case 16: sf_tune().cnn_variant = value; return 0;
+    case 17: sf_tune().cnn_conv_variant = value; return 0;
     default: sf_set_error("sf_debug_set: unknown key %d", key); return -1;
   }
 }

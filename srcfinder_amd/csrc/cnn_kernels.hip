@@ -344,7 +344,16 @@ struct ConvDst {
   int ld[3], off[3], end[3];
 };
 
-template <int BK, int BN>
+// EXP: timing experiments of tools/microbench/convigemm.hip (0 in production): 1 no global loads after the first chunk,
+// 2 no LDS stores after the first chunk, 4 one MFMA step per chunk, 8 no epilogue stores
+// BUF: the tile loads are raw buffer loads -- the lane's byte offset in a VGPR (an out-of-range value for a tap outside
+// the image or a row / channel past the end: the load returns 0, no branch), the (tap, channel chunk) offset in an
+// SGPR, the per-row tap validity in a 9-bit mask computed once.  The pointer form below spends ~260 scalar and vector
+// instructions per chunk and wave on bounds tests and 64-bit addresses beside 32 MFMAs; the matrix pipe idles a
+// quarter of the time waiting for waves that are all in that phase (PMC: tools/pmc_bin.sh on tools/microbench/convigemm).
+// Needs every operand below 2 GB (host-checked; larger tensors take the pointer form).
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+template <int BK, int BN, int EXP = 0, bool BUF = false>
 __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in, int M, int H, int W, int Cin, int ld_in,
                                                      const float *__restrict__ wt, const float *__restrict__ bias, int Cout,
                                                      int ks, ConvDst dst) {
@@ -389,7 +398,57 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   float4 ra[NPA], rb[NPB];
+  // ---- buffer form: descriptors, per-row offsets and tap masks
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned rowoff[NPA], vmask[NPA], woff[NPB];
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  if (BUF) {
+    const size_t shift = ((size_t)pad * W + pad) * ld_in;          // taps are addressed from (y - pad, x - pad): offsets >= 0
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in) - shift, 0,
+                                            (unsigned)(((size_t)M * ld_in + 2 * shift) * 4 + 64), 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wt), 0, (unsigned)((size_t)Cout * taps * Cin * 4), 0x00020000);
+#pragma unroll
+    for (int a = 0; a < NPA; ++a) {
+      const int m = m0 + ri + PPP * a;
+      const int mm = m < M ? m : 0;
+      rowoff[a] = (unsigned)(((size_t)mm * ld_in + 4 * q) * 4);
+      unsigned vm = 0;
+      for (int tp = 0; tp < taps; ++tp) {
+        const int yy = py[a] + tp / ks - pad, xx = px[a] + tp % ks - pad;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) vm |= 1u << tp;
+      }
+      vmask[a] = vm;
+    }
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+      const int co = n0 + ri + PPP * b;
+      woff[b] = wok[b] ? (unsigned)(((size_t)co * taps * Cin + 4 * q) * 4) : OOB;
+    }
+  }
+  int g_tap = 0, g_ty = 0, g_tx = 0, g_c0 = 0;                      // the chunk the next gload() fetches (buffer form)
   auto gload = [&](int it) {
+    if (BUF) {
+      const int tap = g_tap;
+      const unsigned sa = (unsigned)(((g_ty * W + g_tx) * ld_in + g_c0) * 4);
+      const unsigned sb = (unsigned)((tap * Cin + g_c0) * 4);
+      g_c0 += BK;
+      if (g_c0 == Cin) {
+        g_c0 = 0;
+        ++g_tap;
+        if (++g_tx == ks) { g_tx = 0; ++g_ty; }
+      }
+#pragma unroll
+      for (int a = 0; a < NPA; ++a) {
+        const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsA, ((vmask[a] >> tap) & 1u) ? rowoff[a] : OOB, sa, 0);
+        ra[a] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+#pragma unroll
+      for (int b = 0; b < NPB; ++b) {
+        const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsB, woff[b], sb, 0);
+        rb[b] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+      return;
+    }
     const int tap = it / nchunk, c0 = (it - tap * nchunk) * BK;
     const int dy = tap / ks - pad, dx = tap % ks - pad;
 #pragma unroll
@@ -424,9 +483,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in
   const float *ap = As + (lane >> 5) * LDA + 32 * wave + (lane & 31);
   const float *bp = Bs + (lane >> 5) * LDB + (lane & 31);
   for (int it = 0; it < nit; ++it) {
-    if (it + 1 < nit) gload(it + 1);
+    if (it + 1 < nit && !(EXP & 1)) gload(it + 1);
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
+    for (int kk = 0; kk < ((EXP & 4) ? 1 : BK / 2); ++kk) {
       const float a = ap[2 * kk * LDA];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -436,7 +495,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in
     }
     __syncthreads();
     if (it + 1 < nit) {
-      lstore();
+      if (!(EXP & 2)) lstore();
       __syncthreads();
     }
   }
@@ -453,7 +512,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M) op[(size_t)m * ld] = fmaxf(acc[t][r] + bb, 0.f);
+        if (m < M && (!(EXP & 8) || acc[t][r] == 123.456f)) op[(size_t)m * ld] = fmaxf(acc[t][r] + bb, 0.f);
       }
     }
   }
@@ -496,7 +555,13 @@ template <int BK, int BN>
 int launch_conv(const float *in, int M, int H, int W, int Cin, int ld_in, const float *wt, const float *bias, int Cout,
                 int ks, const ConvDst &dst, hipStream_t st) {
   dim3 grid(sf_cdiv(M, 128), sf_cdiv(Cout, BN));
-  hipLaunchKernelGGL((k_conv_igemm<BK, BN>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
+  const size_t abytes = ((size_t)M * ld_in + 2 * ((size_t)(ks >> 1) * W + (ks >> 1)) * ld_in) * 4 + 64;
+  const size_t bbytes = (size_t)Cout * ks * ks * Cin * 4;
+  const size_t lim = (size_t)0x7ff00000 - ((size_t)ks * W + ks) * ld_in * 4;      // offsets + the tap offset stay below 2^31
+  if (abytes < lim && bbytes < lim && sf_tune().cnn_conv_variant == 0)
+    hipLaunchKernelGGL((k_conv_igemm<BK, BN, 0, true>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
+  else
+    hipLaunchKernelGGL((k_conv_igemm<BK, BN, 0, false>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
   SF_LAUNCH_CHECK("k_conv_igemm");
   return 0;
 }
@@ -568,15 +633,16 @@ static int conv_dispatch(const float *in, int N, int H, int W, int Cin, int ld_i
   const long long Ml = (long long)N * H * W;
   if (Ml > 2000000000LL) { sf_set_error("sf_cnn_conv: batch too large"); return -1; }
   const int M = (int)Ml;
-  const bool wide = Cout >= 48;
-  if (Cin % 32 == 0)
-    return wide ? launch_conv<32, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)
-                : launch_conv<32, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st);
-  if (Cin % 16 == 0)
-    return wide ? launch_conv<16, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)
-                : launch_conv<16, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st);
-  return wide ? launch_conv<8, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)
-              : launch_conv<8, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st);
+  // N tile: 96 where it pads the output channels no more than 64 does (288 = 3 x 96, 192 = 2 x 96), 32 for narrow layers
+  const int bn = Cout < 48 ? 32 : ((sf_cdiv(Cout, 96) * 96 <= sf_cdiv(Cout, 64) * 64) ? 96 : 64);
+#define SF_CONV(BK)                                                                                         \
+  return bn == 96 ? launch_conv<BK, 96>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)             \
+       : bn == 64 ? launch_conv<BK, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)             \
+                  : launch_conv<BK, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)
+  if (Cin % 32 == 0) { SF_CONV(32); }
+  if (Cin % 16 == 0) { SF_CONV(16); }
+  SF_CONV(8);
+#undef SF_CONV
 }
 
 int sf_cnn_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias, int Cout,

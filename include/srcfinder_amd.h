@@ -272,6 +272,13 @@ int sf_cnn_maxpool(const float *in, int N, int H, int W, int C, int ksize, int s
 int sf_cnn_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias, int Cout,
                 int ksize, float *out, int ld_out, int ch_off, void *stream);
 
+/* Inception branch 4 (googlenet1.py:213-214) in one call: MaxPool2d(3, stride 1, pad 1, ceil_mode) into pooled_scratch
+ * (N*H*W*Cin floats), then the 1x1 BasicConv2d.  `in` is dense ([N][H][W][Cin]).  (A form that takes the pool inside
+ * the convolution's tile fetch exists behind sf_debug_set(18, 1); it reads the tile nine times through the L1 and
+ * measured 3 % slower end to end.) */
+int sf_cnn_pool_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias, int Cout,
+                     float *out, int ld_out, int ch_off, float *pooled_scratch, void *stream);
+
 /* The three 1x1 BasicConv2d that read the same inception input (branch1, branch2[0], branch3[0];
  * googlenet1.py:199-210) as ONE GEMM: w = [c0+c1+c2][Cin] (the three folded weight sets stacked), output channels
  * [0,c0) -> out0 (+off0, stride ld0), [c0,c0+c1) -> out1, the rest -> out2. */

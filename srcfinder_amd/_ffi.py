@@ -40,6 +40,7 @@ SIGNATURES = {
     "sf_cnn_conv1_pool": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp, vp]),
     "sf_cnn_maxpool": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "sf_cnn_conv": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, i32, i32, vp]),
+    "sf_cnn_pool_conv": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp, vp]),
     "sf_cnn_conv_split3": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, i32, vp, i32, i32,
                                  vp, i32, i32, vp]),
     "sf_cnn_head": (i32, [vp, i32, i32, i32, vp, vp, vp, i64, f32, vp, vp]),

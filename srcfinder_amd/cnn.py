@@ -243,8 +243,15 @@ class GoogLeNetHIP(object):
                    "sf_cnn_conv_split3(%s)" % name)
         self._conv(t2, name + ".branch2.1", y, c1)
         self._conv(t3, name + ".branch3.1", y, c1 + c3)
-        pooled = self._pool(x, "pool_s1", 3, 1, 1)
-        self._conv(pooled, name + ".branch4.1", y, c1 + c3 + c5)
+        if self.sfx or x.shape[3] != cin:           # fp16 path / strided input: pool, then convolve
+            pooled = self._pool(x, "pool_s1", 3, 1, 1)
+            self._conv(pooled, name + ".branch4.1", y, c1 + c3 + c5)
+        else:                                       # pool + 1x1 convolution in one C call
+            w4, b4 = self.w[name + ".branch4.1"]
+            scratch = self._buf("pool_s1", (N, H, W, cin))
+            _ffi.check(_ffi.lib().sf_cnn_pool_conv(_ffi.ptr(x), N, H, W, cin, cin, _ffi.ptr(w4), _ffi.ptr(b4), w4.shape[0],
+                                                   _ffi.ptr(y), y.shape[3], c1 + c3 + c5, _ffi.ptr(scratch), _ffi.stream_ptr()),
+                       "sf_cnn_pool_conv(%s)" % name)
         return y
 
     def _trunk(self, a1, taps=None, pooled=False):

@@ -304,6 +304,7 @@ int sf_debug_set(int key, int value) {
     case 15: sf_tune().det_variant = value; return 0;
     case 16: sf_tune().cnn_variant = value; return 0;
     case 17: sf_tune().cnn_conv_variant = value; return 0;
+    case 18: sf_tune().cnn_pool_variant = value; return 0;
     default: sf_set_error("sf_debug_set: unknown key %d", key); return -1;
   }
 }

@@ -39,6 +39,7 @@ struct SfTune {
   int sweep4r_waves = 8;      // key 8: waves per workgroup of the rank-factored sweep
   int wide_eigh_variant = 0;  // key 10: 1 = the single-workgroup eigensolver for every wide matrix
   int score_wgs = 0;          // key 12: workgroups per CU k_score_blk2 is sized for (0 = occupancy query)
+  int cnn_pool_variant = 0;   // key 18: 1 = branch-4 pool taken inside the 1x1 convolution's tile fetch (sf_cnn_pool_conv; slower)
   int cnn_conv_variant = 0;   // key 17: 1 = pointer-form tile loads in k_conv_igemm (cnn_kernels.hip)
   int cnn_variant = 0;        // key 16: 1 = the 8 x 8 conv1+pool kernel (cnn_kernels.hip)
   int det_variant = 0;        // key 15: 1 = the plain window rule of the exact-determinant pass in one round

@@ -104,8 +104,7 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
                                    s.c3r, 0, t3, s.c5r, 0, stream))) return rc;
       if ((rc = sf_cnn_conv(t2, n, hw, hw, s.c3r, s.c3r, W_(L.b2[i]), B_(L.b2[i]), s.c3, 3, y, cout, s.c1, stream))) return rc;
       if ((rc = sf_cnn_conv(t3, n, hw, hw, s.c5r, s.c5r, W_(L.b3[i]), B_(L.b3[i]), s.c5, 3, y, cout, s.c1 + s.c3, stream))) return rc;
-      if ((rc = sf_cnn_maxpool(x, n, hw, hw, cin, 3, 1, 1, pooled, hw, hw, stream))) return rc;
-      if ((rc = sf_cnn_conv(pooled, n, hw, hw, cin, cin, W_(L.b4[i]), B_(L.b4[i]), s.pp, 1, y, cout, s.c1 + s.c3 + s.c5, stream))) return rc;
+      if ((rc = sf_cnn_pool_conv(x, n, hw, hw, cin, cin, W_(L.b4[i]), B_(L.b4[i]), s.pp, y, cout, s.c1 + s.c3 + s.c5, pooled, stream))) return rc;
       float *t = x; x = y; y = t;
       cin = cout;
       if (i == 1 || i == 6) {      // maxpool3 after 3b (3x3 s2), maxpool4 after 4e (2x2 s2), both ceil_mode (:68, :75)

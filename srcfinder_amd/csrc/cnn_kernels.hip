@@ -353,7 +353,10 @@ struct ConvDst {
 // quarter of the time waiting for waves that are all in that phase (PMC: tools/pmc_bin.sh on tools/microbench/convigemm).
 // Needs every operand below 2 GB (host-checked; larger tensors take the pointer form).
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-template <int BK, int BN, int EXP = 0, bool BUF = false>
+// POOL (buffer form, 1x1 convolutions only): the A tile is the 3x3 stride-1 pad-1 max pool of the input, taken while it is
+// fetched -- nine loads and eight maxima per element instead of a pooled copy in HBM (inception branch 4,
+// googlenet1.py:213-214).  Activations are >= 0 after ReLU, so the zero an out-of-range load returns is the identity.
+template <int BK, int BN, int EXP = 0, bool BUF = false, bool POOL = false>
 __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in, int M, int H, int W, int Cin, int ld_in,
                                                      const float *__restrict__ wt, const float *__restrict__ bias, int Cout,
                                                      int ks, ConvDst dst) {
@@ -402,8 +405,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in
   constexpr unsigned OOB = 0x80000000u;
   unsigned rowoff[NPA], vmask[NPA], woff[NPB];
   __amdgpu_buffer_rsrc_t rsA, rsB;
+  const int fks = POOL ? 3 : ks, fpad = POOL ? 1 : pad;             // the footprint the tile fetch reads around a pixel
   if (BUF) {
-    const size_t shift = ((size_t)pad * W + pad) * ld_in;          // taps are addressed from (y - pad, x - pad): offsets >= 0
+    const size_t shift = ((size_t)fpad * W + fpad) * ld_in;        // taps are addressed from (y - pad, x - pad): offsets >= 0
     rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in) - shift, 0,
                                             (unsigned)(((size_t)M * ld_in + 2 * shift) * 4 + 64), 0x00020000);
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wt), 0, (unsigned)((size_t)Cout * taps * Cin * 4), 0x00020000);
@@ -413,8 +417,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in
       const int mm = m < M ? m : 0;
       rowoff[a] = (unsigned)(((size_t)mm * ld_in + 4 * q) * 4);
       unsigned vm = 0;
-      for (int tp = 0; tp < taps; ++tp) {
-        const int yy = py[a] + tp / ks - pad, xx = px[a] + tp % ks - pad;
+      for (int tp = 0; tp < fks * fks; ++tp) {
+        const int yy = py[a] + tp / fks - fpad, xx = px[a] + tp % fks - fpad;
         if (yy >= 0 && yy < H && xx >= 0 && xx < W) vm |= 1u << tp;
       }
       vmask[a] = vm;
@@ -427,6 +431,28 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in
   }
   int g_tap = 0, g_ty = 0, g_tx = 0, g_c0 = 0;                      // the chunk the next gload() fetches (buffer form)
   auto gload = [&](int it) {
+    if (BUF && POOL) {
+      const unsigned sb = (unsigned)(g_c0 * 4);
+#pragma unroll
+      for (int a = 0; a < NPA; ++a) {
+        float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const unsigned so = (unsigned)((((tp / 3) * W + tp % 3) * ld_in + g_c0) * 4);
+          const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsA, ((vmask[a] >> tp) & 1u) ? rowoff[a] : OOB, so, 0);
+          mx = make_float4(fmaxf(mx.x, __uint_as_float(v.x)), fmaxf(mx.y, __uint_as_float(v.y)),
+                           fmaxf(mx.z, __uint_as_float(v.z)), fmaxf(mx.w, __uint_as_float(v.w)));
+        }
+        ra[a] = mx;
+      }
+#pragma unroll
+      for (int b = 0; b < NPB; ++b) {
+        const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsB, woff[b], sb, 0);
+        rb[b] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+      g_c0 += BK;
+      return;
+    }
     if (BUF) {
       const int tap = g_tap;
       const unsigned sa = (unsigned)(((g_ty * W + g_tx) * ld_in + g_c0) * 4);
@@ -551,19 +577,44 @@ __global__ __launch_bounds__(256) void k_head(const float *__restrict__ in, int 
   }
 }
 
-template <int BK, int BN>
+// returns 1 when the buffer form cannot take these operands (>= 2 GB) and POOL was asked for: the caller pools separately
+template <int BK, int BN, bool POOL = false>
 int launch_conv(const float *in, int M, int H, int W, int Cin, int ld_in, const float *wt, const float *bias, int Cout,
                 int ks, const ConvDst &dst, hipStream_t st) {
   dim3 grid(sf_cdiv(M, 128), sf_cdiv(Cout, BN));
-  const size_t abytes = ((size_t)M * ld_in + 2 * ((size_t)(ks >> 1) * W + (ks >> 1)) * ld_in) * 4 + 64;
+  const int fk = POOL ? 3 : ks;
+  const size_t abytes = ((size_t)M * ld_in + 2 * ((size_t)(fk >> 1) * W + (fk >> 1)) * ld_in) * 4 + 64;
   const size_t bbytes = (size_t)Cout * ks * ks * Cin * 4;
-  const size_t lim = (size_t)0x7ff00000 - ((size_t)ks * W + ks) * ld_in * 4;      // offsets + the tap offset stay below 2^31
-  if (abytes < lim && bbytes < lim && sf_tune().cnn_conv_variant == 0)
+  const size_t lim = (size_t)0x7ff00000 - ((size_t)fk * W + fk) * ld_in * 4;      // offsets + the tap offset stay below 2^31
+  const bool buf = abytes < lim && bbytes < lim && sf_tune().cnn_conv_variant == 0;
+  if (POOL) {
+    if (!buf) return 1;
+    hipLaunchKernelGGL((k_conv_igemm<BK, BN, 0, true, POOL>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
+  } else if (buf) {
     hipLaunchKernelGGL((k_conv_igemm<BK, BN, 0, true>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
-  else
+  } else {
     hipLaunchKernelGGL((k_conv_igemm<BK, BN, 0, false>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
+  }
   SF_LAUNCH_CHECK("k_conv_igemm");
   return 0;
+}
+
+template <bool POOL = false>
+static int conv_dispatch(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias,
+                         int Cout, int ksize, const ConvDst &dst, hipStream_t st) {
+  const long long Ml = (long long)N * H * W;
+  if (Ml > 2000000000LL) { sf_set_error("sf_cnn_conv: batch too large"); return -1; }
+  const int M = (int)Ml;
+  // N tile: 96 where it pads the output channels no more than 64 does (288 = 3 x 96, 192 = 2 x 96), 32 for narrow layers
+  const int bn = Cout < 48 ? 32 : ((sf_cdiv(Cout, 96) * 96 <= sf_cdiv(Cout, 64) * 64) ? 96 : 64);
+#define SF_CONV(BK)                                                                                         \
+  return bn == 96 ? launch_conv<BK, 96, POOL>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)       \
+       : bn == 64 ? launch_conv<BK, 64, POOL>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)       \
+                  : launch_conv<BK, 32, POOL>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)
+  if (Cin % 32 == 0) { SF_CONV(32); }
+  if (Cin % 16 == 0) { SF_CONV(16); }
+  SF_CONV(8);
+#undef SF_CONV
 }
 
 }  // namespace
@@ -628,23 +679,6 @@ int sf_cnn_maxpool(const float *in, int N, int H, int W, int C, int ksize, int s
   return 0;
 }
 
-static int conv_dispatch(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias,
-                         int Cout, int ksize, const ConvDst &dst, hipStream_t st) {
-  const long long Ml = (long long)N * H * W;
-  if (Ml > 2000000000LL) { sf_set_error("sf_cnn_conv: batch too large"); return -1; }
-  const int M = (int)Ml;
-  // N tile: 96 where it pads the output channels no more than 64 does (288 = 3 x 96, 192 = 2 x 96), 32 for narrow layers
-  const int bn = Cout < 48 ? 32 : ((sf_cdiv(Cout, 96) * 96 <= sf_cdiv(Cout, 64) * 64) ? 96 : 64);
-#define SF_CONV(BK)                                                                                         \
-  return bn == 96 ? launch_conv<BK, 96>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)             \
-       : bn == 64 ? launch_conv<BK, 64>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)             \
-                  : launch_conv<BK, 32>(in, M, H, W, Cin, ld_in, w, bias, Cout, ksize, dst, st)
-  if (Cin % 32 == 0) { SF_CONV(32); }
-  if (Cin % 16 == 0) { SF_CONV(16); }
-  SF_CONV(8);
-#undef SF_CONV
-}
-
 int sf_cnn_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias, int Cout,
                 int ksize, float *out, int ld_out, int ch_off, void *stream) {
   if (!in || !w || !bias || !out || N < 1 || (ksize != 1 && ksize != 3) || (Cin & 7) || (ld_in & 3) || Cin > ld_in ||
@@ -658,6 +692,27 @@ int sf_cnn_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const 
   d.off[0] = d.off[1] = d.off[2] = ch_off;
   d.end[0] = d.end[1] = d.end[2] = Cout;
   return conv_dispatch(in, N, H, W, Cin, ld_in, w, bias, Cout, ksize, d, (hipStream_t)stream);
+}
+
+int sf_cnn_pool_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias, int Cout,
+                     float *out, int ld_out, int ch_off, float *pooled_scratch, void *stream) {
+  if (!in || !w || !bias || !out || !pooled_scratch || N < 1 || (Cin & 7) || (ld_in & 3) || Cin != ld_in || ch_off < 0 ||
+      ch_off + Cout > ld_out) {
+    sf_set_error("sf_cnn_pool_conv: bad argument (Cin multiple of 8, dense input)");
+    return -1;
+  }
+  ConvDst d{};
+  d.p[0] = d.p[1] = d.p[2] = out;
+  d.ld[0] = d.ld[1] = d.ld[2] = ld_out;
+  d.off[0] = d.off[1] = d.off[2] = ch_off;
+  d.end[0] = d.end[1] = d.end[2] = Cout;
+  if (sf_tune().cnn_pool_variant == 1) {     // measured slower (27.2 k vs 28.0 k tiles/s): nine tile reads through the L1
+    const int rc = conv_dispatch<true>(in, N, H, W, Cin, ld_in, w, bias, Cout, 1, d, (hipStream_t)stream);
+    if (rc <= 0) return rc;
+  }
+  // default: pool into the scratch tensor, then convolve
+  if (int rc = sf_cnn_maxpool(in, N, H, W, Cin, 3, 1, 1, pooled_scratch, H, W, stream)) return rc;
+  return conv_dispatch(pooled_scratch, N, H, W, Cin, Cin, w, bias, Cout, 1, d, (hipStream_t)stream);
 }
 
 int sf_cnn_conv_split3(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias,

@@ -139,6 +139,26 @@ def test_c_driver_equals_the_python_sequenced_graph(gold):
     assert L.sf_cnn_score_rows(None, None, 4, 4, 0, 4, None, None, 8, None, 0, None) == -1      # argument errors, no launch
 
 
+def test_kernel_forms_of_the_tile_scorer_agree_bit_for_bit(gold):
+    """The production kernels against their earlier forms (sf_debug_set keys 16-18): the 8 x 8 conv1+pool kernel with the
+    conv tile in LDS, the pointer-form tile fetch of the convolutions, the branch-4 pool taken inside the 1x1
+    convolution's fetch.  Max and the per-output summation order are the same in every form: equal saliency maps."""
+    import torch
+    from srcfinder_amd import _ffi
+    net = cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024))
+    plane = synthetic_plane(9, 6, seed=12)
+    plane[4, 1] = -9999.0
+    ref = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=27)
+    L = _ffi.lib()
+    for key in (16, 17, 18):
+        L.sf_debug_set(key, 1)
+        try:
+            got = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=27)
+        finally:
+            L.sf_debug_set(key, 0)
+        assert torch.equal(got, ref), key
+
+
 def test_gpu_list_scores_row_blocks_from_threads(gold, net):
     """``gpus=[...]`` (the script's ``-g 0 1 ...``, cnn_pred_pipeline.py:113-116): one network and one host thread per
     listed device, contiguous row blocks, assembled once.  On a one-GPU box the list [0, 0, 0] drives the same code with

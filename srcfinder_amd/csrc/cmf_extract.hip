@@ -515,7 +515,22 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
     return 0;
   }
   const int ncb = sf_cdiv(ncols, 64);
-  if (fuse && sf_tune().extract_variant != 2 && p == 72) {     // the production window: software-pipelined kernel
+  if (fuse && (sf_tune().extract_variant == 0 || sf_tune().extract_variant == 3) && p == 72) {
+    // the production window: software-pipelined kernel, FOUR lines per tile (72 row loads in flight per wave, 74 KB of
+    // LDS, two workgroups per CU: 147 KB of loads in flight per CU against 110 KB with two-line tiles at three
+    // workgroups -- 10.45 / 10.40 against 10.64 / 10.48 ms per flightline, same box, same bits; tools/tune_extract.py)
+    const int tl = sf_tune().extract_variant == 3 ? 3 : 4, csx = (tl * 72) | 1;
+    const size_t ldsx = (size_t)64 * csx * sizeof(float);
+    if (tl == 3) {
+      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_pipe<3, 72>), ldsx)) return rc;
+      hipLaunchKernelGGL((k_extract_pipe<3, 72>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), ldsx, st, cube, lines, bands, samples,
+                         s0, ncols, b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);
+    } else {
+      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_pipe<4, 72>), ldsx)) return rc;
+      hipLaunchKernelGGL((k_extract_pipe<4, 72>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), ldsx, st, cube, lines, bands, samples,
+                         s0, ncols, b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);
+    }
+  } else if (fuse && sf_tune().extract_variant != 2 && p == 72) {     // variant 5 (any other value): two lines per tile, round 1's form
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_pipe<TL, 72>), maxlds)) return rc;
     hipLaunchKernelGGL((k_extract_pipe<TL, 72>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), lds, st, cube, lines, bands, samples,
                        s0, ncols, b0, PS, xt, mask_t, lpw, cs, ncb, nchunk, sum_part, cnt_part);

@@ -273,7 +273,8 @@ int sf_cnn_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const 
                 int ksize, float *out, int ld_out, int ch_off, void *stream);
 
 /* Inception branch 4 (googlenet1.py:213-214) in one call: MaxPool2d(3, stride 1, pad 1, ceil_mode) into pooled_scratch
- * (N*H*W*Cin floats), then the 1x1 BasicConv2d.  `in` is dense ([N][H][W][Cin]).  (A form that takes the pool inside
+ * (N*H*W*Cin floats), then the 1x1 BasicConv2d.  `in` is dense ([N][H][W][Cin]) and NON-NEGATIVE (a concatenation of
+ * ReLU outputs, as every inception input is): the pool kernel relies on 0 being the identity of max.  (A form that takes the pool inside
  * the convolution's tile fetch exists behind sf_debug_set(18, 1); it reads the tile nine times through the L1 and
  * measured 3 % slower end to end.) */
 int sf_cnn_pool_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias, int Cout,

@@ -7,6 +7,7 @@
 #include "cmf_common.h"
 
 typedef float f16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -331,6 +332,49 @@ __global__ void k_maxpool(const float *__restrict__ in, int N, int H, int W, int
     if (oy0 + k < Ho) *reinterpret_cast<float4 *>(out + (((size_t)n * Ho + oy0 + k) * Wo + ox) * C + 4 * c4) = acc[k];
 }
 
+// The 3x3 stride-1 pad-1 pool of the inception branch 4 (nine launches per batch, 1.3 of its 18 ms): the same strip of four
+// output rows per thread, with the 18 loads of the strip issued up front as raw buffer loads -- a tap outside the image
+// takes an out-of-range offset and returns 0, the identity for the non-negative activations it is applied to -- instead
+// of two runtime-bounded loops with one load in flight.
+__global__ __launch_bounds__(256) void k_maxpool_s1(const float *__restrict__ in, int N, int H, int W, int C,
+                                                     float *__restrict__ out) {
+  const int c4n = C >> 2;
+  const int hob = (H + PR - 1) / PR;
+  const size_t total = (size_t)N * hob * W * c4n;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c4 = (int)(i % c4n);
+  size_t r = i / c4n;
+  const int ox = (int)(r % W); r /= W;
+  const int oyb = (int)(r % hob);
+  const int n = (int)(r / hob);
+  const int oy0 = oyb * PR;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (unsigned)((size_t)N * H * W * C * 4), 0x00020000);
+  const unsigned base = (unsigned)((((size_t)n * H + oy0) * W + ox) * C + 4 * c4) * 4u;    // (oy0, ox) of this image
+  const unsigned rowb = (unsigned)(W * C * 4), colb = (unsigned)(C * 4);
+  float4 m[PR + 2];
+#pragma unroll
+  for (int j = 0; j < PR + 2; ++j) {                       // input rows oy0 - 1 + j
+    const int y = oy0 - 1 + j;
+    const bool yok = y >= 0 && y < H;
+    float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const bool ok = yok && ox + dx >= 0 && ox + dx < W;
+      const unsigned off = ok ? base + (unsigned)(j - 1) * rowb + (unsigned)dx * colb : 0x80000000u;
+      const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      mx = make_float4(fmaxf(mx.x, __uint_as_float(v.x)), fmaxf(mx.y, __uint_as_float(v.y)), fmaxf(mx.z, __uint_as_float(v.z)),
+                       fmaxf(mx.w, __uint_as_float(v.w)));
+    }
+    m[j] = mx;
+  }
+#pragma unroll
+  for (int k = 0; k < PR; ++k)
+    if (oy0 + k < H)
+      *reinterpret_cast<float4 *>(out + (((size_t)n * H + oy0 + k) * W + ox) * C + 4 * c4) = max4(max4(m[k], m[k + 1]), m[k + 2]);
+}
+
 // ---- implicit-GEMM convolution, 1x1 or 3x3 (pad k/2), stride 1, + folded-BN bias + ReLU ----------------------------
 // (BasicConv2d, googlenet1.py:266-275).  D[m][co] = sum_{tap,ci} in[pixel(m)+tap][ci] * w[co][tap][ci];
 // block tile 128 pixels x BN channels, k-chunk BK input channels of one tap; each wave owns 32 pixel rows and all
@@ -352,7 +396,6 @@ struct ConvDst {
 // instructions per chunk and wave on bounds tests and 64-bit addresses beside 32 MFMAs; the matrix pipe idles a
 // quarter of the time waiting for waves that are all in that phase (PMC: tools/pmc_bin.sh on tools/microbench/convigemm).
 // Needs every operand below 2 GB (host-checked; larger tensors take the pointer form).
-typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 // POOL (buffer form, 1x1 convolutions only): the A tile is the 3x3 stride-1 pad-1 max pool of the input, taken while it is
 // fetched -- nine loads and eight maxima per element instead of a pooled copy in HBM (inception branch 4,
 // googlenet1.py:213-214).  Activations are >= 0 after ReLU, so the zero an out-of-range load returns is the identity.
@@ -710,8 +753,16 @@ int sf_cnn_pool_conv(const float *in, int N, int H, int W, int Cin, int ld_in, c
     const int rc = conv_dispatch<true>(in, N, H, W, Cin, ld_in, w, bias, Cout, 1, d, (hipStream_t)stream);
     if (rc <= 0) return rc;
   }
-  // default: pool into the scratch tensor, then convolve
-  if (int rc = sf_cnn_maxpool(in, N, H, W, Cin, 3, 1, 1, pooled_scratch, H, W, stream)) return rc;
+  // default: pool into the scratch tensor, then convolve.  The block input is a concatenation of ReLU outputs (>= 0): the
+  // strip kernel with zero-returning out-of-range loads applies (k_maxpool_s1); variant 2 = the general pool kernel
+  if ((Cin & 3) == 0 && (size_t)N * H * W * Cin * 4 < 0x7ff00000u && sf_tune().cnn_pool_variant != 2) {
+    const size_t total = (size_t)N * ((H + PR - 1) / PR) * W * (Cin / 4);
+    hipLaunchKernelGGL(k_maxpool_s1, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, N, H, W, Cin,
+                       pooled_scratch);
+    SF_LAUNCH_CHECK("k_maxpool_s1");
+  } else if (int rc = sf_cnn_maxpool(in, N, H, W, Cin, 3, 1, 1, pooled_scratch, H, W, stream)) {
+    return rc;
+  }
   return conv_dispatch(pooled_scratch, N, H, W, Cin, Cin, w, bias, Cout, 1, d, (hipStream_t)stream);
 }
 

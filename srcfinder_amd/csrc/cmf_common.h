@@ -25,28 +25,7 @@ int sf_fail_hip(hipError_t e, const char *what);
 // remembered per (device, function) so the driver is asked only when the size grows).  Thread safe.  c_api.hip
 int sf_lds_attr(const void *fn, size_t bytes);
 
-// Tuning / experiment knobs (sf_debug_set): a per-THREAD context, zero-initialised = the built-in choices.  The library
-// holds no process-wide mutable state: a thread that flips a knob (tools/tune_*.py, the kernel-variant tests) changes
-// only the launches it issues itself.
-struct SfTune {
-  int score_variant = 0;      // key 1: score kernel form (cmf_score.hip): 100 = round 1, 10 / 11 = k_score_blk2 plain / nt
-  int score_lpw = 0;          // key 2: lines per workgroup of the column-block score kernel
-  int score_xcd = 1;          // key 3: XCD-aware block map of the column-block score kernel
-  int sweep_variant = 0;      // key 4: 1 = force the 16x16x4 sweep, 2 = full-rank 4x4x4 sweep only
-  int cov_variant = 0;        // key 5: 1 = force the 16x16x4 covariance, 3 = two waves per SIMD
-  int extract_variant = 0;    // key 6: 1 = never the flat (narrow-cube) kernel, 2 = the unpipelined blocked kernel, 3 / 5 = 3- / 2-line tiles in the pipelined kernel (default 4)
-  int eigh_lpp = 0;           // key 7: lanes per column pair of the Jacobi eigensolver
-  int sweep4r_waves = 8;      // key 8: waves per workgroup of the rank-factored sweep
-  int wide_eigh_variant = 0;  // key 10: 1 = the single-workgroup eigensolver for every wide matrix
-  int score_wgs = 0;          // key 12: workgroups per CU k_score_blk2 is sized for (0 = occupancy query)
-  int cnn_pool_variant = 0;   // key 18: 1 = branch-4 pool taken inside the 1x1 convolution's tile fetch (sf_cnn_pool_conv; slower)
-  int cnn_conv_variant = 0;   // key 17: 1 = pointer-form tile loads in k_conv_igemm (cnn_kernels.hip)
-  int cnn_variant = 0;        // key 16: 1 = the 8 x 8 conv1+pool kernel (cnn_kernels.hip)
-  int det_variant = 0;        // key 15: 1 = the plain window rule of the exact-determinant pass in one round
-  int lu_variant = 0;         // key 14: 1 = the unblocked LU in the determinant passes (linalg.hip)
-  int score_exp = 0;          // key 13: timing experiments of k_score_blk2 (only with -DSF_SCORE_EXPERIMENTS)
-};
-SfTune &sf_tune();   // c_api.hip (thread_local)
+#include "sf_tune.h"   // the per-thread tuning / experiment knobs (sf_debug_set)
 
 static inline int sf_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t sf_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

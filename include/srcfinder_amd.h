@@ -81,6 +81,16 @@ int sf_cmf_wide_stats_target(const void *xt, int xt_f64, const uint8_t *mask_t, 
                              const double *target, double *cov, double *d, double *lam, double *evec, int32_t *status,
                              double *nll, int32_t *alphaidx, void *scratch, void *stream);
 
+/* det() over/underflow exactly as scipy's running LU-pivot product has it (robust_mf.py:111-113) for windows of up to 96
+ * bands, after sf_cmf_loocv: the finite grid points next to one whose total log-determinant left the float64 range
+ * (window > 0: at most `window` per crossing, in rounds of four; window <= 0: every grid point) are factorised for real
+ * -- G = n beta 1e4 S + alpha 1e4 T, T = target[ncols][p][p] or diag S when target is NULL -- and marked +inf (NaN) in nll
+ * where the product is 0 (not finite); alphaidx is recomputed (numpy.argmin, first NaN wins).  Wide windows do this inside
+ * sf_cmf_wide_stats.  scratch >= sf_cmf_exact_det_scratch_bytes(...). */
+size_t sf_cmf_exact_det_scratch_bytes(int p, int ncols, int nalpha, int window);
+int sf_cmf_exact_det(const double *cov, const double *target, const int32_t *nloo, const int32_t *status, const double *alphas,
+                     int nalpha, int p, int ncols, int window, double *nll, int32_t *alphaidx, void *scratch, void *stream);
+
 /* Stage 4, full shrinkage target (multimodal -f: T = cov(I_reg), robust_mf.py:99, :131, :354) -- the same restatement one
  * congruence further: target = L L^T (Cholesky), eigendecomposition of L^-1 S L^-T, and outputs d = diag(L),
  * evec_j = D (L^-T v_j) chosen so that stages 5-7 run unchanged (they only form D^-1 evec^T and 2 sum log d = log det T).

@@ -28,6 +28,8 @@ SIGNATURES = {
     "sf_cmf_wide_stats": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "sf_cmf_wide_stats_target": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                        vp]),
+    "sf_cmf_exact_det_scratch_bytes": (sz, [i32, i32, i32, i32]),
+    "sf_cmf_exact_det": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "sf_cmf_eigh_general": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "sf_cmf_loocv": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "sf_cmf_filter": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),

@@ -315,7 +315,9 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
     P, st = _ffi.ptr, _ffi.stream_ptr()
     f64 = dict(dtype=torch.float64, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
-    ws = _Workspace.get(L.sf_cmf_workspace_bytes(lines, p, ncols, nalpha), dev)
+    det_window = 8                      # exact det() semantics on narrow windows: grid points per range crossing (two rounds)
+    ws = _Workspace.get(max(L.sf_cmf_workspace_bytes(lines, p, ncols, nalpha),
+                            0 if wide else L.sf_cmf_exact_det_scratch_bytes(p, ncols, nalpha, det_window)), dev)
     xt = torch.empty((ncols, lines, ps), dtype=torch.float32, device=dev)
     mask = torch.empty((ncols, lines), dtype=torch.uint8, device=dev)
     nuse_col, nuse_k, status_k, aidx_k = (torch.empty(ncols, **i32) for _ in range(4))
@@ -352,6 +354,10 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
         if want_alpha:
             check(L.sf_cmf_loocv(P(xt), 0, P(m), P(n_loo), P(mu), P(d), P(lam), P(evec), P(status), P(alphas), nalpha,
                                  lines, p, ncols, P(nll), P(aidx_k), P(ws), st), "sf_cmf_loocv")
+            # a cluster of fewer rows than bands puts det(G_alpha) at the edge of the float64 range for the small alphas:
+            # the grid points next to a lost one are factorised for real (scipy's running pivot product, :111-113)
+            check(L.sf_cmf_exact_det(P(S), P(target) if target is not None else None, P(n_loo), P(status), P(alphas), nalpha, p,
+                                     ncols, det_window, P(nll), P(aidx_k), P(ws), st), "sf_cmf_exact_det")
 
     check(L.sf_cmf_extract_columns(P(cube), lines, bands, samples, s0, s1, a0 - 1, p, P(xt), P(mask), st), "sf_cmf_extract_columns")
     if labels is None:
@@ -662,6 +668,11 @@ def looshrinkage(I_zm, alphas, nll, n, I_reg=[]):
     _ffi.check(L.sf_cmf_loocv(_ffi.ptr(xt), 1, _ffi.ptr(mask), _ffi.ptr(nloo), _ffi.ptr(mu), _ffi.ptr(d),
                               _ffi.ptr(lam), _ffi.ptr(evec), _ffi.ptr(status), _ffi.ptr(al), nalpha, rows, p, 1,
                               _ffi.ptr(nll_d), _ffi.ptr(aidx), _ffi.ptr(ws), st), "sf_cmf_loocv")
+    # det() over/underflow as the running pivot product has it: every grid point factorised for real (201 small LUs)
+    dws = _Workspace.get(max(L.sf_cmf_workspace_bytes(rows, p, 1, nalpha), L.sf_cmf_exact_det_scratch_bytes(p, 1, nalpha, 0)), dev)
+    _ffi.check(L.sf_cmf_exact_det(_ffi.ptr(S), _ffi.ptr(T_d) if T_d is not None else None, _ffi.ptr(nloo), _ffi.ptr(status),
+                                  _ffi.ptr(al), nalpha, p, 1, 0, _ffi.ptr(nll_d), _ffi.ptr(aidx), _ffi.ptr(dws), st),
+               "sf_cmf_exact_det")
     nll[:] = nll_d[0].cpu().numpy()
     mindex = int(aidx.item())
     alpha = float(alphas_np[mindex]) if mindex >= 0 else 0.0

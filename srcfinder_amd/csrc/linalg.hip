@@ -291,7 +291,7 @@ __global__ void k_det_jobs(const double *__restrict__ nll, const double *__restr
     if (v == __builtin_inf() || v != v) continue;
     bool near = false;
     for (int j = max(0, i - window); j <= min(nalpha - 1, i + window) && !near; ++j) {
-      const double vj = nll[(size_t)c * nalpha + j], rj = rest[(size_t)c * nalpha + j];
+      const double vj = nll[(size_t)c * nalpha + j], rj = rest ? rest[(size_t)c * nalpha + j] : 0.0;
       near = (vj == __builtin_inf()) && (rj == rj) && (rj != __builtin_inf());
     }
     if (near) push(i);
@@ -311,13 +311,13 @@ __global__ void k_det_round(const double *__restrict__ nll, const double *__rest
                             int32_t *__restrict__ njobs, int cap, int32_t *__restrict__ state) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncols || status[c] != 0) return;
-  const double *v = nll + (size_t)c * nalpha, *rs = rest + (size_t)c * nalpha;
+  const double *v = nll + (size_t)c * nalpha, *rs = rest ? rest + (size_t)c * nalpha : nullptr;
   const double inf = __builtin_inf();
   auto push = [&](int i) {
     const int k = atomicAdd(njobs, 1);
     if (k < cap) jobs[k] = c * nalpha + i;
   };
-  auto lost = [&](int i) { return v[i] == inf && rs[i] == rs[i] && rs[i] != inf; };
+  auto lost = [&](int i) { return v[i] == inf && (!rs || (rs[i] == rs[i] && rs[i] != inf)); };
   auto finite = [&](int i) { return v[i] == v[i] && v[i] != inf && v[i] != -inf; };
   int32_t *s = state + 4 * (size_t)c;
   if (round == 0) {
@@ -431,6 +431,11 @@ __global__ void k_det_apply(const int32_t *__restrict__ jobs, const int32_t *__r
   if (k >= *njobs || k >= cap) return;
   const int job = jobs[k];
   const double dt = det[k];
+  if (!rest) {      // no split of the NLL at hand (narrow windows): the factorisation only decides finite / lost
+    if (dt == 0.0) nll[job] = __builtin_inf();
+    else if (!(dt > 0.0 && dt < __builtin_inf())) nll[job] = 0.5 * log(dt);     // +inf -> inf, -inf / NaN -> NaN
+    return;
+  }
   nll[job] = (dt == 0.0) ? __builtin_inf() : 0.5 * log(dt) + rest[job];
 }
 __global__ void k_argmin_nan_first(const double *__restrict__ nll, const int32_t *__restrict__ status, int ncols, int nalpha,
@@ -504,6 +509,25 @@ int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *s
 }
 
 extern "C" {
+
+/* The exact-determinant pass as its own entry (windows of up to 96 bands: the fused stage-5 kernels keep no split of the
+ * NLL into log det + rest): the grid points next to one whose total log-determinant left the float64 range -- window > 0:
+ * at most `window` per crossing, in rounds of four; window <= 0: every grid point -- are factorised for real
+ * (G = n beta 1e4 S + alpha 1e4 T, T = target or diag S) and those whose running pivot product is 0 or not finite
+ * (robust_mf.py:111-113) are marked in nll; alphaidx is recomputed with numpy.argmin's rule.
+ * scratch >= sf_cmf_exact_det_scratch_bytes(p, ncols, nalpha, window). */
+size_t sf_cmf_exact_det_scratch_bytes(int p, int ncols, int nalpha, int window) {
+  return sf_exact_det_scratch_bytes(sf_geom(1, p, ncols, nalpha), window);
+}
+int sf_cmf_exact_det(const double *cov, const double *target, const int32_t *nloo, const int32_t *status, const double *alphas,
+                     int nalpha, int p, int ncols, int window, double *nll, int32_t *alphaidx, void *scratch, void *stream) {
+  if (!cov || !nloo || !status || !alphas || !nll || !alphaidx || !scratch || p < 1 || ncols < 1 || nalpha < 1) {
+    sf_set_error("sf_cmf_exact_det: bad argument");
+    return -1;
+  }
+  return sf_launch_exact_det(cov, nloo, status, alphas, sf_geom(1, p, ncols, nalpha), window, nullptr, nll, alphaidx, scratch,
+                             (hipStream_t)stream, target);
+}
 
 /* scipy.linalg.det semantics (cmf/robust_mf.py:86-90) for a batch of n x n float64 matrices: LU with partial pivoting,
  * the running product of the diagonal in index order (prefixes that reach inf or 0 stay there), 0 for an exactly

@@ -928,6 +928,40 @@ def test_linalg_wrappers_follow_scipy(torch_cuda):
         cmf.inv(np.zeros((4, 4)))
 
 
+def test_starved_clusters_take_the_exact_determinant_pass(torch_cuda, library):
+    """Clusters of 15 .. 70 rows in a 72-band window (S singular, the shrinkage makes G_alpha regular): for the small alphas
+    det(G_alpha) underflows, the first finite grid point is the minimum, and WHICH point is the first finite one is decided by
+    the running pivot product of the reference's LU (robust_mf.py:111-113) -- tools/fuzz_multimodal.py seed 321 found the
+    total log-determinant off by one grid point there.  sf_cmf_exact_det after stage 5: alpha indices equal to the oracle's,
+    with the diagonal and with the full-column target; the function-level looshrinkage: the same finite / inf pattern."""
+    cube = make_cube_numpy(500, 4, seed=4711, abscf_full=library[:, 2], nodata_lines=2, nodata_column=-1)
+    lab = np.zeros((500, 4), np.int64)
+    lab[60:100, 0] = 1
+    lab[60:85, 1] = 1
+    lab[60:130, 2] = 1
+    lab[200:215, 3] = 1
+    for full in (True, False):
+        res = cmf.robust_mf(cube, library, kmeans=2, labels=lab, full=full, metadata=True, to_numpy=True)
+        with np.errstate(all="ignore"):
+            o = O.robust_mf_multimodal_oracle(cube, library, lab, full=full)
+        assert np.array_equal(res.alphaidx, o["alphaidx"]), (full, res.alphaidx.tolist(), o["alphaidx"].tolist())
+        assert np.array_equal(res.bgmeta, o["bgmeta"])
+        assert np.array_equal(res.out[..., 3] == -9999.0, o["out"][..., 3] == -9999.0)
+    from srcfinder_amd.synth import synth_columns
+    al = cmf.alpha_grid()
+    for seed, nsub, scale in ((6, 20, 1.0), (9, 10, 1.0), (6, 20, 0.2), (11, 30, 0.05)):
+        x = synth_columns(500, 72, seed) * scale
+        sub = x[100:100 + nsub] - x[100:100 + nsub].mean(0)
+        reg = x - x[100:100 + nsub].mean(0)
+        for target in (reg, []):
+            nll_o, nll_g = np.zeros(201), np.zeros(201)
+            with np.errstate(all="ignore"):
+                _, i_o = O.looshrinkage(sub, al, nll_o, 500, target)
+            _, i_g = cmf.looshrinkage(sub, al, nll_g, 500, target)
+            assert np.array_equal(np.isfinite(nll_g), np.isfinite(nll_o)), (seed, nsub, scale, len(target))
+            assert i_g == i_o, (seed, nsub, scale, len(target), i_g, i_o)
+
+
 def test_blocked_lu_determinant(torch_cuda):
     """The blocked determinant kernel (panel of 16 columns in LDS, one column of the trailing part per thread) against
     scipy and against the unblocked kernel: sizes around the panel and thread-count boundaries, rows that need pivoting

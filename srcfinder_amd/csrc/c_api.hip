@@ -56,6 +56,7 @@ Ws carve(void *base, const SfGeom &g) {
     if (sf_cov_scratch_bytes(g) > s) s = sf_cov_scratch_bytes(g);
     if (sf_eigh_scratch_bytes(g) > s) s = sf_eigh_scratch_bytes(g);
     if (sf_loocv_scratch_bytes(g) > s) s = sf_loocv_scratch_bytes(g);
+    if (sf_exact_det_scratch_bytes(g, SF_NARROW_DET_WINDOW) > s) s = sf_exact_det_scratch_bytes(g, SF_NARROW_DET_WINDOW);
   } else {
     if (sf_wide_scratch_bytes(g) > s) s = sf_wide_scratch_bytes(g);
   }
@@ -278,6 +279,11 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
     if ((rc = sf_launch_eigh(w.cov, nuse, g, w.d, w.lam, w.evec, status, w.scratch, st))) return rc;
     if ((rc = sf_launch_loocv(w.xt, 0, w.mask_t, nuse, w.mu, w.d, w.lam, w.evec, status, alphas, g, nll, alphaidx, w.scratch,
                               st)))
+      return rc;
+    // det() at the edge of the float64 range (a column of fewer valid rows than bands): the finite grid points next to a lost
+    // one are factorised for real, robust_mf.py:111-113 (linalg.hip; nine small launches that find nothing to do otherwise)
+    if (sf_tune().det_variant != 2 &&
+        (rc = sf_launch_exact_det(w.cov, nuse, status, alphas, g, SF_NARROW_DET_WINDOW, nullptr, nll, alphaidx, w.scratch, st)))
       return rc;
   }
   if ((rc = sf_launch_filter(w.mu, w.d, w.lam, w.evec, alphas, alphaidx, abscf, reflectance, g, status, w.filt, w.bias, st)))

@@ -376,24 +376,26 @@ __global__ __launch_bounds__(LU_NT) void k_det_grid(const double *__restrict__ c
                                                     int job0, double *__restrict__ work, double *__restrict__ det,
                                                     const double *__restrict__ target) {
   const int slot = blockIdx.x, tid = threadIdx.x;
-  const int jb = job0 + slot;
-  if (jb >= *njobs) return;
-  const int job = jobs[jb], c = job / nalpha, ai = job - c * nalpha;
-  const double n = (double)nloo[c], a = alphas[ai];
-  const double beta = (1.0 - a) / (n - 1.0);
-  const double *S = cov + (size_t)c * p * p;
-  const double *T = target ? target + (size_t)c * p * p : nullptr;   // full shrinkage target (:99), else diag(S)
+  const int nj = min(*njobs, job0);                  // (job0 carries the capacity of the job list)
   double *G = work + (size_t)slot * p * p;
-  for (size_t e = tid; e < (size_t)p * p; e += LU_NT) {
-    const int i = (int)(e / p), j = (int)(e % p);
-    const double s = S[e] * 1e4;
-    double gij = n * (beta * s);
-    if (T) gij += a * (T[e] * 1e4);
-    else if (i == j) gij += a * s;
-    G[e] = gij;
+  for (int jb = slot; jb < nj; jb += gridDim.x) {    // one launch per round: a workgroup walks the job list
+    const int job = jobs[jb], c = job / nalpha, ai = job - c * nalpha;
+    const double n = (double)nloo[c], a = alphas[ai];
+    const double beta = (1.0 - a) / (n - 1.0);
+    const double *S = cov + (size_t)c * p * p;
+    const double *T = target ? target + (size_t)c * p * p : nullptr;   // full shrinkage target (:99), else diag(S)
+    for (size_t e = tid; e < (size_t)p * p; e += LU_NT) {
+      const int i = (int)(e / p), j = (int)(e % p);
+      const double s = S[e] * 1e4;
+      double gij = n * (beta * s);
+      if (T) gij += a * (T[e] * 1e4);
+      else if (i == j) gij += a * s;
+      G[e] = gij;
+    }
+    __syncthreads();
+    lu_factor(G, p, nullptr, det + jb, nullptr, tid);
+    __syncthreads();
   }
-  __syncthreads();
-  lu_factor(G, p, nullptr, det + jb, nullptr, tid);
 }
 // the same through the blocked factorisation (p <= 1000: the panel fits LDS)
 __global__ __launch_bounds__(LB_NT) void k_det_grid_blocked(const double *__restrict__ cov, const int32_t *__restrict__ nloo,
@@ -404,24 +406,26 @@ __global__ __launch_bounds__(LB_NT) void k_det_grid_blocked(const double *__rest
   extern __shared__ __attribute__((aligned(16))) double lb_lds[];
   int *rowof = reinterpret_cast<int *>(lb_lds + (size_t)p * LB_LD);
   const int slot = blockIdx.x, tid = threadIdx.x;
-  const int jb = job0 + slot;
-  if (jb >= *njobs) return;
-  const int job = jobs[jb], c = job / nalpha, ai = job - c * nalpha;
-  const double n = (double)nloo[c], a = alphas[ai];
-  const double beta = (1.0 - a) / (n - 1.0);
-  const double *S = cov + (size_t)c * p * p;
-  const double *T = target ? target + (size_t)c * p * p : nullptr;
+  const int nj = min(*njobs, job0);                  // (job0 carries the capacity of the job list)
   double *G = work + (size_t)slot * p * p;
-  for (size_t e = tid; e < (size_t)p * p; e += LB_NT) {
-    const int i = (int)(e / p), j = (int)(e % p);
-    const double s = S[e] * 1e4;
-    double gij = n * (beta * s);
-    if (T) gij += a * (T[e] * 1e4);
-    else if (i == j) gij += a * s;
-    G[e] = gij;
+  for (int jb = slot; jb < nj; jb += gridDim.x) {    // one launch per round: a workgroup walks the job list
+    const int job = jobs[jb], c = job / nalpha, ai = job - c * nalpha;
+    const double n = (double)nloo[c], a = alphas[ai];
+    const double beta = (1.0 - a) / (n - 1.0);
+    const double *S = cov + (size_t)c * p * p;
+    const double *T = target ? target + (size_t)c * p * p : nullptr;
+    for (size_t e = tid; e < (size_t)p * p; e += LB_NT) {
+      const int i = (int)(e / p), j = (int)(e % p);
+      const double s = S[e] * 1e4;
+      double gij = n * (beta * s);
+      if (T) gij += a * (T[e] * 1e4);
+      else if (i == j) gij += a * s;
+      G[e] = gij;
+    }
+    __syncthreads();
+    lu_det_blocked(G, p, det + jb, lb_lds, rowof, rowof + p);
+    __syncthreads();
   }
-  __syncthreads();
-  lu_det_blocked(G, p, det + jb, lb_lds, rowof, rowof + p);
 }
 
 // nll[job] = 0.5 log(det) + rest, +inf where det == 0 (the reference skips the alpha, :112-113); then numpy.argmin
@@ -491,15 +495,13 @@ int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *s
       hipLaunchKernelGGL(k_det_jobs, dim3(sf_cdiv(g.ncols, 128)), dim3(128), 0, st, nll, rest, status, g.ncols, g.nalpha, window, jobs,
                          njobs, (int)maxjobs);
     SF_LAUNCH_CHECK("k_det_jobs");
-    for (size_t j0 = 0; j0 < cap; j0 += slots) {
-      if (blocked)
-        hipLaunchKernelGGL(k_det_grid_blocked, dim3((unsigned)slots), dim3(LB_NT), lb_lds_bytes(g.p), st, cov, nloo, alphas,
-                           g.nalpha, g.p, jobs, njobs, (int)j0, work, det, target);
-      else
-        hipLaunchKernelGGL(k_det_grid, dim3((unsigned)slots), dim3(LU_NT), 0, st, cov, nloo, alphas, g.nalpha, g.p, jobs, njobs,
-                           (int)j0, work, det, target);
-      SF_LAUNCH_CHECK("k_det_grid");
-    }
+    if (blocked)
+      hipLaunchKernelGGL(k_det_grid_blocked, dim3((unsigned)slots), dim3(LB_NT), lb_lds_bytes(g.p), st, cov, nloo, alphas,
+                         g.nalpha, g.p, jobs, njobs, (int)cap, work, det, target);
+    else
+      hipLaunchKernelGGL(k_det_grid, dim3((unsigned)slots), dim3(LU_NT), 0, st, cov, nloo, alphas, g.nalpha, g.p, jobs, njobs,
+                         (int)cap, work, det, target);
+    SF_LAUNCH_CHECK("k_det_grid");
     hipLaunchKernelGGL(k_det_apply, dim3(sf_cdiv((int)cap, 256)), dim3(256), 0, st, jobs, njobs, det, rest, nll, (int)cap);
     SF_LAUNCH_CHECK("k_det_apply");
   }

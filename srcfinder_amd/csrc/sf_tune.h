@@ -18,8 +18,11 @@ struct SfTune {
   int cnn_pool_variant = 0;   // key 18: 1 = branch-4 pool taken inside the 1x1 convolution's tile fetch (sf_cnn_pool_conv; slower)
   int cnn_conv_variant = 0;   // key 17: 1 = pointer-form tile loads in k_conv_igemm (cnn_kernels.hip)
   int cnn_variant = 0;        // key 16: 1 = the 8 x 8 conv1+pool kernel (cnn_kernels.hip)
-  int det_variant = 0;        // key 15: 1 = the plain window rule of the exact-determinant pass in one round
+  int det_variant = 0;        // key 15: 1 = the plain window rule of the exact-determinant pass in one round, 2 = no pass in sf_cmf_run's narrow branch
   int lu_variant = 0;         // key 14: 1 = the unblocked LU in the determinant passes (linalg.hip)
   int score_exp = 0;          // key 13: timing experiments of k_score_blk2 (only with -DSF_SCORE_EXPERIMENTS)
 };
 SfTune &sf_tune();   // c_api.hip (thread_local)
+
+// exact-determinant pass on windows of up to 96 bands: grid points per range crossing (two rounds of four; linalg.hip)
+constexpr int SF_NARROW_DET_WINDOW = 8;

@@ -309,10 +309,23 @@ __global__ void k_det_jobs(const double *__restrict__ nll, const double *__restr
 __global__ void k_det_round(const double *__restrict__ nll, const double *__restrict__ rest, const int32_t *__restrict__ status,
                             int ncols, int nalpha, int window, int group, int round, int32_t *__restrict__ jobs,
                             int32_t *__restrict__ njobs, int cap, int32_t *__restrict__ state) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wave per column: the common case -- no lost grid point at all (round 0), both sides closed (later rounds) -- is
+  // settled by one coalesced pass of the 64 lanes; only a column with work to do goes on, on lane 0
+  const int c = blockIdx.x;
   if (c >= ncols || status[c] != 0) return;
   const double *v = nll + (size_t)c * nalpha, *rs = rest ? rest + (size_t)c * nalpha : nullptr;
   const double inf = __builtin_inf();
+  if (round == 0) {
+    bool any = false;
+    for (int i = threadIdx.x; i < nalpha; i += 64) any = any || (v[i] == inf);
+    if (!__any(any)) {
+      if (threadIdx.x == 0) { int32_t *s0 = state + 4 * (size_t)c; s0[0] = s0[1] = s0[2] = s0[3] = 0; }
+      return;
+    }
+  } else if (state[4 * (size_t)c + 2] == 0 && state[4 * (size_t)c + 3] == 0) {
+    return;
+  }
+  if (threadIdx.x != 0) return;
   auto push = [&](int i) {
     const int k = atomicAdd(njobs, 1);
     if (k < cap) jobs[k] = c * nalpha + i;
@@ -444,16 +457,24 @@ __global__ void k_det_apply(const int32_t *__restrict__ jobs, const int32_t *__r
 }
 __global__ void k_argmin_nan_first(const double *__restrict__ nll, const int32_t *__restrict__ status, int ncols, int nalpha,
                                    int32_t *__restrict__ alphaidx) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  // numpy.argmin: the first NaN if there is one, else the first occurrence of the minimum; -1 when every entry is +inf
+  // (robust_mf.py:119-125).  One wave per column, coalesced loads, the (value, index) pairs reduced with shuffles.
+  const int c = blockIdx.x, lane = threadIdx.x;
   if (c >= ncols || status[c] != 0) return;
-  int idx = -1;
+  int nanidx = 0x7fffffff, idx = 0x7fffffff;
   double best = __builtin_inf();
-  for (int i = 0; i < nalpha; ++i) {
+  for (int i = lane; i < nalpha; i += 64) {
     const double v = nll[(size_t)c * nalpha + i];
-    if (v != v) { idx = i; break; }
-    if (v < best) { best = v; idx = i; }
+    if (v != v) { if (i < nanidx) nanidx = i; }
+    else if (v < best) { best = v; idx = i; }           // (ascending i per lane: the first occurrence stays)
   }
-  alphaidx[c] = idx;
+  for (int o = 32; o > 0; o >>= 1) {
+    const int on = __shfl_xor(nanidx, o, 64), oi = __shfl_xor(idx, o, 64);
+    const double ob = __shfl_xor(best, o, 64);
+    nanidx = min(nanidx, on);
+    if (ob < best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+  }
+  if (lane == 0) alphaidx[c] = nanidx != 0x7fffffff ? nanidx : (best < __builtin_inf() ? idx : -1);
 }
 
 }  // namespace
@@ -489,7 +510,7 @@ int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *s
     const size_t cap = (r == 0) ? maxjobs : std::min(maxjobs, (size_t)g.ncols * 2 * DET_GROUP);
     SF_HIP(hipMemsetAsync(njobs, 0, sizeof(int32_t), st));
     if (rounds)
-      hipLaunchKernelGGL(k_det_round, dim3(sf_cdiv(g.ncols, 128)), dim3(128), 0, st, nll, rest, status, g.ncols, g.nalpha, window,
+      hipLaunchKernelGGL(k_det_round, dim3(g.ncols), dim3(64), 0, st, nll, rest, status, g.ncols, g.nalpha, window,
                          DET_GROUP, r, jobs, njobs, (int)maxjobs, state);
     else
       hipLaunchKernelGGL(k_det_jobs, dim3(sf_cdiv(g.ncols, 128)), dim3(128), 0, st, nll, rest, status, g.ncols, g.nalpha, window, jobs,
@@ -505,7 +526,7 @@ int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *s
     hipLaunchKernelGGL(k_det_apply, dim3(sf_cdiv((int)cap, 256)), dim3(256), 0, st, jobs, njobs, det, rest, nll, (int)cap);
     SF_LAUNCH_CHECK("k_det_apply");
   }
-  hipLaunchKernelGGL(k_argmin_nan_first, dim3(sf_cdiv(g.ncols, 128)), dim3(128), 0, st, nll, status, g.ncols, g.nalpha, alphaidx);
+  hipLaunchKernelGGL(k_argmin_nan_first, dim3(g.ncols), dim3(64), 0, st, nll, status, g.ncols, g.nalpha, alphaidx);
   SF_LAUNCH_CHECK("k_argmin_nan_first");
   return 0;
 }

@@ -53,8 +53,8 @@ for case in range(ncase):
                 continue
             xx = np.float64(cube[:, 350:422, s_])
             sizes = [int((valid[:, s_] & (lab[:, s_] == q)).sum()) for q in range(k)]
-            if reject and any(0 < z < 85 for z in sizes):
-                ok = False                                        # (a rejected cluster changes the row sets: no tie analysis)
+            if reject and kk != 0 and 0 < sizes[kk] < 85:
+                ok = False                                        # (a rejected cluster is re-scored with other rows: no tie analysis)
                 continue
             mu_k = xx[rows].mean(0)
             nl = np.zeros(201)

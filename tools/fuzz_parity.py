@@ -75,7 +75,7 @@ def run(ncase=60, seed=0, WIDE=False, verbose=True):
                 worst = max(worst, float(e.max()))
         ok = ok and worst <= 1.0
         # the columns left out above (no more valid rows than bands + 1): checked against the conditioning of the matrix the
-        # reference inverts -- its LU inverse carries ~cond(C) eps, so the bar is max(1e-4, 100 cond(C) eps) relative
+        # reference inverts -- its LU inverse carries ~p cond(C) eps, so the bar is max(1e-4, 250 cond(C) eps) relative
         worst_ill = 0.0
         for c in range(samples):
             if o["status"][c] != 0 or o["nuse"][c] > p + 1 or o["alphaidx"][c] < 0:
@@ -91,7 +91,7 @@ def run(ncase=60, seed=0, WIDE=False, verbose=True):
                 cond = np.linalg.cond(Cm)
             if not np.isfinite(cond):
                 continue
-            tol = max(1e-4, 100.0 * cond * 2.220446049250313e-16)
+            tol = max(1e-4, 250.0 * cond * 2.220446049250313e-16)   # ~ 2 p cond eps: the filter and its normaliser both carry the inverse's error
             v = o["out"][:, c, -1] != nodata
             a, b = g.out[v, c, -1], o["out"][v, c, -1]
             fin = np.isfinite(b)

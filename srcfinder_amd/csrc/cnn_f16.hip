@@ -23,7 +23,12 @@ struct ConvDstH {
   int ld[3], off[3], end[3];
 };
 
-template <int BN>
+// BUF: raw buffer loads for the tile fetch (cnn_kernels.hip: the lane's byte offset in a VGPR, an out-of-range offset for a
+// tap outside the image / a row, channel chunk or output channel past the end, the (tap, chunk) offset in an SGPR) -- the
+// pointer form's bounds tests and 64-bit addresses are ~150 instructions per chunk and wave beside EIGHT matrix
+// instructions here.  Operands below 2 GB (host-checked).
+typedef unsigned hu4_t __attribute__((ext_vector_type(4)));
+template <int BN, bool BUF = false>
 __global__ __launch_bounds__(256) void k_conv_igemm_f16(const _Float16 *__restrict__ in, int M, int H, int W, int Cin,
                                                          int ld_in, const _Float16 *__restrict__ wt,
                                                          const float *__restrict__ bias, int Cout, int ks, ConvDstH dst) {
@@ -69,7 +74,56 @@ __global__ __launch_bounds__(256) void k_conv_igemm_f16(const _Float16 *__restri
 
   const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
   h8_t ra[2], rb[NPB];
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned rowoff[2], vmask[2], woff[NPB];
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  int g_tap = 0, g_ty = 0, g_tx = 0, g_c0 = 0;
+  if (BUF) {
+    const size_t shift = ((size_t)pad * W + pad) * ld_in;          // taps are addressed from (y - pad, x - pad): offsets >= 0
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(in) - shift, 0,
+                                            (unsigned)(((size_t)M * ld_in + 2 * shift) * 2 + 64), 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(wt), 0, (unsigned)((size_t)Cout * taps * Cin * 2), 0x00020000);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int m = m0 + ri + 64 * a;
+      const int mm = m < M ? m : 0;
+      rowoff[a] = (unsigned)(((size_t)mm * ld_in + 8 * q) * 2);
+      unsigned vm = 0;
+      for (int tp = 0; tp < taps; ++tp) {
+        const int yy = py[a] + tp / ks - pad, xx = px[a] + tp % ks - pad;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) vm |= 1u << tp;
+      }
+      vmask[a] = vm;
+    }
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+      const int co = n0 + ri + 64 * b;
+      woff[b] = wok[b] ? (unsigned)(((size_t)co * taps * Cin + 8 * q) * 2) : OOB;
+    }
+  }
+  auto as_h8 = [](hu4_t v) {
+    union { hu4_t u; h8_t h; } c;
+    c.u = v;
+    return c.h;
+  };
   auto gload = [&](int it) {
+    if (BUF) {
+      const bool kin = g_c0 + 8 * q < Cin;          // Cin is a multiple of 8: whole chunk in or out
+      const unsigned sa = (unsigned)(((g_ty * W + g_tx) * ld_in + g_c0) * 2);
+      const unsigned sb = (unsigned)((g_tap * Cin + g_c0) * 2);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        ra[a] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rsA, (kin && ((vmask[a] >> g_tap) & 1u)) ? rowoff[a] : OOB, sa, 0));
+#pragma unroll
+      for (int b = 0; b < NPB; ++b) rb[b] = as_h8(__builtin_amdgcn_raw_buffer_load_b128(rsB, kin ? woff[b] : OOB, sb, 0));
+      g_c0 += BK;
+      if (g_c0 >= Cin) {
+        g_c0 = 0;
+        ++g_tap;
+        if (++g_tx == ks) { g_tx = 0; ++g_ty; }
+      }
+      return;
+    }
     const int tap = it / nchunk, c0 = (it - tap * nchunk) * BK;
     const int dy = tap / ks - pad, dx = tap % ks - pad;
     const bool kin = c0 + 8 * q < Cin;              // Cin is a multiple of 8: whole chunk in or out
@@ -260,7 +314,13 @@ template <int BN>
 int launch_conv_h(const _Float16 *in, int M, int H, int W, int Cin, int ld_in, const _Float16 *wt, const float *bias,
                   int Cout, int ks, const ConvDstH &dst, hipStream_t st) {
   dim3 grid(sf_cdiv(M, 128), sf_cdiv(Cout, BN));
-  hipLaunchKernelGGL((k_conv_igemm_f16<BN>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
+  const size_t abytes = ((size_t)M * ld_in + 2 * ((size_t)(ks >> 1) * W + (ks >> 1)) * ld_in) * 2 + 64;
+  const size_t bbytes = (size_t)Cout * ks * ks * Cin * 2;
+  const size_t lim = (size_t)0x7ff00000 - ((size_t)ks * W + ks) * ld_in * 2;
+  if (abytes < lim && bbytes < lim && sf_tune().cnn_conv_variant == 0)
+    hipLaunchKernelGGL((k_conv_igemm_f16<BN, true>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
+  else
+    hipLaunchKernelGGL((k_conv_igemm_f16<BN>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
   SF_LAUNCH_CHECK("k_conv_igemm_f16");
   return 0;
 }

@@ -14,9 +14,9 @@ def main(path):
             rows.append((int(r["Start_Timestamp"]), n, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                          r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Grid_Size_Y", ""), r.get("Workgroup_Size_X", "")))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if r[1].startswith("k_conv1")]
-    i0 = starts[-1]
-    i1 = next(i for i in range(i0, len(rows)) if rows[i][1] == "k_head")
+    heads = [i for i, r in enumerate(rows) if r[1].startswith("k_head")]
+    i1 = heads[-1]                                            # the last batch: from the launch after the previous head
+    i0 = heads[-2] + 1 if len(heads) > 1 else 0
     tot = sum(r[2] for r in rows[i0:i1 + 1])
     print("%-28s %10s %8s %9s %6s" % ("kernel", "grid_x", "grid_y", "us", "share"))
     for r in rows[i0:i1 + 1]:

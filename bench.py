@@ -84,7 +84,7 @@ def main():
     # A production run works through a queue of flightlines: `depth` of them are in flight on this GPU, each on its own
     # HIP stream with its own scratch and product buffer (srcfinder_amd/inflight.py), so one flightline's latency-bound
     # stages (eigensolver, rank factorisation: one workgroup per column) run beside another's streaming stages; the
-    # gather of flightline i (RCCL, its own stream) overlaps the compute of the following ones.  Every step is still
+    # gather of flightline i (RCCL, behind it on its slot's stream) overlaps the compute of the other slots.  Every step is still
     # one complete pass over the whole flightline and all K of them finish inside the timed region.
     # ONE depth policy for every N (default 3): the 1 / 2 / 4 / 8-GPU values are then measured the same way.  The same K
     # steps are then repeated with ONE flightline in flight: that pass gives the latency of a single flightline
@@ -92,7 +92,6 @@ def main():
     # its HIP-event time includes kernels of the other streams).
     from srcfinder_amd.inflight import FlightlinePipeline
     L = _ffi.lib()
-    comm = torch.cuda.Stream(device=dev)         # packs and feeds the collective; never the stream submit() waits on
 
     def barrier():
         if world > 1 or force_dist:
@@ -102,36 +101,33 @@ def main():
     def timed_pass(depth):
         pipe = FlightlinePipeline(depth, dev)
         outs = [torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev) for _ in range(depth)]
-        pending = [None] * depth                 # per slot: (gather handle, event "the slot's product has been packed")
+        pending = [None] * depth                 # per slot: the gather handle of the flightline that used it last
         state = {}
 
         def step():
             slot = pipe.slot_of_next()
+            st = pipe.streams[slot]
             if pending[slot] is not None:
-                h, packed = pending[slot]
-                pipe.streams[slot].wait_event(packed)    # flightline i - depth's scores have left this slot's product buffer
-                with torch.cuda.stream(comm):
-                    h.wait()                             # its image, assembled on rank 0
+                with torch.cuda.stream(st):
+                    pending[slot].wait()                 # flightline i - depth: its image, assembled on rank 0
                 pending[slot] = None
             t = pipe.submit(cube, lib, out=outs[slot], out_column0=0, active=(a0, a1))
             if world > 1 or force_dist:
-                # the single RCCL gather of the score image: the float64 CMF band of every
-                # rank's block, 8 B/pixel; the RGB copy stays with the rank that read those columns
-                with torch.cuda.stream(comm):
-                    t.wait(comm)                         # only the comm stream waits for the slot's compute
-                    h = sd.gather_columns(outs[slot][..., 3], samples, dst=0, async_op=True)
-                    packed = torch.cuda.Event()
-                    packed.record(comm)
-                pending[slot] = (h, packed)
+                # the single RCCL gather of the score image: the float64 CMF band of every rank's block,
+                # 8 B/pixel; the RGB copy stays with the rank that read those columns.  Enqueued on the SLOT's own stream,
+                # behind its flightline: the other slots' flightlines run beside it, and no stream waits on another one's
+                # event -- a cross-stream fence per step (the first version packed and gathered on a communication stream)
+                # costs 0.65 ms of a 1.65 ms shard step on this stack (tools/gather_host_probe.py)
+                with torch.cuda.stream(st):
+                    pending[slot] = sd.gather_columns(outs[slot][..., 3], samples, dst=0, async_op=True)
             state["res"] = t.result
 
         def drain():
-            with torch.cuda.stream(comm):
-                for i in range(depth):
-                    if pending[i] is not None:
-                        pending[i][0].wait()
-                        pending[i] = None
-            comm.synchronize()
+            for i in range(depth):
+                if pending[i] is not None:
+                    with torch.cuda.stream(pipe.streams[i]):
+                        pending[i].wait()
+                    pending[i] = None
             pipe.synchronize()
 
         for _ in range(depth):                   # setup, not warmup: every slot allocates its scratch once

@@ -36,13 +36,13 @@ def _assemble(recv, shape, axis, samples, world, as_int16):
     import torch
     if recv is None:
         return None
-    # one pass: every rank's [ncols_r, ...] block is written straight into its column range of the final layout
-    full_shape = list(shape)
+    # one pass: every rank's block (padded along the column axis) is written straight into its column range
+    full_shape = list(recv[0].shape)
     full_shape[axis] = samples
     full = torch.empty(full_shape, dtype=recv[0].dtype, device=recv[0].device)
     for r in range(world):
         a, b = shard_columns(samples, world, r)
-        full.narrow(axis, a, b - a).copy_(recv[r][:b - a].movedim(0, axis))
+        full.narrow(axis, a, b - a).copy_(recv[r].narrow(axis, 0, b - a))
     return full.view(torch.int16) if as_int16 else full
 
 
@@ -74,10 +74,14 @@ def gather_columns(block, samples: int, *, axis=None, group=None, dst: int = 0, 
     if block.shape[axis] != b - a:
         raise ValueError("rank %d holds columns [%d, %d) but the block has %d along axis %d"
                          % (rank, a, b, block.shape[axis], axis))
-    x = block.movedim(axis, 0)                                                           # -> [ncols_r, ...]
+    # the block padded ALONG its column axis to the largest shard (no transposition: plain strided copies on both sides)
     maxc = max(b - a for a, b in (shard_columns(samples, world, r) for r in range(world)))
-    send = torch.zeros((maxc,) + tuple(x.shape[1:]), dtype=block.dtype, device=block.device)
-    send[:x.shape[0]].copy_(x)
+    shp = list(block.shape)
+    shp[axis] = maxc
+    send = torch.empty(shp, dtype=block.dtype, device=block.device)
+    send.narrow(axis, 0, b - a).copy_(block)
+    if b - a < maxc:
+        send.narrow(axis, b - a, maxc - (b - a)).zero_()
     recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     work = dist.gather(send, recv, dst=dst, group=group, async_op=async_op)
     h = GatherHandle(work if async_op else None, send, recv, (tuple(block.shape), axis, samples, world, as_int16))

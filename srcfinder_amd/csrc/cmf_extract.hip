@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_extract(const float *__restrict__ cube,
 __device__ __forceinline__ void xt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // (152 VGPRs: three workgroups per CU; forcing four -- 128 VGPRs -- spills and is slower: 1.96 against 1.43 ms)
-template <int TL, int P>
+template <int TL, int P, bool NTS = false>
 __global__ __launch_bounds__(256) void k_extract_pipe(const float *__restrict__ cube, int L, int B, int C, int s0,
                                                        int Cs, int b0, int PS, float *__restrict__ xt,
                                                        uint8_t *__restrict__ mask_t, int lines_per_wg, int cs, int ncb,
@@ -217,7 +217,10 @@ __global__ __launch_bounds__(256) void k_extract_pipe(const float *__restrict__ 
         for (int j = 0; j < NST; ++j) r[j] = src[min(lane + 64 * j, nel - 1)];   // the LDS reads first, then the stores
 #pragma unroll
         for (int j = 0; j < NST; ++j)
-          if (lane + 64 * j < nel) dst[lane + 64 * j] = r[j];
+          if (lane + 64 * j < nel) {
+            if (NTS) __builtin_nontemporal_store(r[j], dst + lane + 64 * j);
+            else dst[lane + 64 * j] = r[j];
+          }
       }
     } else {
       for (int c = wave; c < ncol; c += 4) {
@@ -524,6 +527,10 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
     if (tl == 3) {
       if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_pipe<3, 72>), ldsx)) return rc;
       hipLaunchKernelGGL((k_extract_pipe<3, 72>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), ldsx, st, cube, lines, bands, samples,
+                         s0, ncols, b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);
+    } else if (!sf_tune().extract_nt) {     // non-temporal xt stores (3.4 GB, re-read only after the whole pass): -0.08 ms alone, same bits
+      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_pipe<4, 72, true>), ldsx)) return rc;
+      hipLaunchKernelGGL((k_extract_pipe<4, 72, true>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), ldsx, st, cube, lines, bands, samples,
                          s0, ncols, b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);
     } else {
       if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_pipe<4, 72>), ldsx)) return rc;

@@ -13,8 +13,8 @@ lines, samples = 20000, 598
 cube = make_cube_torch(lines, samples, seed=1234, abscf_full=lib[:, 2], device="cuda", nodata_column=199)
 L = _ffi.lib()
 ref = None
-for var in (5, 3, 0, 5):
-    L.sf_debug_set(6, var)
+for var in (5, 3, 0, 5, 100):
+    L.sf_debug_set(6, 0 if var == 100 else var); L.sf_debug_set(19, 1 if var == 100 else 0)   # 100 = four-line tiles with PLAIN stores (default: non-temporal)
     r = cmf.robust_mf(cube, lib)          # warm
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -28,12 +28,12 @@ for var in (5, 3, 0, 5):
     if ref is None:
         ref = key
     print("extract variant %d: %.3f ms per flightline (one in flight)%s" % (var, a.elapsed_time(b) / 5, same), flush=True)
-L.sf_debug_set(6, 0)
+L.sf_debug_set(6, 0); L.sf_debug_set(19, 0)
 
 # three flightlines in flight (the bench's headline mode)
 from srcfinder_amd.inflight import FlightlinePipeline
-for var in (5, 0, 5, 0):
-    L.sf_debug_set(6, var)
+for var in (0, 100, 0, 100):
+    L.sf_debug_set(6, 0); L.sf_debug_set(19, 1 if var == 100 else 0)
     pipe = FlightlinePipeline(3)
     outs = [torch.empty((lines, samples, 4), dtype=torch.float64, device="cuda") for _ in range(3)]
     for i in range(6):

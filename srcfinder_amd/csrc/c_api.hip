@@ -312,6 +312,7 @@ int sf_debug_set(int key, int value) {
     case 17: sf_tune().cnn_conv_variant = value; return 0;
     case 18: sf_tune().cnn_pool_variant = value; return 0;
     case 19: sf_tune().extract_nt = value; return 0;
+    case 20: sf_tune().sweep4_form = value; return 0;
     default: sf_set_error("sf_debug_set: unknown key %d", key); return -1;
   }
 }

@@ -680,6 +680,375 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_sweep4s: the rank-factored sweep of k_sweep4r as ONE hand-scheduled instruction stream per 16-row tile (round 3).
+// Same three products, same accumulation order inside every chain (GEMM1: band steps ascending, GEMM2a: eigen groups
+// ascending, GEMM2b: factor groups ascending), but
+//   * every MFMA operand that comes from LDS travels through one register ring filled by in-order asm reads that run a
+//     fixed number of reads AHEAD of their use across phase boundaries, awaited with counted s_waitcnt lgkmcnt(N) --
+//     k_sweep4r waited for lgkmcnt(0) at each of its 18 + 18 band / eigen steps with the last read issued two MFMAs
+//     earlier (an LDS round trip exposed 36 times per tile);
+//   * operands of two consecutive MFMAs sit side by side in LDS and arrive as one ds_read_b128 (234 + 42 + 7 reads per
+//     tile instead of 541);
+//   * the tile prologue is branch-free: the column mean comes in nine unconditional 16-byte reads (k_sweep4r's
+//     `rowok ? x - mu : 0` compiled to 18 exec-masked blocks, each an LDS read + lgkmcnt(0)), the next tile's rows are
+//     fetched from an address that does not depend on the validity byte (which k_sweep4r loaded and WAITED for before
+//     it could issue the row loads), and an invalid row is switched off where the data is narrowest: its 7 (9) values
+//     of t are set to 0, so q = 1 exactly as with x = 0 (a NaN row stays inside its own column of every product);
+//   What it does NOT do is get rid of the vector instructions, and they are what is left: on gfx950 every VALU instruction
+//   issued beside the 4x4x4 fp64 MFMA stream costs ~6 cycles of matrix time even with two waves per SIMD
+//   (tools/microbench/mix4w.hip: 3 VALU per 8 MFMA take the pipe from 72 to 56 TFLOP/s -- this kernel's rate; LDS reads,
+//   s_waitcnt and s_nop are free).  Measured by leaving a class out (SF_SWEEP_EXPERIMENTS, results wrong, MFMAs kept):
+//   the row reduction (221 of the 323) 0.40 ms, conversion + centring (36) 0.19 ms, the 42 DPP moves 0.05 ms, squares
+//   and validity selects 0.03 + 0.05 ms; with every one of them gone the launch is 4.9 ms, not 4.2: profiles/r03_sweep_ablation.txt.
+//   (The hardware's A-block broadcast -- cbsz / abid, which would replace the three DPP-rotated copies of t -- assembles
+//   for v_mfma_f64_4x4x4_4b_f64 but is ignored by gfx950: tools/microbench/mfma4_layout.hip modes 1-3.)
+template <int NK>
+struct SwS {
+  static constexpr int NJ = S4J, NM = S4M, NKP = (NK + 1) / 2, NG = NM / 4;   // NG full groups of 4 alpha tiles + one tile
+  static constexpr int R1 = NJ * (NJ / 2);   // W block pairs (GEMM1 A operands), ds_read_b128
+  static constexpr int R2 = NJ * NKP;        // -U block pairs (GEMM2a A operands), ds_read_b128 (odd NK: last pair half empty)
+  static constexpr int R3 = NG * NK * 2;     // W fragment pairs of the full alpha-tile groups (GEMM2b B operands), ds_read_b128
+  static constexpr int R4 = NK;              // W fragments of the 13th alpha tile, ds_read_b64
+  static constexpr int NR = R1 + R2 + R3 + R4;
+  static constexpr int LEAD12 = 8, LEAD3 = 4, RING = 10;
+  static_assert(NM == 4 * NG + 1 && NJ % 2 == 0, "tile structure");
+  static constexpr int lead(int c) { return c < R1 + R2 ? LEAD12 : LEAD3; }
+  // reads issued when unit c (= read c and the MFMAs it feeds) is awaited
+  static constexpr int issued(int c) {
+    int m = 0;
+    for (int i = 0; i <= c; ++i) {
+      int t = i + lead(i);
+      if (t > NR) t = NR;
+      if (t > m) m = t;
+    }
+    return m;
+  }
+  // LDS layout (doubles)
+  static constexpr int OW = 0;                               // [R1][16][2]
+  static constexpr int OU = OW + R1 * 32;                    // [R2][16][2]
+  static constexpr int OF = OU + R2 * 32;                    // [R3][64][2]
+  static constexpr int OL = OF + R3 * 128;                   // [R4][64]
+  static constexpr int OM = OL + R4 * 64;                    // mu [72]
+  static constexpr int TOTAL = OM + 4 * NJ;
+  static constexpr size_t lds_bytes() { return (size_t)TOTAL * sizeof(double); }
+};
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ d2_t lds_ld128(unsigned addr) {
+  d2_t r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ double lds_ld64(unsigned addr) {
+  double r;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int CNT>
+__device__ __forceinline__ void lds_await(d2_t &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+template <int CNT>
+__device__ __forceinline__ void lds_await(d2_t &a, d2_t &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT)); }
+template <int CNT>
+__device__ __forceinline__ void lds_await(double &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+template <int CNT>
+__device__ __forceinline__ void lds_await9(d2_t (&m)[9]) {
+  asm volatile("s_waitcnt lgkmcnt(%9)"
+               : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8])
+               : "n"(CNT));
+}
+
+// EXP (timing experiments, wrong results, -DSF_SWEEP_EXPERIMENTS): bit 0 no row reduction, 1 no conversion / centring,
+// 2 no DPP rotations, 3 no squares, 4 no validity selects -- the MFMAs and LDS reads stay
+template <int NK, int EXP = 0>
+__global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+                                                    const int32_t *__restrict__ nuse, const double *__restrict__ mu,
+                                                    const double *__restrict__ ufrag_g, const double *__restrict__ wfrag2_g,
+                                                    const int32_t *__restrict__ lrok, const double *__restrict__ lam,
+                                                    const double *__restrict__ wfrag,
+                                                    size_t wstride, const int32_t *__restrict__ status,
+                                                    const double *__restrict__ alphas, int nalpha, int L, int p,
+                                                    int PS, int rows_per_wg, double *__restrict__ part) {
+  using S = SwS<NK>;
+  constexpr int NJ = S::NJ, NM = S::NM, NA16 = NM * 16, NW = 8, NKP = S::NKP, NG = S::NG;
+  constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, NR = S::NR, RING = S::RING;
+  constexpr int NK2 = SF_LR_K2 / 4;          // stride of the global fragment layout (shared by both ranks)
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  double *po = part + ((size_t)c * nsplit + split) * 2 * NA16;
+  if (status[c] != 0 || lrok[c] != (NK == SF_LR_K / 4 ? 1 : 2)) return;   // another instantiation / k_sweep4 takes these columns
+  // ---- prologue: the tables, permuted into the pair layouts
+  {
+    double *mus = sm + S::OM;
+    // W blocks scaled by 1/sqrt(lam_j): GEMM1 then yields the whitened coordinates y_j/sqrt(lam_j) (unit variance) and
+    // z their squares, which is what the row-scaled factorisation of cmf_lowrank.hip multiplies
+    for (int i = tid; i < 4 * NJ; i += 64 * NW) mus[i] = (i < p) ? 1.0 / sqrt(lam[(size_t)c * p + i]) : 1.0;   // (mus: scratch here)
+    __syncthreads();
+    {
+      const double *wsrc = wfrag + (size_t)c * wstride;   // [(s*18 + jg)*16 + 4q + n]
+      for (int i = tid; i < NJ * NJ * 16; i += 64 * NW) {
+        const int blk = i >> 4, sl = i & 15, s = blk / NJ, jg = blk - s * NJ;
+        sm[S::OW + ((s * (NJ / 2) + (jg >> 1)) * 16 + sl) * 2 + (jg & 1)] = wsrc[i] * mus[4 * jg + (i & 3)];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * NJ; i += 64 * NW) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
+    {
+      const double *us = ufrag_g + (size_t)c * (NJ * NK2 * 16);   // [(jg*NK2 + mg)*16 + 4q + n]
+      for (int i = tid; i < NJ * NKP * 32; i += 64 * NW) {
+        const int h = i & 1, sl = (i >> 1) & 15, pr = i >> 5, jg = pr / NKP, mg = 2 * (pr - jg * NKP) + h;
+        sm[S::OU + i] = (mg < NK) ? us[(jg * NK2 + mg) * 16 + sl] : 0.0;
+      }
+      const double *ws = wfrag2_g + (size_t)c * (NM * NK2 * 64);   // [(M*NK2 + mg)*64 + lane]
+      for (int i = tid; i < R3 * 128; i += 64 * NW) {
+        const int kk = i & 1, ln = (i >> 1) & 63, r = i >> 7;        // r = (gr*NK + mg)*2 + h
+        const int h = r & 1, gm = r >> 1, gr = gm / NK, mg = gm - gr * NK, M = 4 * gr + 2 * h + kk;
+        sm[S::OF + i] = ws[(M * NK2 + mg) * 64 + ln];
+      }
+      for (int i = tid; i < NK * 64; i += 64 * NW) sm[S::OL + i] = ws[((NM - 1) * NK2 + (i >> 6)) * 64 + (i & 63)];
+    }
+  }
+  __syncthreads();
+
+  double P[NM], N[NM];
+  int E[NM], sg[NM];   // sg: OR of the sign words of every q seen (a negative q makes log(q), hence the NLL, NaN in the reference)
+#pragma unroll
+  for (int u = 0; u < NM; ++u) { P[u] = 1.0; N[u] = 0.0; E[u] = 0; sg[u] = 0; }
+  int ntile = 0;
+  int nrowok = 0;   // valid rows seen by this lane (lanes with g == 0 cover every row of the wave's tiles once)
+
+  const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
+  const uint8_t *mp = mask_t + (size_t)c * L;
+  const float *xc = xt + (size_t)c * L * PS + NJ * g;
+  const unsigned smb = (unsigned)(size_t)sm;
+  const unsigned wadr = smb + S::OW * 8 + (4 * g + (lane & 3)) * 16;
+  const unsigned uadr = smb + S::OU * 8 + (4 * g + (lane & 3)) * 16;
+  const unsigned fadr = smb + S::OF * 8 + lane * 16;
+  const unsigned ladr = smb + S::OL * 8 + lane * 8;
+  const unsigned madr = smb + S::OM * 8 + g * (NJ * 8);
+  const double qnan = __builtin_nan("");
+
+  float xraw[NJ];
+  bool rowok_next;
+  auto fetch = [&](int r0, float (&dst)[NJ], bool &ok) {
+    const int row = r0 + li, rowc = row < rend ? row : rend - 1;   // the address does not depend on the validity byte
+    ok = (mp[rowc] != 0) && (row < rend);
+    const float *xp = xc + (size_t)rowc * PS;
+#pragma unroll
+    for (int s = 0; s < NJ; s += 2) sf_load2(xp + s, dst[s], dst[s + 1]);
+  };
+  int r0 = rbeg + 16 * wave;
+  if (r0 < rend) fetch(r0, xraw, rowok_next);
+
+  for (; r0 < rend; r0 += 16 * NW) {
+    const bool rowok = rowok_next;
+    nrowok += (rowok && g == 0) ? 1 : 0;
+    d2_t ring[RING];
+    double ringl[RING];
+    double x[NJ], z[NJ], t[4][NK], acc[4][4];
+    d2_t mur[NJ / 2];
+    auto issue = [&](auto rc) {   // read r of the tile's stream into its ring slot
+      constexpr int r = decltype(rc)::value;
+      if constexpr (r < R1) ring[r % RING] = lds_ld128<r * 256>(wadr);
+      else if constexpr (r < R1 + R2) ring[r % RING] = lds_ld128<(r - R1) * 256>(uadr);
+      else if constexpr (r < R1 + R2 + R3) ring[r % RING] = lds_ld128<(r - R1 - R2) * 1024>(fadr);
+      else ringl[r % RING] = lds_ld64<(r - R1 - R2 - R3) * 512>(ladr);
+    };
+    auto cvt = [&](auto sc) {     // x[s] = row value - column mean  (fp64, as the reference centres)
+      constexpr int s = decltype(sc)::value;
+      double v = (double)xraw[s] - ((s & 1) ? mur[s >> 1].y : mur[s >> 1].x);
+      if constexpr ((EXP & 2) != 0) {
+        v = (s & 1) ? mur[s >> 1].y : mur[s >> 1].x;
+        asm volatile("" :: "v"(xraw[s]));
+      }
+      if constexpr (3 * NJ + s >= 4 * NJ - 3) v = (NJ * g + s < p) ? v : 0.0;   // p >= 69: only bands 69..71 can lie beyond the window
+      x[s] = v;
+    };
+    static_for<0, NJ / 2>([&](auto ic) { mur[decltype(ic)::value] = lds_ld128<decltype(ic)::value * 16>(madr); });
+    static_for<0, S::issued(0)>(issue);
+    lds_await9<S::issued(0)>(mur);
+    cvt(std::integral_constant<int, 0>{});
+    cvt(std::integral_constant<int, 1>{});
+
+    // Row reduction of alpha tile u from acc[k][0..3] (the q of 4 rows), in four stages of independent instructions:
+    //   m = q0 q1 q2 q3,  nu = (q0+q1) q2 q3 + (q2+q3) q0 q1  (= m sum 1/q_s),  N <- N m + nu P,  P <- P m  (P: mantissa, exponent in E)
+    double rm01[4], rm23[4], rs01[4], rs23[4], rm[4], rnu[4];
+    auto reduce_stage = [&](auto grc, auto stagec) {
+      constexpr int gq = decltype(grc)::value, stage = decltype(stagec)::value;
+      constexpr int ntl = (NM - gq * 4) < 4 ? (NM - gq * 4) : 4;
+#pragma unroll
+      for (int k = 0; k < ntl; ++k) {
+        const int u = gq * 4 + k;
+        if constexpr (stage == 0) {
+          const double q0 = acc[k][0], q1 = acc[k][1], q2 = acc[k][2], q3 = acc[k][3];
+          rm01[k] = q0 * q1; rm23[k] = q2 * q3; rs01[k] = q0 + q1; rs23[k] = q2 + q3;
+          int sw = sg[u];                                        // any q < 0 so far (two v_or3_b32)
+          sw = (sw | __double2hiint(q0)) | __double2hiint(q1);
+          sg[u] = (sw | __double2hiint(q2)) | __double2hiint(q3);
+        } else if constexpr (stage == 1) {
+          rm[k] = rm01[k] * rm23[k];
+          rnu[k] = __builtin_fma(rs01[k], rm23[k], rs23[k] * rm01[k]);
+        } else if constexpr (stage == 2) {
+          N[u] = __builtin_fma(N[u], rm[k], rnu[k] * P[u]);   // N m + nu P
+          P[u] = P[u] * rm[k];                                // P m
+        } else {
+          const int e = __builtin_amdgcn_frexp_exp(P[u]);
+          P[u] = __builtin_amdgcn_frexp_mant(P[u]);
+          N[u] = __builtin_amdgcn_ldexp(N[u], -e);
+          E[u] += e;
+        }
+      }
+    };
+    auto reduce_group = [&](auto grc) {
+      if constexpr ((EXP & 1) != 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) asm volatile("" :: "v"(acc[k][q]));
+        return;
+      }
+      static_for<0, 4>([&](auto sc) { reduce_stage(grc, sc); });
+    };
+
+    static_for<0, NR>([&](auto cc) {
+      constexpr int u = decltype(cc)::value;   // unit = read u + the MFMAs it feeds
+      constexpr int slot = u % RING;
+      constexpr bool pairwait = (u < R1 + R2);                                  // phases 1, 2: one wait per two units
+      if constexpr (!pairwait || (u & 1) == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (u >= R1 + R2 + R3) lds_await<S::issued(u) - u - 1>(ringl[slot]);
+        else if constexpr (!pairwait) lds_await<S::issued(u) - u - 1>(ring[slot]);
+        else lds_await<S::issued(u) - u - 2>(ring[slot], ring[(u + 1) % RING]);   // R1, R2 are even: u + 1 is in the same phase
+      }
+      if constexpr (u < R1) {
+        constexpr int s = u / (NJ / 2), jg = 2 * (u % (NJ / 2));
+        if constexpr (s == 0) {
+          z[jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].x, x[s], 0.0, 0, 0, 0);
+          z[jg + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].y, x[s], 0.0, 0, 0, 0);
+        } else {
+          z[jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].x, x[s], z[jg], 0, 0, 0);
+          z[jg + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].y, x[s], z[jg + 1], 0, 0, 0);
+        }
+        if constexpr (jg == 0 && s + 2 < NJ) cvt(std::integral_constant<int, s + 2>{});   // two band steps ahead
+        if constexpr (u == (NJ - 2) * (NJ / 2)) {   // every raw value is converted: the next tile's rows may land in xraw
+          if (r0 + 16 * NW < rend) fetch(r0 + 16 * NW, xraw, rowok_next);
+        }
+        if constexpr (u == R1 - 1 && (EXP & 8) == 0) z[0] = z[0] * z[0];
+      } else if constexpr (u < R1 + R2) {
+        constexpr int v = u - R1, jg = v / NKP, mg = 2 * (v % NKP);
+        if constexpr (jg == 0) {
+          t[0][mg] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].x, z[jg], 0.0, 0, 0, 0);
+          if constexpr (mg + 1 < NK) t[0][mg + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].y, z[jg], 0.0, 0, 0, 0);
+        } else {
+          t[0][mg] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].x, z[jg], t[0][mg], 0, 0, 0);
+          if constexpr (mg + 1 < NK) t[0][mg + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].y, z[jg], t[0][mg + 1], 0, 0, 0);
+        }
+        if constexpr (mg == 2 && jg + 1 < NJ && (EXP & 8) == 0) z[jg + 1] = z[jg + 1] * z[jg + 1];   // the square the next eigen group multiplies
+        if constexpr (u == R1 + R2 - 1) {   // an invalid row leaves every q of the tile at 1
+          if constexpr ((EXP & 16) == 0) {
+#pragma unroll
+            for (int m = 0; m < NK; ++m) t[0][m] = rowok ? t[0][m] : 0.0;
+          }
+#pragma unroll
+          for (int m = 0; m < NK; ++m) {   // block m of rotation s meets row group (m + s) % 4
+            if constexpr ((EXP & 4) != 0) {
+              t[1][m] = t[2][m] = t[3][m] = t[0][m];
+            } else {
+              t[1][m] = dpp_row<0x124>(t[0][m]);  // row_ror:4
+              t[2][m] = dpp_row<0x128>(t[0][m]);  // row_ror:8
+              t[3][m] = dpp_row<0x12C>(t[0][m]);  // row_ror:12
+            }
+          }
+        }
+      } else if constexpr (u < R1 + R2 + R3) {
+        constexpr int v = u - R1 - R2, h = v & 1, gm = v >> 1, gr = gm / NK, jg = gm - gr * NK;
+        static_for<0, 2>([&](auto kc) {
+          constexpr int kk = decltype(kc)::value, k = 2 * h + kk;
+          const double b = kk ? ring[slot].y : ring[slot].x;
+          static_for<0, 4>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (jg == 0 && (EXP & 4) != 0)   // distinct chains although the four A operands are the same register
+              acc[k][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(t[s][jg], b, s == 0 ? 1.0 : (s == 1 ? 2.0 : (s == 2 ? 0.5 : 4.0)), 0, 0, 0);
+            else if constexpr (jg == 0) acc[k][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(t[s][jg], b, 1.0, 0, 0, 0);
+            else acc[k][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(t[s][jg], b, acc[k][s], 0, 0, 0);
+          });
+        });
+        if constexpr (h == 1 && jg == NK - 1) reduce_group(std::integral_constant<int, gr>{});   // the group is complete
+      } else {
+        constexpr int jg = u - R1 - R2 - R3;
+        static_for<0, 4>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          if constexpr (jg == 0 && (EXP & 4) != 0)
+            acc[0][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(t[s][jg], ringl[slot], s == 0 ? 1.0 : (s == 1 ? 2.0 : (s == 2 ? 0.5 : 4.0)), 0, 0, 0);
+          else if constexpr (jg == 0) acc[0][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(t[s][jg], ringl[slot], 1.0, 0, 0, 0);
+          else acc[0][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(t[s][jg], ringl[slot], acc[0][s], 0, 0, 0);
+        });
+        if constexpr (jg == NK - 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          reduce_group(std::integral_constant<int, NG>{});
+        }
+      }
+      // keep the ring `lead` reads ahead
+      if constexpr (u + 1 < NR) static_for<S::issued(u), S::issued(u + 1)>(issue);
+    });
+    ntile += 1;
+  }
+
+  __syncthreads();
+  double *redP = sm;
+  double *redR = redP + NW * NA16;
+  int *redE = reinterpret_cast<int *>(redR + NW * NA16);
+#pragma unroll
+  for (int u = 0; u < NM; ++u) {
+    double pv = P[u], rv = N[u] / P[u] - 4.0 * (double)ntile;   // sum over this lane's rows of (1/q - 1) = beta r/q
+    if (sg[u] < 0) rv = qnan;                                      // applied once, here, instead of per 16-row tile
+    int ev = E[u];
+#pragma unroll
+    for (int msk = 16; msk <= 32; msk <<= 1) {
+      const double po2 = shfl_xor_d(pv, msk);
+      const int eo = __shfl_xor(ev, msk, 64);
+      rv += shfl_xor_d(rv, msk);
+      const double pm = pv * po2;
+      ev += eo + __builtin_amdgcn_frexp_exp(pm);
+      pv = __builtin_amdgcn_frexp_mant(pm);
+    }
+    if (g == 0) {
+      redP[wave * NA16 + 16 * u + li] = pv;
+      redR[wave * NA16 + 16 * u + li] = rv;
+      redE[wave * NA16 + 16 * u + li] = ev;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < NA16; i += 64 * NW) {
+    double pv = 1.0, rv = 0.0;
+    int ev = 0;
+    for (int w = 0; w < NW; ++w) {
+      const double pm = pv * redP[w * NA16 + i];
+      ev += redE[w * NA16 + i] + __builtin_amdgcn_frexp_exp(pm);
+      pv = __builtin_amdgcn_frexp_mant(pm);
+      rv += redR[w * NA16 + i];
+    }
+    po[i] = log(pv) + (double)ev * 0.6931471805599453094;
+    po[NA16 + i] = rv;   // = beta_i sum_k r_k/q_k: k_nll divides (rq_scaled = 1)
+  }
+  // the number of rows this workgroup accumulated, for the beta = 0 term of k_nll: kept in the last padding slot
+  // of the alpha axis (the grid has 201 points, the tiles 208)
+  __syncthreads();
+  int *cred = reinterpret_cast<int *>(sm);
+  for (int off = 32; off > 0; off >>= 1) nrowok += __shfl_xor(nrowok, off, 64);
+  if (lane == 0) cred[wave] = nrowok;
+  __syncthreads();
+  if (tid == 0 && nalpha < NA16) {
+    int tot = 0;
+    for (int w = 0; w < NW; ++w) tot += cred[w];
+    po[2 * NA16 - 1] = (double)tot;
+  }
+}
+
 constexpr size_t sw4r_lds(int nk) { return ((size_t)S4M * nk * 64 + S4J * S4J * 16 + S4J * nk * 16 + 4 * S4J) * sizeof(double); }
 constexpr size_t SW4_LDS = ((size_t)S4M * S4J * 64 + S4J * S4J * 16 + 4 * S4J) * sizeof(double);
 
@@ -706,6 +1075,21 @@ int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
   int rows = sf_cdiv(g.lines, nsplit);
   rows = (rows + 127) / 128 * 128;
 #define SW4R_ARGS xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part
+  const int form = sf_tune().sweep4_form;
+  if (form != 1) {   // the streamed kernel (round 3) for rank 28; rank 36 keeps k_sweep4r (four t copies of 9 do not fit 256 registers)
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK1>), SwS<NK1>::lds_bytes())) return rc;
+    if (form == 0) hipLaunchKernelGGL((k_sweep4s<NK1>), dim3(g.ncols, nsplit), dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS);
+#ifdef SF_SWEEP_EXPERIMENTS
+#define SW4S_EXP(E) if (form == 100 + E) { \
+      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK1, E>), SwS<NK1>::lds_bytes())) return rc; \
+      hipLaunchKernelGGL((k_sweep4s<NK1, E>), dim3(g.ncols, nsplit), dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS); }
+    SW4S_EXP(1) SW4S_EXP(2) SW4S_EXP(4) SW4S_EXP(5) SW4S_EXP(8) SW4S_EXP(16) SW4S_EXP(31)
+#endif
+    SF_LAUNCH_CHECK("k_sweep4s");
+    hipLaunchKernelGGL((k_sweep4r<0, 4, NK2>), dim3(g.ncols, nsplit), dim3(256), sw4r_lds(NK2), st, SW4R_ARGS);
+    SF_LAUNCH_CHECK("k_sweep4r");
+    return 0;
+  }
   if (sf_tune().sweep4r_waves == 4)
     hipLaunchKernelGGL((k_sweep4r<0, 4, NK1>), dim3(g.ncols, nsplit), dim3(256), sw4r_lds(NK1), st, SW4R_ARGS);
   else

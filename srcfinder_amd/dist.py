@@ -3,7 +3,8 @@
 Cross-track columns are independent in the reference's loop (``for col in arange(ncols)``,
 cmf/robust_mf.py:297), so rank r processes the contiguous sample range ``shard_columns(samples, world, r)``
 with exactly the arithmetic of a single-GPU run (results are bit-identical for every column), and the only
-exchange is ONE gather of the finished blocks to the destination rank: ``torch.distributed.gather`` on the
+exchange is ONE gather of the finished score blocks to the destination rank (``gather_columns``; the library call
+``robust_mf_sharded`` that also returns the per-column records and the metadata image packs them into two): ``torch.distributed.gather`` on the
 ``nccl`` backend is RCCL over xGMI; every peer sends its block straight to the root (7 links in parallel,
 <= 48 MB per rank for the float64 4-band product of a 598 x 20000 flightline).  The helper is backend
 agnostic -- the CPU tests drive it with ``gloo``.
@@ -92,26 +93,99 @@ def gather_columns(block, samples: int, *, axis=None, group=None, dst: int = 0, 
 _COLUMN_AXIS = {"out": 1, "bgmeta": 1, "labels": 1, "colstats": 1, "alphaidx": 0, "nuse": 0, "status": 0, "nll": 0}
 
 
+def _as_bytes3(v, axis, lead):
+    """``v`` as a uint8 tensor [lead, ncols_r, bytes]: its column axis in the middle, everything behind it (and the
+    element bytes) folded into the last axis.  ``lead`` is the leading extent shared by the fields of one packed
+    exchange (the line count of the image fields; 1 for per-column records, whose column axis is moved to the front)."""
+    import torch
+    v = v if torch.is_tensor(v) else torch.as_tensor(np.ascontiguousarray(v))
+    if lead == 1:
+        v = v.movedim(axis, 0).contiguous()
+        nc = v.shape[0]
+        return v.view(torch.uint8).reshape(1, nc, -1), tuple(v.shape[1:]), v.dtype
+    assert axis == 1 and v.shape[0] == lead
+    v = v.contiguous()
+    nc = v.shape[1]
+    return v.view(torch.uint8).reshape(lead, nc, -1), tuple(v.shape[2:]), v.dtype
+
+
+def gather_packed(fields, samples: int, *, lead: int = 1, group=None, dst: int = 0):
+    """ONE collective for several per-rank column blocks: ``fields`` maps a name to ``(block, column axis)``; every block
+    becomes a byte slab ``[lead, ncols_r, bytes]`` (``_as_bytes3``), the slabs are concatenated along the byte axis, padded
+    to the largest shard along the column axis and gathered once; ``dst`` gets ``{name: full array}`` (``None`` elsewhere).
+    ``lead`` > 1 packs image-like fields ``[lines, ncols_r, ...]`` without transposing them (lead = lines); ``lead`` = 1
+    packs per-column records (alpha indices, counts, statuses, column statistics, NLL curves).
+    The consumers' layout is the reference's product / metadata image pair (``srcfinder_util.py:1624-1635``)."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    a, b = shard_columns(samples, world, rank)
+    slabs, layout = [], []
+    for name, (v, axis) in fields.items():
+        sl, rest, dtype = _as_bytes3(v, axis, lead)
+        if sl.shape[1] != b - a:
+            raise ValueError("rank %d holds columns [%d, %d) but %s has %d of them" % (rank, a, b, name, sl.shape[1]))
+        slabs.append(sl)
+        layout.append((name, axis, rest, dtype, sl.shape[2]))
+    maxc = max(q - p for p, q in (shard_columns(samples, world, r) for r in range(world)))
+    width = sum(l[4] for l in layout)
+    send = torch.zeros((lead, maxc, width), dtype=torch.uint8, device=slabs[0].device)
+    off = 0
+    for sl in slabs:
+        send[:, :b - a, off:off + sl.shape[2]].copy_(sl)
+        off += sl.shape[2]
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    full = torch.empty((lead, samples, width), dtype=torch.uint8, device=send.device)
+    for r in range(world):
+        p, q = shard_columns(samples, world, r)
+        full[:, p:q].copy_(recv[r][:, :q - p])
+    out, off = {}, 0
+    for name, axis, rest, dtype, nb in layout:
+        v = full[:, :, off:off + nb].contiguous().view(dtype)
+        off += nb
+        if lead == 1:
+            out[name] = v.reshape((samples,) + rest).movedim(0, axis).contiguous()
+        else:
+            out[name] = v.reshape((lead, samples) + rest)
+    return out
+
+
 def robust_mf_sharded(cube_shard, library, samples: int, *, group=None, dst: int = 0, compute=None, **kw):
     """Run the matched filter on this rank's column slice ``cube_shard`` [lines, bands, ncols_r] and gather.
 
     Returns on ``dst`` a dict with the full ``out`` [lines, samples, nb], ``alphaidx``, ``nuse``, ``status``
     [samples] ([samples, k] for alphaidx / status of a multimodal run), ``colstats`` [3, samples] (and ``bgmeta``,
     ``labels`` [lines, samples], ``nll`` when the run produced them); ``None`` elsewhere.
+    TWO collectives whatever the run produced (``gather_packed``): the image-like fields (product, background metadata,
+    labels) as one byte slab per rank, the per-column records as a second, small one.
     ``compute`` defaults to :func:`srcfinder_amd.cmf.robust_mf`; tests inject a CPU stand-in to exercise the
     sharding and the collective without a GPU.
     """
+    import torch.distributed as dist
     if compute is None:
         from .cmf import robust_mf as compute
     res = compute(cube_shard, library, **kw)
-    fields = {}
+    get = (lambda n: res.get(n)) if isinstance(res, dict) else (lambda n: getattr(res, n, None))
+    lines = get("out").shape[0]
+    images, records = {}, {}
     for name, axis in _COLUMN_AXIS.items():
-        v = getattr(res, name, None) if not isinstance(res, dict) else res.get(name)
+        v = get(name)
         if v is None:
             continue
-        fields[name] = gather_columns(v, samples, axis=axis, group=group, dst=dst)
-    import torch.distributed as dist
-    return fields if dist.get_rank(group) == dst else None
+        if axis == 1 and v.ndim >= 2 and v.shape[0] == lines and name != "colstats":
+            images[name] = (v, axis)
+        else:
+            records[name] = (v, axis)
+    full = gather_packed(images, samples, lead=lines, group=group, dst=dst)
+    rec = gather_packed(records, samples, lead=1, group=group, dst=dst)
+    if dist.get_rank(group) != dst:
+        return None
+    full.update(rec)
+    return full
 
 
 # ------------------------------------------------------------------------------------------------------

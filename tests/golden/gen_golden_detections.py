@@ -3,8 +3,10 @@
 
 Only runs in the development container (needs /root/reference).  ``salience_predictions.py`` is run unmodified as
 ``__main__`` (its ``salience2detections`` reads a global of the script body) with the real ``srcfinder_util``
-(``extrema``, ``findobj``, ``sl2latlon`` / ``sl2xy``, ``mapinfo``; the UTM -> lat/lon conversion itself is a third-party
-module that is absent: its stand-in returns the map coordinates it is given); stand-ins: the file reader (``openimgmm`` hands over
+(``extrema``, ``findobj``, ``sl2latlon`` / ``sl2xy`` / ``rotxy`` / ``utm2latlon``, ``mapinfo``; the map info carries the
+rotation of the reference's own sample product, ``rotation=17``; the UTM -> lat/lon conversion itself is a third-party
+module, ``LatLongUTMconversion``, that is absent: it is served by ``oracle/utm_oracle.py``, a statement of that module's
+published series pinned by ``tests/test_geo_cpu.py``); stand-ins: the file reader (``openimgmm`` hands over
 in-memory arrays), and the third-party functions this image lacks, by their published definitions --
 ``skimage.measure.label`` (connectivity 2 -> scipy.ndimage.label with the 3 x 3 structure, same raster numbering) and
 ``statsmodels.robust.scale.mad`` (``median(|a - center|) / c``).  The table the script builds (one row per region) is
@@ -25,7 +27,9 @@ import scipy.ndimage as ndi
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
 LINES, SAMPLES, SEED = 180, 90, 77
-MAPINFO = ["UTM", "1", "1", "367000.0", "3790000.0", "3.3", "3.3", "11", "North", "WGS-84", "units=Meters"]
+# ulx / uly / pixel size / zone / rotation of /root/reference/cnn/samples/ang20200924t211102_ch4mf_v2y1_img.hdr
+MAPINFO = ["UTM", "1", "1", "272247.152557", "3992010.65018", "3.1", "3.1", "11", "North", "WGS-84", "units=Meters",
+           "rotation=17.0000000"]
 
 
 def scene(lines=LINES, samples=SAMPLES, seed=SEED):
@@ -70,10 +74,13 @@ def run_reference(sal, img, prob_thr=0.5, ppmm_thr=250.0):
     sys.modules["gdal"].gdalconst = sys.modules["gdal"].ogr = sys.modules["gdal"].osr = None
     _stub("spectral.io.envi", open=lambda *a, **k: None)
     sys.modules["spectral"].SpyFile = type("SpyFile", (), {})
-    # UTM -> lat/lon is a third-party module (absent): the stand-in passes the map coordinates through, so the table's
-    # "lat" / "lon" columns hold what the reference's own sl2xy computed and handed to the conversion (as arrays)
-    _stub("LatLongUTMconversion", UTMtoLL=lambda datum, e, n, zone: (np.atleast_1d(np.float64(e)), np.atleast_1d(np.float64(n))),
-          LLtoUTM=None)
+    # UTM -> lat/lon is a third-party module (absent): oracle/utm_oracle.py states its series; the reference indexes
+    # the two results (``p[0]``, :109-110), so they are handed over as arrays
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import utm_oracle
+    _stub("LatLongUTMconversion",
+          UTMtoLL=lambda datum, n, e, zone: tuple(np.atleast_1d(v) for v in utm_oracle.UTMtoLL(datum, n, e, zone)),
+          LLtoUTM=utm_oracle.LLtoUTM)
     sys.modules["skimage"].__path__ = []
     _stub("skimage.morphology", disk=lambda r, **k: np.ones((2 * r + 1, 2 * r + 1), bool))
     _stub("skimage.measure", label=lambda a, connectivity=None, **k: ndi.label(a, structure=ndi.generate_binary_structure(a.ndim, connectivity or a.ndim))[0])

@@ -139,7 +139,8 @@ def test_detections_oracle_reproduces_the_reference_table(golden_dir):
     g = np.load(os.path.join(golden_dir, "detections_golden.npz"))
     sal, img = gen.scene(int(g["lines"]), int(g["samples"]), int(g["seed"]))
     mi = [float(v) for v in g["mapinfo"][3:7]]
-    got = DO.detections(sal, img, float(g["prob_thr"]), float(g["ppmm_thr"]), *mi)
+    assert "rotation=17.0000000" in list(g["mapinfo"])          # the rotation of the reference's own sample product
+    got = DO.detections(sal, img, float(g["prob_thr"]), float(g["ppmm_thr"]), *mi, rot=17.0, zone="11", hemi="North")
     assert list(g["columns"]) == DO.HEADER
     assert got.shape == g["table"].shape and len(got) == 14
     assert np.array_equal(got, g["table"])
@@ -151,11 +152,16 @@ def test_detections_gpu_match_reference_table(golden_dir):
     gen = _gen_det(golden_dir)
     g = np.load(os.path.join(golden_dir, "detections_golden.npz"))
     sal, img = gen.scene(int(g["lines"]), int(g["samples"]), int(g["seed"]))
-    mi = dict(zip(("ulx", "uly", "xps", "yps"), (float(v) for v in g["mapinfo"][3:7])))
+    mi = detections.mapinfo([str(v) for v in g["mapinfo"]])     # UTM zone 11 North, rotation 17 degrees
+    assert mi["rotation"] == 17.0 and mi["proj"] == "UTM"
     df = detections.salience2detections(sal, img, float(g["prob_thr"]), float(g["ppmm_thr"]), "ang20200101t000000", mi)
     assert list(df["detid"]) == list(g["detid"])
     got = df[list(g["columns"])].to_numpy(dtype=np.float64)
-    assert np.array_equal(got, g["table"])                       # order statistics, positions, map coordinates: exact
+    geo = [i for i, c in enumerate(g["columns"]) if c.endswith("lat") or c.endswith("lon")]
+    rest = [i for i in range(got.shape[1]) if i not in geo]
+    assert np.array_equal(got[:, rest], g["table"][:, rest])     # order statistics, positions: exact
+    # lat / lon: the same series evaluated through the reference's rotxy (a 2 x 2 dot product) and here in scalar form
+    assert np.abs(got[:, geo] - g["table"][:, geo]).max() < 1e-11
 
 
 @pytest.mark.gpu

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--no-cnn", action="store_true", help="skip the CNN tile-scorer section of the line (BASELINE configs 4/5)")
     ap.add_argument("--cnn-tiles", type=int, default=8192)
     ap.add_argument("--cnn-batch", type=int, default=512)
+    ap.add_argument("--no-wide", action="store_true", help="skip the full-band (p = 425) section of the line (SURVEY 8(d) config F425)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the CMF -> CNN end-to-end section (BASELINE config 4)")
     ap.add_argument("--cpu-columns", type=int, default=12)    # ~7 s of one host core (+ the all-cores sample)
     ap.add_argument("--active", type=str, default="", help="a0,a1 (1-based inclusive) override of the active window, e.g. 1,425")
     ap.add_argument("--in-flight", type=int, default=0,
@@ -207,12 +209,88 @@ def main():
             # the second half of the path (BASELINE.json configs 4 / 5): the per-pixel GoogLeNet tile scorer on the CMF plane
             # this run produced -- its own metric (tiles/s) and its own roofline (fp32 MFMA), inside the same line
             line["cnn"] = cnn_section(res, args.cnn_tiles, args.cnn_batch, not args.no_cpu_baseline)
+        full = world == 1 and (lines, samples, p) == (LINES, SAMPLES, 72)
+        if full and not args.no_e2e:
+            # BASELINE config 4 made visible to the driver: cube -> CMF -> saliency map of the WHOLE flightline
+            line["e2e"] = e2e_section(cube, lib, solo["dt"] / args.steps, line.get("cnn"))
+        if full and not args.no_wide:
+            # SURVEY 8(d) lists the full-band window among the configs: the batched-GEMM path, bounded to three flightlines
+            del main, solo
+            line["wide"] = wide_section(cube, lib)
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
     flush_c_stdio()
     if rank == 0:
         print(json.dumps(line), flush=True)      # the last line of the job's output
+
+
+def wide_section(cube, lib, steps=2):
+    """The same flightline with the full-band window 1..425 (SURVEY.md 8(d) mode F425; the reference's own -R mode,
+    window 5..420, takes the same route): windows wider than 96 bands run the batched-GEMM kernels of cmf_wide.hip.
+    One flightline at a time, one untimed + `steps` timed passes.  8(d)'s fp64 work of the eigen-restatement:
+    2 L p^2 C (covariance) + 2 L p^2 C (Y = X V) + 2 L p A C (sweep) = 10.7 TFLOP at p = 425, against the fp64 matrix peak."""
+    import torch
+    from srcfinder_amd import cmf
+    lines, bands, ncols = cube.shape
+    p, A = bands, 201
+    out = torch.empty((lines, ncols, 4), dtype=torch.float64, device=cube.device)
+    cmf.robust_mf(cube, lib, out=out, active=(1, bands))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cmf.robust_mf(cube, lib, out=out, active=(1, bands))
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flop = 2.0 * lines * p * p * ncols * 2 + 2.0 * lines * p * A * ncols
+    del out
+    cmf._Workspace._bufs.clear()
+    torch.cuda.empty_cache()
+    return {"metric": "CMF Mpixels/s, full-band window", "value": round(lines * ncols / dt / 1e6, 3), "unit": "Mpixel/s",
+            "ms_per_step": round(dt * 1e3, 2), "steps": steps, "dtype": "f64",
+            "config": {"workload": "the same flightline, active window 1..%d (p = %d), 201-point sweep, unimodal, one "
+                                   "flightline in flight" % (bands, p),
+                       "host_enqueue_ms_per_step": round(t_enq / steps * 1e3, 2)},
+            "roofline": {"bound": "mfma", "achieved": round(flop / dt / 1e12, 2), "peak": 78.6, "unit": "TFLOP/s",
+                         "frac": round(flop / dt / 78.6e12, 4), "flop_per_step": flop,
+                         "note": "SURVEY 8(d): 2Lp^2C + 2Lp^2C + 2LpAC fp64 flops of the eigen-restatement over the whole "
+                                 "step (eigensolver, exact-determinant pass and the score kernel included in the time)"}}
+
+
+def e2e_section(cube, lib, cmf_seconds, cnn):
+    """BASELINE config 4 (cube -> CMF -> CNN saliency map) on the benchmark flightline: the CMF step as measured above
+    plus the saliency map of the WHOLE 598 x 20000 plane in the reference's own fast mode (FCN shift-and-stitch,
+    cnn/fcn_pred_pipeline.py; fp32, seeded synthetic weights, one untimed strip first); the per-pixel tile scorer (the
+    parity path) is extrapolated from the rate of the `cnn` section -- it is 11.96 M windows per flightline."""
+    import torch
+    from srcfinder_amd import cmf, cnn as C
+    from srcfinder_amd.cnn_weights import synthetic_state_dict
+    lines, _, ncols = cube.shape
+    net = C.GoogLeNetHIP(synthetic_state_dict(2024), device=cube.device)
+    res = cmf.robust_mf(cube, lib)
+    plane = res.out[..., 3].to(torch.float32).contiguous()
+    C.fcn_predict_flightline(plane[:512].contiguous(), net=net)                  # buffers, code objects
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sal = C.fcn_predict_flightline(plane, net=net)
+    torch.cuda.synchronize()
+    t_fcn = time.perf_counter() - t0
+    valid = float((sal != -9999).float().mean().item())
+    del sal, plane, res, net
+    cmf._Workspace._bufs.clear()
+    torch.cuda.empty_cache()
+    tot = cmf_seconds + t_fcn
+    sec = {"metric": "CMF + CNN saliency map end to end, one flightline on one GPU", "value": round(lines * ncols / tot / 1e6, 3),
+           "unit": "Mpixel/s", "seconds": round(tot, 3), "cmf_seconds": round(cmf_seconds, 4), "cnn_seconds": round(t_fcn, 3),
+           "mode": "fcn shift-and-stitch (the reference's fast mode), fp32", "dtype": "f32",
+           "data": "synthetic weights (seeded), the CMF plane of this flightline", "saliency_valid_fraction": round(valid, 4)}
+    if cnn:
+        t_tiles = lines * ncols / cnn["value"]
+        sec["tile_scorer_projection"] = {"seconds": round(cmf_seconds + t_tiles, 1), "value": round(lines * ncols / (cmf_seconds + t_tiles) / 1e6, 4),
+                                         "unit": "Mpixel/s", "note": "per-pixel tile scorer (parity path) at the measured %.0f tiles/s: "
+                                                                      "%d windows" % (cnn["value"], lines * ncols)}
+    return sec
 
 
 def cnn_section(res, ntiles, batch, with_cpu):

@@ -190,9 +190,14 @@ int sf_debug_lowrank(const double *lam, const int32_t *nuse, const int32_t *stat
  * sf_cmf_score_timing_read() synchronises those events, returns the summed kernel time and the
  * number of launches since the last enable, and clears the list. */
 int sf_cmf_score_timing(int enable);
-/* Tuning knobs for experiments (tools/tune_*.py; the keys are listed at struct SfTune in csrc/cmf_common.h); the
- * defaults are the shipped choices.  The knobs are PER CALLING THREAD: the library holds no process-wide mutable state. */
+/* Tuning knobs for experiments (tools/tune_*.py; the keys are listed at struct SfTune in csrc/sf_tune.h); the
+ * defaults are the shipped choices.  The knobs are PER CALLING THREAD (the library holds no process-wide mutable
+ * state): a knob set on one thread does not reach launches issued from another -- a host that fans work out over
+ * threads copies them with sf_debug_get / sf_debug_set (srcfinder_amd.cnn._predict_multi_gpu does) -- and calls that
+ * have to agree on a layout derived from a knob (the score launch and the column statistics that read its partial
+ * sums, keys 1 / 2) must be issued from the same thread.  The reference has no counterpart (plain Python globals). */
 int sf_debug_set(int key, int value);
+int sf_debug_get(int key, int *value);
 int sf_cmf_score_timing_read(double *total_ms, int *launches);
 
 

@@ -78,6 +78,7 @@ SIGNATURES = {
     "sf_detect_region_stats": (i32, [vp, i32, i32, i32, vp, vp, i32, i32, vp, f64, vp, vp, vp]),
     "sf_cmf_score_timing": (i32, [i32]),
     "sf_debug_set": (i32, [i32, i32]),
+    "sf_debug_get": (i32, [i32, C.POINTER(C.c_int)]),
     "sf_cmf_score_timing_read": (i32, [C.POINTER(f64), C.POINTER(i32)]),
 }
 

@@ -389,9 +389,19 @@ def _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision):
     H = plane.shape[0]
     n = len(gpus)
     parts, errs = [None] * n, [None] * n
+    # the library's tuning knobs are per calling thread: hand the caller's CNN knobs to the workers
+    import ctypes
+    L = _ffi.lib()
+    knobs = {}
+    for key in (16, 17, 18):
+        v = ctypes.c_int(0)
+        _ffi.check(L.sf_debug_get(key, ctypes.byref(v)), "sf_debug_get")
+        knobs[key] = v.value
 
     def work(i):
         try:
+            for key, v in knobs.items():
+                L.sf_debug_set(key, v)
             dev = torch.device("cuda", gpus[i])
             with torch.cuda.device(dev):
                 net = GoogLeNetHIP(weights, device=dev, precision=precision)

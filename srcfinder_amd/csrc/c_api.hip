@@ -293,28 +293,41 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
 }
 
 
-int sf_debug_set(int key, int value) {
+static int *sf_tune_slot(int key) {
+  SfTune &t = sf_tune();
   switch (key) {
-    case 1: sf_tune().score_variant = value; return 0;
-    case 2: sf_tune().score_lpw = value; return 0;
-    case 3: sf_tune().score_xcd = value; return 0;
-    case 4: sf_tune().sweep_variant = value; return 0;
-    case 5: sf_tune().cov_variant = value; return 0;
-    case 6: sf_tune().extract_variant = value; return 0;
-    case 7: sf_tune().eigh_lpp = value; return 0;
-    case 8: sf_tune().sweep4r_waves = value; return 0;
-    case 10: sf_tune().wide_eigh_variant = value; return 0;
-    case 12: sf_tune().score_wgs = value; return 0;
-    case 13: sf_tune().score_exp = value; return 0;
-    case 14: sf_tune().lu_variant = value; return 0;
-    case 15: sf_tune().det_variant = value; return 0;
-    case 16: sf_tune().cnn_variant = value; return 0;
-    case 17: sf_tune().cnn_conv_variant = value; return 0;
-    case 18: sf_tune().cnn_pool_variant = value; return 0;
-    case 19: sf_tune().extract_nt = value; return 0;
-    case 20: sf_tune().sweep4_form = value; return 0;
-    default: sf_set_error("sf_debug_set: unknown key %d", key); return -1;
+    case 1: return &t.score_variant;
+    case 2: return &t.score_lpw;
+    case 3: return &t.score_xcd;
+    case 4: return &t.sweep_variant;
+    case 5: return &t.cov_variant;
+    case 6: return &t.extract_variant;
+    case 7: return &t.eigh_lpp;
+    case 8: return &t.sweep4r_waves;
+    case 10: return &t.wide_eigh_variant;
+    case 12: return &t.score_wgs;
+    case 13: return &t.score_exp;
+    case 14: return &t.lu_variant;
+    case 15: return &t.det_variant;
+    case 16: return &t.cnn_variant;
+    case 17: return &t.cnn_conv_variant;
+    case 18: return &t.cnn_pool_variant;
+    case 19: return &t.extract_nt;
+    case 20: return &t.sweep4_form;
+    default: return nullptr;
   }
+}
+int sf_debug_set(int key, int value) {
+  int *slot = sf_tune_slot(key);
+  if (!slot) { sf_set_error("sf_debug_set: unknown key %d", key); return -1; }
+  *slot = value;
+  return 0;
+}
+int sf_debug_get(int key, int *value) {
+  int *slot = sf_tune_slot(key);
+  if (!slot || !value) { sf_set_error("sf_debug_get: unknown key %d", key); return -1; }
+  *value = *slot;
+  return 0;
 }
 
 int sf_cmf_score_timing(int enable) {

@@ -85,6 +85,9 @@ __global__ __launch_bounds__(256, 1) void k_syrk4(const float *__restrict__ xt, 
 #pragma unroll
     for (int s = 0; s < NG; s += 2) sf_load2(xp + s, xraw[sl][s], xraw[sl][s + 1]);
   };
+  unsigned colm[3];   // lane n = 3 holds bands 54..71: those beyond the window are switched off
+#pragma unroll
+  for (int i = 0; i < 3; ++i) colm[i] = (NG * n + (NG - 3) + i < p) ? 0xffffffffu : 0u;
   int r0 = rbeg + 16 * wave;
   static_for<0, DEPTH>([&](auto sc) { fetch(r0 + 64 * decltype(sc)::value, sc); });
   __syncthreads();   // zeros[]
@@ -96,13 +99,19 @@ __global__ __launch_bounds__(256, 1) void k_syrk4(const float *__restrict__ xt, 
         const bool ok = (rt + rlane < rend) && mk[sl] != 0;
         int opq = 0;
         asm volatile("" : "+v"(opq));   // keep the 18 mean reads inside the iteration (see k_sweep)
-        // invalid row: raw bits -> 0 and mean -> 0, so the operand is exactly 0 whatever the row held
+        // invalid row: raw bits -> 0 and mean -> 0, so the operand is exactly 0 whatever the row held.  The raw bits are
+        // switched off with ONE v_and_b32 per value before the conversion (written as a select the compiler converts first
+        // and selects the two halves of the double: 38 v_cndmask per tile; every VALU instruction of this single wave per
+        // SIMD is ~12 cycles the matrix pipe stands still, tools/microbench/mix4w.hip)
         const double *musl = (ok ? mus + NG * n : zeros) + opq;
+        unsigned okm = ok ? 0xffffffffu : 0u;
+        asm volatile("" : "+v"(okm));   // opaque: otherwise the and is turned back into a select of the CONVERTED value
         double f[NG];
 #pragma unroll
         for (int I = 0; I < NG; ++I) {
-          const float xv = (ok && NG * n + I < p) ? xraw[sl][I] : 0.0f;
-          f[I] = (double)xv - musl[I];
+          unsigned msk = okm;
+          if (4 * NG - 3 <= 3 * NG + I) msk &= colm[I - (NG - 3)];   // only bands 69..71 can lie beyond a window of >= 69
+          f[I] = (double)__uint_as_float(__float_as_uint(xraw[sl][I]) & msk) - musl[I];
         }
         if (EXP != 1) fetch(rt + 64 * DEPTH, sc);
         if constexpr (EXP == 2) {

@@ -165,9 +165,17 @@ __global__ __launch_bounds__(256 * CW) void k_score(const float *__restrict__ cu
             stg[2 * s + (0 ^ sw)] = ra;
             stg[2 * s + (1 ^ sw)] = rb;
           }
+          // lanes exchange data through the wave's LDS block: make the order explicit (no instruction is emitted: a
+          // wave's LDS operations issue in order, but the memory model does not promise it to the compiler)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           const int s = lane >> 1;
           const d2v_t val = stg[2 * s + ((lane & 1) ^ ((s >> 3) & 1))];
           if (32 * h + s < ncol) orow[(size_t)(32 * h + s) * 2 + (lane & 1)] = val;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the reads above before the next half's writes
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (bgmeta && colok) {
           const uint32_t m = (v && st == 0) ? ((uint32_t)(uint16_t)(int16_t)ai << 16) : 0u;

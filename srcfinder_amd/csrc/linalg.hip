@@ -479,11 +479,23 @@ __global__ void k_argmin_nan_first(const double *__restrict__ nll, const int32_t
 
 }  // namespace
 
-constexpr int DET_SLOTS = 512;   // matrices factorised per launch (two rounds of 256 CUs)
+constexpr int DET_SLOTS = 512;   // matrices factorised per launch (two rounds of 256 CUs) ...
+constexpr size_t DET_SLOT_BYTES = (size_t)400 << 20;   // ... within this many bytes of p x p float64 work matrices (p = 425: 290, p = 512: 200)
 constexpr int DET_GROUP = 4;     // grid points per side and round of the deepening rule (k_det_round)
+// The job list holds every grid point of every column whatever the window: a column whose lost points are not two runs at
+// the ends of the grid takes the plain window rule in round 0 and may push up to nalpha jobs (with ncols x 2 x
+// window entries such a column overflowed the list and which jobs survived depended on the order of the atomics).  An int
+// and a double per entry: 2.4 KB per column.  The p x p work matrices are what costs memory; the job loop strides over them.
+static size_t det_maxjobs(const SfGeom &g) { return (size_t)g.ncols * g.nalpha; }
+static size_t det_slots(const SfGeom &g, size_t maxjobs) {
+  size_t slots = DET_SLOT_BYTES / ((size_t)g.p * g.p * sizeof(double));
+  slots = slots < 64 ? 64 : (slots > DET_SLOTS ? DET_SLOTS : slots);
+  return maxjobs < slots ? maxjobs : slots;
+}
 size_t sf_exact_det_scratch_bytes(const SfGeom &g, int window) {
-  const size_t maxjobs = window <= 0 ? (size_t)g.ncols * g.nalpha : (size_t)g.ncols * 2 * window;
-  const size_t slots = maxjobs < DET_SLOTS ? maxjobs : DET_SLOTS;
+  (void)window;
+  const size_t maxjobs = det_maxjobs(g);
+  const size_t slots = det_slots(g, maxjobs);
   return sf_align(slots * g.p * g.p * sizeof(double)) + sf_align(maxjobs * sizeof(int32_t)) + sf_align(maxjobs * sizeof(double)) +
          sf_align(sizeof(int32_t)) + sf_align((size_t)g.ncols * 4 * sizeof(int32_t));
 }
@@ -491,8 +503,8 @@ size_t sf_exact_det_scratch_bytes(const SfGeom &g, int window) {
 int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *status, const double *alphas, const SfGeom &g,
                         int window, const double *rest, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st,
                         const double *target) {
-  const size_t maxjobs = window <= 0 ? (size_t)g.ncols * g.nalpha : (size_t)g.ncols * 2 * window;
-  const size_t slots = maxjobs < DET_SLOTS ? maxjobs : DET_SLOTS;
+  const size_t maxjobs = det_maxjobs(g);
+  const size_t slots = det_slots(g, maxjobs);
   char *p = reinterpret_cast<char *>(scratch);
   double *work = reinterpret_cast<double *>(p); p += sf_align(slots * g.p * g.p * sizeof(double));
   int32_t *jobs = reinterpret_cast<int32_t *>(p); p += sf_align(maxjobs * sizeof(int32_t));
@@ -506,7 +518,7 @@ int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *s
   const bool rounds = window > 0 && sf_tune().det_variant == 0;
   const int nrounds = rounds ? sf_cdiv(window, DET_GROUP) : 1;
   for (int r = 0; r < nrounds; ++r) {
-    // round 0 may hold a plain-window column's 2 x window points, later rounds at most 2 x DET_GROUP per column
+    // round 0 may hold every grid point of a plain-window column, later rounds at most 2 x DET_GROUP per column
     const size_t cap = (r == 0) ? maxjobs : std::min(maxjobs, (size_t)g.ncols * 2 * DET_GROUP);
     SF_HIP(hipMemsetAsync(njobs, 0, sizeof(int32_t), st));
     if (rounds)

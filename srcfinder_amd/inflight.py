@@ -23,6 +23,13 @@ class Ticket:
     def __init__(self, result, event, slot):
         self.result, self.event, self.slot = result, event, slot
 
+    def _mark_in_use(self, stream):
+        import torch
+        for name in ("out", "bgmeta", "colstats", "alphaidx", "nuse", "status", "nll", "labels"):
+            t = getattr(self.result, name, None)
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)
+
     def wait(self, stream=None):
         """Make ``stream`` (default: the current stream) wait for this flightline -- no host synchronisation.  The result
         tensors were allocated on the slot's stream: they are marked as in use by the waiting stream, so the caching
@@ -30,14 +37,16 @@ class Ticket:
         import torch
         stream = stream or torch.cuda.current_stream()
         stream.wait_event(self.event)
-        for name in ("out", "bgmeta", "colstats", "alphaidx", "nuse", "status", "nll", "labels"):
-            t = getattr(self.result, name, None)
-            if torch.is_tensor(t) and t.is_cuda:
-                t.record_stream(stream)
+        self._mark_in_use(stream)
         return self.result
 
     def synchronize(self):
+        """Block the host until this flightline is done.  The results are marked as in use by the CURRENT stream, on which
+        the caller will consume them (without that a consumer kernel on another stream raced the slot's next
+        flightline once the host dropped its references)."""
+        import torch
         self.event.synchronize()
+        self._mark_in_use(torch.cuda.current_stream())
         return self.result
 
 
@@ -62,6 +71,11 @@ class FlightlinePipeline:
         self._n += 1
         st = self.streams[slot]
         st.wait_stream(torch.cuda.current_stream(self.device))
+        # the inputs were allocated on the caller's stream and are read on the slot's: the caller may drop or reuse them
+        # right after submit() without the allocator handing their memory out under the slot
+        for t in (cube_bil, library, kw.get("out"), kw.get("bgmeta")):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(st)
         with torch.cuda.stream(st):
             res = cmf.robust_mf(cube_bil, library, **kw)
             ev = torch.cuda.Event()

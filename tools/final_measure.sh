@@ -1,3 +1,5 @@
+#!/bin/bash
+set -euo pipefail
 mkdir -p gpurun_out/r02f
 tools/pmc_traffic.sh r02f > gpurun_out/r02f/pmc.log 2>&1
 cp gpurun_out/r02f_pmc_traffic.json profiles/r02_pmc_traffic.json

@@ -203,6 +203,8 @@ def main():
                          "measured": "HIP events on the launch stream around the kernel alone, one flightline in flight"},
         }
         line["roofline"].update(pmc_traffic(lines, samples, p, world))
+        if world == 1 and (lines, samples, p) == (LINES, SAMPLES, 72):
+            line["roofline"].update(measured_ceiling(score_ms))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cube, lib, lines, ncols, args.cpu_columns, res, (a0, a1))
         if world == 1 and not args.no_cnn:
@@ -371,6 +373,27 @@ def pmc_traffic(lines, samples, p, world):
     return {"traffic": k["hbm_bytes_per_launch"],
             "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this command at the same kernel "
                               "source, sha %s; not measured by this run)" % rec["kernel_source_sha"]}
+
+
+def measured_ceiling(score_ms):
+    """What a launch with the score kernel's traffic can do on THIS box: tools/microbench/score_ceiling
+    (built by __graft_entry__.build()) moves exactly the launch's bytes in the launch's geometry with none of its arithmetic --
+    72 of 425 bands of every pixel read, the RGB bands read, 32-byte records written -- in eleven forms; the fastest is the
+    ceiling.  Run as a child process on its own 20.3 GB cube while this process idles."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "microbench", "score_ceiling")
+    if not os.path.isfile(exe) or score_ms <= 0:
+        return {}
+    try:
+        txt = subprocess.run([exe], capture_output=True, text=True, timeout=300).stdout
+        last = [l for l in txt.splitlines() if l.startswith("ceiling_ms")][-1].split(None, 3)
+        ceil_ms = float(last[1])
+    except Exception as e:                                   # a diagnostic: never fail the benchmark line over it
+        return {"ceiling_note": "tools/microbench/score_ceiling did not run: %r" % (e,)}
+    return {"ceiling_ms": round(ceil_ms, 4), "frac_of_measured_ceiling": round(ceil_ms / score_ms, 4),
+            "ceiling_frac_of_peak": round(3540160000 / (ceil_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "ceiling_source": "tools/microbench/score_ceiling, same box, same run: best of 11 pure load/store forms of the "
+                              "launch's geometry and bytes (%s)" % last[3]}
 
 
 def flush_c_stdio():

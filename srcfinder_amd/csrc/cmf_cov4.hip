@@ -114,6 +114,13 @@ __global__ __launch_bounds__(256, 1) void k_syrk4(const float *__restrict__ xt, 
           f[I] = (double)__uint_as_float(__float_as_uint(xraw[sl][I]) & msk) - musl[I];
         }
         if (EXP != 1) fetch(rt + 64 * DEPTH, sc);
+        // the asm MFMAs below are invisible to the hazard recogniser: a VALU result (the last v_add_f64 of the centring)
+        // needs wait states before an MFMA may read it as SrcA/B; nothing pads them when the scheduler puts the two
+        // back to back (round 3: with the shorter prologue it did, and tile (0, 0) of every 16 rows came out wrong)
+        static_assert(NG == 18, "operand list of the hazard pad");
+        asm volatile("s_nop 4" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
+                     "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]),
+                     "+v"(f[16]), "+v"(f[17]));   // (the operands pin it between the last conversion and the first MFMA)
         if constexpr (EXP == 2) {
 #pragma unroll
           for (int I = 0; I < NG; ++I) acc[I] += f[I];

@@ -20,6 +20,18 @@
 namespace {
 
 constexpr int EIG_MAXSWEEP = 30;
+// -DSF_EIGH_STAMPS: thread 0 of a workgroup sums the s_memtime deltas of the phases of a Jacobi step (diagnostic build only;
+// the sums go to the unused rotation log of the column, tools/probe_eigh.py --stamps prints them).  Round 3, one 72 x 72
+// matrix alone on the chip, 710 steps: 2220 cycles per step = operands landed 610 + dot product reduced 260 + rotation
+// parameters 270 + rotation and stores issued 700 + barrier 270 + sweep prologue 10 -- every phase scales with the
+// instructions a WAVE issues (~8 cycles per fp64 instruction), not with the SIMD's load: seven lanes per pair (nine pairs
+// per wave = exactly four waves instead of 4.5, eleven rows per lane, dot product summed through LDS) halves the barrier
+// phase and loses more in the others (0.70 against 0.65 ms); three partial sums in the dot product change nothing.
+#ifdef SF_EIGH_STAMPS
+#define EIG_STAMP(i) do { if (tid == 0) { const long long t_ = __builtin_readcyclecounter(); stamp[i] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define EIG_STAMP(i) do { } while (0)
+#endif
 
 // 8-lane butterfly sum with DPP lane swaps (no LDS traffic): xor 1, xor 2, then half-row mirror (the
 // partner sits in the other quad, whose four lanes already hold the same partial).
@@ -164,6 +176,10 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
   const double tol = (double)p2 * 2.220446049250313e-16;
   const double tol2 = tol * tol;
   int nsteps = 0;  // fallback only: steps whose rotations have to be replayed on V
+#ifdef SF_EIGH_STAMPS
+  long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+  const long long tstart = tprev;
+#endif
   // ---------------- phase 1: orthogonalise the columns of G (record the rotations in the fallback)
   for (int sweep = 0; sweep < EIG_MAXSWEEP; ++sweep) {
     bool rotated = false;
@@ -188,6 +204,7 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
     double xa[EIG_RMAX];
 #pragma unroll
     for (int i = 0; i < EIG_RMAX; ++i) xa[i] = 0.0;
+    EIG_STAMP(0);   // sweep prologue (norms)
     for (int s = 0; s < m; ++s) {
       if (active) {
         int kk = acol - s;
@@ -213,12 +230,20 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
         }
         const bool leaving = (kk == 0) || (s == m - 1);  // after this step the a-column is someone's b-column / the sweep ends
         const double aa = nrm[a], bb = nrm[b];
+#ifdef SF_EIGH_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        EIG_STAMP(1);   // operands landed
+#endif
         double ab = 0;
 #pragma unroll
         for (int i = 0; i < EIG_RMAX; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
         ab = (LPP == 16) ? sum16(ab) : ((LPP == 8) ? sum8(ab) : sum4(ab));
         const double ab2 = aa * bb;
         double cs = 1.0, sn = 0.0;
+#ifdef SF_EIGH_STAMPS
+        asm volatile("" : "+v"(ab));
+        EIG_STAMP(2);   // dot product reduced
+#endif
         if (ab2 > 0.0 && ab * ab > tol2 * ab2) {  // uniform over the pair's 8 lanes
           rotated = true;
           // tan(2 theta) = 2ab / (bb - aa), small-angle branch, no division:
@@ -230,6 +255,10 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
           cs = h * rh;
           sn = fabs(gam) * rinv * 0.5 * rh;
           sn = ((tau < 0.0) != (gam < 0.0)) ? -sn : sn;
+#ifdef SF_EIGH_STAMPS
+          asm volatile("" : "+v"(sn), "+v"(cs));
+          EIG_STAMP(3);   // rotation parameters
+#endif
 #pragma unroll
           for (int i = 0; i < EIG_RMAX; ++i) {
             const double na = cs * xa[i] - sn * xb[i];
@@ -252,7 +281,9 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
         reload = (kk == 0);                              // next step this group owns column s + npairs instead
         if (kk == 0) { acol = s + npairs; acol = acol >= m ? acol - m : acol; }
       }
+      EIG_STAMP(4);     // rotation applied, stores issued
       lds_barrier();
+      EIG_STAMP(5);     // barrier
     }
     if (rotated) flag[1] = 1;  // benign race: every writer stores 1
     __syncthreads();
@@ -264,6 +295,12 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
   }
   __syncthreads();
   if (chol_ok && tid == 0) rot[(size_t)c * rot_stride] = make_double2((double)(nsteps / m), 0.0);  // tools/probe_eigh.py
+#ifdef SF_EIGH_STAMPS
+  if (chol_ok && tid == 0) {
+    for (int i = 0; i < 6; ++i) rot[(size_t)c * rot_stride + 1 + i] = make_double2((double)stamp[i], 0.0);
+    rot[(size_t)c * rot_stride + 7] = make_double2((double)(__builtin_readcyclecounter() - tstart), 0.0);
+  }
+#endif
   if (chol_ok) {
     // G = U diag(sigma): lam = sigma^2, eigenvector = normalised column
     for (int j = tid; j < p; j += nthr) {

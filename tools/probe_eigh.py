@@ -30,3 +30,7 @@ for lpp, nc in itertools.product((8, 4, 16), (1, 75, 598)):
     stride = 30 * (p - 1) * (p // 2) * 2   # doubles per column of the rotation log (EIG_MAXSWEEP * steps * pairs * 2)
     sw = ws.view(torch.float64)[: nc * stride : stride].cpu().numpy()
     print("lanes/pair %d ncols %5d : %.3f ms per call; rotating sweeps min/max %d/%d" % (lpp, nc, a.elapsed_time(b) / 3, sw.min(), sw.max()))
+    if "--stamps" in sys.argv:      # library built with -DSF_EIGH_STAMPS: s_memtime ticks (100 MHz?) summed over the Jacobi phase of column 0
+        v = ws.view(torch.float64)[2:16:2].cpu().numpy()
+        names = ("sweep prologue", "operands landed", "dot reduced", "rotation parameters", "rotation + stores issued", "barrier", "whole Jacobi phase")
+        print("    stamps (ticks, column 0): " + ", ".join("%s %d" % (n, x) for n, x in zip(names, v)))

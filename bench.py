@@ -359,20 +359,25 @@ def kernel_source_sha():
 def pmc_traffic(lines, samples, p, world):
     """HBM bytes per launch of the score kernel from the PMC passes of tools/pmc_traffic.sh (FETCH_SIZE x2 + WRITE_SIZE,
     separate rocprofv3 --pmc runs of this very command).  Counters cannot be read from inside the run, so the figure
-    comes from the committed record -- and ONLY when that record was taken from the kernel source that is being run
-    (same sha) on the same geometry; otherwise `traffic` stays null."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.isfile(path) or (lines, samples, p, world) != (LINES, SAMPLES, 72, 1):
+    comes from the newest committed record (profiles/rNN_pmc_traffic.json) -- and ONLY when that record was taken from the
+    kernel source that is being run (same sha) on the same geometry; otherwise `traffic` stays null."""
+    import glob
+    if (lines, samples, p, world) != (LINES, SAMPLES, 72, 1):
         return {}
-    rec = json.load(open(path))
-    if rec.get("kernel_source_sha") != kernel_source_sha():
-        return {"traffic_note": "profiles/r02_pmc_traffic.json was taken from a different kernel source: not quoted"}
-    k = rec["kernels"].get("k_score")
-    if not k:
-        return {}
-    return {"traffic": k["hbm_bytes_per_launch"],
-            "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc passes of this command at the same kernel "
-                              "source, sha %s; not measured by this run)" % rec["kernel_source_sha"]}
+    sha = kernel_source_sha()
+    note = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):   # newest round first
+        rec = json.load(open(path))
+        name = "profiles/" + os.path.basename(path)
+        if rec.get("kernel_source_sha") != sha:
+            note = {"traffic_note": "%s was taken from a different kernel source: not quoted" % name}
+            continue
+        k = rec["kernels"].get("k_score")
+        if k:
+            return {"traffic": k["hbm_bytes_per_launch"],
+                    "traffic_source": "%s (rocprofv3 --pmc passes of this command at the same kernel source, sha %s; not "
+                                      "measured by this run)" % (name, sha)}
+    return note
 
 
 def measured_ceiling(score_ms):

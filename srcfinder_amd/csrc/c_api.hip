@@ -314,6 +314,7 @@ static int *sf_tune_slot(int key) {
     case 18: return &t.cnn_pool_variant;
     case 19: return &t.extract_nt;
     case 20: return &t.sweep4_form;
+    case 21: return &t.sweep_grid;
     default: return nullptr;
   }
 }

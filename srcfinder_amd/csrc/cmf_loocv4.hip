@@ -770,7 +770,7 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
                                                     const double *__restrict__ wfrag,
                                                     size_t wstride, const int32_t *__restrict__ status,
                                                     const double *__restrict__ alphas, int nalpha, int L, int p,
-                                                    int PS, int rows_per_wg, double *__restrict__ part) {
+                                                    int PS, int rows_per_wg, double *__restrict__ part, int split_fastest) {
   using S = SwS<NK>;
   constexpr int NJ = S::NJ, NM = S::NM, NA16 = NM * 16, NW = 8, NKP = S::NKP, NG = S::NG;
   constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, NR = S::NR, RING = S::RING;
@@ -778,7 +778,10 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
+  // grid (column, split) or (split, column): with the splits fastest the workgroups that load one column's tables run at the
+  // same time (the tables come from HBM once and from L2 for the rest); results do not depend on the order
+  const int c = split_fastest ? blockIdx.y : blockIdx.x, split = split_fastest ? blockIdx.x : blockIdx.y;
+  const int nsplit = split_fastest ? gridDim.x : gridDim.y;
   double *po = part + ((size_t)c * nsplit + split) * 2 * NA16;
   if (status[c] != 0 || lrok[c] != (NK == SF_LR_K / 4 ? 1 : 2)) return;   // another instantiation / k_sweep4 takes these columns
   // ---- prologue: the tables, permuted into the pair layouts
@@ -1078,11 +1081,13 @@ int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
   const int form = sf_tune().sweep4_form;
   if (form != 1) {   // the streamed kernel (round 3) for rank 28; rank 36 keeps k_sweep4r (four t copies of 9 do not fit 256 registers)
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK1>), SwS<NK1>::lds_bytes())) return rc;
-    if (form == 0) hipLaunchKernelGGL((k_sweep4s<NK1>), dim3(g.ncols, nsplit), dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS);
+    const int sfast = sf_tune().sweep_grid != 1;
+    const dim3 grid = sfast ? dim3(nsplit, g.ncols) : dim3(g.ncols, nsplit);
+    if (form == 0) hipLaunchKernelGGL((k_sweep4s<NK1>), grid, dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS, sfast);
 #ifdef SF_SWEEP_EXPERIMENTS
 #define SW4S_EXP(E) if (form == 100 + E) { \
       if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK1, E>), SwS<NK1>::lds_bytes())) return rc; \
-      hipLaunchKernelGGL((k_sweep4s<NK1, E>), dim3(g.ncols, nsplit), dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS); }
+      hipLaunchKernelGGL((k_sweep4s<NK1, E>), grid, dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS, sfast); }
     SW4S_EXP(1) SW4S_EXP(2) SW4S_EXP(4) SW4S_EXP(5) SW4S_EXP(8) SW4S_EXP(16) SW4S_EXP(31)
 #endif
     SF_LAUNCH_CHECK("k_sweep4s");

@@ -11,6 +11,7 @@ struct SfTune {
   int sweep_variant = 0;      // key 4: 1 = force the 16x16x4 sweep, 2 = full-rank 4x4x4 sweep only
   int cov_variant = 0;        // key 5: 1 = force the 16x16x4 covariance, 3 = two waves per SIMD
   int extract_variant = 0;    // key 6: 1 = never the flat (narrow-cube) kernel, 2 = the unpipelined blocked kernel, 3 / 5 = 3- / 2-line tiles in the pipelined kernel (default 4)
+  int sweep_grid = 0;         // key 21: k_sweep4s workgroup order: 0 = the splits of a column adjacent (default), 1 = columns fastest (round 2's order)
   int extract_nt = 0;         // key 19: 1 = plain (not non-temporal) xt stores in the pipelined extract kernel
   int eigh_lpp = 0;           // key 7: lanes per column pair of the Jacobi eigensolver
   int sweep4r_waves = 8;      // key 8: waves per workgroup of the rank-factored sweep (k_sweep4r, form 1)

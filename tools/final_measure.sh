@@ -1,21 +1,39 @@
 #!/bin/bash
+# usage (GPU box, repo root): tools/final_measure.sh <round tag, e.g. r03>
+# The round's measurement set: PMC traffic / MFMA-busy / SQ-wait passes, rocprofv3 kernel stats of the one-in-flight bench, the
+# default bench line, the 75-column shard line, the wide-window profile, CNN layers.  Everything lands in gpurun_out/<tag>f/;
+# copies into profiles/ happen only when every step succeeded (set -e).
 set -euo pipefail
-mkdir -p gpurun_out/r02f
-tools/pmc_traffic.sh r02f > gpurun_out/r02f/pmc.log 2>&1
-cp gpurun_out/r02f_pmc_traffic.json profiles/r02_pmc_traffic.json
-cp gpurun_out/r02f_pmc_traffic.json gpurun_out/r02f/pmc_traffic.json
-tools/prof_bench.sh r02fif1 --in-flight 1 --steps 5 --warmup 2 > gpurun_out/r02f/prof_if1.log 2>&1
-grep "^{\"metric\"" gpurun_out/prof_r02fif1.log | tail -1 > gpurun_out/r02f/bench_line_inflight1_rocprof.json
-cp gpurun_out/r02fif1_kstats.txt gpurun_out/r02f/kstats_inflight1.txt
-rm -rf gpurun_out/prof_r02fif1 gpurun_out/pmc_r02f_FETCH_SIZE gpurun_out/pmc_r02f_WRITE_SIZE
-python bench.py > gpurun_out/r02f/bench_line.json 2> gpurun_out/r02f/bench_line.err
-python bench.py --samples 75 --no-cnn > gpurun_out/r02f/bench_line_shard75.json 2> /dev/null
-python bench.py --active 1,425 --steps 3 --warmup 1 --no-cnn --no-cpu-baseline > gpurun_out/r02f/bench_line_fullband425.json 2> /dev/null
-tools/prof_bench.sh r02fwide --active 1,425 --steps 2 --warmup 1 --no-cpu-baseline --no-cnn --in-flight 1 > gpurun_out/r02f/prof_wide.log 2>&1
-cp gpurun_out/r02fwide_kstats.txt gpurun_out/r02f/kstats_fullband425.txt
-rm -rf gpurun_out/prof_r02fwide
-root=$(pwd); mkdir -p gpurun_out/r02f/cnnprof; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $root/gpurun_out/r02f/cnnprof -o p -- python3 $root/tools/bench_cnn.py --tiles 1024 --batch 512 > $root/gpurun_out/r02f/cnnprof.log 2>&1
-cd $root; t=$(find gpurun_out/r02f/cnnprof -name "*kernel_trace.csv" | head -1); python3 tools/cnn_layers.py $t > gpurun_out/r02f/cnn_layers.txt; rm -rf gpurun_out/r02f/cnnprof
-python tools/bench_cnn.py --tiles 8192 --batch 512 > gpurun_out/r02f/cnn_bench_line.json
-cut -c1-600 gpurun_out/r02f/bench_line.json; echo; cut -c1-300 gpurun_out/r02f/bench_line_shard75.json; echo; cut -c1-300 gpurun_out/r02f/bench_line_fullband425.json; echo; tail -3 gpurun_out/r02f/cnn_layers.txt
+tag=${1:-r03}
+out=gpurun_out/${tag}f
+mkdir -p $out
+B="--no-cpu-baseline --no-cnn --no-e2e --no-wide"
+tools/pmc_traffic.sh ${tag}f > $out/pmc.log 2>&1
+cp gpurun_out/${tag}f_pmc_traffic.json $out/pmc_traffic.json
+tools/pmc_mfma.sh ${tag}f > $out/pmc_mfma.txt 2>&1
+tools/pmc_sq.sh ${tag}f k_sweep4s > $out/pmc_sq.txt 2>&1
+tools/prof_bench.sh ${tag}fif1 --in-flight 1 --steps 5 --warmup 2 $B > $out/prof_if1.log 2>&1
+grep "^{\"metric\"" gpurun_out/prof_${tag}fif1.log | tail -1 > $out/bench_line_inflight1_rocprof.json
+cp gpurun_out/${tag}fif1_kstats.txt $out/kstats_inflight1.txt
+rm -rf gpurun_out/prof_${tag}fif1 gpurun_out/pmc_${tag}f_FETCH_SIZE gpurun_out/pmc_${tag}f_WRITE_SIZE gpurun_out/pmc_mfma_${tag}f gpurun_out/pmc_sq_${tag}f
+python bench.py > $out/bench_line.json 2> $out/bench_line.err
+python bench.py --samples 75 --no-cnn > $out/bench_line_shard75.json 2> /dev/null
+python bench.py --samples 75 --no-cnn --in-flight 1 --no-cpu-baseline > $out/bench_line_shard75_inflight1.json 2> /dev/null
+tools/prof_bench.sh ${tag}fwide --active 1,425 --steps 2 --warmup 1 $B --in-flight 1 > $out/prof_wide.log 2>&1
+cp gpurun_out/${tag}fwide_kstats.txt $out/kstats_fullband425.txt
+rm -rf gpurun_out/prof_${tag}fwide
+root=$(pwd); mkdir -p $out/cnnprof; cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $root/$out/cnnprof -o p -- python3 $root/tools/bench_cnn.py --tiles 1024 --batch 512 > $root/$out/cnnprof.log 2>&1
+cd $root; t=$(find $out/cnnprof -name "*kernel_trace.csv" | head -1); python3 tools/cnn_layers.py $t > $out/cnn_layers.txt; rm -rf $out/cnnprof
+# every step succeeded: the judged copies
+cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json
+cp $out/pmc_mfma.txt profiles/${tag}_pmc_mfma_busy.txt
+cp $out/pmc_sq.txt profiles/${tag}_pmc_sq_waits.txt
+cp $out/kstats_inflight1.txt profiles/${tag}_bench_kernel_stats_inflight1.txt
+cp $out/bench_line_inflight1_rocprof.json profiles/${tag}_bench_line_inflight1_rocprof.json
+cp $out/bench_line.json profiles/${tag}_bench_line.json
+cp $out/bench_line_shard75.json profiles/${tag}_bench_line_shard75.json
+cp $out/bench_line_shard75_inflight1.json profiles/${tag}_bench_line_shard75_inflight1.json
+cp $out/kstats_fullband425.txt profiles/${tag}_fullband425_kernel_stats.txt
+cp $out/cnn_layers.txt profiles/${tag}_cnn_layers.txt
+cut -c1-700 $out/bench_line.json; echo; cut -c1-300 $out/bench_line_shard75.json; echo; tail -3 $out/cnn_layers.txt

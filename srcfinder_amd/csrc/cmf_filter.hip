@@ -62,9 +62,19 @@ __global__ __launch_bounds__(128) void k_filter(const double *__restrict__ mu, c
     double s = 0.0;
     for (int j = 0; j < p; ++j) s += wv[j];
     s_norm = s;  // t^T C^-1 t
-    if (!(fabs(s) > 0.0) || !(fabs(s) <= 1.79769313486231570e+308)) s_bad = 1;
+    if (!s_bad && s == 0.0) s_bad = 2;
+    else if (!(fabs(s) > 0.0) || !(fabs(s) <= 1.79769313486231570e+308)) s_bad = 1;
   }
   __syncthreads();
+  if (s_bad == 2) {
+    // t^T C^-1 t == 0 with a positive definite C: the target is the zero vector (a library without absorption in the
+    // window, a zero column mean).  The reference divides by it (robust_mf.py:380-381): 0 / 0, every valid row of the
+    // column scores NaN -- a NaN filter on a status-0 column, as for status 3 above
+    const double qn = __builtin_nan("");
+    for (int b = tid; b < p; b += 128) fo[b] = qn;
+    if (tid == 0) bias[c] = qn;
+    return;
+  }
   if (s_bad) {
     for (int b = tid; b < p; b += 128) fo[b] = 0.0;
     if (tid == 0) { bias[c] = 0.0; status[c] = 2; }

@@ -1121,6 +1121,24 @@ def test_column_with_a_single_valid_row(torch_cuda, library):
     assert score_close(res.out[:, ok, 3], o["out"][:, ok, 3]).all()
 
 
+def test_zero_target_scores_nan_like_the_reference(torch_cuda, library):
+    """A library without absorption in the window makes the target t = abscf * mu the zero vector: the reference divides by
+    t^T C^-1 t = 0 (robust_mf.py:380-381) and every valid row scores NaN (0 / 0); status stays 0, the alpha index is kept,
+    NODATA rows stay NODATA.  (Rounds 1-2 returned status 2 and zeros here.)"""
+    lib0 = library.copy()
+    lib0[:, 2] = 0.0
+    cube = make_cube_numpy(160, 5, seed=11, abscf_full=library[:, 2], nodata_column=1, nodata_lines=3)
+    res = cmf.robust_mf(cube, lib0, metadata=True, to_numpy=True)
+    with np.errstate(all="ignore"):
+        o = O.robust_mf_oracle(cube, lib0)
+    assert np.array_equal(res.status, o["status"]) and list(res.status) == [0, 1, 0, 0, 0]
+    assert np.array_equal(res.alphaidx, o["alphaidx"]) and np.array_equal(res.bgmeta, o["bgmeta"])
+    assert np.array_equal(np.isnan(res.out[..., 3]), np.isnan(o["out"][..., 3])) and np.isnan(res.out[10, 0, 3])
+    assert np.array_equal(res.out[..., 3] == -9999.0, o["out"][..., 3] == -9999.0)
+    assert np.array_equal(res.out[..., :3], o["out"][..., :3])
+    assert np.array_equal(res.colstats[0], o["colstats"][0]) and np.isnan(res.colstats[1, 0]) and np.isnan(o["colstats"][1, 0])
+
+
 def test_multimodal_and_wide_column_shards(torch_cuda, golden_dir, library):
     """columns=(s0, s1) on the multimodal branch (injected labels, -r) and on a wide window: the shard's product equals
     the same columns of the full run bit for bit (per-column arithmetic independent of the sharding)."""

@@ -2,7 +2,8 @@
 # usage (GPU box, repo root): tools/final_measure.sh <round tag, e.g. r03>
 # The round's measurement set: PMC traffic / MFMA-busy / SQ-wait passes, rocprofv3 kernel stats of the one-in-flight bench, the
 # default bench line, the 75-column shard line, the wide-window profile, CNN layers.  Everything lands in gpurun_out/<tag>f/;
-# copies into profiles/ happen only when every step succeeded (set -e).
+# copies into profiles/ happen only when every step succeeded (set -e); gpurun merges only gpurun_out/ back, so repeat the
+# copies on the development side: for f in ...; see the cp lines at the end.
 set -euo pipefail
 tag=${1:-r03}
 out=gpurun_out/${tag}f

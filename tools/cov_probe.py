@@ -1,3 +1,4 @@
+"""Which entries of the 4x4x4 covariance differ from numpy.cov (found the missing hazard pad before the first asm MFMA of a tile, round 3)."""
 import os, sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch

@@ -85,7 +85,6 @@ __global__ __launch_bounds__(256, 1) void k_syrk4(const float *__restrict__ xt, 
 #pragma unroll
     for (int s = 0; s < NG; s += 2) sf_load2(xp + s, xraw[sl][s], xraw[sl][s + 1]);
   };
-  const bool full72 = p >= PS;
   unsigned colm[3];   // lane n = 3 holds bands 54..71: those beyond the window are switched off
 #pragma unroll
   for (int i = 0; i < 3; ++i) colm[i] = (NG * n + (NG - 3) + i < p) ? 0xffffffffu : 0u;
@@ -108,18 +107,11 @@ __global__ __launch_bounds__(256, 1) void k_syrk4(const float *__restrict__ xt, 
         unsigned okm = ok ? 0xffffffffu : 0u;
         asm volatile("" : "+v"(okm));   // opaque: otherwise the and is turned back into a select of the CONVERTED value
         double f[NG];
-        // a tile whose 16 rows are all valid and whose window is the full 72 bands needs no masking at all (wave-uniform)
-        const bool plain = full72 && (__builtin_amdgcn_ballot_w64(ok) == ~0ull);
-        if (plain) {
 #pragma unroll
-          for (int I = 0; I < NG; ++I) f[I] = (double)xraw[sl][I] - musl[I];
-        } else {
-#pragma unroll
-          for (int I = 0; I < NG; ++I) {
-            unsigned msk = okm;
-            if (4 * NG - 3 <= 3 * NG + I) msk &= colm[I - (NG - 3)];   // only bands 69..71 can lie beyond a window of >= 69
-            f[I] = (double)__uint_as_float(__float_as_uint(xraw[sl][I]) & msk) - musl[I];
-          }
+        for (int I = 0; I < NG; ++I) {
+          unsigned msk = okm;
+          if (4 * NG - 3 <= 3 * NG + I) msk &= colm[I - (NG - 3)];   // only bands 69..71 can lie beyond a window of >= 69
+          f[I] = (double)__uint_as_float(__float_as_uint(xraw[sl][I]) & msk) - musl[I];
         }
         if (EXP != 1) fetch(rt + 64 * DEPTH, sc);
         // the asm MFMAs below are invisible to the hazard recogniser: a VALU result (the last v_add_f64 of the centring)

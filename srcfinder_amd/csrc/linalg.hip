@@ -480,7 +480,8 @@ __global__ void k_argmin_nan_first(const double *__restrict__ nll, const int32_t
 }  // namespace
 
 constexpr int DET_SLOTS = 512;   // matrices factorised per launch (two rounds of 256 CUs) ...
-constexpr size_t DET_SLOT_BYTES = (size_t)400 << 20;   // ... within this many bytes of p x p float64 work matrices (p = 425: 290, p = 512: 200)
+constexpr size_t DET_SLOT_BYTES = (size_t)1 << 30;     // ... within this many bytes of p x p float64 work matrices (p = 425: all 512, p = 512: 512;
+                                                       // 290 slots at p = 425 cost the pass 13.4 instead of 9.1 ms per launch: the workgroups pair up on a CU)
 constexpr int DET_GROUP = 4;     // grid points per side and round of the deepening rule (k_det_round)
 // The job list holds every grid point of every column whatever the window: a column whose lost points are not two runs at
 // the ends of the grid takes the plain window rule in round 0 and may push up to nalpha jobs (with ncols x 2 x

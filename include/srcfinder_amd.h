@@ -34,7 +34,10 @@ extern "C" {
 int sf_version(void);
 const char *sf_last_error_string(void);
 
-/* Largest column-major scratch the fused driver needs for a shard of `ncols` columns. */
+/* Largest column-major scratch the fused driver needs for a shard of `ncols` columns.  For windows wider than
+ * SF_MAX_ACTIVE_FUSED it includes the exact-determinant pass's scratch: a job list of ncols * nalpha entries (12 bytes each)
+ * and up to 512 p x p float64 work matrices within 1 GB (740 MB at p = 425); every stream slot of a host that keeps several
+ * flightlines in flight (srcfinder_amd.inflight) holds its own workspace. */
 size_t sf_cmf_workspace_bytes(int lines, int p, int ncols, int nalpha);
 
 /* Stage 1 -- column extract (robust_mf.py:298), valid-row mask (:282,:299): transposes the active

@@ -170,14 +170,20 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
   float xraw[NJ];
   bool rowok_next;
   auto fetch = [&](int r0, float (&dst)[NJ], bool &ok) {
-    const int row = r0 + li;
-    ok = (row < rend) && (mp[row < rend ? row : rbeg] != 0);
-    const float *xp = xc + (size_t)(ok ? row : rbeg) * PS;
+    const int row = r0 + li, rowc = row < rend ? row : rend - 1;   // round 3: the address does not wait for the validity byte
+    ok = (mp[rowc] != 0) && (row < rend);
+    const float *xp = xc + (size_t)rowc * PS;
 #pragma unroll
     for (int s = 0; s < NJ; s += 2) sf_load2(xp + s, dst[s], dst[s + 1]);
   };
   int r0 = rbeg + 16 * wave;
   if (r0 < rend) fetch(r0, xraw, rowok_next);
+  unsigned colm4[3];   // lane group g = 3 holds bands 54..71: those beyond the window are switched off
+#pragma unroll
+  for (int i = 0; i < 3; ++i) colm4[i] = (NJ * g + (NJ - 3) + i < p) ? 0xffffffffu : 0u;
+  double *zeros4 = mus + 4 * NJ;   // 18 zeros behind the mean (the LDS block has room: see SW4_LDS)
+  if (tid < NJ) zeros4[tid] = 0.0;
+  __syncthreads();
 
   if (EXP == 4) r0 = rend;   // timing experiment: prologue + final reduction only
   for (; r0 < rend; r0 += 16 * 4) {
@@ -187,12 +193,17 @@ __global__ __launch_bounds__(256, 1) void k_sweep4(const float *__restrict__ xt,
     asm volatile("" : "+v"(opq));  // keeps the loop-invariant LDS operand reads inside the iteration (see k_sweep)
     const double *cfl = cf + opq;
     const double *wfl = wf + opq;
-    const double *musl = mus + opq;
+    // branch-free (round 3; the select form compiled to 18 exec-masked blocks, each an LDS read + lgkmcnt(0)): an invalid
+    // row's raw bits and its mean are switched to 0, so its operand is exactly 0 whatever the row held
+    const double *musl = (rowok ? mus + NJ * g : zeros4) + opq;
+    unsigned okm = rowok ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(okm));
     double x[NJ];
 #pragma unroll
     for (int s = 0; s < NJ; ++s) {
-      const int b = NJ * g + s;
-      x[s] = (rowok && b < p) ? (double)xraw[s] - musl[b] : 0.0;
+      unsigned msk = okm;
+      if (s >= NJ - 3) msk &= colm4[s - (NJ - 3)];
+      x[s] = (double)__uint_as_float(__float_as_uint(xraw[s]) & msk) - musl[s];
     }
     if (r0 + 64 < rend) fetch(r0 + 64, xraw, rowok_next);
     // ---- GEMM1: 18 independent chains, one 4-band step at a time.  The A blocks of step s+1 are read (in-order
@@ -1053,7 +1064,7 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
 }
 
 constexpr size_t sw4r_lds(int nk) { return ((size_t)S4M * nk * 64 + S4J * S4J * 16 + S4J * nk * 16 + 4 * S4J) * sizeof(double); }
-constexpr size_t SW4_LDS = ((size_t)S4M * S4J * 64 + S4J * S4J * 16 + 4 * S4J) * sizeof(double);
+constexpr size_t SW4_LDS = ((size_t)S4M * S4J * 64 + S4J * S4J * 16 + 4 * S4J + S4J) * sizeof(double);   // c fragments, W blocks, mean, 18 zeros
 
 template <int EXP>
 int launch_sweep4_t(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
@@ -1079,11 +1090,11 @@ int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
   rows = (rows + 127) / 128 * 128;
 #define SW4R_ARGS xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part
   const int form = sf_tune().sweep4_form;
-  if (form != 1) {   // the streamed kernel (round 3) for rank 28; rank 36 keeps k_sweep4r (four t copies of 9 do not fit 256 registers)
+  if (form != 1) {   // the streamed kernel (round 3), both ranks
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK1>), SwS<NK1>::lds_bytes())) return rc;
     const int sfast = sf_tune().sweep_grid != 1;
     const dim3 grid = sfast ? dim3(nsplit, g.ncols) : dim3(g.ncols, nsplit);
-    if (form == 0) hipLaunchKernelGGL((k_sweep4s<NK1>), grid, dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS, sfast);
+    if (form == 0 || form == 3) hipLaunchKernelGGL((k_sweep4s<NK1>), grid, dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS, sfast);
 #ifdef SF_SWEEP_EXPERIMENTS
 #define SW4S_EXP(E) if (form == 100 + E) { \
       if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK1, E>), SwS<NK1>::lds_bytes())) return rc; \
@@ -1091,8 +1102,16 @@ int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
     SW4S_EXP(1) SW4S_EXP(2) SW4S_EXP(4) SW4S_EXP(5) SW4S_EXP(8) SW4S_EXP(16) SW4S_EXP(31)
 #endif
     SF_LAUNCH_CHECK("k_sweep4s");
-    hipLaunchKernelGGL((k_sweep4r<0, 4, NK2>), dim3(g.ncols, nsplit), dim3(256), sw4r_lds(NK2), st, SW4R_ARGS);
-    SF_LAUNCH_CHECK("k_sweep4r");
+    // rank 36 (lrok == 2): the streamed kernel fits two waves per SIMD there too (250 registers; round 2's k_sweep4r needed
+    // one wave per SIMD for its wider t copies): 2.90 against 3.41 ms per stage-5 call on 256 rank-36 columns
+    // (tools/tune_sweep_rank36.py); sf_debug_set(20, 3) keeps k_sweep4r<0,4,9> for these columns
+    if (form != 3) {
+      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK2>), SwS<NK2>::lds_bytes())) return rc;
+      hipLaunchKernelGGL((k_sweep4s<NK2>), grid, dim3(512), SwS<NK2>::lds_bytes(), st, SW4R_ARGS, sfast);
+    } else {
+      hipLaunchKernelGGL((k_sweep4r<0, 4, NK2>), dim3(g.ncols, nsplit), dim3(256), sw4r_lds(NK2), st, SW4R_ARGS);
+    }
+    SF_LAUNCH_CHECK("k_sweep4s(rank 36)");
     return 0;
   }
   if (sf_tune().sweep4r_waves == 4)

@@ -741,7 +741,8 @@ struct SwS {
   static constexpr int OF = OU + R2 * 32;                    // [R3][64][2]
   static constexpr int OL = OF + R3 * 128;                   // [R4][64]
   static constexpr int OM = OL + R4 * 64;                    // mu [72]
-  static constexpr int TOTAL = OM + 4 * NJ;
+  static constexpr int OS = OM + 4 * NJ;                     // 1/sqrt(lam) [72] (prologue only)
+  static constexpr int TOTAL = OS + 4 * NJ;
   static constexpr size_t lds_bytes() { return (size_t)TOTAL * sizeof(double); }
 };
 
@@ -772,7 +773,8 @@ __device__ __forceinline__ void lds_await9(d2_t (&m)[9]) {
 }
 
 // EXP (timing experiments, wrong results, -DSF_SWEEP_EXPERIMENTS): bit 0 no row reduction, 1 no conversion / centring,
-// 2 no DPP rotations, 3 no squares, 4 no validity selects -- the MFMAs and LDS reads stay
+// 2 no DPP rotations, 3 no squares, 4 no validity selects -- the MFMAs and LDS reads stay; bit 5 no tiles at all (what the
+// table prologue + epilogue of every workgroup cost), bit 6 no table prologue (tiles on whatever the LDS holds)
 template <int NK, int EXP = 0>
 __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
                                                     const int32_t *__restrict__ nuse, const double *__restrict__ mu,
@@ -795,36 +797,69 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
   const int nsplit = split_fastest ? gridDim.x : gridDim.y;
   double *po = part + ((size_t)c * nsplit + split) * 2 * NA16;
   if (status[c] != 0 || lrok[c] != (NK == SF_LR_K / 4 ? 1 : 2)) return;   // another instantiation / k_sweep4 takes these columns
-  // ---- prologue: the tables, permuted into the pair layouts
-  {
-    double *mus = sm + S::OM;
+  // ---- prologue: the tables, permuted into the pair layouts.  Every global load of the workgroup is issued first (16-byte
+  // loads, compile-time trip counts: ~17 per thread in flight at once), then the LDS stores: with one workgroup per CU
+  // nothing else runs on the CU meanwhile, and a load-store loop paid one L2 round trip per iteration
+  if constexpr ((EXP & 64) == 0) {
+    constexpr int NT = 64 * NW;
+    constexpr int NW2 = NJ * NJ * 8, NU2 = NJ * NKP * 16, NF2 = R3 * 64, NL2 = NK * 32;   // 16-byte pieces of the four tables
+    constexpr int IW = (NW2 + NT - 1) / NT, IU = (NU2 + NT - 1) / NT, IF = (NF2 + NT - 1) / NT, IL = (NL2 + NT - 1) / NT;
+    static_assert(IL == 1 && 4 * NJ <= NT, "one piece per thread");
+    double *mus = sm + S::OM, *scl = sm + S::OS;
+    const d2_t *wsrc = reinterpret_cast<const d2_t *>(wfrag + (size_t)c * wstride);            // [(s*18 + jg)*16 + 4q + n]
+    const d2_t *us = reinterpret_cast<const d2_t *>(ufrag_g + (size_t)c * (NJ * NK2 * 16));    // [(jg*NK2 + mg)*16 + 4q + n]
+    const double *ws = wfrag2_g + (size_t)c * (NM * NK2 * 64);                                 // [(M*NK2 + mg)*64 + lane]
+    const d2_t zero2 = {0.0, 0.0};
+    d2_t vw[IW], vu[IU], vf[IF], vl;
+    double lamv = 1.0, muv = 0.0;
+    if (tid < p) { lamv = lam[(size_t)c * p + tid]; muv = mu[(size_t)c * p + tid]; }
+#pragma unroll
+    for (int k = 0; k < IW; ++k) { const int i = tid + k * NT; vw[k] = (i < NW2) ? wsrc[i] : zero2; }
+#pragma unroll
+    for (int k = 0; k < IU; ++k) {
+      const int i = tid + k * NT, sl2 = i & 7, h = (i >> 3) & 1, pr = i >> 4, jg = pr / NKP, mg = 2 * (pr - jg * NKP) + h;
+      vu[k] = (i < NU2 && mg < NK) ? us[(jg * NK2 + mg) * 8 + sl2] : zero2;
+    }
+#pragma unroll
+    for (int k = 0; k < IF; ++k) {
+      const int i = tid + k * NT, ln2 = i & 31, kk = (i >> 5) & 1, r = i >> 6;   // r = (gr*NK + mg)*2 + h
+      const int h = r & 1, gm = r >> 1, gr = gm / NK, mg = gm - gr * NK, M = 4 * gr + 2 * h + kk;
+      vf[k] = (i < NF2) ? *reinterpret_cast<const d2_t *>(ws + (M * NK2 + mg) * 64 + 2 * ln2) : zero2;
+    }
+    vl = (tid < NL2) ? *reinterpret_cast<const d2_t *>(ws + ((NM - 1) * NK2 + (tid >> 5)) * 64 + 2 * (tid & 31)) : zero2;
     // W blocks scaled by 1/sqrt(lam_j): GEMM1 then yields the whitened coordinates y_j/sqrt(lam_j) (unit variance) and
     // z their squares, which is what the row-scaled factorisation of cmf_lowrank.hip multiplies
-    for (int i = tid; i < 4 * NJ; i += 64 * NW) mus[i] = (i < p) ? 1.0 / sqrt(lam[(size_t)c * p + i]) : 1.0;   // (mus: scratch here)
+    if (tid < 4 * NJ) { scl[tid] = (tid < p) ? 1.0 / sqrt(lamv) : 1.0; mus[tid] = muv; }
     __syncthreads();
-    {
-      const double *wsrc = wfrag + (size_t)c * wstride;   // [(s*18 + jg)*16 + 4q + n]
-      for (int i = tid; i < NJ * NJ * 16; i += 64 * NW) {
-        const int blk = i >> 4, sl = i & 15, s = blk / NJ, jg = blk - s * NJ;
-        sm[S::OW + ((s * (NJ / 2) + (jg >> 1)) * 16 + sl) * 2 + (jg & 1)] = wsrc[i] * mus[4 * jg + (i & 3)];
+#pragma unroll
+    for (int k = 0; k < IW; ++k) {
+      const int i = tid + k * NT;
+      if (i < NW2) {
+        const int blk = i >> 3, sl = 2 * (i & 7), s = blk / NJ, jg = blk - s * NJ;
+        double *dst = sm + S::OW + ((s * (NJ / 2) + (jg >> 1)) * 16 + sl) * 2 + (jg & 1);
+        dst[0] = vw[k].x * scl[4 * jg + (sl & 3)];
+        dst[2] = vw[k].y * scl[4 * jg + (sl & 3) + 1];
       }
     }
-    __syncthreads();
-    for (int i = tid; i < 4 * NJ; i += 64 * NW) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
-    {
-      const double *us = ufrag_g + (size_t)c * (NJ * NK2 * 16);   // [(jg*NK2 + mg)*16 + 4q + n]
-      for (int i = tid; i < NJ * NKP * 32; i += 64 * NW) {
-        const int h = i & 1, sl = (i >> 1) & 15, pr = i >> 5, jg = pr / NKP, mg = 2 * (pr - jg * NKP) + h;
-        sm[S::OU + i] = (mg < NK) ? us[(jg * NK2 + mg) * 16 + sl] : 0.0;
+#pragma unroll
+    for (int k = 0; k < IU; ++k) {
+      const int i = tid + k * NT, sl2 = i & 7, h = (i >> 3) & 1, pr = i >> 4;
+      if (i < NU2) {
+        double *dst = sm + S::OU + pr * 32 + 4 * sl2 + h;
+        dst[0] = vu[k].x;
+        dst[2] = vu[k].y;
       }
-      const double *ws = wfrag2_g + (size_t)c * (NM * NK2 * 64);   // [(M*NK2 + mg)*64 + lane]
-      for (int i = tid; i < R3 * 128; i += 64 * NW) {
-        const int kk = i & 1, ln = (i >> 1) & 63, r = i >> 7;        // r = (gr*NK + mg)*2 + h
-        const int h = r & 1, gm = r >> 1, gr = gm / NK, mg = gm - gr * NK, M = 4 * gr + 2 * h + kk;
-        sm[S::OF + i] = ws[(M * NK2 + mg) * 64 + ln];
-      }
-      for (int i = tid; i < NK * 64; i += 64 * NW) sm[S::OL + i] = ws[((NM - 1) * NK2 + (i >> 6)) * 64 + (i & 63)];
     }
+#pragma unroll
+    for (int k = 0; k < IF; ++k) {
+      const int i = tid + k * NT, ln2 = i & 31, kk = (i >> 5) & 1, r = i >> 6;
+      if (i < NF2) {
+        double *dst = sm + S::OF + r * 128 + 4 * ln2 + kk;
+        dst[0] = vf[k].x;
+        dst[2] = vf[k].y;
+      }
+    }
+    if (tid < NL2) *reinterpret_cast<d2_t *>(sm + S::OL + 2 * tid) = vl;
   }
   __syncthreads();
 
@@ -835,7 +870,7 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
   int ntile = 0;
   int nrowok = 0;   // valid rows seen by this lane (lanes with g == 0 cover every row of the wave's tiles once)
 
-  const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
+  const int rbeg = split * rows_per_wg, rend = (EXP & 32) ? rbeg : min(L, rbeg + rows_per_wg);
   const uint8_t *mp = mask_t + (size_t)c * L;
   const float *xc = xt + (size_t)c * L * PS + NJ * g;
   const unsigned smb = (unsigned)(size_t)sm;
@@ -1099,7 +1134,7 @@ int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
 #define SW4S_EXP(E) if (form == 100 + E) { \
       if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK1, E>), SwS<NK1>::lds_bytes())) return rc; \
       hipLaunchKernelGGL((k_sweep4s<NK1, E>), grid, dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS, sfast); }
-    SW4S_EXP(1) SW4S_EXP(2) SW4S_EXP(4) SW4S_EXP(5) SW4S_EXP(8) SW4S_EXP(16) SW4S_EXP(31)
+    SW4S_EXP(1) SW4S_EXP(2) SW4S_EXP(4) SW4S_EXP(5) SW4S_EXP(8) SW4S_EXP(16) SW4S_EXP(31) SW4S_EXP(32) SW4S_EXP(64) SW4S_EXP(96)
 #endif
     SF_LAUNCH_CHECK("k_sweep4s");
     // rank 36 (lrok == 2): the streamed kernel fits two waves per SIMD there too (250 registers; round 2's k_sweep4r needed

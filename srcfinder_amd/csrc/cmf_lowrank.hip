@@ -12,7 +12,7 @@
 // The factorisation is a Householder QR with column pivoting of B^T (208 x 72), stopped after K steps:
 //   B^T P = Q R   =>   B = (P R_K^T) (Q_K^T) + E,   |E| = the largest remaining column norm,
 // backward stable whatever the conditioning (B is numerically singular by design -- no Gram matrix, no
-// inverse).  One 576-thread workgroup per column, the matrix in LDS, 8 lanes per column with DPP reductions.  A column whose remaining norm
+// inverse).  One 576-thread workgroup per column, 8 lanes per column with DPP reductions, the matrix in their registers.  A column whose remaining norm
 // after K steps is not below 1e-14 |R_00| (q then moves by <= 72 x 1e-14 x |R_00| ~ 5e-16; the rounding floor is ~7e-16 |R_00|), or whose
 // correlation matrix is not safely positive definite (condition > 1e10), is flagged and swept by the full-rank kernel.
 #include "cmf_common.h"
@@ -24,7 +24,6 @@ constexpr int LR_NA = 16 * SF_SW4_NM;      // 208
 constexpr int LR_K = SF_LR_K;              // 28: the fast rank
 constexpr int LR_K2 = SF_LR_K2;            // 36: second chance for spectra with a wider eigenvalue range
 constexpr int LR_NK2 = LR_K2 / 4;          // fragment layout stride (both ranks share the 36-wide layout)
-constexpr int LR_LDA = LR_NA + 1;          // column stride in LDS (odd: threads on different columns, same row)
 constexpr int LR_TPC = 8;                  // lanes per column in the update (8-lane DPP reductions, no LDS partials)
 constexpr int LR_NT = 576;                 // 72 columns x 8 lanes = 9 waves
 constexpr int LR_PK = 5;                   // row slots (of 8 rows) that can touch the diagonal: 8 * 5 = 40 > K2
@@ -57,25 +56,31 @@ __device__ __forceinline__ double lr_sum16(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
-                                                    const int32_t *__restrict__ status, const double *__restrict__ alphas,
-                                                    int nalpha, int p, double *__restrict__ ufrag, double *__restrict__ wfrag,
-                                                    int32_t *__restrict__ lrok) {
-  extern __shared__ double A[];                 // [LR_P][LR_LDA] column-major: column j = the 208 coefficients of eigen index j
+// Round 3: the matrix lives in REGISTERS.  An 8-lane group owns one column (26 values per lane) for the whole
+// factorisation; what the groups share is the reflector of the step, which the pivot's group writes once -- scaled, with its
+// unit diagonal and the zeros above it -- into row s of the reflector store V[36][208] (60 KB of LDS instead of the
+// 120 KB matrix: two workgroups per CU, 598 columns in two rounds instead of three, and a step moves a third of the
+// LDS bytes it used to).  Q_K is formed in registers as well (16 lanes per column, reflectors read from V).  Same
+// arithmetic in the same order as the LDS-resident form of round 2: the fragments are bit-identical.
+__global__ __launch_bounds__(LR_NT)
+void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
+               const int32_t *__restrict__ status, const double *__restrict__ alphas,
+               int nalpha, int p, double *__restrict__ ufrag, double *__restrict__ wfrag,
+               int32_t *__restrict__ lrok) {
+  __shared__ double V[LR_K2][LR_NA];            // reflector s: 0 above row s, 1 at row s, x_i * scale below
   __shared__ double cnorm[LR_P];                // squared norms of the remaining columns, rows >= current (-1: pivoted)
   __shared__ double cnorm2[LR_P];               // the same over the rows below the current one
-  __shared__ int posof[LR_P];                   // step at which a column was pivoted, -1 if never
   __shared__ double tau_s[LR_K2];
   __shared__ double s_al[LR_NA], s_be[LR_NA], s_lam[LR_P];
-  __shared__ int perm[LR_K2];                   // perm[s] = the column pivoted at step s
-  __shared__ int freecol[LR_K2];                 // never-pivoted columns that hold Q_K afterwards
-  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  __shared__ double s_r00;
+  constexpr int NV = LR_NA / LR_TPC;            // 26 values of its column per lane
+  const int c = blockIdx.x, tid = threadIdx.x;
   if (status[c] != 0) {
     if (tid == 0) lrok[c] = 0;
     return;
   }
   const double n = (double)nuse[c];
-  // ---- B^T: A[j][i] = beta_i / (n beta_i lam_j + alpha_i)   (zero for the padding alpha / eigen indices).
+  // ---- B^T: a[j][i] = beta_i / (n beta_i lam_j + alpha_i)   (zero for the padding alpha / eigen indices).
   //      alpha, beta and lam are staged in LDS first: two dependent global loads per entry would dominate the kernel.
   for (int i = tid; i < LR_NA; i += LR_NT) {
     const double a = (i < nalpha) ? alphas[i] : 1.0;
@@ -83,48 +88,52 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
     s_be[i] = (i < nalpha) ? (1.0 - a) / (n - 1.0) : 0.0;
   }
   for (int j = tid; j < LR_P; j += LR_NT) s_lam[j] = (j < p) ? lam[(size_t)c * p + j] : 1.0;
+  if (tid == 0) s_r00 = 0.0;
   __syncthreads();
-  for (int idx = tid; idx < LR_P * LR_NA; idx += LR_NT) {
-    const int j = idx / LR_NA, i = idx - j * LR_NA;
-    const double a = s_al[i], beta = s_be[i], lj = s_lam[j];
-    const double v = lj * beta / ((n * beta) * lj + a);
-    A[j * LR_LDA + i] = (i < nalpha && j < p) ? v : 0.0;
-  }
+  const int col = tid >> 3, sub = tid & 7;   // column `col` (0..71), rows sub, sub+8, ...
   // (row-scaled: what is factored is B'_ji = lam_j B_ji, all entries in [0, 1/n); the sweep feeds it the whitened
   //  squares z_j / lam_j -- of order one whatever the spectrum -- so the factorisation error is relative to what each
   //  eigen-direction actually contributes to q, not to the largest entry of B, which is 1/(n lam_min).)
+  double av[NV];
+  {
+    const double lj = s_lam[col];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = sub + LR_TPC * k;
+      const double a = s_al[i], beta = s_be[i];
+      const double v = lj * beta / ((n * beta) * lj + a);
+      av[k] = (i < nalpha && col < p) ? v : 0.0;
+    }
+  }
   bool lam_ok = true;
   {
     double lmin = 1.7976931348623157e308, lmax = 0.0;
     for (int j = 0; j < p; ++j) { lmin = fmin(lmin, s_lam[j]); lmax = fmax(lmax, s_lam[j]); }
     lam_ok = (lmin > 1e-10 * lmax) && (lmax <= 1.7976931348623157e308);   // positive definite, condition < 1e10
   }
-  if (tid < LR_P) posof[tid] = -1;
-  __syncthreads();
-  const int col = tid >> 3, sub = tid & 7;   // update role: column `col` (0..71), rows sub, sub+8, ...
   {
     double s0 = 0.0, s1 = 0.0;
-    for (int i = sub; i < LR_NA; i += LR_TPC) {
-      const double v = A[col * LR_LDA + i];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const double v = av[k];
       s0 = __builtin_fma(v, v, s0);
-      if (i > 0) s1 = __builtin_fma(v, v, s1);
+      if (sub + LR_TPC * k > 0) s1 = __builtin_fma(v, v, s1);
     }
     s0 = lr_sum8(s0);
     s1 = lr_sum8(s1);
     if (sub == 0) { cnorm[col] = s0; cnorm2[col] = s1; }
   }
   __syncthreads();
-  // Two barriers per step.  No column is physically moved: a pivoted column keeps its place (posof[col] = its step),
-  // every wave finds the pivot for itself (same data, same tie-break), every lane forms the reflector's scalars
-  // from the carried norms -- cnorm = rows >= s, cnorm2 = rows > s, both summed afresh by the update of the
-  // previous step, so nothing is obtained by subtraction.
-  double r00 = 0.0;
-  bool mine_done = false;                       // this group's column has been pivoted
+  // Two barriers per step.  Every wave finds the pivot for itself (same data, same tie-break); the pivot's group forms the
+  // reflector's scalars from the carried norms -- cnorm = rows >= s, cnorm2 = rows > s, both summed afresh by the update
+  // of the previous step, so nothing is obtained by subtraction -- and publishes the reflector; the others apply it.
+  int mypos = -1;                               // step at which this group's column was pivoted
   int kuse = 0;                                 // accepted rank: LR_K, LR_K2 or 0 (full-rank sweep)
   for (int s = 0; s < LR_K2; ++s) {
     if (s == LR_K) {   // rank 28 reached: is the trailing block already at the rounding floor?  (same answer in every thread)
       double bn = 0.0;
       for (int j = 0; j < LR_P; ++j) bn = fmax(bn, cnorm[j]);
+      const double r00 = s_r00;
       if (sqrt(bn) <= 1e-14 * r00 && r00 > 0.0) { kuse = LR_K; break; }
     }
     // pivot = the remaining column of largest norm (lowest index on ties; pivoted columns carry -1).  Every 8-lane
@@ -141,58 +150,58 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
     lr_argmax_step<0x4E>(bv, bi);
     lr_argmax_step<0x141>(bv, bi);
     const int pv = bi;
-    const double *xs = A + pv * LR_LDA;
-    const double alpha = xs[s], xn2 = cnorm2[pv];
-    double tau = 0.0, scale = 0.0, betah = alpha;
-    if (xn2 > 0.0) {
-      const double h2 = __builtin_fma(alpha, alpha, xn2);
-      double y = __builtin_amdgcn_rsq(h2);                     // 1/sqrt(h2): hardware estimate + two Newton steps
-      y = y * __builtin_fma(-0.5 * h2 * y, y, 1.5);
-      y = y * __builtin_fma(-0.5 * h2 * y, y, 1.5);
-      betah = -copysign(h2 * y, alpha);
-      const double den = alpha - betah;                        // same sign as alpha, |den| >= |alpha|: no cancellation
-      double rd = __builtin_amdgcn_rcp(den);
-      rd = rd * __builtin_fma(-den, rd, 2.0);
-      rd = rd * __builtin_fma(-den, rd, 2.0);
-      scale = rd;
-      tau = den * (y * (alpha < 0.0 ? -1.0 : 1.0));            // (betah - alpha)/betah = den / (sign(alpha) sqrt(h2))
-    }
-    if (s == 0) r00 = fabs(betah);
-    // v = x * scale (v_s = 1 implicit), in registers of every lane for its rows
-    double vr[(LR_NA + LR_TPC - 1) / LR_TPC];
-    // rows >= 32 are below every diagonal position (s < 28): only the first four row slots need the predicates
+    if (col == pv) {
+      // this group's column is the pivot: alpha = its entry in row s (held by lane s % 8, slot s / 8)
+      double alpha = 0.0;
 #pragma unroll
-    for (int k = 0; k < LR_PK; ++k) {
-      const int i = sub + LR_TPC * k;
-      vr[k] = (i > s) ? xs[i] * scale : ((i == s) ? 1.0 : 0.0);
-    }
+      for (int k = 0; k < LR_PK; ++k) alpha = (sub + LR_TPC * k == s) ? av[k] : alpha;
+      alpha = lr_sum8(alpha);                                    // exactly one lane holds it: the sum is the value
+      const double xn2 = cnorm2[pv];
+      double tau = 0.0, scale = 0.0, betah = alpha;
+      if (xn2 > 0.0) {
+        const double h2 = __builtin_fma(alpha, alpha, xn2);
+        double y = __builtin_amdgcn_rsq(h2);                     // 1/sqrt(h2): hardware estimate + two Newton steps
+        y = y * __builtin_fma(-0.5 * h2 * y, y, 1.5);
+        y = y * __builtin_fma(-0.5 * h2 * y, y, 1.5);
+        betah = -copysign(h2 * y, alpha);
+        const double den = alpha - betah;                        // same sign as alpha, |den| >= |alpha|: no cancellation
+        double rd = __builtin_amdgcn_rcp(den);
+        rd = rd * __builtin_fma(-den, rd, 2.0);
+        rd = rd * __builtin_fma(-den, rd, 2.0);
+        scale = rd;
+        tau = den * (y * (alpha < 0.0 ? -1.0 : 1.0));            // (betah - alpha)/betah = den / (sign(alpha) sqrt(h2))
+      }
+      // v = x * scale (v_s = 1); rows >= 40 are below every diagonal position (s < 36): only the first five row slots
+      // need the predicates.  R_ss = betah takes the diagonal entry's place in the column.
 #pragma unroll
-    for (int k = LR_PK; k < LR_NA / LR_TPC; ++k) vr[k] = xs[sub + LR_TPC * k] * scale;
-    __syncthreads();   // every lane has read column pv (and the norms) before they change
-    if (col == pv) {   // the pivot's own group stores v, R_ss and the bookkeeping while the others update
-#pragma unroll
-      for (int k = 0; k < LR_NA / LR_TPC; ++k) {
+      for (int k = 0; k < LR_PK; ++k) {
         const int i = sub + LR_TPC * k;
-        if (k >= LR_PK || i > s) A[pv * LR_LDA + i] = vr[k];
+        V[s][i] = (i > s) ? av[k] * scale : ((i == s) ? 1.0 : 0.0);
+        av[k] = (i == s) ? betah : av[k];
       }
+#pragma unroll
+      for (int k = LR_PK; k < NV; ++k) V[s][sub + LR_TPC * k] = av[k] * scale;
       if (sub == 0) {
-        A[pv * LR_LDA + s] = betah;
         tau_s[s] = tau;
-        perm[s] = pv;
-        posof[pv] = s;
-        cnorm[pv] = -1.0;
+        if (s == 0) s_r00 = fabs(betah);
       }
-      mine_done = true;
-    } else if (!mine_done) {
+      mypos = s;
+    }
+    __syncthreads();   // the reflector is published
+    if (col == pv) {
+      if (sub == 0) cnorm[pv] = -1.0;   // (after the barrier: the other groups read the norms for their pivot search before it)
+    } else if (mypos < 0) {
       // ---- apply H = I - tau v v^T; squared norms of what is left in rows > s and in rows > s+1
-      double *ac = A + col * LR_LDA;
-      double av[(LR_NA + LR_TPC - 1) / LR_TPC];
+      // (the reflector is read from LDS twice rather than kept: 26 + 26 values per lane would not leave room for two
+      //  workgroups per CU)
+      const double tau = tau_s[s];
+      const double *vs = V[s] + sub;
       double w = 0.0;
 #pragma unroll
-      for (int k = 0; k < LR_NA / LR_TPC; ++k) {
+      for (int k = 0; k < NV; ++k) {
         const int i = sub + LR_TPC * k;
-        av[k] = (k >= LR_PK || i >= s) ? ac[i] : 0.0;
-        w = __builtin_fma(vr[k], av[k], w);
+        const double a = (k >= LR_PK || i >= s) ? av[k] : 0.0;
+        w = __builtin_fma(vs[LR_TPC * k], a, w);
       }
       const double wt = tau * lr_sum8(w);
       double nn = 0.0, nn2 = 0.0;
@@ -200,17 +209,17 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
       for (int k = 0; k < LR_PK; ++k) {
         const int i = sub + LR_TPC * k;
         if (i >= s) {
-          const double nv = __builtin_fma(-wt, vr[k], av[k]);
-          ac[i] = nv;
+          const double nv = __builtin_fma(-wt, vs[LR_TPC * k], av[k]);
+          av[k] = nv;
           if (i > s) nn = __builtin_fma(nv, nv, nn);
           if (i > s + 1) nn2 = __builtin_fma(nv, nv, nn2);
         }
       }
       double nb = 0.0;
 #pragma unroll
-      for (int k = LR_PK; k < LR_NA / LR_TPC; ++k) {
-        const double nv = __builtin_fma(-wt, vr[k], av[k]);
-        ac[sub + LR_TPC * k] = nv;
+      for (int k = LR_PK; k < NV; ++k) {
+        const double nv = __builtin_fma(-wt, vs[LR_TPC * k], av[k]);
+        av[k] = nv;
         nb = __builtin_fma(nv, nv, nb);
       }
       nn += nb;
@@ -224,67 +233,60 @@ __global__ __launch_bounds__(LR_NT) void k_lowrank(const double *__restrict__ la
   if (kuse == 0) {   // what is left after K2 steps
     double bn = 0.0;
     for (int j = 0; j < LR_P; ++j) bn = fmax(bn, cnorm[j]);
+    const double r00 = s_r00;
     if (sqrt(bn) <= 1e-14 * r00 && r00 > 0.0) kuse = LR_K2;
   }
   if (!lam_ok) kuse = 0;   // (near-)singular or indefinite correlation matrix: the full-rank kernel
   if (tid == 0) lrok[c] = (kuse == LR_K) ? 1 : ((kuse == LR_K2) ? 2 : 0);
   if (kuse == 0) return;
-  // ---- U fragments: ufrag[(jg*NK + mg)*16 + 4q + n] = -U[4jg+q][4mg+n];  U[j][m] = R[m][column j]: rows m <= posof[j]
-  //      of a pivoted column (below them sits its reflector), all K rows of the others
-  double *uo = ufrag + (size_t)c * (SF_SW4_NJ * LR_NK2 * 16);
-  for (int idx = tid; idx < LR_P * LR_K2; idx += LR_NT) {
-    const int j = idx / LR_K2, m = idx - j * LR_K2;
-    const int pj = posof[j];
-    const double r = (m < kuse && (pj < 0 || m <= pj)) ? A[j * LR_LDA + m] : 0.0;
-    const int jg = j >> 2, q = j & 3, mg = m >> 2, nn = m & 3;
-    uo[(jg * LR_NK2 + mg) * 16 + 4 * q + nn] = -r;
+  // ---- U fragments: ufrag[(jg*NK + mg)*16 + 4q + n] = -U[4jg+q][4mg+n];  U[j][m] = R[m][column j]: rows m <= its step
+  //      of a pivoted column (below them sat its reflector), all K rows of the others -- straight from the registers
+  {
+    double *uo = ufrag + (size_t)c * (SF_SW4_NJ * LR_NK2 * 16);
+    const int jg = col >> 2, q = col & 3;
+#pragma unroll
+    for (int k = 0; k < LR_PK; ++k) {
+      const int m = sub + LR_TPC * k;
+      if (m < LR_K2) {
+        const double r = (m < kuse && (mypos < 0 || m <= mypos)) ? av[k] : 0.0;
+        uo[(jg * LR_NK2 + (m >> 2)) * 16 + 4 * q + (m & 3)] = -r;
+      }
+    }
   }
-  __syncthreads();
-  // ---- Q_K = H_0 ... H_{K-1} [I_K; 0], formed in K of the columns that were never pivoted (their R entries have
-  //      been exported); reflector s sits in column perm[s].  16 lanes per column.
-  if (tid == 0) {
-    int m = 0;
-    for (int j = 0; j < LR_P && m < kuse; ++j)
-      if (posof[j] < 0) freecol[m++] = j;
-  }
-  __syncthreads();
-  for (int idx = tid; idx < kuse * LR_NA; idx += LR_NT) {
-    const int m = idx / LR_NA, i = idx - m * LR_NA;
-    A[freecol[m] * LR_LDA + i] = (i == m) ? 1.0 : 0.0;
-  }
-  __syncthreads();
-  const int qcol = tid >> 4, qsub = tid & 15;   // up to 36 columns x 16 lanes = 576 threads
-  for (int s = kuse - 1; s >= 0; --s) {
-    const double *v = A + perm[s] * LR_LDA;
-    const double tau = tau_s[s];
-    if (qcol < kuse) {
-      double *qc = A + freecol[qcol] * LR_LDA;
-      double vv[(LR_NA + 15) / 16], qv[(LR_NA + 15) / 16];
+  // ---- Q_K = H_0 ... H_{K-1} [I_K; 0]: column m in the registers of a 16-lane group (13 values per lane), reflectors
+  //      from V.  The columns are independent: no barrier between reflectors.
+  constexpr int NQ = LR_NA / 16;
+  const int qcol = tid >> 4, qsub = tid & 15;   // 36 columns x 16 lanes = 576 threads
+  double qv[NQ];
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) qv[k] = (qsub + 16 * k == qcol) ? 1.0 : 0.0;
+  if (qcol < kuse) {
+    for (int s = kuse - 1; s >= 0; --s) {
+      const double tau = tau_s[s];
+      double vv[NQ];
       double w = 0.0;
 #pragma unroll
-      for (int k = 0; k < (LR_NA + 15) / 16; ++k) {
+      for (int k = 0; k < NQ; ++k) {
         const int i = qsub + 16 * k;
-        vv[k] = (i > s && i < LR_NA) ? v[i] : ((i == s) ? 1.0 : 0.0);
-        qv[k] = (i >= s && i < LR_NA) ? qc[i] : 0.0;
-        w = __builtin_fma(vv[k], qv[k], w);
+        vv[k] = V[s][i];
+        const double qm = (i >= s) ? qv[k] : 0.0;
+        w = __builtin_fma(vv[k], qm, w);
       }
       const double wt = tau * lr_sum16(w);
 #pragma unroll
-      for (int k = 0; k < (LR_NA + 15) / 16; ++k) {
+      for (int k = 0; k < NQ; ++k) {
         const int i = qsub + 16 * k;
-        if (i >= s && i < LR_NA) qc[i] = __builtin_fma(-wt, vv[k], qv[k]);
+        qv[k] = (i >= s) ? __builtin_fma(-wt, vv[k], qv[k]) : qv[k];
       }
     }
-    // columns are independent: no barrier between reflectors
   }
-  __syncthreads();
   // ---- W fragments: wfrag[(M*NK + mg)*64 + lane], lane = 16q + 4mm + n  ->  W[4mg+q][16M + 4mm + n] = Q[alpha][m]
-  double *wo = wfrag + (size_t)c * (SF_SW4_NM * LR_NK2 * 64);
-  for (int idx = tid; idx < SF_SW4_NM * LR_NK2 * 64; idx += LR_NT) {
-    const int ln = idx & 63, blk = idx >> 6;
-    const int M = blk / LR_NK2, mg = blk - M * LR_NK2;
-    const int q = ln >> 4, a = 16 * M + (ln & 15);
-    wo[idx] = (4 * mg + q < kuse) ? A[freecol[4 * mg + q] * LR_LDA + a] : 0.0;
+  {
+    double *wo = wfrag + (size_t)c * (SF_SW4_NM * LR_NK2 * 64);
+    const int mg = qcol >> 2, q = qcol & 3;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)    // alpha = 16 k + qsub: alpha tile M = k
+      wo[(k * LR_NK2 + mg) * 64 + 16 * q + qsub] = (qcol < kuse) ? qv[k] : 0.0;
   }
 }
 
@@ -297,9 +299,7 @@ size_t sf_lowrank_bytes(const SfGeom &g) {
 
 int sf_launch_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas, const SfGeom &g,
                       double *ufrag, double *wfrag, int32_t *lrok, hipStream_t st) {
-  const size_t lds = (size_t)LR_P * LR_LDA * sizeof(double);
-  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_lowrank), lds)) return rc;
-  hipLaunchKernelGGL(k_lowrank, dim3(g.ncols), dim3(LR_NT), lds, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok);
+  hipLaunchKernelGGL(k_lowrank, dim3(g.ncols), dim3(LR_NT), 0, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok);
   SF_LAUNCH_CHECK("k_lowrank");
   return 0;
 }

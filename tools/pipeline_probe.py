@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Two whole flightlines in flight on two HIP streams (inter-flightline pipelining): throughput and kernel times."""
+"""Whole flightlines in flight on DEPTH HIP streams (inter-flightline pipelining): ms per flightline, sequential and pipelined.
+usage: pipeline_probe.py [samples] [depth] [key=value ...]   (sf_debug_set knobs for this thread, e.g. 20=1 8=4)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,6 +12,10 @@ lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library
 lines = 20000
 NS = int(sys.argv[1]) if len(sys.argv) > 1 else 598
 DEPTH = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+from srcfinder_amd import _ffi
+for kv in sys.argv[3:]:
+    k, v = kv.split("=")
+    _ffi.lib().sf_debug_set(int(k), int(v))
 cube = make_cube_torch(lines, NS, seed=1, abscf_full=lib[:, 2])
 outs = [torch.empty((lines, NS, 4), dtype=torch.float64, device="cuda") for _ in range(DEPTH)]
 bufs = {}

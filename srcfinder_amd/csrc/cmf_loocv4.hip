@@ -775,7 +775,10 @@ __device__ __forceinline__ void lds_await9(d2_t (&m)[9]) {
 // EXP (timing experiments, wrong results, -DSF_SWEEP_EXPERIMENTS): bit 0 no row reduction, 1 no conversion / centring,
 // 2 no DPP rotations, 3 no squares, 4 no validity selects -- the MFMAs and LDS reads stay; bit 5 no tiles at all (what the
 // table prologue + epilogue of every workgroup cost), bit 6 no table prologue (tiles on whatever the LDS holds)
-template <int NK, int EXP = 0>
+// RN: the running products are renormalised (mantissa / exponent split) after every RN-th tile of a wave.  A nonzero finite q of this
+// sweep lies in [~1e-17, ~1e3] (1 + a sum of O(1) terms in fp64), so the product of the 4 RN = 16 values a lane folds in between two
+// splits stays inside [1e-272, 1e48]: scaling by powers of two is exact there, the results are bit-identical to RN = 1.
+template <int NK, int EXP = 0, int RN = 4>
 __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
                                                     const int32_t *__restrict__ nuse, const double *__restrict__ mu,
                                                     const double *__restrict__ ufrag_g, const double *__restrict__ wfrag2_g,
@@ -893,7 +896,8 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
   int r0 = rbeg + 16 * wave;
   if (r0 < rend) fetch(r0, xraw, rowok_next);
 
-  for (; r0 < rend; r0 += 16 * NW) {
+  for (; r0 < rend;) {
+  for (int it = 0; it < RN && r0 < rend; ++it, r0 += 16 * NW) {
     const bool rowok = rowok_next;
     nrowok += (rowok && g == 0) ? 1 : 0;
     d2_t ring[RING];
@@ -960,7 +964,7 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
           for (int q = 0; q < 4; ++q) asm volatile("" :: "v"(acc[k][q]));
         return;
       }
-      static_for<0, 4>([&](auto sc) { reduce_stage(grc, sc); });
+      static_for<0, (RN == 1 ? 4 : 3)>([&](auto sc) { reduce_stage(grc, sc); });
     };
 
     static_for<0, NR>([&](auto cc) {
@@ -1046,6 +1050,16 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
     });
     ntile += 1;
   }
+    if constexpr (RN > 1) {
+#pragma unroll
+      for (int u = 0; u < NM; ++u) {
+        const int e = __builtin_amdgcn_frexp_exp(P[u]);
+        P[u] = __builtin_amdgcn_frexp_mant(P[u]);
+        N[u] = __builtin_amdgcn_ldexp(N[u], -e);
+        E[u] += e;
+      }
+    }
+  }
 
   __syncthreads();
   double *redP = sm;
@@ -1130,6 +1144,10 @@ int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
     const int sfast = sf_tune().sweep_grid != 1;
     const dim3 grid = sfast ? dim3(nsplit, g.ncols) : dim3(g.ncols, nsplit);
     if (form == 0 || form == 3) hipLaunchKernelGGL((k_sweep4s<NK1>), grid, dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS, sfast);
+    if (form == 4) {   // renormalisation after every tile (the form of the round's first half): A/B and the bit-identity test
+      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK1, 0, 1>), SwS<NK1>::lds_bytes())) return rc;
+      hipLaunchKernelGGL((k_sweep4s<NK1, 0, 1>), grid, dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS, sfast);
+    }
 #ifdef SF_SWEEP_EXPERIMENTS
 #define SW4S_EXP(E) if (form == 100 + E) { \
       if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK1, E>), SwS<NK1>::lds_bytes())) return rc; \

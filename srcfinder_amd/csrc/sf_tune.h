@@ -15,7 +15,7 @@ struct SfTune {
   int extract_nt = 0;         // key 19: 1 = plain (not non-temporal) xt stores in the pipelined extract kernel
   int eigh_lpp = 0;           // key 7: lanes per column pair of the Jacobi eigensolver
   int sweep4r_waves = 8;      // key 8: waves per workgroup of the rank-factored sweep (k_sweep4r, form 1)
-  int sweep4_form = 0;        // key 20: rank-28 sweep kernel: 0 = k_sweep4s (round 3: one streamed ring), 1 = k_sweep4r (round 2, both ranks), 3 = k_sweep4r for the rank-36 columns only; 100 + bits = timing experiments (-DSF_SWEEP_EXPERIMENTS)
+  int sweep4_form = 0;        // key 20: rank-28 sweep kernel: 0 = k_sweep4s (round 3: one streamed ring), 1 = k_sweep4r (round 2, both ranks), 3 = k_sweep4r for the rank-36 columns only, 4 = k_sweep4s renormalising after every tile; 100 + bits = timing experiments (-DSF_SWEEP_EXPERIMENTS)
   int wide_eigh_variant = 0;  // key 10: 1 = the single-workgroup eigensolver for every wide matrix
   int score_wgs = 0;          // key 12: workgroups per CU k_score_blk2 is sized for (0 = occupancy query)
   int cnn_pool_variant = 0;   // key 18: 1 = branch-4 pool taken inside the 1x1 convolution's tile fetch (sf_cnn_pool_conv; slower)

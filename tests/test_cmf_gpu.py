@@ -1125,7 +1125,9 @@ def test_sweep_kernels_agree_bit_for_bit(torch_cuda, library):
     """Round 3's streamed sweep kernel (k_sweep4s: one operand ring per tile, validity applied on t, 16-byte operand pairs)
     against round 2's (k_sweep4r, sf_debug_set(20, 1)): same accumulation order in every chain, so the NLL curves are equal
     bit for bit -- on windows of 72 and 70 bands (out-of-window bands switched off), with a ragged line count (a second,
-    short row split; tiles that end inside a 16-row group), NaN / negative rows and an all-NODATA column."""
+    short row split; tiles that end inside a 16-row group), NaN / negative rows and an all-NODATA column.  Form 4 is the
+    streamed kernel renormalising its running products after every tile instead of every fourth (scaling by powers of two:
+    the same bits)."""
     from srcfinder_amd import _ffi
     L = _ffi.lib()
     cube = make_cube_numpy(2500, 21, seed=31, abscf_full=library[:, 2], nodata_column=4, nodata_lines=5)
@@ -1135,16 +1137,17 @@ def test_sweep_kernels_agree_bit_for_bit(torch_cuda, library):
     dev = torch_cuda.as_tensor(cube).cuda()
     for active in ((351, 422), (352, 421)):
         runs = []
-        for form in (1, 0):
+        for form in (1, 4, 0):
             L.sf_debug_set(20, form)
             try:
                 runs.append(cmf.robust_mf(dev, library, active=active, metadata=True, to_numpy=True, return_nll=True))
             finally:
                 L.sf_debug_set(20, 0)
-        old, new = runs
-        assert np.array_equal(old.status, new.status) and np.array_equal(old.alphaidx, new.alphaidx)
-        assert np.array_equal(old.nll, new.nll, equal_nan=True), active
-        assert np.array_equal(old.out, new.out, equal_nan=True) and np.array_equal(old.bgmeta, new.bgmeta)
+        new = runs[-1]
+        for old in runs[:-1]:
+            assert np.array_equal(old.status, new.status) and np.array_equal(old.alphaidx, new.alphaidx)
+            assert np.array_equal(old.nll, new.nll, equal_nan=True), active
+            assert np.array_equal(old.out, new.out, equal_nan=True) and np.array_equal(old.bgmeta, new.bgmeta)
         assert (new.status == 0).sum() == 20 and np.isfinite(new.nll[new.status == 0]).any()
 
 

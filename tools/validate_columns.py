@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """One-off wide parity check at full size: N evenly spaced columns of the benchmark flightline, GPU against the
-faithful numpy oracle (alpha index exact, scores 1e-4).  python tools/validate_columns.py [ncols_to_check]"""
+faithful numpy oracle (alpha index exact, scores 1e-4).  python tools/validate_columns.py [ncols_to_check] [lines] [samples]
+(lines beyond 20000: a long flightline -- 70000 x 598 x 425 is a 71 GB cube -- exercises the 64-bit index arithmetic and the
+line-dependent split counts)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +14,8 @@ from oracle import cmf_oracle as O
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
-lines, samples = 20000, 598
+lines = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+samples = int(sys.argv[3]) if len(sys.argv) > 3 else 598
 cube = make_cube_torch(lines, samples, seed=1234, abscf_full=lib[:, 2], nodata_column=samples // 3)
 res = cmf.robust_mf(cube, lib)
 cols = sorted(set(int(round(i * (samples - 1) / (n - 1))) for i in range(n)) - {samples // 3})

@@ -402,7 +402,7 @@ def full_flightline(torch_cuda, library):
 
 def test_full_flightline_598x20000x425(torch_cuda, library, full_flightline):
     """The headline configuration itself: validity == NODATA placement exactly, idempotent re-run bit-identical,
-    sum of a column's scores ~ 0, and 9 evenly spaced columns plus the all-NODATA column against the faithful oracle
+    sum of a column's scores ~ 0, and 24 evenly spaced columns plus the all-NODATA column against the faithful oracle
     (alpha index and valid-row sets exact, scores 1e-4 relative)."""
     torch = torch_cuda
     cube, r1 = full_flightline
@@ -428,7 +428,7 @@ def test_full_flightline_598x20000x425(torch_cuda, library, full_flightline):
         want = cube[:, b, :].double()
         want[:, samples // 3] = 0.0
         assert torch.equal(r1.out[..., k], want)
-    cols = sorted(set([int(round(i * (samples - 1) / 8)) for i in range(9)] + [samples // 3]))
+    cols = sorted(set([int(round(i * (samples - 1) / 23)) for i in range(24)] + [samples // 3]))
     host = cube[:, :, cols].cpu().numpy()
     o = O.robust_mf_oracle(host, library)
     got = r1.out[:, cols, :].cpu().numpy()

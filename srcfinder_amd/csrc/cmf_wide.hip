@@ -545,6 +545,11 @@ __device__ __forceinline__ bool bj_rotation(double aa, double bb, double ab, dou
   return true;
 }
 
+// RM: rows per lane the unrolled loops cover (16 RM >= p2): the loops of the first version always ran EG_RMAX = 32 iterations,
+// five of them on zeros at p = 425 (0.672 -> 0.659 s per full-band flightline, same bits).  The kernels are bound by the latency of a
+// step's dependent chain, not by its instruction count: EIGHT lanes per pair (two waves per workgroup, half the replicated
+// rotation-parameter work) take 0.89 s (tools/ab_wide.py).
+template <int RM>
 __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratch, int p2, int LDr, int nblk, int mblk, int step,
                                                      const int32_t *__restrict__ cflag, const int32_t *__restrict__ done,
                                                      int32_t *__restrict__ rot) {
@@ -612,9 +617,9 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
         int a, b;
         rr_pair_w(s, k, BJ_B - 1, a, b);
         double *ga = sm + (size_t)(blk * BJ_B + a) * LDr + sub, *gb = sm + (size_t)(blk * BJ_B + b) * LDr + sub;
-        double xa[EG_RMAX], xb[EG_RMAX];
+        double xa[RM], xb[RM];
 #pragma unroll
-        for (int i = 0; i < EG_RMAX; ++i) {
+        for (int i = 0; i < RM; ++i) {
           const int ii = min(i, nr - 1);
           const double u = ga[16 * ii], v = gb[16 * ii];
           xa[i] = i < nr ? u : 0.0;
@@ -622,14 +627,14 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
         }
         double ab = 0.0;
 #pragma unroll
-        for (int i = 0; i < EG_RMAX; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
+        for (int i = 0; i < RM; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
         ab = dpp_sum16(ab);
         const double aa = nrm[blk * BJ_B + a], bbn = nrm[blk * BJ_B + b];
         double cs, sn;
         if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {
           rotated = true;
 #pragma unroll
-          for (int i = 0; i < EG_RMAX; ++i) {
+          for (int i = 0; i < RM; ++i) {
             if (i < nr) {
               ga[16 * i] = cs * xa[i] - sn * xb[i];
               gb[16 * i] = sn * xa[i] + cs * xb[i];
@@ -647,27 +652,27 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
   }
   // ---- the 256 cross pairs: group i owns a_i (registers), meets b_(i + t) mod 16 at step t
   if (!lone) {
-    double xa[EG_RMAX];
+    double xa[RM];
     double *ga = sm + (size_t)grp * LDr + sub;
 #pragma unroll
-    for (int i = 0; i < EG_RMAX; ++i) { const int ii = min(i, nr - 1); const double u = ga[16 * ii]; xa[i] = i < nr ? u : 0.0; }
+    for (int i = 0; i < RM; ++i) { const int ii = min(i, nr - 1); const double u = ga[16 * ii]; xa[i] = i < nr ? u : 0.0; }
     double aa = nrm[grp];
     for (int t = 0; t < BJ_B; ++t) {
       const int j = (grp + t) & (BJ_B - 1);
       double *gb = sm + (size_t)(BJ_B + j) * LDr + sub;
-      double xb[EG_RMAX];
+      double xb[RM];
 #pragma unroll
-      for (int i = 0; i < EG_RMAX; ++i) { const int ii = min(i, nr - 1); const double v = gb[16 * ii]; xb[i] = i < nr ? v : 0.0; }
+      for (int i = 0; i < RM; ++i) { const int ii = min(i, nr - 1); const double v = gb[16 * ii]; xb[i] = i < nr ? v : 0.0; }
       double ab = 0.0;
 #pragma unroll
-      for (int i = 0; i < EG_RMAX; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
+      for (int i = 0; i < RM; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
       ab = dpp_sum16(ab);
       const double bbn = nrm[BJ_B + j];
       double cs, sn;
       if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {
         rotated = true;
 #pragma unroll
-        for (int i = 0; i < EG_RMAX; ++i) {
+        for (int i = 0; i < RM; ++i) {
           const double na = cs * xa[i] - sn * xb[i], nb = sn * xa[i] + cs * xb[i];
           xa[i] = na;
           if (i < nr) gb[16 * i] = nb;
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
       __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < EG_RMAX; ++i) if (i < nr) ga[16 * i] = xa[i];
+    for (int i = 0; i < RM; ++i) if (i < nr) ga[16 * i] = xa[i];
   }
   if (rotated) any = 1;
   __syncthreads();
@@ -700,6 +705,7 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
 // Steps > 0 of a sweep: cross pairs only.  Group i of 16 lanes takes column a_i straight from global memory into
 // registers (rows sub, sub + 16, ...: 128-byte segments) and puts it back at the end; only the b block goes through
 // LDS (55 KB at p = 425) -- two workgroups per CU, so one's copies run under the other's rotations.
+template <int RM>
 __global__ __launch_bounds__(BJ_NT) void k_blockjac_x(double *__restrict__ gscratch, int p2, int LDr, int nblk, int mblk, int step,
                                                        const int32_t *__restrict__ cflag, const int32_t *__restrict__ done,
                                                        int32_t *__restrict__ rot) {
@@ -742,16 +748,16 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac_x(double *__restrict__ gscra
   // this group's a column (zero past the last real column)
   const int acol = ba * BJ_B + grp;
   double *ga = G + (size_t)min(acol, p2 - 1) * p2 + sub;
-  double xa[EG_RMAX];
+  double xa[RM];
 #pragma unroll
-  for (int i = 0; i < EG_RMAX; ++i) {
+  for (int i = 0; i < RM; ++i) {
     const int ii = min(i, nr - 1);
     const double u = ga[16 * ii];
     xa[i] = (i < nr && acol < p2) ? u : 0.0;
   }
   double aa = 0.0;
 #pragma unroll
-  for (int i = 0; i < EG_RMAX; ++i) aa = __builtin_fma(xa[i], xa[i], aa);
+  for (int i = 0; i < RM; ++i) aa = __builtin_fma(xa[i], xa[i], aa);
   aa = dpp_sum16(aa);
   __syncthreads();
   {
@@ -765,19 +771,19 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac_x(double *__restrict__ gscra
   for (int t = 0; t < BJ_B; ++t) {
     const int j = (grp + t) & (BJ_B - 1);
     double *gb = sm + (size_t)j * LDr + sub;
-    double xb[EG_RMAX];
+    double xb[RM];
 #pragma unroll
-    for (int i = 0; i < EG_RMAX; ++i) { const int ii = min(i, nr - 1); const double v = gb[16 * ii]; xb[i] = i < nr ? v : 0.0; }
+    for (int i = 0; i < RM; ++i) { const int ii = min(i, nr - 1); const double v = gb[16 * ii]; xb[i] = i < nr ? v : 0.0; }
     double ab = 0.0;
 #pragma unroll
-    for (int i = 0; i < EG_RMAX; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
+    for (int i = 0; i < RM; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
     ab = dpp_sum16(ab);
     const double bbn = nrm[j];
     double cs, sn;
     if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {
       rotated = true;
 #pragma unroll
-      for (int i = 0; i < EG_RMAX; ++i) {
+      for (int i = 0; i < RM; ++i) {
         const double na = cs * xa[i] - sn * xb[i], nb = sn * xa[i] + cs * xb[i];
         xa[i] = na;
         if (i < nr) gb[16 * i] = nb;
@@ -791,7 +797,7 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac_x(double *__restrict__ gscra
   if (rotated) any = 1;
   if (acol < p2) {
 #pragma unroll
-    for (int i = 0; i < EG_RMAX; ++i) if (i < nr) ga[16 * i] = xa[i];
+    for (int i = 0; i < RM; ++i) if (i < nr) ga[16 * i] = xa[i];
   }
   __syncthreads();
   {
@@ -1041,19 +1047,29 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
   int LDr = p2;
   while ((LDr % 32) != 16) ++LDr;
   const size_t lds = ((size_t)2 * BJ_B * LDr + 2 * BJ_B) * sizeof(double);
-  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac), lds)) return rc;
-  const size_t ldsx = ((size_t)BJ_B * LDr + BJ_B) * sizeof(double);
-  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac_x), ldsx)) return rc;
   const int nsteps = (mblk > 1) ? mblk - 1 : 1;
-  for (int sweep = 0; sweep < 16; ++sweep) {       // converged matrices drop out by their flag; no host round trip
-    // (10-12 sweeps on flightline-like spectra; a matrix still rotating after 16 is redone by k_eigh_global, mode 2)
-    hipLaunchKernelGGL(k_blockjac, dim3(mblk / 2 > 0 ? mblk / 2 : 1, nb), dim3(BJ_NT), lds, st, gv, p2, LDr, nblk, mblk > 1 ? mblk : 2, 0,
-                       cflag, done, rot);
-    for (int s = 1; s < nsteps; ++s) {
-      hipLaunchKernelGGL(k_blockjac_x, dim3(mblk / 2, nb), dim3(BJ_NT), ldsx, st, gv, p2, LDr, nblk, mblk, s, cflag, done, rot);
-    }
-    hipLaunchKernelGGL(k_blockjac_flags, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, done, rot);
+  const int nrmax = sf_cdiv(p2, 16);
+#define BJ_SWEEPS(RM)                                                                                                            \
+  {                                                                                                                              \
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac<RM>), lds)) return rc;                                    \
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac_x<RM>), ldsx)) return rc;                                 \
+    for (int sweep = 0; sweep < 16; ++sweep) { /* converged matrices drop out by their flag; no host round trip */               \
+      /* (10-12 sweeps on flightline-like spectra; a matrix still rotating after 16 is redone by k_eigh_global, mode 2) */        \
+      hipLaunchKernelGGL(k_blockjac<RM>, dim3(mblk / 2 > 0 ? mblk / 2 : 1, nb), dim3(BJ_NT), lds, st, gv, p2, LDr, nblk,         \
+                         mblk > 1 ? mblk : 2, 0, cflag, done, rot);                                                              \
+      for (int s = 1; s < nsteps; ++s)                                                                                           \
+        hipLaunchKernelGGL(k_blockjac_x<RM>, dim3(mblk / 2, nb), dim3(BJ_NT), ldsx, st, gv, p2, LDr, nblk, mblk, s, cflag, done, \
+                           rot);                                                                                                 \
+      hipLaunchKernelGGL(k_blockjac_flags, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, done, rot);                             \
+    }                                                                                                                            \
   }
+  const size_t ldsx = ((size_t)BJ_B * LDr + BJ_B) * sizeof(double);
+  if (nrmax <= 8) BJ_SWEEPS(8)
+  else if (nrmax <= 16) BJ_SWEEPS(16)
+  else if (nrmax <= 24) BJ_SWEEPS(24)
+  else if (nrmax <= 28) BJ_SWEEPS(28)
+  else BJ_SWEEPS(32)
+#undef BJ_SWEEPS
   SF_LAUNCH_CHECK("k_blockjac");
   hipLaunchKernelGGL(k_blockjac_leftover, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, cflag, done);
   hipLaunchKernelGGL(k_blockjac_finish, dim3(nb), dim3(512), 0, st, gv, p, p2, c0, cflag, lam, evec);

@@ -548,7 +548,8 @@ __device__ __forceinline__ bool bj_rotation(double aa, double bb, double ab, dou
 // RM: rows per lane the unrolled loops cover (16 RM >= p2): the loops of the first version always ran EG_RMAX = 32 iterations,
 // five of them on zeros at p = 425 (0.672 -> 0.659 s per full-band flightline, same bits).  The kernels are bound by the latency of a
 // step's dependent chain, not by its instruction count: EIGHT lanes per pair (two waves per workgroup, half the replicated
-// rotation-parameter work) take 0.89 s (tools/ab_wide.py).
+// rotation-parameter work) take 0.89 s, thirty-two (eight waves, half the rows per lane, one LDS-crossbar exchange in the dot
+// product) 0.735 s (tools/ab_wide.py): sixteen is the optimum of this structure.
 template <int RM>
 __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratch, int p2, int LDr, int nblk, int mblk, int step,
                                                      const int32_t *__restrict__ cflag, const int32_t *__restrict__ done,

@@ -36,7 +36,7 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    from . import cmf, envi
+    from . import cmf, envi, ingest
 
     try:
         gas = cmf.gas_from_library_name(args.library)
@@ -50,11 +50,19 @@ def main(argv=None):
     nodata = float(meta.get('data ignore value', -9999))
     libdata = np.float64(np.loadtxt(args.library))
     stime = time.time()
-    cube = np.ascontiguousarray(envi.to_bil(mm, meta), dtype=np.float32)
+    # file -> HBM: only the active window and the RGB bands leave the memory map (the reference slices the same bands
+    # out of its memmap, :206-208, :298, :395-397), line chunks through pinned buffers with asynchronous copies (ingest.py)
+    if len(rgb_bands) not in (0, 3):
+        raise Exception('invalid value of rgb_bands argument: %s' % (tuple(rgb_bands),))         # :225-226
+    cube = ingest.stage_cube(mm, active, rgb_bands, interleave=str(meta.get('interleave', 'bsq')).lower())
+    if args.verbose:
+        print('staged %d of %d bands: %.2f GB in %.2f s (%.1f GB/s, host fill %.2f s)'
+              % (cube.stats['bands_moved'], cube.stats['bands_total'], cube.stats['bytes'] / 1e9, cube.stats['seconds'],
+                 cube.stats['GBps'], cube.stats['host_fill_seconds']))
     res = cmf.robust_mf(cube, libdata, gas=gas, reflectance=args.reflectance, kmeans=args.kmeans, pcadim=args.pcadim,
                         reject=args.reject, full=args.full, model=args.model, rgb_bands=rgb_bands, nodata=nodata,
-                        metadata=args.metadata, to_numpy=True)
-    nrows, nbands, ncols = cube.shape
+                        metadata=args.metadata)
+    nrows, _, ncols = cube.shape
     outmeta = {k: v for k, v in meta.items()
                if k not in ('smoothing factors', 'wavelength', 'wavelength units', 'fwhm')}   # :229-230
     outmeta['lines'] = nrows
@@ -67,7 +75,7 @@ def main(argv=None):
         outmeta['band names'] = ['CH4 Absorption (ppm x m)']
     outmeta['model parameters'] = res.modelparms
     out_mm = envi.create_image(args.output, outmeta, np.float64, 'bip')
-    out_mm[...] = res.out
+    ingest.fetch_product(res.out, out_mm)               # device -> file through pinned chunks
     out_mm.flush()
     if args.metadata:
         alphas = cmf.alpha_grid()
@@ -77,9 +85,9 @@ def main(argv=None):
         bgmeta['alphas'] = '{%s}' % (str(alphas)[1:-1])
         bgmeta['band names'] = '{cluster_id, alpha_index}'                                      # :273-277
         bg_mm = envi.create_image(args.output + '_bgmeta', bgmeta, np.int16, 'bip')
-        bg_mm[...] = res.bgmeta
+        ingest.fetch_product(res.bgmeta, bg_mm)
         bg_mm.flush()
-    colnum, colavg, colstd = res.colstats
+    colnum, colavg, colstd = res.colstats.cpu().numpy()
     if args.verbose:
         for col in range(ncols):
             print('Column %i mean: %e, std: %e' % (col, colavg[col], colstd[col]))

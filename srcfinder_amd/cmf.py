@@ -181,17 +181,38 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
     rgb_bands = tuple(int(b) for b in rgb_bands)
     if len(rgb_bands) not in (0, 3):
         raise Exception("invalid value of rgb_bands argument: %s" % (rgb_bands,))         # robust_mf.py:225-226
-    if not torch.is_tensor(cube_bil):
-        cube_bil = torch.from_numpy(np.array(cube_bil, dtype=np.float32, order="C", copy=True))
+    a0, a1 = active if active is not None else active_window(gas, reflectance)
+    p = a1 - a0 + 1
+    # A host cube (ndarray / memmap / CPU tensor) is never copied whole: only the active window and the RGB bands are
+    # staged into a compact device cube through pinned buffers (ingest.py; what the reference's memmap slicing does,
+    # robust_mf.py:206-208, :298, :395-397).  A resident CUDA tensor is used where it lies.
+    from . import ingest
+    compact = None
+    if isinstance(cube_bil, ingest.CompactCube):
+        compact = cube_bil
+        if compact.active != (int(a0), int(a1)) and active is not None:
+            raise ValueError("compact cube holds window %s, not %s" % (compact.active, (a0, a1)))
+        if len(rgb_bands) == 3 and compact.rgb_bands != rgb_bands:
+            raise ValueError("compact cube holds RGB bands %s, not %s" % (compact.rgb_bands, rgb_bands))
+        a0, a1 = compact.active
+        p = a1 - a0 + 1
+    elif not (torch.is_tensor(cube_bil) and cube_bil.is_cuda):
+        host = cube_bil.numpy() if torch.is_tensor(cube_bil) else cube_bil
+        if getattr(host, "ndim", 0) != 3:
+            raise TypeError("cube must be float32 [lines, bands, samples]")
+        compact = ingest.stage_cube(host, (a0, a1), rgb_bands)
+    if compact is not None:
+        cube_bil = compact.tensor
+        b0 = 0                                         # the window starts at band 0 of the compact cube
+        rgb_dev = compact.compact_rgb if len(rgb_bands) == 3 else (0, 0, 0)
+    else:
+        b0 = a0 - 1
+        rgb_dev = rgb_bands if len(rgb_bands) == 3 else (0, 0, 0)
     if cube_bil.dtype != torch.float32 or cube_bil.dim() != 3:
         raise TypeError("cube must be float32 [lines, bands, samples]")
-    if not cube_bil.is_cuda:
-        cube_bil = cube_bil.cuda()
     cube_bil = cube_bil.contiguous()
     dev = cube_bil.device
     lines, bands, samples = cube_bil.shape
-    a0, a1 = active if active is not None else active_window(gas, reflectance)
-    p = a1 - a0 + 1
     s0, s1 = (0, samples) if columns is None else (int(columns[0]), int(columns[1]))
     ncols = s1 - s0
     abscf = _device_const(_abscf_from_library(library, a0, a1), dev)
@@ -218,8 +239,8 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
         nll = torch.empty((ncols, nalpha), dtype=torch.float64, device=dev) if return_nll else None
         L = _ffi.lib()
         if kmeans > 1:
-            r = rgb_bands if nb == 4 else (0, 0, 0)
-            res = _multimodal(torch, L, cube_bil, lines, bands, samples, s0, s1, a0, p, abscf, alphas, nalpha,
+            r = rgb_dev
+            res = _multimodal(torch, L, cube_bil, lines, bands, samples, s0, s1, b0 + 1, p, abscf, alphas, nalpha,
                               bool(reflectance), r, float(nodata), out_t, out_samples, out_s0, nb, bgmeta, kmeans,
                               int(pcadim), labels, int(kmeans_seed), int(kmeans_iters), bool(reject), bool(full),
                               int((a1 - a0) * 1.2), bool(return_nll), model == "empirical")   # bgminsamp, robust_mf.py:200
@@ -233,9 +254,9 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
             return res
         wsb = L.sf_cmf_workspace_bytes(lines, p, ncols, nalpha)
         ws = _Workspace.get(wsb, dev)
-        r = rgb_bands if nb == 4 else (0, 0, 0)
+        r = rgb_dev
         if model == "empirical":
-            _empirical(torch, L, cube_bil, lines, bands, samples, s0, s1, a0, p, abscf, alphas, bool(reflectance), r,
+            _empirical(torch, L, cube_bil, lines, bands, samples, s0, s1, b0 + 1, p, abscf, alphas, bool(reflectance), r,
                        float(nodata), out_t, out_samples, out_s0, nb, alphaidx, nuse, status, colstats, ws)
             res = CMFResult(out=out_t, bgmeta=None, colstats=colstats, alphaidx=alphaidx, nuse=nuse, status=status, nll=None,
                             modelparms=model_parameters(reflectance, (a0, a1), modelname="empirical"))
@@ -243,7 +264,7 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
                 for k in ("out", "colstats", "alphaidx", "nuse", "status"):
                     setattr(res, k, getattr(res, k).cpu().numpy())
             return res
-        rc = L.sf_cmf_run(_ffi.ptr(cube_bil), lines, bands, samples, s0, s1, a0 - 1, p, _ffi.ptr(abscf),
+        rc = L.sf_cmf_run(_ffi.ptr(cube_bil), lines, bands, samples, s0, s1, b0, p, _ffi.ptr(abscf),
                           _ffi.ptr(alphas), nalpha, int(bool(reflectance)), r[0], r[1], r[2], float(nodata),
                           _ffi.ptr(out_t), out_samples, out_s0, nb, _ffi.ptr(alphaidx), _ffi.ptr(nuse),
                           _ffi.ptr(status), _ffi.ptr(colstats), _ffi.ptr(bgmeta), _ffi.ptr(nll), _ffi.ptr(ws),
@@ -432,6 +453,55 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
         colstats[0] = torch.where(nuse_col > 0, nuse_col.to(torch.float64), colstats[0])
     return CMFResult(out=out_t, bgmeta=bgmeta, colstats=colstats, alphaidx=alphaidx, nuse=nuse_col, status=status,
                      labels=labels_valid.t().contiguous(), nll=nll_all)
+
+
+def sweep_routes(cube_bil, library=None, *, gas="ch4", reflectance=False, active=None, columns=None):
+    """Which sweep kernel each column of a flightline takes (diagnostic; bench.py reports it beside the step time).
+
+    The production-window sweep multiplies by the rank-28 or rank-36 factorisation of its coefficient matrix when the
+    column's eigenvalue spectrum allows it (cmf_lowrank.hip) and by the full matrix otherwise: 814 / 954 / 1260 MFMAs per
+    16-row tile -- the reference pays one cost for any data (robust_mf.py:105-117).  Runs stages 1-4 through the C ABI and
+    the factorisation's test hook; returns counts {"rank28", "rank36", "full", "skipped"} (skipped: status != 0)."""
+    torch = _torch()
+    if not (torch.is_tensor(cube_bil) and cube_bil.is_cuda):
+        raise TypeError("sweep_routes needs the resident cube")
+    dev = cube_bil.device
+    lines, bands, samples = cube_bil.shape
+    a0, a1 = active if active is not None else active_window(gas, reflectance)
+    p = a1 - a0 + 1
+    if not 69 <= p <= 72:
+        return {"note": "windows other than 69..72 bands take one route (p = %d)" % p}
+    s0, s1 = (0, samples) if columns is None else (int(columns[0]), int(columns[1]))
+    ncols = s1 - s0
+    L = _ffi.lib()
+    P, st, check = _ffi.ptr, _ffi.stream_ptr(), _ffi.check
+    alphas_np = alpha_grid()
+    al = _device_const(alphas_np, dev)
+    nalpha = len(alphas_np)
+    with torch.cuda.device(dev):
+        ws = _Workspace.get(L.sf_cmf_workspace_bytes(lines, p, ncols, nalpha), dev)
+        f64 = dict(dtype=torch.float64, device=dev)
+        ps = (p + 3) // 4 * 4
+        xt = torch.empty((ncols, lines, ps), dtype=torch.float32, device=dev)
+        mask = torch.empty((ncols, lines), dtype=torch.uint8, device=dev)
+        nuse = torch.empty(ncols, dtype=torch.int32, device=dev)
+        status = torch.empty(ncols, dtype=torch.int32, device=dev)
+        mu, d, lam = (torch.empty((ncols, p), **f64) for _ in range(3))
+        S, evec = torch.empty((ncols, p, p), **f64), torch.empty((ncols, p, p), **f64)
+        check(L.sf_cmf_extract_columns(P(cube_bil.contiguous()), lines, bands, samples, s0, s1, a0 - 1, p, P(xt), P(mask), st),
+              "sf_cmf_extract_columns")
+        check(L.sf_cmf_column_mean(P(xt), 0, P(mask), lines, p, ncols, P(nuse), P(mu), P(ws), st), "sf_cmf_column_mean")
+        check(L.sf_cmf_covariance(P(xt), 0, P(mask), P(nuse), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
+        check(L.sf_cmf_eigh(P(S), P(nuse), p, ncols, P(d), P(lam), P(evec), P(status), P(ws), st), "sf_cmf_eigh")
+        ufrag = torch.empty((ncols, 18 * 9 * 16), **f64)
+        wfrag = torch.empty((ncols, 13 * 9 * 64), **f64)
+        lrok = torch.empty(ncols, dtype=torch.int32, device=dev)
+        check(L.sf_debug_lowrank(P(lam), P(nuse), P(status), P(al), nalpha, p, ncols, P(ufrag), P(wfrag), P(lrok), st),
+              "sf_debug_lowrank")
+        ok = status == 0
+        counts = {"rank28": int(((lrok == 1) & ok).sum()), "rank36": int(((lrok == 2) & ok).sum()),
+                  "full": int(((lrok == 0) & ok).sum()), "skipped": int((~ok).sum())}
+    return counts
 
 
 # ------------------------------------------------------------------------------------------------------

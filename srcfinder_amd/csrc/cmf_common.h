@@ -154,6 +154,9 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
                          const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
                          double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st,
                          const double *target = nullptr);   // target [ncols][p][p]: full shrinkage target (-f), else diag(S)
+// cmf_wjac.hip: the sweeps of the blocked one-sided Jacobi with its rotations on the matrix cores
+int sf_launch_wide_blockjac_mfma(double *gv, int p2, int nb, const int32_t *cflag, int32_t *done, int32_t *rot, int sweeps,
+                                 hipStream_t st);
 int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
                          const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
                          hipStream_t st, double *rest = nullptr);   // rest: the NLL without its determinant term

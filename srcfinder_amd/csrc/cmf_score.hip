@@ -62,12 +62,24 @@ __device__ __forceinline__ void score_fma(const float (&x)[SC_LPI][SC_UB], const
   }
 }
 
+template <int SC_LPI, int SC_UB>
+__device__ __forceinline__ void score_sum(const float (&x)[SC_LPI][SC_UB], double (&acc)[SC_LPI]) {
+#pragma unroll
+  for (int bb = 0; bb < SC_UB; ++bb)
+#pragma unroll
+    for (int j = 0; j < SC_LPI; ++j) acc[j] += (double)x[j][bb];
+}
+
 // WGL: the 64 filter vectors are read from a transposed global copy wT[band][column] (L2-resident) instead of
 // LDS -- for windows too wide for a [p][64] float64 LDS tile.
 // CW: 64-column blocks per workgroup.  With CW = 2 the two halves of a 128-column block read ADJACENT 256-byte row
 // segments at the same time from the same CU, so the 128-byte lines straddling their boundary are fetched once
 // (the row stride, 2392 B, is not a multiple of the line size: every segment starts mid-line).
-template <bool RGB, int SC_LPI, int SC_UB, bool WGL, int CW = 1, bool STG = false>
+// TRAF (sf_debug_set(1, 200), bench.py `in_step_traffic_ms`): the launch's traffic with none of its work -- the same loads
+// in the same order, the same staged record stores, but the "score" is the plain sum of the loaded values: no filter table
+// (no LDS fill, no weight reads), no validity test, no statistics, no metadata image.  Wrong results by design; it exists so
+// that the traffic bound can be timed in the kernel's own position inside the step.
+template <bool RGB, int SC_LPI, int SC_UB, bool WGL, int CW = 1, bool STG = false, bool TRAF = false>
 __global__ __launch_bounds__(256 * CW) void k_score(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs,
                                                 int b0, int p, const double *__restrict__ filt,
                                                 const double *__restrict__ bias, const int32_t *__restrict__ status,
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(256 * CW) void k_score(const float *__restrict__ cu
   const int col = colbase + lanec;
   double *ws = ws_all + (size_t)half * p * 64;
 
-  if (!WGL) {
+  if (!WGL && !TRAF) {
     for (int idx = tid; idx < CW * 64 * p; idx += 256 * CW) {
       const int hh = idx / (64 * p), r = idx - hh * (64 * p);
       const int cl = r / p, b = r - cl * p;
@@ -128,9 +140,11 @@ __global__ __launch_bounds__(256 * CW) void k_score(const float *__restrict__ cu
     score_load<SC_LPI, SC_UB>(xa, lp, 0, p, C, lanec);
     for (int bc = 0; bc < p; bc += 2 * SC_UB) {
       if (bc + SC_UB < p) score_load<SC_LPI, SC_UB>(xb, lp, bc + SC_UB, p, C, lanec);
-      score_fma<SC_LPI, SC_UB>(xa, wsrc, wld, bc, p, lane, acc, ok);
+      if (TRAF) score_sum<SC_LPI, SC_UB>(xa, acc); else score_fma<SC_LPI, SC_UB>(xa, wsrc, wld, bc, p, lane, acc, ok);
       if (bc + 2 * SC_UB < p) score_load<SC_LPI, SC_UB>(xa, lp, bc + 2 * SC_UB, p, C, lanec);
-      if (bc + SC_UB < p) score_fma<SC_LPI, SC_UB>(xb, wsrc, wld, bc + SC_UB, p, lane, acc, ok);
+      if (bc + SC_UB < p) {
+        if (TRAF) score_sum<SC_LPI, SC_UB>(xb, acc); else score_fma<SC_LPI, SC_UB>(xb, wsrc, wld, bc + SC_UB, p, lane, acc, ok);
+      }
     }
     float rgbv[SC_LPI][3];
     if (RGB) {
@@ -153,7 +167,7 @@ __global__ __launch_bounds__(256 * CW) void k_score(const float *__restrict__ cu
         if (j >= nl) break;
         const bool v = ok[j];
         const double sc = v ? ((st == 2) ? 0.0 : (acc[j] - mybias)) : nodata;
-        if (v && colok) { s1 += sc; s2 += sc * sc; }
+        if (!TRAF && v && colok) { s1 += sc; s2 += sc * sc; }
         const bool cp = st != 1;
         const d2v_t ra = {cp ? (double)rgbv[j][0] : 0.0, cp ? (double)rgbv[j][1] : 0.0};
         const d2v_t rb = {cp ? (double)rgbv[j][2] : 0.0, sc};
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(256 * CW) void k_score(const float *__restrict__ cu
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (bgmeta && colok) {
+        if (!TRAF && bgmeta && colok) {
           const uint32_t m = (v && st == 0) ? ((uint32_t)(uint16_t)(int16_t)ai << 16) : 0u;
           reinterpret_cast<uint32_t *>(bgmeta)[(size_t)(l + j) * oS + os0 + col] = m;
         }
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(256 * CW) void k_score(const float *__restrict__ cu
       }
     }
   }
-  if (stat_part) {
+  if (!TRAF && stat_part) {
     sred[wv][lane][0] = s1;
     sred[wv][lane][1] = s2;
     __syncthreads();
@@ -566,20 +580,20 @@ __global__ void k_filt_transpose(const double *__restrict__ filt, int Cs, int p,
   wT[i] = (c < Cs && b < p) ? filt[(size_t)c * p + b] : 0.0;
 }
 
-template <bool RGB, int LPI, int UB, bool WGL = false, int CW = 1, bool STG = false>
+template <bool RGB, int LPI, int UB, bool WGL = false, int CW = 1, bool STG = false, bool TRAF = false>
 int launch_score_t(const float *cube, int lines, int bands, int samples, int s0, int ncols, int b0, int p,
                    const double *filt, const double *bias, const int32_t *status, const int32_t *alphaidx, int rgb0,
                    int rgb1, int rgb2, double nodata, double *out, int out_samples, int out_s0, int16_t *bgmeta,
                    double *stat_part, int lpw, hipStream_t st, hipEvent_t ea, hipEvent_t eb, const double *wT = nullptr,
                    int ldw = 0) {
   const size_t lds = WGL ? 0 : (size_t)CW * p * 64 * sizeof(double);
-  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_score<RGB, LPI, UB, WGL, CW, STG>), lds)) return rc;
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_score<RGB, LPI, UB, WGL, CW, STG, TRAF>), lds)) return rc;
   const int nchunk = sf_cdiv(lines, lpw);
   const int ncb = sf_cdiv(ncols, 64 * CW);
   const int xcd = sf_tune().score_xcd;
   const int nblk = xcd ? sf_xcd_grid(ncb, nchunk) : ncb * nchunk;
   if (ea) SF_HIP(hipEventRecord(ea, st));
-  hipLaunchKernelGGL((k_score<RGB, LPI, UB, WGL, CW, STG>), dim3(nblk), dim3(256 * CW), lds, st, cube, lines, bands, samples, s0, ncols, b0,
+  hipLaunchKernelGGL((k_score<RGB, LPI, UB, WGL, CW, STG, TRAF>), dim3(nblk), dim3(256 * CW), lds, st, cube, lines, bands, samples, s0, ncols, b0,
                      p, filt, bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, out_samples, out_s0, bgmeta, stat_part,
                      lpw, ncb, nchunk, xcd, wT, ldw);
   SF_LAUNCH_CHECK("k_score");
@@ -689,6 +703,7 @@ int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0
     case 8: return launch_score_t<true, 4, 8, false, 2>(SC_ARGS);
     case 9: return launch_score_t<true, 4, 4, false, 2>(SC_ARGS);
     case 100: return launch_score_t<true, 8, 4>(SC_ARGS);                    // round 1: 16-byte pieces stored by the lanes
+    case 200: return launch_score_t<true, 8, 4, false, 1, true, true>(SC_ARGS);   // the production launch's traffic only (timing)
     default: return launch_score_t<true, 8, 4, false, 1, true>(SC_ARGS);     // 8 lines x 4 bands per batch, staged stores
   }
 }

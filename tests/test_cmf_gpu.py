@@ -428,18 +428,99 @@ def test_full_flightline_598x20000x425(torch_cuda, library, full_flightline):
         want = cube[:, b, :].double()
         want[:, samples // 3] = 0.0
         assert torch.equal(r1.out[..., k], want)
-    cols = sorted(set([int(round(i * (samples - 1) / 23)) for i in range(24)] + [samples // 3]))
-    host = cube[:, :, cols].cpu().numpy()
-    o = O.robust_mf_oracle(host, library)
-    got = r1.out[:, cols, :].cpu().numpy()
-    nod = o["out"][..., 3] == -9999.0
-    assert np.array_equal(got[..., 3] == -9999.0, nod)
-    assert score_close(got[..., 3][~nod], o["out"][..., 3][~nod]).all()
+    # oracle columns on every usable host core (spawned workers, OMP_NUM_THREADS=1; oracle/pool.py): 8 per core, at
+    # least 120 of the 598 -- ~2 s each on one core, so the wall time is that of the 25 columns the serial check took
+    from oracle import pool as OP
+    ncheck = min(samples - 1, max(120, 8 * OP.usable_cores()))
+    cols = sorted(set([int(round(i * (samples - 1) / (ncheck - 1))) for i in range(ncheck)] + [samples // 3]))
+    a0, a1 = cmf.active_window("ch4", False)
+    host = cube[:, a0 - 1:a1, :].index_select(2, torch.as_tensor(cols, device=cube.device)).cpu().numpy()
+    o = OP.oracle_columns(host, library[a0 - 1:a1, 2], per_job=2)
+    got = r1.out[:, cols, 3].cpu().numpy()
+    nod = o["score"] == -9999.0
+    assert np.array_equal(got == -9999.0, nod)
+    assert score_close(got[~nod], o["score"][~nod]).all()
     so = o["status"] == 0
     assert np.array_equal(st[cols], o["status"])
-    assert np.array_equal(r1.alphaidx.cpu().numpy()[cols][so], o["alphaidx"][so])
+    aidx = r1.alphaidx.cpu().numpy()[cols]
+    assert np.array_equal(aidx[so], o["alphaidx"][so])
     assert np.array_equal(r1.nuse.cpu().numpy()[cols], o["nuse"])
-    assert np.array_equal(r1.bgmeta[:, cols, :].cpu().numpy(), o["bgmeta"])
+    bg = r1.bgmeta[:, cols, :].cpu().numpy()
+    assert not bg[..., 0].any()                                            # cluster band: 0 when k = 1 (:327)
+    want_bg = np.where(nod | ~so[None, :], 0, o["alphaidx"][None, :]).astype(np.int16)
+    assert np.array_equal(bg[..., 1], want_bg)
+    print("full-size parity: %d oracle columns on %d workers in %.1f s" % (len(cols), o["workers"], o["seconds"]))
+
+
+def test_full_flightline_wide_window_against_oracle(torch_cuda, library, full_flightline):
+    """The full-band window (the route of the reference's -R window 5..420, robust_mf.py:186-187) at
+    benchmark size: validity placement over the whole flightline, and TWO columns against the faithful oracle at
+    20000 x 425 (~45 s each on a core, side by side in the spawned pool): alpha index exact, scores 1e-4 relative."""
+    torch = torch_cuda
+    from oracle import pool as OP
+    cube, _ = full_flightline
+    lines, bands, samples = cube.shape
+    res = cmf.robust_mf(cube, library, active=(1, bands), metadata=True)
+    torch.cuda.synchronize()
+    valid = torch.ones((lines, samples), dtype=torch.bool, device=cube.device)
+    for b in range(bands):
+        x = cube[:, b, :]
+        valid &= (x >= 0) & torch.isfinite(x)
+    assert torch.equal(res.out[..., 3] != -9999.0, valid)
+    assert torch.equal(res.nuse.long(), valid.sum(dim=0))
+    cols = [97, 431]
+    host = cube.index_select(2, torch.as_tensor(cols, device=cube.device)).cpu().numpy()
+    o = OP.oracle_columns(host, library[:, 2], per_job=1)
+    got = res.out[:, cols, 3].cpu().numpy()
+    nod = o["score"] == -9999.0
+    assert np.array_equal(got == -9999.0, nod)
+    assert np.array_equal(res.status.cpu().numpy()[cols], o["status"])
+    assert np.array_equal(res.alphaidx.cpu().numpy()[cols], o["alphaidx"])
+    assert score_close(got[~nod], o["score"][~nod]).all()
+    del res
+    cmf._Workspace._bufs.clear()
+    torch.cuda.empty_cache()
+
+
+def test_host_cube_is_staged_compact_and_bit_identical(torch_cuda, library):
+    """N3 ingest: a HOST cube (ndarray, any ENVI interleave) reaches the GPU as the active window + the RGB bands only
+    (pinned chunks, asynchronous copies; ingest.py) and gives the product of the resident full cube bit for bit --
+    unimodal, metadata, reflectance window, score-only output, column shards, multimodal with injected labels."""
+    torch = torch_cuda
+    from srcfinder_amd import ingest
+    cube = make_cube_numpy(300, 70, seed=31, abscf_full=library[:, 2])
+    dev_cube = torch.as_tensor(cube).cuda()
+    for kw in (dict(metadata=True), dict(reflectance=True), dict(rgb_bands=()), dict(columns=(5, 41)),
+               dict(gas="co2", rgb_bands=(10, 400, 424))):
+        want = cmf.robust_mf(dev_cube, library, **kw)
+        got = cmf.robust_mf(cube, library, **kw)
+        assert torch.equal(got.out, want.out) and torch.equal(got.alphaidx, want.alphaidx)
+        assert torch.equal(got.colstats, want.colstats) and torch.equal(got.nuse, want.nuse)
+        assert got.modelparms == want.modelparms
+        if kw.get("metadata"):
+            assert torch.equal(got.bgmeta, want.bgmeta)
+    # the staging itself: shape, band order, statistics, small chunks (several trips round the two buffers), pageable mode
+    a0, a1 = cmf.active_window("ch4", False)
+    for il, src in (("bil", cube), ("bip", np.ascontiguousarray(cube.transpose(0, 2, 1))),
+                    ("bsq", np.ascontiguousarray(cube.transpose(1, 0, 2)))):
+        for pinned in (True, False):
+            cc = ingest.stage_cube(src, (a0, a1), (60, 42, 24), interleave=il, chunk_bytes=1 << 20, pinned=pinned, threads=3)
+            assert cc.shape == (300, 75, 70) and cc.compact_rgb == (72, 73, 74) and cc.stats["bands_moved"] == 75
+            bits = lambda t: t.contiguous().view(torch.int32)          # (the cube holds a NaN: compare bit patterns)
+            assert torch.equal(bits(cc.tensor[:, :72]), bits(dev_cube[:, a0 - 1:a1]))
+            assert torch.equal(bits(cc.tensor[:, 72:]), bits(dev_cube[:, [60, 42, 24]]))
+    want = cmf.robust_mf(dev_cube, library, metadata=True)
+    got = cmf.robust_mf(cc, library, metadata=True)
+    assert torch.equal(got.out, want.out) and torch.equal(got.bgmeta, want.bgmeta)
+    labels = np.random.default_rng(5).integers(0, 2, size=(300, 70))
+    want = cmf.robust_mf(dev_cube, library, kmeans=2, labels=labels, metadata=True)
+    got = cmf.robust_mf(cube, library, kmeans=2, labels=labels, metadata=True)
+    assert torch.equal(got.out, want.out) and torch.equal(got.bgmeta, want.bgmeta)
+    # and the way back
+    host = ingest.fetch_product(want.out, chunk_bytes=1 << 18)
+    assert np.array_equal(host, want.out.cpu().numpy())
+    with pytest.raises(IndexError):
+        ingest.stage_cube(cube, (a0, a1), (60, 42, 999))
 
 
 def test_full_flightline_shard_is_bit_identical(torch_cuda, library, full_flightline):

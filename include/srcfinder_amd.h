@@ -188,6 +188,10 @@ int sf_cmf_column_profile_robust(const double *img, int lines, int samples, int 
 int sf_debug_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas,
                      int nalpha, int p, int ncols, double *ufrag, double *wfrag, int32_t *lrok, void *stream);
 
+/* Test / tuning hook: phase clocks of the wide-window Jacobi visits (cmf_wjac.hip), accumulated while
+ * sf_debug_set(22, 1) is on: out8 = visits, load, Gram, rotations, update, store ticks, early exits, 0. */
+int sf_debug_wjac_stamps(unsigned long long *out8, int reset);
+
 /* Timing hook for bench.py's roofline line: while enabled, every sf_cmf_score launch (direct or
  * inside sf_cmf_run) is bracketed by a fresh pair of HIP events on the launch stream.
  * sf_cmf_score_timing_read() synchronises those events, returns the summed kernel time and the

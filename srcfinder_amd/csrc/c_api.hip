@@ -315,6 +315,7 @@ static int *sf_tune_slot(int key) {
     case 19: return &t.extract_nt;
     case 20: return &t.sweep4_form;
     case 21: return &t.sweep_grid;
+    case 22: return &t.wjac_stamps;
     default: return nullptr;
   }
 }

@@ -1042,7 +1042,9 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
   hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 3, cflag, unit);
   SF_LAUNCH_CHECK("k_eigh_global(prep)");
   if (int rc = wide_chol(gv, p, p2, nb, cflag, st)) return rc;
-  if (sf_tune().wide_eigh_variant != 2) {   // round 4: the rotations of a visit on its 32 x 32 Gram matrix, applied by MFMA
+  if (sf_tune().wide_eigh_variant == 3 || sf_tune().wide_eigh_variant == 4) {
+    // round 4 experiment (cmf_wjac.hip): the rotations of a visit on its 32 x 32 Gram matrix, applied by MFMA.  Same results,
+    // 6 % SLOWER than the scalar kernels below (profiles/r04_wjac_phase_clocks.txt): not the default.
     if (int rc = sf_launch_wide_blockjac_mfma(gv, p2, nb, cflag, done, rot, 16, st)) return rc;
     hipLaunchKernelGGL(k_blockjac_leftover, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, cflag, done);
     hipLaunchKernelGGL(k_blockjac_finish, dim3(nb), dim3(512), 0, st, gv, p, p2, c0, cflag, lam, evec);

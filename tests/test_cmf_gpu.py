@@ -1119,20 +1119,23 @@ def test_cli_multimodal_flags_reach_the_device_path(torch_cuda, tmp_path, librar
 
 
 def test_wide_eigensolver_variants_agree(torch_cuda, golden_dir, library):
-    """The blocked eigensolver of the wide path (default) and the single-workgroup kernel it replaced (debug key 10)
-    give the same product on the reference's reflectance configuration (p = 416): alpha indices exact, scores 1e-9."""
+    """The blocked eigensolver of the wide path (default), the single-workgroup kernel it replaced (debug key 10 = 1) and
+    the Gram-space / MFMA forms of round 4 (cmf_wjac.hip, key 10 = 3 / 4) give the same product on the reference's
+    reflectance configuration (p = 416): alpha indices exact, scores 1e-9."""
     L = _ffi.lib()
     cube = make_cube_numpy(300, 5, seed=4, abscf_full=library[:, 2], nodata_column=2)
     a = cmf.robust_mf(cube, library, reflectance=True, to_numpy=True)
-    L.sf_debug_set(10, 1)
-    try:
-        b = cmf.robust_mf(cube, library, reflectance=True, to_numpy=True)
-    finally:
-        L.sf_debug_set(10, 0)
-    assert np.array_equal(a.alphaidx, b.alphaidx) and np.array_equal(a.status, b.status)
-    nod = a.out[..., 3] == -9999.0
-    assert np.array_equal(nod, b.out[..., 3] == -9999.0)
-    np.testing.assert_allclose(a.out[..., 3][~nod], b.out[..., 3][~nod], rtol=1e-9, atol=1e-12 * np.abs(b.out[..., 3][~nod]).max())
+    for variant in (1, 3, 4):
+        L.sf_debug_set(10, variant)
+        try:
+            b = cmf.robust_mf(cube, library, reflectance=True, to_numpy=True)
+        finally:
+            L.sf_debug_set(10, 0)
+        assert np.array_equal(a.alphaidx, b.alphaidx) and np.array_equal(a.status, b.status)
+        nod = a.out[..., 3] == -9999.0
+        assert np.array_equal(nod, b.out[..., 3] == -9999.0)
+        np.testing.assert_allclose(a.out[..., 3][~nod], b.out[..., 3][~nod], rtol=1e-9,
+                                   atol=1e-12 * np.abs(b.out[..., 3][~nod]).max())
 
 
 def test_multimodal_return_nll(torch_cuda, golden_dir, library):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Wide-window eigensolver A/B: round 3's blocked Jacobi with scalar rotations (sf_debug_set(10, 2)) against the
-Gram-space / MFMA form (default, cmf_wjac.hip) through sf_cmf_wide_stats on one batch of synthetic columns:
+"""Wide-window eigensolver A/B: round 3's blocked Jacobi with scalar rotations (the default) against the
+Gram-space / MFMA form (sf_debug_set(10, 4), cmf_wjac.hip) through sf_cmf_wide_stats on one batch of synthetic columns:
 eigen-residual |R v - lam v| / |R|, orthogonality |V^T V - I|, eigenvalue / NLL agreement, alpha index, ms per call.
     python tools/ab_wjac.py [ncols=36] [rows=1536] [p=425] [reps=3]"""
 import os, sys, time
@@ -34,7 +34,20 @@ ws = torch.empty(L.sf_cmf_workspace_bytes(rows, p, ncols, nalpha), dtype=torch.u
 P, st = _ffi.ptr, _ffi.stream_ptr()
 _ffi.check(L.sf_cmf_column_mean(P(xt), 0, P(mask), rows, p, ncols, P(nuse), P(mu), P(ws), st), "mean")
 res = {}
-for name, variant in (("scalar (r3)", 2), ("gram/mfma (r4)", 0), ("scalar (r3) again", 2), ("gram/mfma (r4) again", 0)):
+import ctypes
+def stamps(variant):
+    buf = (ctypes.c_ulonglong * 8)()
+    L.sf_debug_set(10, variant)
+    L.sf_debug_set(22, 1)
+    L.sf_debug_wjac_stamps(None, 1)
+    run(); torch.cuda.synchronize()
+    L.sf_debug_wjac_stamps(buf, 1)
+    L.sf_debug_set(22, 0)
+    v = list(buf)
+    nv, nf = max(v[0], 1), max(v[0] - v[6], 1)
+    print("   phase clocks, cycles per visit: visits %d (ended after the Gram test: %d)  load %.0f  gram %.0f  rotations %.0f  update %.0f  store %.0f"
+          % (v[0], v[6], v[1] / nv, v[2] / nv, v[3] / nf, v[4] / nf, v[5] / nf))
+for name, variant in (("scalar (r3)", 0), ("gram/mfma 4 waves", 3), ("gram/mfma (r4)", 4), ("scalar (r3) again", 0), ("gram/mfma (r4) again", 4)):
     L.sf_debug_set(10, variant)
     S = torch.empty((ncols, p, p), **f64); d = torch.empty((ncols, p), **f64); lam = torch.empty((ncols, p), **f64)
     evec = torch.empty((ncols, p, p), **f64); status = torch.empty(ncols, dtype=torch.int32, device=dev)
@@ -54,6 +67,8 @@ for name, variant in (("scalar (r3)", 2), ("gram/mfma (r4)", 0), ("scalar (r3) a
     orth = (V.transpose(1, 2) @ V - torch.eye(p, **f64)).abs().amax(dim=(1, 2))
     res[name] = dict(lam=torch.sort(lam, dim=1).values.cpu().numpy(), nll=nll.cpu().numpy(), aidx=aidx.cpu().numpy(),
                      status=status.cpu().numpy())
+    if variant in (4, 3) and "again" not in name:
+        stamps(variant)
     print("%-22s %8.2f ms/call   max residual %.2e   max |V^T V - I| %.2e   status!=0: %d   lam range %.2e .. %.2e"
           % (name, ms, float(resid.max()), float(orth.max()), int((status != 0).sum()), float(lam.min()), float(lam.max())))
 L.sf_debug_set(10, 0)

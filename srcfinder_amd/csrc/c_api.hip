@@ -316,6 +316,7 @@ static int *sf_tune_slot(int key) {
     case 20: return &t.sweep4_form;
     case 21: return &t.sweep_grid;
     case 22: return &t.wjac_stamps;
+    case 23: return &t.wide_gemm_variant;
     default: return nullptr;
   }
 }

@@ -154,6 +154,15 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
                          const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
                          double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st,
                          const double *target = nullptr);   // target [ncols][p][p]: full shrinkage target (-f), else diag(S)
+// cmf_wgemm.hip: the wide-window covariance and sweep on the 4x4x4 fp64 MFMA, fused with centring / squaring / row reduction
+int sf_wgemm_splits(const SfGeom &g);
+size_t sf_wgemm_operand_bytes(const SfGeom &g);   // W and C of g.ncols columns
+size_t sf_wgemm_part_bytes(const SfGeom &g);      // the sweep partials of the whole flightline
+int sf_launch_wsyrk(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
+                    int c0, int nb, double *cov, hipStream_t st);
+int sf_launch_wsweep(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nloo, const double *mu, const double *d,
+                     const double *lam, const double *evec, const int32_t *status, const double *alphas, const SfGeom &g, int c0,
+                     int nb, void *opnd, double *part, hipStream_t st);
 // cmf_wjac.hip: the sweeps of the blocked one-sided Jacobi with its rotations on the matrix cores
 int sf_launch_wide_blockjac_mfma(double *gv, int p2, int nb, const int32_t *cflag, int32_t *done, int32_t *rot, int sweeps,
                                  hipStream_t st);

@@ -1,0 +1,549 @@
+// Wide-window statistics, round 4: the two contractions on v_mfma_f64_4x4x4_f64, fused with what surrounds them.
+//
+// Round 3 ran the wide windows (more than 96 bands: the reference's reflectance window 5..420, cmf/robust_mf.py:186-187;
+// the full-band stress shape) as separate kernels around a generic 16x16x4 GEMM (cmf_wide.hip: k_center -> X~ in float64,
+// k_dgemm covariance, k_dgemm Y^2, k_dgemm r, k_nllrows): 166 MB of float64 scratch per column (X~, Z, r), so 36 columns
+// per batch, every operand round-tripping HBM, and an instruction (16x16x4) that peaks at 47 TFLOP/s on MI355X where the
+// 4x4x4 form reaches 71 (tools/microbench/mfma64.hip).  Here:
+//
+//   k_wsyrk   S = X~^T X~ / (n - 1)  (numpy.cov as called by looshrinkage, robust_mf.py:52-70, :98, :130) straight from
+//             the extracted float32 rows: centring, validity mask and promotion happen on the way into LDS, 128 x 128
+//             band tiles (upper triangle of tiles), four waves of 64 x 64, K = all rows of the column.
+//   k_wsweep  the LOO sweep of robust_mf.py:105-117 in its eigen form: per 64-row tile
+//                 Y = X~ W   (W = D^-1 V)      -> registers (each wave a quarter of the columns of Y)
+//                 Z = Y.^2                      -> the same registers, already in the A-operand layout of the next product
+//                 r = Z C    (C[j][a] = 1 / (n beta_a lam_j + alpha_a))   four alphas at a time, summed over the waves
+//                 sum_k log(1 - beta r), sum_k r / (1 - beta r)            -> per (column, row split) partials for k_nll
+//             W and C stream through LDS in 4-band / 4-alpha chunks (L2-resident: 1.5 + 0.7 MB per column); nothing
+//             but the 2 x 208 partial sums per (column, split) is written.  No float64 scratch per column any more.
+//
+// MFMA operand roles (validated by cmf_cov4.hip / cmf_wjac.hip): D_m[i][j] += sum_k A_m[i][k] B_m[k][j] for the four
+// blocks m, lane = 16 q + 4 m + n, A[i][k] at (q = k, n = i), B[k][j] at (q = k, n = j), D[i][j] at (q = i, n = j).
+#include "cmf_common.h"
+
+namespace {
+
+// --------------------------------------------------------------------------------------------------------------------
+// k_wsyrk
+// --------------------------------------------------------------------------------------------------------------------
+constexpr int SY_T = 128;              // band tile
+constexpr int SY_KC = 16;              // rows per LDS chunk
+constexpr int SY_LD = 2 * SY_T + 16;   // doubles per chunk row: [I bands | J bands] + pad (272 = 16 mod 32)
+
+__device__ __forceinline__ void sy_load4(const float *p, double (&v)[4]) {
+  const float4 f = *reinterpret_cast<const float4 *>(p);
+  v[0] = (double)f.x; v[1] = (double)f.y; v[2] = (double)f.z; v[3] = (double)f.w;
+}
+__device__ __forceinline__ void sy_load4(const double *p, double (&v)[4]) {
+  const double2 a = *reinterpret_cast<const double2 *>(p), b = *reinterpret_cast<const double2 *>(p + 2);
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+
+template <typename XT>
+__global__ __launch_bounds__(256, 2) void k_wsyrk(const XT *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+                                                   const int32_t *__restrict__ nuse, const double *__restrict__ mu, int L, int p,
+                                                   int ps, int ntile, double *__restrict__ cov) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];   // [2][SY_KC][SY_LD], then mu [2 * SY_T]
+  double *mus = sm + 2 * SY_KC * SY_LD;
+  const int c = blockIdx.y;
+  int ti = 0, tj = 0;
+  {   // tile pair blockIdx.x of the upper triangle, row-major
+    int rem = blockIdx.x, rowlen = ntile;
+    while (rem >= rowlen) { rem -= rowlen; ++ti; --rowlen; }
+    tj = ti + rem;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, m = (lane >> 2) & 3, n = lane & 3;
+  const int wi = wave >> 1, wj = wave & 1;
+  for (int i = tid; i < 2 * SY_T; i += 256) {
+    const int b = (i < SY_T ? ti * SY_T : tj * SY_T - SY_T) + i;
+    mus[i] = (b < p) ? mu[(size_t)c * p + b] : 0.0;
+  }
+  const XT *xc = xt + (size_t)c * L * ps;
+  const uint8_t *mp = mask_t + (size_t)c * L;
+  // loader role: row r of the chunk, four band quads (quad = c4 + 16 u: u = 0, 1 in the I half, 2, 3 in the J half)
+  const int lr = tid >> 4, c4 = tid & 15;
+  int gband[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int quad = c4 + 16 * u;
+    gband[u] = ((quad < 32) ? ti * SY_T : tj * SY_T - SY_T) + 4 * quad;
+  }
+  double pre[4][4];
+  bool prok;
+  auto gload = [&](int r0) {
+    const int row = r0 + lr;
+    const int rr = row < L ? row : L - 1;
+    prok = (row < L) && (mp[rr] != 0);
+    const XT *rp = xc + (size_t)rr * ps;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (gband[u] < ps) sy_load4(rp + gband[u], pre[u]);
+      else { pre[u][0] = pre[u][1] = pre[u][2] = pre[u][3] = 0.0; }
+    }
+  };
+  auto lstore = [&](int buf) {
+    double *dst = sm + ((size_t)buf * SY_KC + lr) * SY_LD;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int quad = c4 + 16 * u;
+      double o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (prok && gband[u] + e < p) ? pre[u][e] - mus[4 * quad + e] : 0.0;
+      *reinterpret_cast<double2 *>(dst + 4 * quad) = make_double2(o[0], o[1]);
+      *reinterpret_cast<double2 *>(dst + 4 * quad + 2) = make_double2(o[2], o[3]);
+    }
+  };
+  double acc[4][16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.0;
+  __syncthreads();   // mus
+  gload(0);
+  lstore(0);
+  const int nchunk = (L + SY_KC - 1) / SY_KC;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunk) gload((ch + 1) * SY_KC);
+    __syncthreads();   // chunk ch is in sm[buf]; everybody is done with sm[buf ^ 1] (chunk ch - 1)
+    const double *xs = sm + (size_t)buf * SY_KC * SY_LD;
+#pragma unroll
+    for (int k4 = 0; k4 < SY_KC / 4; ++k4) {
+      const double *row = xs + (size_t)(4 * k4 + q) * SY_LD;
+      double a[4], b[16];
+#pragma unroll
+      for (int I = 0; I < 4; ++I) a[I] = row[64 * wi + 16 * I + 4 * m + n];
+#pragma unroll
+      for (int J = 0; J < 16; ++J) b[J] = row[SY_T + 64 * wj + 4 * J + n];
+#pragma unroll
+      for (int I = 0; I < 4; ++I)
+#pragma unroll
+        for (int J = 0; J < 16; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[I], b[J], acc[I][J], 0, 0, 0);
+    }
+    if (ch + 1 < nchunk) lstore(buf ^ 1);
+  }
+  const double inv = 1.0 / ((double)nuse[c] - 1.0);
+  double *co = cov + (size_t)c * p * p;
+#pragma unroll
+  for (int I = 0; I < 4; ++I)
+#pragma unroll
+    for (int J = 0; J < 16; ++J) {
+      const int bi = ti * SY_T + 64 * wi + 16 * I + 4 * m + q, bj = tj * SY_T + 64 * wj + 4 * J + n;
+      if (bi < p && bj < p) {
+        const double v = acc[I][J] * inv;
+        co[(size_t)bi * p + bj] = v;
+        if (ti != tj) co[(size_t)bj * p + bi] = v;
+      }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// operands of the sweep: W zero-padded to [P16][LDW] (row-major) and C in chunks of 8 alphas, [NCC][LDW][8]: the byte
+// images the sweep's LDS buffers hold (global_load_lds copies are lane-linear: LDS image = global image)
+// --------------------------------------------------------------------------------------------------------------------
+__global__ void k_wmat_p(const double *__restrict__ evec, const double *__restrict__ d, int p, int P16, int LDW,
+                         double *__restrict__ W) {
+  const int c = blockIdx.y;
+  const double *ev = evec + (size_t)c * p * p, *dd = d + (size_t)c * p;
+  double *o = W + (size_t)c * P16 * LDW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P16 * LDW; i += gridDim.x * blockDim.x) {
+    const int b = i / LDW, j = i - b * LDW;
+    o[i] = (b < p && j < p) ? ev[(size_t)j * p + b] / dd[b] : 0.0;
+  }
+}
+__global__ void k_cmat_t(const double *__restrict__ lam, const int32_t *__restrict__ nloo, const int32_t *__restrict__ status,
+                         const double *__restrict__ alphas, int nalpha, int NCC, int p, int LDW, double *__restrict__ Ct) {
+  const int c = blockIdx.y;
+  const double nn = (double)nloo[c];
+  const bool ok = status[c] == 0;
+  const double *lc = lam + (size_t)c * p;
+  double *o = Ct + (size_t)c * NCC * LDW * 8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NCC * LDW * 8; i += gridDim.x * blockDim.x) {
+    const int ch = i / (LDW * 8), r = i - ch * (LDW * 8), j = r >> 3, a = 8 * ch + (r & 7);
+    double v = 0.0;
+    if (ok && a < nalpha && j < p) {
+      const double al = alphas[a];
+      const double beta = (1.0 - al) / (nn - 1.0);
+      v = 1.0 / ((nn * beta) * lc[j] + al);
+    }
+    o[i] = v;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// k_wsweep
+// --------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double ws_cvt(float x) { return (double)x; }
+__device__ __forceinline__ double ws_cvt(double x) { return x; }
+typedef __attribute__((address_space(3))) void ws_lds_void;
+typedef const __attribute__((address_space(1))) void ws_glb_void;
+
+template <int CTRL>
+__device__ __forceinline__ double ws_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// phase clocks of the sweep's tiles (sf_debug_set(22, 1); sf_debug_wsweep_stamps): [0] tiles, [1] Y = X~ W, [2] r = Z C + rows
+__device__ unsigned long long g_ws_stamps[4];
+
+constexpr int WS_CH = 16;   // bands per W chunk
+constexpr int WS_CA = 8;    // alphas per C chunk (two groups of four: their row reductions are interleaved)
+
+// XT: float32 (the extracted cube) or float64 (the function-level looshrinkage()).  NI: 16-row groups per tile.
+// NJW: 4-column groups of Y per wave (LDW = 16 NJW >= P16).  One chunk = 16 rows of W (16 x LDW doubles, 55 KB at LDW = 432)
+// or 8 alphas of C ([LDW][8], half that), copied global -> LDS by global_load_lds (no registers), two buffers: the copy of chunk
+// s + 1 is issued right after the barrier that publishes chunk s and has that chunk's 432 MFMAs per wave to land.  X is
+// streamed beside W (16 bands x the tile's rows), centred and promoted when it is read as an operand.
+template <typename XT, int NI, int NJW>
+__global__ __launch_bounds__(256) void k_wsweep(const XT *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+                                                 const int32_t *__restrict__ nloo, const double *__restrict__ mu,
+                                                 const double *__restrict__ Wp, const double *__restrict__ Ct,
+                                                 const int32_t *__restrict__ status, const double *__restrict__ alphas, int nalpha,
+                                                 int NA, int L, int p, int ps, int P16, int rows_per_wg, int nsplit, int ncols,
+                                                 double *__restrict__ part, int stamp) {
+  constexpr int RT = 16 * NI;        // rows per tile
+  constexpr int LDW = 16 * NJW;
+  constexpr int CHD = WS_CH * LDW;   // doubles per chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  // ---- LDS carve (ws_lds_bytes below)
+  double *Bs = reinterpret_cast<double *>(smraw);                 // [2][CHD]
+  double *mus = Bs + 2 * CHD;                                      // [P16]
+  double *red = mus + P16;                                         // [2][4][NI][64]
+  double *Pacc = red + 2 * 4 * NI * 64;                            // [NA]
+  double *Sacc = Pacc + NA;                                        // [NA]
+  double *betas = Sacc + NA;                                       // [NA]
+  XT *Xs = reinterpret_cast<XT *>(betas + NA);                     // [2][WS_CH][RT]
+  int *Eacc = reinterpret_cast<int *>(Xs + 2 * WS_CH * RT);        // [NA]
+  int *Nacc = Eacc + NA;                                           // [NA]
+  int *rowok = Nacc + NA;                                          // [RT]
+
+  // XCD-aware order: the splits of a column are adjacent on ONE XCD (its L2 holds the column's W and C)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int c = 8 * (slot / nsplit) + xcd, split = slot % nsplit;
+  if (c >= ncols) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, m = (lane >> 2) & 3, n = lane & 3;
+  double *po = part + ((size_t)c * nsplit + split) * 2 * NA;
+  if (status[c] != 0) {
+    for (int i = tid; i < 2 * NA; i += 256) po[i] = 0.0;
+    return;
+  }
+  const double nn = (double)nloo[c];
+  for (int i = tid; i < NA; i += 256) {
+    Pacc[i] = 1.0;
+    Sacc[i] = 0.0;
+    Eacc[i] = 0;
+    Nacc[i] = 0;
+    betas[i] = (i < nalpha) ? (1.0 - alphas[i]) / (nn - 1.0) : 0.0;
+  }
+  for (int i = tid; i < P16; i += 256) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
+  const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
+  const XT *xc = xt + (size_t)c * L * ps;
+  const uint8_t *mp = mask_t + (size_t)c * L;
+  const char *Wc = reinterpret_cast<const char *>(Wp + (size_t)c * P16 * LDW);
+  const int NKC = P16 / WS_CH, NCC = NA / WS_CA, NS = NKC + NCC;
+  const char *Cc = reinterpret_cast<const char *>(Ct + (size_t)c * NCC * LDW * WS_CA);
+  const int j0w = 4 * NJW * wave;              // first Y column of this wave
+  constexpr int NPIECE = CHD * 8 / 1024;       // 1 KB wave-pieces per W chunk (LDW is a multiple of 16: CHD * 8 = 2048 NJW)
+  constexpr int CCD = WS_CA * LDW;             // doubles per C chunk
+  // chunk s of the stream -> Bs[s & 1]: s < NKC: rows 16 s .. of W; else alpha chunk s - NKC of C.  Lane-linear copies.
+  auto glds = [&](int s) {
+    const char *src = (s < NKC ? Wc + (size_t)s * CHD * 8 : Cc + (size_t)(s - NKC) * CCD * 8) + lane * 16;
+    char *dst = reinterpret_cast<char *>(Bs + (size_t)(s & 1) * CHD);
+    const int npc = s < NKC ? NPIECE : NPIECE / 2;
+    for (int pc = wave; pc < npc; pc += 4)
+      __builtin_amdgcn_global_load_lds((ws_glb_void *)(src + (size_t)pc * 1024), (ws_lds_void *)(dst + (size_t)pc * 1024), 16, 0, 0);
+  };
+  // the X chunk of W chunk s: lane item = (row, band quad) of [RT rows][4 quads]
+  const int xrow = tid % RT, xq = tid / RT;
+  const bool xact = tid < 4 * RT;
+  XT xv[4];
+  auto xload = [&](int s, int r0) {
+    const int b = WS_CH * s + 4 * xq;
+    if (xact && b + 3 < ps) {
+      const XT *src = xc + (size_t)min(r0 + xrow, L - 1) * ps + b;
+      if constexpr (sizeof(XT) == 4) {
+        const float4 f = *reinterpret_cast<const float4 *>(src);
+        xv[0] = f.x; xv[1] = f.y; xv[2] = f.z; xv[3] = f.w;
+      } else {
+        const double2 a = *reinterpret_cast<const double2 *>(src), b2 = *reinterpret_cast<const double2 *>(src + 2);
+        xv[0] = a.x; xv[1] = a.y; xv[2] = b2.x; xv[3] = b2.y;
+      }
+    } else {
+      xv[0] = xv[1] = xv[2] = xv[3] = (XT)0;
+    }
+  };
+  auto xstore = [&](int s) {
+    if (xact) {
+      XT *dst = Xs + (size_t)(s & 1) * WS_CH * RT;
+      const int b = WS_CH * s + 4 * xq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[(4 * xq + e) * RT + xrow] = (b + e < p) ? xv[e] : (XT)0;
+    }
+  };
+  // rows of the tile x the two alphas ai0, ai1 of this wave (one per alpha group of the chunk), their chains interleaved: the
+  // four waves' partial r summed, q = 1 - beta r, product and sum over the valid rows (fixed reduction tree: butterfly inside
+  // the 16-lane rows, then (row0 row1)(row2 row3)), folded into the split's running (mantissa, exponent, sum, flag) by lane 0
+  auto rdl = [](double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+  };
+  auto nll_rows2 = [&](int ai0, int ai1) {
+    if (ai0 >= nalpha) return;   // wave-uniform (ai1 > ai0)
+    const bool two = ai1 < nalpha;
+    const double beta0 = betas[ai0], beta1 = betas[two ? ai1 : ai0];
+    double prod0 = 1.0, ssum0 = 0.0, prod1 = 1.0, ssum1 = 0.0;
+    int neg = 0;
+#pragma unroll
+    for (int rr = 0; rr < RT; rr += 64) {
+      const int row = rr + lane;
+      if (row < RT) {
+        const int I = row >> 4, src = 16 * (row & 3) + 4 * ((row >> 2) & 3) + wave;
+        const double *rp0 = red, *rp1 = red + 4 * NI * 64;
+        const double r0v = (rp0[(0 * NI + I) * 64 + src] + rp0[(1 * NI + I) * 64 + src]) +
+                           (rp0[(2 * NI + I) * 64 + src] + rp0[(3 * NI + I) * 64 + src]);
+        const double r1v = (rp1[(0 * NI + I) * 64 + src] + rp1[(1 * NI + I) * 64 + src]) +
+                           (rp1[(2 * NI + I) * 64 + src] + rp1[(3 * NI + I) * 64 + src]);
+        const bool ok = rowok[row] != 0;
+        const double q0 = __builtin_fma(-beta0, r0v, 1.0), q1 = __builtin_fma(-beta1, r1v, 1.0);
+        // r / q by reciprocal + two Newton steps (1-2 ulp; the IEEE division sequence is 4x the instructions)
+        double y0 = __builtin_amdgcn_rcp(q0), y1 = __builtin_amdgcn_rcp(q1);
+        y0 = __builtin_fma(y0, __builtin_fma(-q0, y0, 1.0), y0);
+        y1 = __builtin_fma(y1, __builtin_fma(-q1, y1, 1.0), y1);
+        y0 = __builtin_fma(y0, __builtin_fma(-q0, y0, 1.0), y0);
+        y1 = __builtin_fma(y1, __builtin_fma(-q1, y1, 1.0), y1);
+        neg |= (ok && q0 < 0.0) ? 1 : 0;
+        neg |= (ok && two && q1 < 0.0) ? 2 : 0;
+        prod0 *= ok ? q0 : 1.0;
+        prod1 *= ok ? q1 : 1.0;
+        ssum0 += ok ? r0v * y0 : 0.0;
+        ssum1 += ok ? r1v * y1 : 0.0;
+      }
+    }
+    prod0 *= ws_dpp<0xB1>(prod0);  prod1 *= ws_dpp<0xB1>(prod1);  ssum0 += ws_dpp<0xB1>(ssum0);  ssum1 += ws_dpp<0xB1>(ssum1);
+    prod0 *= ws_dpp<0x4E>(prod0);  prod1 *= ws_dpp<0x4E>(prod1);  ssum0 += ws_dpp<0x4E>(ssum0);  ssum1 += ws_dpp<0x4E>(ssum1);
+    prod0 *= ws_dpp<0x141>(prod0); prod1 *= ws_dpp<0x141>(prod1); ssum0 += ws_dpp<0x141>(ssum0); ssum1 += ws_dpp<0x141>(ssum1);
+    prod0 *= ws_dpp<0x140>(prod0); prod1 *= ws_dpp<0x140>(prod1); ssum0 += ws_dpp<0x140>(ssum0); ssum1 += ws_dpp<0x140>(ssum1);
+    const double pw0 = (rdl(prod0, 0) * rdl(prod0, 16)) * (rdl(prod0, 32) * rdl(prod0, 48));
+    const double pw1 = (rdl(prod1, 0) * rdl(prod1, 16)) * (rdl(prod1, 32) * rdl(prod1, 48));
+    const double sw0 = (rdl(ssum0, 0) + rdl(ssum0, 16)) + (rdl(ssum0, 32) + rdl(ssum0, 48));
+    const double sw1 = (rdl(ssum1, 0) + rdl(ssum1, 16)) + (rdl(ssum1, 32) + rdl(ssum1, 48));
+    const int n0 = __any(neg & 1) ? 1 : 0, n1 = __any(neg & 2) ? 1 : 0;
+    if (lane == 0) {
+      const double pm0 = Pacc[ai0] * pw0;
+      Eacc[ai0] += __builtin_amdgcn_frexp_exp(pm0);
+      Pacc[ai0] = __builtin_amdgcn_frexp_mant(pm0);
+      Sacc[ai0] += sw0;
+      Nacc[ai0] |= n0;
+      if (two) {
+        const double pm1 = Pacc[ai1] * pw1;
+        Eacc[ai1] += __builtin_amdgcn_frexp_exp(pm1);
+        Pacc[ai1] = __builtin_amdgcn_frexp_mant(pm1);
+        Sacc[ai1] += sw1;
+        Nacc[ai1] |= n1;
+      }
+    }
+  };
+
+  for (int r0 = rbeg; r0 < rend; r0 += RT) {
+    __syncthreads();   // the previous tile's readers of Bs / Xs / rowok / red are done
+    unsigned long long tk0 = 0, tk1 = 0;
+    if (stamp) tk0 = __builtin_readcyclecounter();
+    if (tid < RT) rowok[tid] = (r0 + tid < rend) && (mp[min(r0 + tid, L - 1)] != 0);
+    glds(0);
+    xload(0, r0);
+    xstore(0);
+    double acc[NI][NJW];
+#pragma unroll
+    for (int I = 0; I < NI; ++I)
+#pragma unroll
+      for (int J = 0; J < NJW; ++J) acc[I][J] = 0.0;
+    for (int s = 0; s < NS; ++s) {
+      __syncthreads();   // chunk s has landed in Bs[s & 1] (the barrier's vmcnt(0)), its X chunk is stored; chunk s - 1 is consumed
+      if (s + 1 < NS) glds(s + 1);
+      const double *bs = Bs + (size_t)(s & 1) * CHD;
+      if (s < NKC) {
+        if (s + 1 < NKC) xload(s + 1, r0);
+        // ---- Y^T tile += W^T X~^T over 16 bands: A operand W[16 s + 4 k4 + q][j0w + 4 J + n], B operand X~[row 16 I + 4 m + n][band]
+        const XT *xs = Xs + (size_t)(s & 1) * WS_CH * RT;
+#pragma unroll
+        for (int k4 = 0; k4 < WS_CH / 4; ++k4) {
+          double xr[NI];
+          const double mub = mus[WS_CH * s + 4 * k4 + q];
+#pragma unroll
+          for (int I = 0; I < NI; ++I) xr[I] = ws_cvt(xs[(4 * k4 + q) * RT + 16 * I + 4 * m + n]) - mub;
+          const double *brow = bs + (size_t)(4 * k4 + q) * LDW + j0w + n;
+#pragma unroll
+          for (int J = 0; J < NJW; ++J) {
+            const double wr = brow[4 * J];
+#pragma unroll
+            for (int I = 0; I < NI; ++I) acc[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(wr, xr[I], acc[I][J], 0, 0, 0);
+          }
+        }
+        if (s + 1 < NKC) xstore(s + 1);
+        if (s == NKC - 1) {   // Z = Y.^2: lane (q, m, n) holds Z[row 16 I + 4 m + n][col j0w + 4 J + q]
+          if (stamp) tk1 = __builtin_readcyclecounter();
+#pragma unroll
+          for (int I = 0; I < NI; ++I)
+#pragma unroll
+            for (int J = 0; J < NJW; ++J) acc[I][J] = acc[I][J] * acc[I][J];
+        }
+      } else {
+        // ---- the chunk's two alpha groups: r[row][alpha] over this wave's columns of Z, A operand Z, B operand
+        //      C[col j0w + 4 J + q][alpha 8 ch + 4 t + n]; the waves' partials meet in red, one wave per alpha finishes them
+        const int ch = s - NKC;
+        double ra[NI], rb[NI];
+#pragma unroll
+        for (int I = 0; I < NI; ++I) { ra[I] = 0.0; rb[I] = 0.0; }
+        const double *bcol = bs + (size_t)(j0w + q) * WS_CA + n;
+#pragma unroll
+        for (int J = 0; J < NJW; ++J) {
+          const double ca = bcol[(size_t)4 * WS_CA * J], cb = bcol[(size_t)4 * WS_CA * J + 4];
+#pragma unroll
+          for (int I = 0; I < NI; ++I) {
+            ra[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[I][J], ca, ra[I], 0, 0, 0);
+            rb[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[I][J], cb, rb[I], 0, 0, 0);
+          }
+        }
+        // lane (q, m, n): r[row 16 I + 4 m + q][alpha 8 ch + 4 t + n] -> red[t][wave][I][lane]
+#pragma unroll
+        for (int I = 0; I < NI; ++I) {
+          red[(wave * NI + I) * 64 + lane] = ra[I];
+          red[4 * NI * 64 + (wave * NI + I) * 64 + lane] = rb[I];
+        }
+        __syncthreads();   // the four partials of both alpha groups are in red (rewritten after the next chunk barrier)
+        nll_rows2(WS_CA * ch + wave, WS_CA * ch + 4 + wave);
+      }
+    }
+    if (stamp && tid == 0) {
+      const unsigned long long tk2 = __builtin_readcyclecounter();
+      atomicAdd(&g_ws_stamps[0], 1ull);
+      atomicAdd(&g_ws_stamps[1], tk1 - tk0);
+      atomicAdd(&g_ws_stamps[2], tk2 - tk1);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < NA; i += 256) {
+    if (i < nalpha) {
+      po[i] = log(Pacc[i]) + (double)Eacc[i] * 0.6931471805599453094;
+      po[NA + i] = Nacc[i] ? __builtin_nan("") : Sacc[i];
+    } else {
+      po[i] = 0.0;
+      po[NA + i] = 0.0;
+    }
+  }
+}
+
+template <typename XT, int NI, int NJW>
+size_t ws_lds_bytes(int P16, int NA) {
+  const int RT = 16 * NI;
+  size_t b = (size_t)(2 * WS_CH * 16 * NJW + P16 + 2 * 4 * NI * 64 + 3 * NA) * sizeof(double);
+  b += (size_t)2 * WS_CH * RT * sizeof(XT);
+  b += (size_t)(2 * NA + RT) * sizeof(int);
+  return b;
+}
+
+template <typename XT, int NI, int NJW>
+int ws_launch(const void *xt, const uint8_t *mask_t, const int32_t *nloo, const double *mu, const double *Wp, const double *Ct,
+              const int32_t *status, const double *alphas, const SfGeom &g, int P16, int NA, int rows, int nsplit, double *part,
+              hipStream_t st) {
+  const size_t lds = ws_lds_bytes<XT, NI, NJW>(P16, NA);
+  if (lds > 160 * 1024) {
+    sf_set_error("wide sweep: %d bands need %zu bytes of LDS", g.p, lds);
+    return -2;
+  }
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsweep<XT, NI, NJW>), lds)) return rc;
+  const int grid = 8 * sf_cdiv(g.ncols, 8) * nsplit;
+  hipLaunchKernelGGL((k_wsweep<XT, NI, NJW>), dim3(grid), dim3(256), lds, st, reinterpret_cast<const XT *>(xt), mask_t, nloo, mu, Wp,
+                     Ct, status, alphas, g.nalpha, NA, g.lines, g.p, g.ps, P16, rows, nsplit, g.ncols, part, sf_tune().wjac_stamps);
+  SF_LAUNCH_CHECK("k_wsweep");
+  return 0;
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+int sf_wgemm_splits(const SfGeom &g) {   // a function of the number of lines only (bit-identical shards, cmf_common.h)
+  // 32 splits of 640 rows at 20000 lines: the 32 CUs of an XCD then work on ONE column at a time (sf_launch_wsweep's block
+  // order), whose W and C (2.2 MB) stay in that XCD's 4 MB L2 while its ten 64-row tiles per split stream them
+  int ns = sf_cdiv(g.lines, 640);
+  if (ns > 32) ns = 32;
+  return ns < 1 ? 1 : ns;
+}
+static int wg_p16(const SfGeom &g) { return (g.p + 15) / 16 * 16; }
+static int wg_ldw(const SfGeom &g) { return g.p <= 256 ? 256 : (g.p <= 432 ? 432 : 512); }   // 16 NJW of the instantiation used
+static int wg_na(const SfGeom &g) { return g.nu * 16; }   // (a multiple of the 8 alphas of a C chunk)   // alpha slots = the stride k_nll reads the partials with
+// scratch of the fused route: W [ncols][P16][LDW], Ct [ncols][NA / 16][LDW][16], the sweep partials [ncols][nsplit][2][NA]
+size_t sf_wgemm_operand_bytes(const SfGeom &g) {
+  const size_t P16 = wg_p16(g), LDW = wg_ldw(g), NA = wg_na(g);
+  return sf_align((size_t)g.ncols * P16 * LDW * sizeof(double)) + sf_align((size_t)g.ncols * NA * LDW * sizeof(double));
+}
+size_t sf_wgemm_part_bytes(const SfGeom &g) {
+  return sf_align((size_t)g.ncols * sf_wgemm_splits(g) * 2 * wg_na(g) * sizeof(double));
+}
+
+int sf_launch_wsyrk(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
+                    int c0, int nb, double *cov, hipStream_t st) {
+  const int ntile = sf_cdiv(g.p, SY_T);
+  const int npair = ntile * (ntile + 1) / 2;
+  const size_t lds = ((size_t)2 * SY_KC * SY_LD + 2 * SY_T) * sizeof(double);
+  const size_t colx = (size_t)g.lines * g.ps;
+  if (xt_f64) {
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsyrk<double>), lds)) return rc;
+    hipLaunchKernelGGL(k_wsyrk<double>, dim3(npair, nb), dim3(256), lds, st, reinterpret_cast<const double *>(xt) + (size_t)c0 * colx,
+                       mask_t + (size_t)c0 * g.lines, nuse + c0, mu + (size_t)c0 * g.p, g.lines, g.p, g.ps, ntile,
+                       cov + (size_t)c0 * g.p * g.p);
+  } else {
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsyrk<float>), lds)) return rc;
+    hipLaunchKernelGGL(k_wsyrk<float>, dim3(npair, nb), dim3(256), lds, st, reinterpret_cast<const float *>(xt) + (size_t)c0 * colx,
+                       mask_t + (size_t)c0 * g.lines, nuse + c0, mu + (size_t)c0 * g.p, g.lines, g.p, g.ps, ntile,
+                       cov + (size_t)c0 * g.p * g.p);
+  }
+  SF_LAUNCH_CHECK("k_wsyrk");
+  return 0;
+}
+
+// the sweep of columns c0 .. c0 + nb - 1: operands into `opnd` (sf_wgemm_operand_bytes of the nb-column geometry), partials
+// into part[(c0 + c) * nsplit + split] of the whole-flightline array
+int sf_launch_wsweep(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nloo, const double *mu, const double *d,
+                     const double *lam, const double *evec, const int32_t *status, const double *alphas, const SfGeom &g, int c0,
+                     int nb, void *opnd, double *part, hipStream_t st) {
+  const int P16 = wg_p16(g), LDW = wg_ldw(g), NA = wg_na(g), nsplit = sf_wgemm_splits(g);
+  const int rows = sf_cdiv(sf_cdiv(g.lines, nsplit), 64) * 64;   // whole 64-row tiles (also a multiple of the 32- / 16-row tiles)
+  SfGeom gb = g;
+  gb.ncols = nb;
+  double *Wp = reinterpret_cast<double *>(opnd);
+  double *Ct = reinterpret_cast<double *>(reinterpret_cast<char *>(opnd) + sf_align((size_t)nb * P16 * LDW * sizeof(double)));
+  const size_t colx = (size_t)g.lines * g.ps * (xt_f64 ? sizeof(double) : sizeof(float));
+  const void *xb = reinterpret_cast<const char *>(xt) + (size_t)c0 * colx;
+  hipLaunchKernelGGL(k_wmat_p, dim3(128, nb), dim3(256), 0, st, evec + (size_t)c0 * g.p * g.p, d + (size_t)c0 * g.p, g.p, P16, LDW, Wp);
+  SF_LAUNCH_CHECK("k_wmat_p");
+  hipLaunchKernelGGL(k_cmat_t, dim3(64, nb), dim3(256), 0, st, lam + (size_t)c0 * g.p, nloo + c0, status + c0, alphas, g.nalpha,
+                     NA / 8, g.p, LDW, Ct);
+  SF_LAUNCH_CHECK("k_cmat_t");
+  double *pb = part + (size_t)c0 * nsplit * 2 * NA;
+#define WS_GO(XT, NI, NJW)                                                                                                        \
+  return ws_launch<XT, NI, NJW>(xb, mask_t + (size_t)c0 * g.lines, nloo + c0, mu + (size_t)c0 * g.p, Wp, Ct, status + c0, alphas, gb, \
+                                P16, NA, rows, nsplit, pb, st)
+  if (!xt_f64) {
+    if (LDW == 256) WS_GO(float, 4, 16);
+    if (LDW == 432) WS_GO(float, 4, 27);
+    WS_GO(float, 2, 32);
+  } else {
+    if (LDW == 256) WS_GO(double, 2, 16);
+    if (LDW == 432) WS_GO(double, 2, 27);
+    WS_GO(double, 2, 32);
+  }
+#undef WS_GO
+}
+
+extern "C" int sf_debug_wsweep_stamps(unsigned long long *out4, int reset) {
+  if (out4) SF_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_ws_stamps), 4 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    SF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ws_stamps), z, sizeof(z)));
+  }
+  return 0;
+}

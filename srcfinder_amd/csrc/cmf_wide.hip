@@ -1006,10 +1006,40 @@ int sf_exact_det_window(const SfGeom &g) { return ((size_t)g.ncols * g.nalpha <=
 static size_t wide_target_bytes(const SfGeom &g) {
   return sf_align((size_t)sf_wide_batch(g) * (2 * (size_t)g.p * g.p * sizeof(double) + sizeof(int32_t)));
 }
-size_t sf_wide_scratch_bytes(const SfGeom &g) {
+// ---- the fused route of round 4 (cmf_wgemm.hip): no float64 copies of X~, Z, r -- a column needs its eigensolver work
+// matrices (2 p2^2), the sweep operands W and C, and, on the full-target route, L and B.  All columns of a flightline in one group when 8 GB hold them.
+static size_t fused_col_bytes(const SfGeom &g) {
+  const size_t p = g.p, p2 = g.p + (g.p & 1);
+  SfGeom one = g;
+  one.ncols = 1;
+  return sf_align(2 * p2 * p2 * sizeof(double)) + sf_wgemm_operand_bytes(one) + sf_align(2 * p * p * sizeof(double)) + 256;
+}
+int sf_wide_group(const SfGeom &g) {
+  // The eigensolver streams every factor (2 p2^2 doubles are allocated, p2^2 are live) once per Jacobi step: a group whose
+  // factors fit the 256 MB Infinity Cache runs its visits ~15 % faster than one that spills to HBM (598 matrices of p = 425:
+  // 38.5 us per round of 512 workgroups against 33 with 200), and 13 x 150 workgroups are 3.8 rounds, paid as 4.
+  const size_t p2 = g.p + (g.p & 1);
+  size_t b = (size_t)230e6 / (p2 * p2 * sizeof(double));
+  const size_t bmem = ((size_t)8 << 30) / fused_col_bytes(g);
+  if (b > bmem) b = bmem;
+  if (b < 1) b = 1;
+  if (b > (size_t)g.ncols) b = g.ncols;
+  const int ngroups = sf_cdiv(g.ncols, (int)b);
+  return sf_cdiv(g.ncols, ngroups);   // balanced groups
+}
+static size_t fused_scratch_bytes(const SfGeom &g) {
+  const size_t gb = sf_wide_group(g), ngr = sf_cdiv(g.ncols, (int)gb);
+  return ngr * gb * fused_col_bytes(g) + sf_wgemm_part_bytes(g) + sf_align((size_t)g.ncols * g.nalpha * sizeof(double)) +
+         sf_exact_det_scratch_bytes(g, sf_exact_det_window(g)) + 4096;
+}
+static size_t legacy_scratch_bytes(const SfGeom &g) {
   return (size_t)sf_wide_batch(g) * wide_col_bytes(g) + wide_target_bytes(g) +
          sf_align((size_t)g.ncols * wide_nll_splits(g) * 2 * g.nu * 16 * sizeof(double)) +
          sf_align((size_t)g.ncols * g.nalpha * sizeof(double)) + sf_exact_det_scratch_bytes(g, sf_exact_det_window(g));
+}
+size_t sf_wide_scratch_bytes(const SfGeom &g) {
+  const size_t a = fused_scratch_bytes(g), b = legacy_scratch_bytes(g);   // (the round-3 route stays selectable: sf_debug_set(23, 1))
+  return a > b ? a : b;
 }
 
 // blocked Cholesky of the nb matrices in gv whose flag is 0 (flag -> 1 where a pivot is not positive)
@@ -1091,6 +1121,60 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
   return 0;
 }
 
+// Round 4: covariance and sweep by the fused 4x4x4 kernels of cmf_wgemm.hip, the eigensolver on groups of up to 200 columns.
+static int wide_stats_fused(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const int32_t *nloo,
+                            const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
+                            double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st,
+                            const double *target) {
+  const int p = g.p, p2 = g.p + (g.p & 1);
+  const int gb = sf_wide_group(g), ngr = sf_cdiv(g.ncols, gb);
+  const size_t per = fused_col_bytes(g);
+  SfGeom one = g;
+  one.ncols = 1;
+  const size_t gv_b = sf_align(2 * (size_t)p2 * p2 * sizeof(double)), op_b = sf_wgemm_operand_bytes(one);
+  char *base = reinterpret_cast<char *>(scratch);
+  double *part = reinterpret_cast<double *>(base + (size_t)ngr * gb * per);
+  double *rest = reinterpret_cast<double *>(reinterpret_cast<char *>(part) + sf_wgemm_part_bytes(g));
+  void *det_scratch = reinterpret_cast<char *>(rest) + sf_align((size_t)g.ncols * g.nalpha * sizeof(double));
+  for (int gi = 0; gi < ngr; ++gi) {
+    const int c0 = gi * gb, nb = (g.ncols - c0 < gb) ? g.ncols - c0 : gb;
+    char *gbase = base + (size_t)gi * gb * per;
+    // group layout: gv [nb][2 p2^2] | operands (W | Ct for nb columns) | Lc, Bw [nb][p^2] | flags
+    double *gv = reinterpret_cast<double *>(gbase);
+    void *opnd = gbase + (size_t)gb * gv_b;
+    double *Lc = reinterpret_cast<double *>(gbase + (size_t)gb * (gv_b + op_b));
+    double *Bw = Lc + (size_t)gb * p * p;
+    int32_t *flags = reinterpret_cast<int32_t *>(gbase + (size_t)gb * (per - 256));   // cflag | done | rot | tflag, gb each
+    int32_t *tflag = flags + 3 * gb;
+    static_assert(sizeof(int32_t) == 4, "flags");
+    if ((size_t)4 * gb * sizeof(int32_t) > (size_t)gb * 256) return -2;   // (16 bytes of flags per column: always true)
+    // gv of matrix i must sit at gv + i * 2 p2^2 (the eigensolver kernels index it that way): gv_b may be padded, so the
+    // group's gv block is addressed densely and simply has to fit
+    if (int rc = sf_launch_wsyrk(xt, xt_f64, mask_t, nuse, mu, g, c0, nb, cov, st)) return rc;
+    if (!target) {
+      if (int rc = wide_eigh(cov, nuse, p, p2, c0, nb, d, lam, evec, status, gv, flags, flags + gb, flags + 2 * gb, st)) return rc;
+    } else {
+      hipLaunchKernelGGL(k_wg_load, dim3(64, nb), dim3(256), 0, st, target, nuse, p, p2, c0, gv, flags);
+      SF_LAUNCH_CHECK("k_wg_load");
+      if (int rc = wide_chol(gv, p, p2, nb, flags, st)) return rc;
+      hipLaunchKernelGGL(k_wg_prep, dim3(64, nb), dim3(256), 0, st, gv, flags, cov, p, p2, c0, Lc, Bw, d, tflag);
+      hipLaunchKernelGGL(k_wg_solve<false>, dim3(sf_cdiv(p, 64), nb), dim3(64), 0, st, Lc, Bw, p);
+      hipLaunchKernelGGL(k_wg_transpose, dim3(64, nb), dim3(256), 0, st, Bw, p, 0);
+      hipLaunchKernelGGL(k_wg_solve<false>, dim3(sf_cdiv(p, 64), nb), dim3(64), 0, st, Lc, Bw, p);
+      hipLaunchKernelGGL(k_wg_transpose, dim3(64, nb), dim3(256), 0, st, Bw, p, 1);
+      SF_LAUNCH_CHECK("k_wg_whiten");
+      if (int rc = wide_eigh(Bw, nuse, p, p2, c0, nb, d, lam, evec, status, gv, flags, flags + gb, flags + 2 * gb, st, 1)) return rc;
+      hipLaunchKernelGGL(k_wg_back_in, dim3(64, nb), dim3(256), 0, st, evec, p, c0, Bw);
+      hipLaunchKernelGGL(k_wg_solve<true>, dim3(sf_cdiv(p, 64), nb), dim3(64), 0, st, Lc, Bw, p);
+      hipLaunchKernelGGL(k_wg_back_out, dim3(64, nb), dim3(256), 0, st, Bw, p, c0, d, evec, lam, status, tflag);
+      SF_LAUNCH_CHECK("k_wg_back");
+    }
+    if (int rc = sf_launch_wsweep(xt, xt_f64, mask_t, nloo, mu, d, lam, evec, status, alphas, g, c0, nb, opnd, part, st)) return rc;
+  }
+  if (int rc = sf_launch_nll_finish(part, sf_wgemm_splits(g), nloo, d, lam, status, alphas, g, nll, alphaidx, st, rest)) return rc;
+  return sf_launch_exact_det(cov, nloo, status, alphas, g, sf_exact_det_window(g), rest, nll, alphaidx, det_scratch, st, target);
+}
+
 int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const int32_t *nloo,
                          const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
                          double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st,
@@ -1100,6 +1184,9 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
     return -2;
   }
   if (!nloo) nloo = nuse;
+  if (sf_tune().wide_gemm_variant != 1)
+    return wide_stats_fused(xt, xt_f64, mask_t, nuse, nloo, mu, alphas, g, cov, d, lam, evec, status, nll, alphaidx, scratch, st,
+                            target);
   const int L = g.lines, p = g.p, NA16 = g.nu * 16, p2 = g.p + (g.p & 1);
   const int bc = sf_wide_batch(g);
   const int nsplit = wide_nll_splits(g);

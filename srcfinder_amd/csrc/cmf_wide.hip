@@ -529,6 +529,7 @@ __global__ void k_chol_clean(double *__restrict__ gscratch, int p, int p2, const
 // launch of the sweep, where every block appears exactly once.  Every pair is met once per sweep: a cyclic Jacobi in
 // a blocked order.  Same rotation formula, threshold and carried norms as k_eigh_global.
 constexpr int BJ_B = 16;        // columns per block
+constexpr double BJ_TINY2 = 1e-18;   // (1e-9)^2: a rotation below this ratio leaves only second-order (1e-18) residue
 constexpr int BJ_NT = 256;      // 16 groups of 16 lanes
 
 __device__ __forceinline__ bool bj_rotation(double aa, double bb, double ab, double tol2, double &cs, double &sn) {
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
     if (sub == 0) nrm[j] = sacc;
   }
   __syncthreads();
-  bool rotated = false;
+  bool rotated = false, big = false;
   // ---- the pairs inside each block, once per sweep: 15 steps of 8 pairs per block (groups 0-7: block a, 8-15: block b)
   if (step == 0) {
     const int blk = grp >> 3, k = grp & 7;
@@ -634,6 +635,7 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
         double cs, sn;
         if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {
           rotated = true;
+          big = big || (ab * ab > BJ_TINY2 * (aa * bbn));
 #pragma unroll
           for (int i = 0; i < RM; ++i) {
             if (i < nr) {
@@ -672,6 +674,7 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
       double cs, sn;
       if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {
         rotated = true;
+        big = big || (ab * ab > BJ_TINY2 * (aa * bbn));
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
           const double na = cs * xa[i] - sn * xb[i], nb = sn * xa[i] + cs * xb[i];
@@ -688,6 +691,8 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
     for (int i = 0; i < RM; ++i) if (i < nr) ga[16 * i] = xa[i];
   }
   if (rotated) any = 1;
+  __syncthreads();   // (a lane's "1" must not land on another lane's "2")
+  if (big) any = 2;
   __syncthreads();
   // ---- store
   for (int cblk = 0; cblk < (lone ? 1 : 2); ++cblk) {
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
       dst[idx] = *reinterpret_cast<const double2 *>(sm + (size_t)(cblk * BJ_B + cc) * LDr + 2 * r2);
     }
   }
-  if (tid == 0 && any) rot[mtx] = 1;
+  if (tid == 0 && any) atomicMax(&rot[mtx], any);
 }
 
 // Steps > 0 of a sweep: cross pairs only.  Group i of 16 lanes takes column a_i straight from global memory into
@@ -768,7 +773,7 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac_x(double *__restrict__ gscra
     if (sub == 0) nrm[grp] = sacc;
   }
   __syncthreads();
-  bool rotated = false;
+  bool rotated = false, big = false;
   for (int t = 0; t < BJ_B; ++t) {
     const int j = (grp + t) & (BJ_B - 1);
     double *gb = sm + (size_t)j * LDr + sub;
@@ -783,6 +788,7 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac_x(double *__restrict__ gscra
     double cs, sn;
     if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {
       rotated = true;
+      big = big || (ab * ab > BJ_TINY2 * (aa * bbn));
 #pragma unroll
       for (int i = 0; i < RM; ++i) {
         const double na = cs * xa[i] - sn * xb[i], nb = sn * xa[i] + cs * xb[i];
@@ -796,6 +802,8 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac_x(double *__restrict__ gscra
     __syncthreads();
   }
   if (rotated) any = 1;
+  __syncthreads();   // (a workgroup's "1" must not land on another lane's "2")
+  if (big) any = 2;
   if (acol < p2) {
 #pragma unroll
     for (int i = 0; i < RM; ++i) if (i < nr) ga[16 * i] = xa[i];
@@ -811,14 +819,17 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac_x(double *__restrict__ gscra
       dst[idx] = *reinterpret_cast<const double2 *>(sm + (size_t)cc * LDr + 2 * r2);
     }
   }
-  if (tid == 0 && any) rot[mtx] = 1;
+  if (tid == 0 && any) atomicMax(&rot[mtx], any);
 }
 
-// after a sweep: a matrix without a rotation is finished
+// after a sweep: a matrix without a rotation is finished -- and so is one whose rotations were all TINY (|a.b| <= 1e-9 |a||b|
+// for every pair that rotated; rot = 1): each of those pairs is now orthogonal to working precision and disturbed the others by
+// the square of that ratio, so the sweep that would follow finds nothing above the tolerance (it is the verification sweep a
+// cyclic Jacobi otherwise pays: one of the 12 at p = 425).  rot = 2: some rotation was larger -- another sweep.
 __global__ void k_blockjac_flags(int nb, int32_t *__restrict__ done, int32_t *__restrict__ rot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb) return;
-  if (!rot[i]) done[i] = 1;
+  if (rot[i] < 2) done[i] = 1;
   rot[i] = 0;
 }
 

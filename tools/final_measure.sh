@@ -5,10 +5,10 @@
 # copies into profiles/ happen only when every step succeeded (set -e); gpurun merges only gpurun_out/ back, so repeat the
 # copies on the development side: for f in ...; see the cp lines at the end.
 set -euo pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/${tag}f
 mkdir -p $out
-B="--no-cpu-baseline --no-cnn --no-e2e --no-wide"
+B="--no-cpu-baseline --no-cnn --no-e2e --no-wide --no-ingest --no-routes --no-ceiling"
 tools/pmc_traffic.sh ${tag}f > $out/pmc.log 2>&1
 cp gpurun_out/${tag}f_pmc_traffic.json $out/pmc_traffic.json
 tools/pmc_mfma.sh ${tag}f > $out/pmc_mfma.txt 2>&1
@@ -20,6 +20,12 @@ rm -rf gpurun_out/prof_${tag}fif1 gpurun_out/pmc_${tag}f_FETCH_SIZE gpurun_out/p
 python bench.py > $out/bench_line.json 2> $out/bench_line.err
 python bench.py --samples 75 --no-cnn > $out/bench_line_shard75.json 2> /dev/null
 python bench.py --samples 75 --no-cnn --in-flight 1 --no-cpu-baseline > $out/bench_line_shard75_inflight1.json 2> /dev/null
+# a failed step must not reach profiles/: every record has to be what it claims to be (ADVICE r2 / VERDICT r3 item 9)
+for j in $out/bench_line.json $out/bench_line_shard75.json $out/bench_line_shard75_inflight1.json $out/bench_line_inflight1_rocprof.json; do
+  python3 -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); assert d['value'] > 0 and d['roofline']['avg_launch_ms'] > 0" $j
+done
+python3 -c "import json,sys; d=json.load(open(sys.argv[1])); assert d['kernels']['k_score']['hbm_bytes_per_launch'] > 1e9" $out/pmc_traffic.json
+grep -q "k_score" $out/kstats_inflight1.txt
 tools/prof_bench.sh ${tag}fwide --active 1,425 --steps 2 --warmup 1 $B --in-flight 1 > $out/prof_wide.log 2>&1
 cp gpurun_out/${tag}fwide_kstats.txt $out/kstats_fullband425.txt
 rm -rf gpurun_out/prof_${tag}fwide

@@ -8,7 +8,11 @@ import csv, glob, hashlib, json, os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def load(d, name):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True))
+    # the CSV of the bench.py process itself: the one that holds k_score rows (a child process started under the profiler
+    # would write its own file into the same directory; bench.py no longer starts one there)
+    files = [x for x in files if "k_score" in open(x).read()] or files
+    f = files[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != name:
@@ -19,7 +23,7 @@ def load(d, name):
     return acc
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cnn --no-e2e --no-wide --in-flight 1 (tools/pmc_traffic.sh)",
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cnn --no-e2e --no-wide --no-ingest --no-routes --no-ceiling --in-flight 1 (tools/pmc_traffic.sh)",
        "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section; calibrated in round 1: a 4 GiB streaming read at 4/8/16 B per lane reports 2,097,165 KB; WRITE_SIZE exact on a 4 GiB copy)",
        "workload": "598x20000x425, p=72", "kernels": {}}
 _h = hashlib.sha256()

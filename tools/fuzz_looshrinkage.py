@@ -42,10 +42,13 @@ for case in range(ncase):
     dif = np.nonzero(fo != fg)[0]
     if len(dif) > 16 or (len(dif) and not (np.all(fg[dif]) or rows <= p + 1)):
         ok, why = False, why + " finite pattern %s" % dif[:8]
-    if rows > p + 2 and both.any():          # (rows <= p + 2: the matrices the reference inverts have a condition of 1e10 and more)
+    if rows > p + 1 and both.any():
+        # rows == p + 2: the matrices the reference inverts have a condition of 1e10 and more -- still checked, at the
+        # looser bar that conditioning allows (the case used to be dropped altogether)
         r = np.abs(nll_g[both] - nll_o[both]) / np.maximum(np.abs(nll_o[both]), 1e-300)
-        if r.max() > 1e-7:
-            ok, why = False, why + " nll rel %.2e" % r.max()
+        bar = 1e-7 if rows > p + 2 else 1e-3
+        if r.max() > bar:
+            ok, why = False, why + " nll rel %.2e (bar %.0e)" % (r.max(), bar)
     if i_g == i_o and rows > p + 1 and not np.allclose(c_g, c_o, rtol=1e-8, atol=1e-12 * np.abs(c_o).max()):
         ok, why = False, why + " C"
     cg, co = cmf.cov(x + 3.0), np.cov((x + 3.0).T)

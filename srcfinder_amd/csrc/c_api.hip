@@ -317,6 +317,8 @@ static int *sf_tune_slot(int key) {
     case 21: return &t.sweep_grid;
     case 22: return &t.wjac_stamps;
     case 23: return &t.wide_gemm_variant;
+    case 24: return &t.wsweep_variant;
+    case 25: return &t.wsyrk_variant;
     default: return nullptr;
   }
 }

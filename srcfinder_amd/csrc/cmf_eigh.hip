@@ -94,13 +94,13 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
   double *M = sm;                    // [p2][LD] column-major: M[col*LD + row]; G in phase 1, V in phase 2
   double *dv = sm + (size_t)p2 * LD;  // [p2]
   double *nrm = dv + p2;              // [p2] squared column norms of G, refreshed every sweep
-  __shared__ int flag[2];
+  __shared__ int flag[3];   // [0] bad diagonal, [1] a rotation this sweep, [2] a rotation above the tiny ratio this sweep
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int c = blockIdx.x;
   const double *S = cov + (size_t)c * p * p;
   const int n = nuse[c];
 
-  if (tid < 2) flag[tid] = 0;
+  if (tid < 3) flag[tid] = 0;
   for (int i = tid; i < p2; i += nthr) {
     double v = 0.0;
     if (i < p) v = unit ? 1.0 : sqrt(S[(size_t)i * p + i]);   // unit: the matrix is already whitened (cmf_general.hip)
@@ -182,7 +182,7 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
 #endif
   // ---------------- phase 1: orthogonalise the columns of G (record the rotations in the fallback)
   for (int sweep = 0; sweep < EIG_MAXSWEEP; ++sweep) {
-    bool rotated = false;
+    bool rotated = false, big = false;
     // exact squared norms once per sweep; inside the sweep they are carried through the rotations
     // (|a'|^2 = c^2 aa - 2cs ab + s^2 bb), so a step needs ONE dot product instead of three
     for (int j = tid; j < p2; j += nthr) {
@@ -246,6 +246,7 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
 #endif
         if (ab2 > 0.0 && ab * ab > tol2 * ab2) {  // uniform over the pair's 8 lanes
           rotated = true;
+          big = big || (ab * ab > 1e-18 * ab2);
           // tan(2 theta) = 2ab / (bb - aa), small-angle branch, no division:
           const double tau = bb - aa, gam = 2.0 * ab;
           const double rinv = rsqrt_nr(__builtin_fma(tau, tau, gam * gam));
@@ -286,12 +287,16 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
       EIG_STAMP(5);     // barrier
     }
     if (rotated) flag[1] = 1;  // benign race: every writer stores 1
+    if (big) flag[2] = 1;
     __syncthreads();
-    const int any = flag[1];
+    const int any = flag[1], anybig = flag[2];
     __syncthreads();
-    if (tid == 0) flag[1] = 0;
+    if (tid == 0) { flag[1] = 0; flag[2] = 0; }
     if (!any) break;           // this sweep was all identities: nothing of it to replay
     nsteps = (sweep + 1) * m;
+    // every rotation of the sweep was TINY (|a.b| <= 1e-9 |a||b|): each such pair is now orthogonal to working precision and
+    // disturbed the others by the square of that ratio -- the sweep that would follow is the all-identities verification sweep
+    if (!anybig) break;
   }
   __syncthreads();
   if (chol_ok && tid == 0) rot[(size_t)c * rot_stride] = make_double2((double)(nsteps / m), 0.0);  // tools/probe_eigh.py

@@ -26,25 +26,31 @@ namespace {
 // --------------------------------------------------------------------------------------------------------------------
 // k_wsyrk
 // --------------------------------------------------------------------------------------------------------------------
-constexpr int SY_T = 128;              // band tile
 constexpr int SY_KC = 16;              // rows per LDS chunk
-constexpr int SY_LD = 2 * SY_T + 16;   // doubles per chunk row: [I bands | J bands] + pad (272 = 16 mod 32)
 
-__device__ __forceinline__ void sy_load4(const float *p, double (&v)[4]) {
+__device__ __forceinline__ void sy_load4(const float *p, float (&v)[4]) {
   const float4 f = *reinterpret_cast<const float4 *>(p);
-  v[0] = (double)f.x; v[1] = (double)f.y; v[2] = (double)f.z; v[3] = (double)f.w;
+  v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
 }
 __device__ __forceinline__ void sy_load4(const double *p, double (&v)[4]) {
   const double2 a = *reinterpret_cast<const double2 *>(p), b = *reinterpret_cast<const double2 *>(p + 2);
   v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 
-template <typename XT>
-__global__ __launch_bounds__(256, 2) void k_wsyrk(const XT *__restrict__ xt, const uint8_t *__restrict__ mask_t,
-                                                   const int32_t *__restrict__ nuse, const double *__restrict__ mu, int L, int p,
-                                                   int ps, int ntile, double *__restrict__ cov) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];   // [2][SY_KC][SY_LD], then mu [2 * SY_T]
-  double *mus = sm + 2 * SY_KC * SY_LD;
+// TI: 16-band groups per wave along I (the wave tile is 16 TI x 16 TI bands, the workgroup tile T = 32 TI: 2 x 2 waves).
+// TI = 4: 128-band tiles, 64 accumulators per lane, two workgroups per CU.  TI = 3: 96-band tiles -- 15 tile pairs of 96^2
+// instead of 10 of 128^2 at p = 425 (16 % fewer MFMAs: less of the upper triangle's padding), 36 accumulators, three per CU.
+template <typename XT, int TI, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_wsyrk(const XT *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+                                                     const int32_t *__restrict__ nuse, const double *__restrict__ mu, int L, int p,
+                                                     int ps, int ntile, double *__restrict__ cov) {
+  constexpr int TJ = 4 * TI;           // 4-band groups per wave along J
+  constexpr int T = 32 * TI;           // band tile
+  constexpr int LD = 2 * T + 16;       // doubles per chunk row: [I bands | J bands] + pad (= 16 mod 32)
+  constexpr int NQ = 2 * T / 4;        // 4-band quads per chunk row
+  constexpr int NIT = (SY_KC * NQ + 255) / 256;   // loader items per thread
+  extern __shared__ __attribute__((aligned(16))) double sm[];   // [2][SY_KC][LD], then mu [2 T]
+  double *mus = sm + 2 * SY_KC * LD;
   const int c = blockIdx.y;
   int ti = 0, tj = 0;
   {   // tile pair blockIdx.x of the upper triangle, row-major
@@ -55,50 +61,51 @@ __global__ __launch_bounds__(256, 2) void k_wsyrk(const XT *__restrict__ xt, con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, m = (lane >> 2) & 3, n = lane & 3;
   const int wi = wave >> 1, wj = wave & 1;
-  for (int i = tid; i < 2 * SY_T; i += 256) {
-    const int b = (i < SY_T ? ti * SY_T : tj * SY_T - SY_T) + i;
+  for (int i = tid; i < 2 * T; i += 256) {
+    const int b = (i < T ? ti * T : tj * T - T) + i;
     mus[i] = (b < p) ? mu[(size_t)c * p + b] : 0.0;
   }
   const XT *xc = xt + (size_t)c * L * ps;
   const uint8_t *mp = mask_t + (size_t)c * L;
-  // loader role: row r of the chunk, four band quads (quad = c4 + 16 u: u = 0, 1 in the I half, 2, 3 in the J half)
-  const int lr = tid >> 4, c4 = tid & 15;
-  int gband[4];
+  // loader: item = (row of the chunk, 4-band quad of [I half | J half]); consecutive lanes = consecutive quads of a row
+  int irow[NIT], iquad[NIT], gband[NIT];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int quad = c4 + 16 * u;
-    gband[u] = ((quad < 32) ? ti * SY_T : tj * SY_T - SY_T) + 4 * quad;
+  for (int u = 0; u < NIT; ++u) {
+    const int item = tid + 256 * u;
+    irow[u] = item / NQ;
+    iquad[u] = item - irow[u] * NQ;
+    gband[u] = ((iquad[u] < NQ / 2) ? ti * T : tj * T - T) + 4 * iquad[u];
+    if (item >= SY_KC * NQ) irow[u] = -1;
   }
-  double pre[4][4];
-  bool prok;
+  XT pre[NIT][4];   // raw values of the next chunk (promoted when they are stored)
+  bool prok[NIT];
   auto gload = [&](int r0) {
-    const int row = r0 + lr;
-    const int rr = row < L ? row : L - 1;
-    prok = (row < L) && (mp[rr] != 0);
-    const XT *rp = xc + (size_t)rr * ps;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (gband[u] < ps) sy_load4(rp + gband[u], pre[u]);
-      else { pre[u][0] = pre[u][1] = pre[u][2] = pre[u][3] = 0.0; }
+    for (int u = 0; u < NIT; ++u) {
+      const int row = r0 + max(irow[u], 0);
+      const int rr = row < L ? row : L - 1;
+      prok[u] = (irow[u] >= 0) && (row < L) && (mp[rr] != 0);
+      if (irow[u] >= 0 && gband[u] < ps) sy_load4(xc + (size_t)rr * ps + gband[u], pre[u]);
+      else { pre[u][0] = pre[u][1] = pre[u][2] = pre[u][3] = (XT)0; }
     }
   };
   auto lstore = [&](int buf) {
-    double *dst = sm + ((size_t)buf * SY_KC + lr) * SY_LD;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int quad = c4 + 16 * u;
+    for (int u = 0; u < NIT; ++u) {
+      if (irow[u] < 0) continue;
+      double *dst = sm + ((size_t)buf * SY_KC + irow[u]) * LD + 4 * iquad[u];
       double o[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (prok && gband[u] + e < p) ? pre[u][e] - mus[4 * quad + e] : 0.0;
-      *reinterpret_cast<double2 *>(dst + 4 * quad) = make_double2(o[0], o[1]);
-      *reinterpret_cast<double2 *>(dst + 4 * quad + 2) = make_double2(o[2], o[3]);
+      for (int e = 0; e < 4; ++e) o[e] = (prok[u] && gband[u] + e < p) ? (double)pre[u][e] - mus[4 * iquad[u] + e] : 0.0;
+      *reinterpret_cast<double2 *>(dst) = make_double2(o[0], o[1]);
+      *reinterpret_cast<double2 *>(dst + 2) = make_double2(o[2], o[3]);
     }
   };
-  double acc[4][16];
+  double acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] = 0.0;
+    for (int j = 0; j < TJ; ++j) acc[i][j] = 0.0;
   __syncthreads();   // mus
   gload(0);
   lstore(0);
@@ -107,29 +114,29 @@ __global__ __launch_bounds__(256, 2) void k_wsyrk(const XT *__restrict__ xt, con
     const int buf = ch & 1;
     if (ch + 1 < nchunk) gload((ch + 1) * SY_KC);
     __syncthreads();   // chunk ch is in sm[buf]; everybody is done with sm[buf ^ 1] (chunk ch - 1)
-    const double *xs = sm + (size_t)buf * SY_KC * SY_LD;
+    const double *xs = sm + (size_t)buf * SY_KC * LD;
 #pragma unroll
     for (int k4 = 0; k4 < SY_KC / 4; ++k4) {
-      const double *row = xs + (size_t)(4 * k4 + q) * SY_LD;
-      double a[4], b[16];
+      const double *row = xs + (size_t)(4 * k4 + q) * LD;
+      double a[TI], b[TJ];
 #pragma unroll
-      for (int I = 0; I < 4; ++I) a[I] = row[64 * wi + 16 * I + 4 * m + n];
+      for (int I = 0; I < TI; ++I) a[I] = row[16 * TI * wi + 16 * I + 4 * m + n];
 #pragma unroll
-      for (int J = 0; J < 16; ++J) b[J] = row[SY_T + 64 * wj + 4 * J + n];
+      for (int J = 0; J < TJ; ++J) b[J] = row[T + 16 * TI * wj + 4 * J + n];
 #pragma unroll
-      for (int I = 0; I < 4; ++I)
+      for (int I = 0; I < TI; ++I)
 #pragma unroll
-        for (int J = 0; J < 16; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[I], b[J], acc[I][J], 0, 0, 0);
+        for (int J = 0; J < TJ; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[I], b[J], acc[I][J], 0, 0, 0);
     }
     if (ch + 1 < nchunk) lstore(buf ^ 1);
   }
   const double inv = 1.0 / ((double)nuse[c] - 1.0);
   double *co = cov + (size_t)c * p * p;
 #pragma unroll
-  for (int I = 0; I < 4; ++I)
+  for (int I = 0; I < TI; ++I)
 #pragma unroll
-    for (int J = 0; J < 16; ++J) {
-      const int bi = ti * SY_T + 64 * wi + 16 * I + 4 * m + q, bj = tj * SY_T + 64 * wj + 4 * J + n;
+    for (int J = 0; J < TJ; ++J) {
+      const int bi = ti * T + 16 * TI * wi + 16 * I + 4 * m + q, bj = tj * T + 16 * TI * wj + 4 * J + n;
       if (bi < p && bj < p) {
         const double v = acc[I][J] * inv;
         co[(size_t)bi * p + bj] = v;
@@ -189,7 +196,6 @@ __device__ __forceinline__ double ws_dpp(double v) {
 // phase clocks of the sweep's tiles (sf_debug_set(22, 1); sf_debug_wsweep_stamps): [0] tiles, [1] Y = X~ W, [2] r = Z C + rows
 __device__ unsigned long long g_ws_stamps[4];
 
-constexpr int WS_CH = 16;   // bands per W chunk
 constexpr int WS_CA = 8;    // alphas per C chunk (two groups of four: their row reductions are interleaved)
 
 // XT: float32 (the extracted cube) or float64 (the function-level looshrinkage()).  NI: 16-row groups per tile.
@@ -197,8 +203,10 @@ constexpr int WS_CA = 8;    // alphas per C chunk (two groups of four: their row
 // or 8 alphas of C ([LDW][8], half that), copied global -> LDS by global_load_lds (no registers), two buffers: the copy of chunk
 // s + 1 is issued right after the barrier that publishes chunk s and has that chunk's 432 MFMAs per wave to land.  X is
 // streamed beside W (16 bands x the tile's rows), centred and promoted when it is read as an operand.
-template <typename XT, int NI, int NJW>
-__global__ __launch_bounds__(256) void k_wsweep(const XT *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+// CH: bands per W chunk (16: 55 KB chunks, one workgroup per CU; 8: half that, two workgroups per CU -- or one beside a
+// workgroup of another kernel, e.g. the eigensolver of another column group).  OCC: workgroups per CU the registers allow.
+template <typename XT, int NI, int NJW, int CH, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_wsweep(const XT *__restrict__ xt, const uint8_t *__restrict__ mask_t,
                                                  const int32_t *__restrict__ nloo, const double *__restrict__ mu,
                                                  const double *__restrict__ Wp, const double *__restrict__ Ct,
                                                  const int32_t *__restrict__ status, const double *__restrict__ alphas, int nalpha,
@@ -206,7 +214,8 @@ __global__ __launch_bounds__(256) void k_wsweep(const XT *__restrict__ xt, const
                                                  double *__restrict__ part, int stamp) {
   constexpr int RT = 16 * NI;        // rows per tile
   constexpr int LDW = 16 * NJW;
-  constexpr int CHD = WS_CH * LDW;   // doubles per chunk
+  constexpr int WS_CH = CH;
+  constexpr int CHD = (CH > WS_CA ? CH : WS_CA) * LDW;   // doubles per chunk buffer
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   // ---- LDS carve (ws_lds_bytes below)
   double *Bs = reinterpret_cast<double *>(smraw);                 // [2][CHD]
@@ -247,19 +256,20 @@ __global__ __launch_bounds__(256) void k_wsweep(const XT *__restrict__ xt, const
   const int NKC = P16 / WS_CH, NCC = NA / WS_CA, NS = NKC + NCC;
   const char *Cc = reinterpret_cast<const char *>(Ct + (size_t)c * NCC * LDW * WS_CA);
   const int j0w = 4 * NJW * wave;              // first Y column of this wave
-  constexpr int NPIECE = CHD * 8 / 1024;       // 1 KB wave-pieces per W chunk (LDW is a multiple of 16: CHD * 8 = 2048 NJW)
+  constexpr int WCD = CH * LDW;                // doubles per W chunk
   constexpr int CCD = WS_CA * LDW;             // doubles per C chunk
+  constexpr int NPIECE = WCD * 8 / 1024, NPIECE_C = CCD * 8 / 1024;   // 1 KB wave-pieces (LDW is a multiple of 16)
   // chunk s of the stream -> Bs[s & 1]: s < NKC: rows 16 s .. of W; else alpha chunk s - NKC of C.  Lane-linear copies.
   auto glds = [&](int s) {
-    const char *src = (s < NKC ? Wc + (size_t)s * CHD * 8 : Cc + (size_t)(s - NKC) * CCD * 8) + lane * 16;
+    const char *src = (s < NKC ? Wc + (size_t)s * WCD * 8 : Cc + (size_t)(s - NKC) * CCD * 8) + lane * 16;
     char *dst = reinterpret_cast<char *>(Bs + (size_t)(s & 1) * CHD);
-    const int npc = s < NKC ? NPIECE : NPIECE / 2;
+    const int npc = s < NKC ? NPIECE : NPIECE_C;
     for (int pc = wave; pc < npc; pc += 4)
       __builtin_amdgcn_global_load_lds((ws_glb_void *)(src + (size_t)pc * 1024), (ws_lds_void *)(dst + (size_t)pc * 1024), 16, 0, 0);
   };
   // the X chunk of W chunk s: lane item = (row, band quad) of [RT rows][4 quads]
   const int xrow = tid % RT, xq = tid / RT;
-  const bool xact = tid < 4 * RT;
+  const bool xact = tid < (CH / 4) * RT;
   XT xv[4];
   auto xload = [&](int s, int r0) {
     const int b = WS_CH * s + 4 * xq;
@@ -436,27 +446,27 @@ __global__ __launch_bounds__(256) void k_wsweep(const XT *__restrict__ xt, const
   }
 }
 
-template <typename XT, int NI, int NJW>
+template <typename XT, int NI, int NJW, int CH>
 size_t ws_lds_bytes(int P16, int NA) {
   const int RT = 16 * NI;
-  size_t b = (size_t)(2 * WS_CH * 16 * NJW + P16 + 2 * 4 * NI * 64 + 3 * NA) * sizeof(double);
-  b += (size_t)2 * WS_CH * RT * sizeof(XT);
+  size_t b = (size_t)(2 * (CH > WS_CA ? CH : WS_CA) * 16 * NJW + P16 + 2 * 4 * NI * 64 + 3 * NA) * sizeof(double);
+  b += (size_t)2 * CH * RT * sizeof(XT);
   b += (size_t)(2 * NA + RT) * sizeof(int);
   return b;
 }
 
-template <typename XT, int NI, int NJW>
+template <typename XT, int NI, int NJW, int CH, int OCC>
 int ws_launch(const void *xt, const uint8_t *mask_t, const int32_t *nloo, const double *mu, const double *Wp, const double *Ct,
               const int32_t *status, const double *alphas, const SfGeom &g, int P16, int NA, int rows, int nsplit, double *part,
               hipStream_t st) {
-  const size_t lds = ws_lds_bytes<XT, NI, NJW>(P16, NA);
+  const size_t lds = ws_lds_bytes<XT, NI, NJW, CH>(P16, NA);
   if (lds > 160 * 1024) {
     sf_set_error("wide sweep: %d bands need %zu bytes of LDS", g.p, lds);
     return -2;
   }
-  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsweep<XT, NI, NJW>), lds)) return rc;
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsweep<XT, NI, NJW, CH, OCC>), lds)) return rc;
   const int grid = 8 * sf_cdiv(g.ncols, 8) * nsplit;
-  hipLaunchKernelGGL((k_wsweep<XT, NI, NJW>), dim3(grid), dim3(256), lds, st, reinterpret_cast<const XT *>(xt), mask_t, nloo, mu, Wp,
+  hipLaunchKernelGGL((k_wsweep<XT, NI, NJW, CH, OCC>), dim3(grid), dim3(256), lds, st, reinterpret_cast<const XT *>(xt), mask_t, nloo, mu, Wp,
                      Ct, status, alphas, g.nalpha, NA, g.lines, g.p, g.ps, P16, rows, nsplit, g.ncols, part, sf_tune().wjac_stamps);
   SF_LAUNCH_CHECK("k_wsweep");
   return 0;
@@ -484,25 +494,28 @@ size_t sf_wgemm_part_bytes(const SfGeom &g) {
   return sf_align((size_t)g.ncols * sf_wgemm_splits(g) * 2 * wg_na(g) * sizeof(double));
 }
 
-int sf_launch_wsyrk(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
-                    int c0, int nb, double *cov, hipStream_t st) {
-  const int ntile = sf_cdiv(g.p, SY_T);
+template <typename XT, int TI, int OCC>
+static int wsyrk_go(const void *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g, int c0, int nb,
+                    double *cov, hipStream_t st) {
+  constexpr int T = 32 * TI;
+  const int ntile = sf_cdiv(g.p, T);
   const int npair = ntile * (ntile + 1) / 2;
-  const size_t lds = ((size_t)2 * SY_KC * SY_LD + 2 * SY_T) * sizeof(double);
+  const size_t lds = ((size_t)2 * SY_KC * (2 * T + 16) + 2 * T) * sizeof(double);
   const size_t colx = (size_t)g.lines * g.ps;
-  if (xt_f64) {
-    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsyrk<double>), lds)) return rc;
-    hipLaunchKernelGGL(k_wsyrk<double>, dim3(npair, nb), dim3(256), lds, st, reinterpret_cast<const double *>(xt) + (size_t)c0 * colx,
-                       mask_t + (size_t)c0 * g.lines, nuse + c0, mu + (size_t)c0 * g.p, g.lines, g.p, g.ps, ntile,
-                       cov + (size_t)c0 * g.p * g.p);
-  } else {
-    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsyrk<float>), lds)) return rc;
-    hipLaunchKernelGGL(k_wsyrk<float>, dim3(npair, nb), dim3(256), lds, st, reinterpret_cast<const float *>(xt) + (size_t)c0 * colx,
-                       mask_t + (size_t)c0 * g.lines, nuse + c0, mu + (size_t)c0 * g.p, g.lines, g.p, g.ps, ntile,
-                       cov + (size_t)c0 * g.p * g.p);
-  }
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsyrk<XT, TI, OCC>), lds)) return rc;
+  hipLaunchKernelGGL((k_wsyrk<XT, TI, OCC>), dim3(npair, nb), dim3(256), lds, st, reinterpret_cast<const XT *>(xt) + (size_t)c0 * colx,
+                     mask_t + (size_t)c0 * g.lines, nuse + c0, mu + (size_t)c0 * g.p, g.lines, g.p, g.ps, ntile,
+                     cov + (size_t)c0 * g.p * g.p);
   SF_LAUNCH_CHECK("k_wsyrk");
   return 0;
+}
+int sf_launch_wsyrk(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
+                    int c0, int nb, double *cov, hipStream_t st) {
+  const bool t128 = sf_tune().wsyrk_variant == 1;   // 1: 128-band tiles (first form of the round); default 96
+  if (xt_f64) return t128 ? wsyrk_go<double, 4, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st)
+                          : wsyrk_go<double, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
+  return t128 ? wsyrk_go<float, 4, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st)
+              : wsyrk_go<float, 3, 3>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
 }
 
 // the sweep of columns c0 .. c0 + nb - 1: operands into `opnd` (sf_wgemm_operand_bytes of the nb-column geometry), partials
@@ -524,17 +537,19 @@ int sf_launch_wsweep(const void *xt, int xt_f64, const uint8_t *mask_t, const in
                      NA / 8, g.p, LDW, Ct);
   SF_LAUNCH_CHECK("k_cmat_t");
   double *pb = part + (size_t)c0 * nsplit * 2 * NA;
-#define WS_GO(XT, NI, NJW)                                                                                                        \
-  return ws_launch<XT, NI, NJW>(xb, mask_t + (size_t)c0 * g.lines, nloo + c0, mu + (size_t)c0 * g.p, Wp, Ct, status + c0, alphas, gb, \
+#define WS_GO(XT, NI, NJW, CH, OCC)                                                                                               \
+  return ws_launch<XT, NI, NJW, CH, OCC>(xb, mask_t + (size_t)c0 * g.lines, nloo + c0, mu + (size_t)c0 * g.p, Wp, Ct, status + c0, alphas, gb, \
                                 P16, NA, rows, nsplit, pb, st)
+  const int lite = sf_tune().wsweep_variant;   // 1: 32-row tiles, 8-band chunks, two workgroups per CU
   if (!xt_f64) {
-    if (LDW == 256) WS_GO(float, 4, 16);
-    if (LDW == 432) WS_GO(float, 4, 27);
-    WS_GO(float, 2, 32);
+    if (LDW == 256) WS_GO(float, 4, 16, 16, 1);
+    if (LDW == 432 && lite == 1) WS_GO(float, 2, 27, 8, 2);
+    if (LDW == 432) WS_GO(float, 4, 27, 16, 1);
+    WS_GO(float, 2, 32, 16, 1);
   } else {
-    if (LDW == 256) WS_GO(double, 2, 16);
-    if (LDW == 432) WS_GO(double, 2, 27);
-    WS_GO(double, 2, 32);
+    if (LDW == 256) WS_GO(double, 2, 16, 16, 1);
+    if (LDW == 432) WS_GO(double, 2, 27, 16, 1);
+    WS_GO(double, 2, 32, 16, 1);
   }
 #undef WS_GO
 }

@@ -822,6 +822,140 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac_x(double *__restrict__ gscra
   if (tid == 0 && any) atomicMax(&rot[mtx], any);
 }
 
+// Round 4: TWO block pairs per workgroup, four blocks per visit.  The blocks of step 0's pairs form "super-blocks" K = (a_K, b_K)
+// (their inner and mutual pairs are k_blockjac's, the first launch of a sweep); the remaining pairs are those between
+// super-blocks, and a circle method over the SUPER-blocks schedules them: a visit of the super-pair (K, L) holds a_K and b_K
+// in the registers of its two 256-thread teams and a_L, b_L in LDS, rotates (a_K, a_L) | (b_K, b_L) and then, the teams swapping
+// their LDS block, (a_K, b_L) | (b_K, a_L).  Four block pairs per four blocks moved instead of one per two: half the memory
+// traffic per rotation (the visits of a step move 5 TB/s, profiles/r04_wjac_phase_clocks.txt), half the launches per sweep
+// (14 instead of 27 at p = 425).  Every pair of columns still meets exactly once per sweep; same rotation formula, threshold
+// and carried norms as k_blockjac_x.
+template <int RM>
+__global__ __launch_bounds__(2 * BJ_NT) void k_blockjac_q(double *__restrict__ gscratch, int p2, int LDr, int nblk, int mblk, int sstep,
+                                                           const int32_t *__restrict__ cflag, const int32_t *__restrict__ done,
+                                                           int32_t *__restrict__ rot) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];   // [2][BJ_B][LDr] (the blocks of L), then nrm[2][BJ_B]
+  double *nrm = sm + (size_t)2 * BJ_B * LDr;
+  __shared__ int any;
+  const int mtx = blockIdx.y;
+  if (cflag[mtx] != 0 || done[mtx]) return;
+  const int msb = mblk >> 1, msbE = msb + (msb & 1);     // super-blocks; an even number of circle slots
+  int K, Ls;
+  rr_pair_w(sstep, blockIdx.x, msbE - 1, K, Ls);
+  if (K >= msb || Ls >= msb) return;
+  int blkA[2], blkB[2];
+  rr_pair_w(0, K, mblk - 1, blkA[0], blkA[1]);
+  rr_pair_w(0, Ls, mblk - 1, blkB[0], blkB[1]);
+  const int tid = threadIdx.x, team = tid >> 8, grp = (tid >> 4) & 15, sub = tid & 15;
+  double *G = gscratch + (size_t)mtx * 2 * p2 * p2;
+  const int nr = (p2 - sub + 15) >> 4;
+  const double tol = (double)p2 * 2.220446049250313e-16, tol2 = tol * tol;
+  if (tid == 0) any = 0;
+  constexpr int BJ_U = 8;
+  const int half = p2 >> 1;
+  // ---- both blocks of L -> LDS (a block index past the last block: zeros, never stored)
+  for (int slot = 0; slot < 2; ++slot) {
+    const int c0 = blkB[slot] * BJ_B;
+    const int n2 = (blkB[slot] < nblk ? min(BJ_B, p2 - c0) : 0) * half;
+    const double2 *src = reinterpret_cast<const double2 *>(G + (size_t)min(c0, p2 - 1) * p2);
+    for (int base = tid; base < BJ_B * half; base += 2 * BJ_NT * BJ_U) {
+      double2 v[BJ_U];
+#pragma unroll
+      for (int u = 0; u < BJ_U; ++u) {
+        const int idx = base + 2 * BJ_NT * u;
+        v[u] = (idx < n2) ? src[idx] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < BJ_U; ++u) {
+        const int idx = base + 2 * BJ_NT * u;
+        if (idx < BJ_B * half) {
+          const int cc = idx / half, r2 = idx - cc * half;
+          *reinterpret_cast<double2 *>(sm + (size_t)(slot * BJ_B + cc) * LDr + 2 * r2) = v[u];
+        }
+      }
+    }
+  }
+  // ---- this team's block of K: group grp keeps column a_grp in registers for the whole visit
+  const int ablk = blkA[team];
+  const int acol = ablk * BJ_B + grp;
+  const bool areal = ablk < nblk && acol < p2;
+  double *ga = G + (size_t)min(acol, p2 - 1) * p2 + sub;
+  double xa[RM];
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+    const int ii = min(i, nr - 1);
+    const double u = ga[16 * ii];
+    xa[i] = (i < nr && areal) ? u : 0.0;
+  }
+  double aa = 0.0;
+#pragma unroll
+  for (int i = 0; i < RM; ++i) aa = __builtin_fma(xa[i], xa[i], aa);
+  aa = dpp_sum16(aa);
+  __syncthreads();
+  {
+    // exact squared norms of the LDS columns: team t sums slot t
+    double sacc = 0.0;
+    for (int i = 0; i < nr; ++i) { const double x = sm[(size_t)(team * BJ_B + grp) * LDr + sub + 16 * i]; sacc = __builtin_fma(x, x, sacc); }
+    sacc = dpp_sum16(sacc);
+    if (sub == 0) nrm[team * BJ_B + grp] = sacc;
+  }
+  __syncthreads();
+  bool rotated = false, big = false;
+#pragma unroll 1
+  for (int ss = 0; ss < 2; ++ss) {
+    const int slot = team ^ ss;                 // sub-step 0: (a_K, a_L) | (b_K, b_L); sub-step 1: the teams swap their LDS block
+    double *bbase = sm + (size_t)slot * BJ_B * LDr;
+    double *nb = nrm + slot * BJ_B;
+    for (int t = 0; t < BJ_B; ++t) {
+      const int j = (grp + t) & (BJ_B - 1);
+      double *gb = bbase + (size_t)j * LDr + sub;
+      double xb[RM];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) { const int ii = min(i, nr - 1); const double v = gb[16 * ii]; xb[i] = i < nr ? v : 0.0; }
+      double ab = 0.0;
+#pragma unroll
+      for (int i = 0; i < RM; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
+      ab = dpp_sum16(ab);
+      const double bbn = nb[j];
+      double cs, sn;
+      if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {
+        rotated = true;
+        big = big || (ab * ab > BJ_TINY2 * (aa * bbn));
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+          const double na = cs * xa[i] - sn * xb[i], nbv = sn * xa[i] + cs * xb[i];
+          xa[i] = na;
+          if (i < nr) gb[16 * i] = nbv;
+        }
+        const double cc = cs * cs, s2 = sn * sn, x2 = 2.0 * cs * sn * ab;
+        if (sub == 0) nb[j] = s2 * aa + x2 + cc * bbn;
+        aa = cc * aa - x2 + s2 * bbn;
+      }
+      __syncthreads();
+    }
+  }
+  if (rotated) any = 1;
+  __syncthreads();   // (a lane's "1" must not land on another lane's "2")
+  if (big) any = 2;
+  if (areal) {
+#pragma unroll
+    for (int i = 0; i < RM; ++i) if (i < nr) ga[16 * i] = xa[i];
+  }
+  __syncthreads();
+  for (int slot = 0; slot < 2; ++slot) {
+    if (blkB[slot] >= nblk) continue;
+    const int c0 = blkB[slot] * BJ_B;
+    const int n2 = min(BJ_B, p2 - c0) * half;
+    double2 *dst = reinterpret_cast<double2 *>(G + (size_t)c0 * p2);
+#pragma unroll 4
+    for (int idx = tid; idx < n2; idx += 2 * BJ_NT) {
+      const int cc = idx / half, r2 = idx - cc * half;
+      dst[idx] = *reinterpret_cast<const double2 *>(sm + (size_t)(slot * BJ_B + cc) * LDr + 2 * r2);
+    }
+  }
+  if (tid == 0 && any) atomicMax(&rot[mtx], any);
+}
+
 // after a sweep: a matrix without a rotation is finished -- and so is one whose rotations were all TINY (|a.b| <= 1e-9 |a||b|
 // for every pair that rotated; rot = 1): each of those pairs is now orthogonal to working precision and disturbed the others by
 // the square of that ratio, so the sweep that would follow finds nothing above the tolerance (it is the verification sweep a
@@ -1106,16 +1240,26 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
   {                                                                                                                              \
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac<RM>), lds)) return rc;                                    \
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac_x<RM>), ldsx)) return rc;                                 \
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac_q<RM>), lds)) return rc;                                  \
     for (int sweep = 0; sweep < 16; ++sweep) { /* converged matrices drop out by their flag; no host round trip */               \
       /* (10-12 sweeps on flightline-like spectra; a matrix still rotating after 16 is redone by k_eigh_global, mode 2) */        \
       hipLaunchKernelGGL(k_blockjac<RM>, dim3(mblk / 2 > 0 ? mblk / 2 : 1, nb), dim3(BJ_NT), lds, st, gv, p2, LDr, nblk,         \
                          mblk > 1 ? mblk : 2, 0, cflag, done, rot);                                                              \
-      for (int s = 1; s < nsteps; ++s)                                                                                           \
-        hipLaunchKernelGGL(k_blockjac_x<RM>, dim3(mblk / 2, nb), dim3(BJ_NT), ldsx, st, gv, p2, LDr, nblk, mblk, s, cflag, done, \
-                           rot);                                                                                                 \
+      if (quad) {                                                                                                                \
+        for (int s = 1; s < msbE; ++s)                                                                                           \
+          hipLaunchKernelGGL(k_blockjac_q<RM>, dim3(msbE / 2, nb), dim3(2 * BJ_NT), lds, st, gv, p2, LDr, nblk, mblk, s, cflag,  \
+                             done, rot);                                                                                         \
+      } else {                                                                                                                   \
+        for (int s = 1; s < nsteps; ++s)                                                                                         \
+          hipLaunchKernelGGL(k_blockjac_x<RM>, dim3(mblk / 2, nb), dim3(BJ_NT), ldsx, st, gv, p2, LDr, nblk, mblk, s, cflag,     \
+                             done, rot);                                                                                         \
+      }                                                                                                                          \
       hipLaunchKernelGGL(k_blockjac_flags, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, done, rot);                             \
     }                                                                                                                            \
   }
+  // quad visits (k_blockjac_q): the default whenever there are at least two super-blocks; sf_debug_set(10, 5): the pair visits
+  const int msb = mblk / 2, msbE = msb + (msb & 1);
+  const bool quad = msb >= 2 && sf_tune().wide_eigh_variant != 5;
   const size_t ldsx = ((size_t)BJ_B * LDr + BJ_B) * sizeof(double);
   if (nrmax <= 8) BJ_SWEEPS(8)
   else if (nrmax <= 16) BJ_SWEEPS(16)

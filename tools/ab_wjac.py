@@ -47,7 +47,7 @@ def stamps(variant):
     nv, nf = max(v[0], 1), max(v[0] - v[6], 1)
     print("   phase clocks, cycles per visit: visits %d (ended after the Gram test: %d)  load %.0f  gram %.0f  rotations %.0f  update %.0f  store %.0f"
           % (v[0], v[6], v[1] / nv, v[2] / nv, v[3] / nf, v[4] / nf, v[5] / nf))
-for name, variant in (("scalar (r3)", 0), ("gram/mfma 4 waves", 3), ("gram/mfma (r4)", 4), ("scalar (r3) again", 0), ("gram/mfma (r4) again", 4)):
+for name, variant in (("scalar (r3)", 5), ("quad visits (r4)", 0), ("gram/mfma (r4)", 4), ("scalar (r3) again", 5), ("quad visits (r4) again", 0)):
     L.sf_debug_set(10, variant)
     S = torch.empty((ncols, p, p), **f64); d = torch.empty((ncols, p), **f64); lam = torch.empty((ncols, p), **f64)
     evec = torch.empty((ncols, p, p), **f64); status = torch.empty(ncols, dtype=torch.int32, device=dev)
@@ -67,12 +67,12 @@ for name, variant in (("scalar (r3)", 0), ("gram/mfma 4 waves", 3), ("gram/mfma 
     orth = (V.transpose(1, 2) @ V - torch.eye(p, **f64)).abs().amax(dim=(1, 2))
     res[name] = dict(lam=torch.sort(lam, dim=1).values.cpu().numpy(), nll=nll.cpu().numpy(), aidx=aidx.cpu().numpy(),
                      status=status.cpu().numpy())
-    if variant in (4, 3) and "again" not in name:
+    if variant in (4,) and "again" not in name:
         stamps(variant)
     print("%-22s %8.2f ms/call   max residual %.2e   max |V^T V - I| %.2e   status!=0: %d   lam range %.2e .. %.2e"
           % (name, ms, float(resid.max()), float(orth.max()), int((status != 0).sum()), float(lam.min()), float(lam.max())))
 L.sf_debug_set(10, 0)
-a, b = res["scalar (r3)"], res["gram/mfma (r4)"]
+a, b = res["scalar (r3)"], res["quad visits (r4)"]
 print("eigenvalues: max rel diff %.2e" % np.max(np.abs(a["lam"] - b["lam"]) / np.abs(a["lam"])))
 fin = np.isfinite(a["nll"]) & np.isfinite(b["nll"])
 print("NLL: inf pattern equal %s, max rel diff %.2e, alpha index equal %s (%s)"

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, OCC) void k_wsyrk(const XT *__restrict__ xt, c
   constexpr int LD = 2 * T + 16;       // doubles per chunk row: [I bands | J bands] + pad (= 16 mod 32)
   constexpr int NQ = 2 * T / 4;        // 4-band quads per chunk row
   constexpr int NIT = (SY_KC * NQ + 255) / 256;   // loader items per thread
-  extern __shared__ __attribute__((aligned(16))) double sm[];   // [2][SY_KC][LD], then mu [2 T]
+  extern __shared__ __attribute__((aligned(16))) double sm[];   // [2][SY_KC][LD], then mu [2 T], zeros [2 T]
   double *mus = sm + 2 * SY_KC * LD;
   const int c = blockIdx.y;
   int ti = 0, tj = 0;
@@ -67,15 +67,23 @@ __global__ __launch_bounds__(256, OCC) void k_wsyrk(const XT *__restrict__ xt, c
   }
   const XT *xc = xt + (size_t)c * L * ps;
   const uint8_t *mp = mask_t + (size_t)c * L;
-  // loader: item = (row of the chunk, 4-band quad of [I half | J half]); consecutive lanes = consecutive quads of a row
-  int irow[NIT], iquad[NIT], gband[NIT];
+  // loader: item = (row of the chunk, 4-band quad of [I half | J half]); consecutive lanes = consecutive quads of a row.
+  // Everything that does not change from chunk to chunk is worked out once: the item's source offset, its LDS slot, and the
+  // number of its bands inside the window -- a chunk then costs a mask, one conversion and one subtraction per
+  // element (the SIMD's vector instructions take matrix time: profiles/r04_pmc_wide_window.txt).  An invalid row reads its
+  // means from a zero table and has its bits masked off: exactly 0 whatever the row held.
+  double *zeros = mus + 2 * T;           // [2 T] zeros
+  for (int i = tid; i < 2 * T; i += 256) zeros[i] = 0.0;
+  int irow[NIT], ioff[NIT], lslot[NIT], nv[NIT];   // nv: bands of the quad inside the window (4 except at the window's end)
 #pragma unroll
   for (int u = 0; u < NIT; ++u) {
     const int item = tid + 256 * u;
-    irow[u] = item / NQ;
-    iquad[u] = item - irow[u] * NQ;
-    gband[u] = ((iquad[u] < NQ / 2) ? ti * T : tj * T - T) + 4 * iquad[u];
-    if (item >= SY_KC * NQ) irow[u] = -1;
+    const int r = item / NQ, qd = item - r * NQ;
+    const int gb = ((qd < NQ / 2) ? ti * T : tj * T - T) + 4 * qd;
+    irow[u] = (item < SY_KC * NQ) ? r : -1;
+    ioff[u] = min(gb, ps - 4);                       // (a quad past the padded row: any in-bounds address, masked off below)
+    lslot[u] = r * LD + 4 * qd;
+    nv[u] = min(max(p - gb, 0), 4);
   }
   XT pre[NIT][4];   // raw values of the next chunk (promoted when they are stored)
   bool prok[NIT];
@@ -85,18 +93,26 @@ __global__ __launch_bounds__(256, OCC) void k_wsyrk(const XT *__restrict__ xt, c
       const int row = r0 + max(irow[u], 0);
       const int rr = row < L ? row : L - 1;
       prok[u] = (irow[u] >= 0) && (row < L) && (mp[rr] != 0);
-      if (irow[u] >= 0 && gband[u] < ps) sy_load4(xc + (size_t)rr * ps + gband[u], pre[u]);
-      else { pre[u][0] = pre[u][1] = pre[u][2] = pre[u][3] = (XT)0; }
+      sy_load4(xc + (size_t)rr * ps + ioff[u], pre[u]);
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
       if (irow[u] < 0) continue;
-      double *dst = sm + ((size_t)buf * SY_KC + irow[u]) * LD + 4 * iquad[u];
+      double *dst = sm + (size_t)buf * SY_KC * LD + lslot[u];
+      const double *mq = (prok[u] ? mus : zeros) + (lslot[u] - irow[u] * LD);
+      const int nvu = prok[u] ? nv[u] : 0;
       double o[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (prok[u] && gband[u] + e < p) ? (double)pre[u][e] - mus[4 * iquad[u] + e] : 0.0;
+      for (int e = 0; e < 4; ++e) {
+        const unsigned mk = (e < nvu) ? 0xffffffffu : 0u;
+        if constexpr (sizeof(XT) == 4) {
+          o[e] = (double)__uint_as_float(__float_as_uint(pre[u][e]) & mk) - mq[e];
+        } else {
+          o[e] = (mk ? pre[u][e] : 0.0) - mq[e];
+        }
+      }
       *reinterpret_cast<double2 *>(dst) = make_double2(o[0], o[1]);
       *reinterpret_cast<double2 *>(dst + 2) = make_double2(o[2], o[3]);
     }
@@ -500,7 +516,7 @@ static int wsyrk_go(const void *xt, const uint8_t *mask_t, const int32_t *nuse, 
   constexpr int T = 32 * TI;
   const int ntile = sf_cdiv(g.p, T);
   const int npair = ntile * (ntile + 1) / 2;
-  const size_t lds = ((size_t)2 * SY_KC * (2 * T + 16) + 2 * T) * sizeof(double);
+  const size_t lds = ((size_t)2 * SY_KC * (2 * T + 16) + 4 * T) * sizeof(double);
   const size_t colx = (size_t)g.lines * g.ps;
   if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsyrk<XT, TI, OCC>), lds)) return rc;
   hipLaunchKernelGGL((k_wsyrk<XT, TI, OCC>), dim3(npair, nb), dim3(256), lds, st, reinterpret_cast<const XT *>(xt) + (size_t)c0 * colx,
@@ -511,11 +527,13 @@ static int wsyrk_go(const void *xt, const uint8_t *mask_t, const int32_t *nuse, 
 }
 int sf_launch_wsyrk(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
                     int c0, int nb, double *cov, hipStream_t st) {
-  const bool t128 = sf_tune().wsyrk_variant == 1;   // 1: 128-band tiles (first form of the round); default 96
-  if (xt_f64) return t128 ? wsyrk_go<double, 4, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st)
-                          : wsyrk_go<double, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
-  return t128 ? wsyrk_go<float, 4, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st)
-              : wsyrk_go<float, 3, 3>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
+  // 128-band tiles by default; 96-band tiles (16 % fewer MFMAs at p = 425, more operand traffic per MFMA) with two or three
+  // workgroups per CU measured within 1 % of it on the full-band flightline (sf_debug_set(25, 2 / 3))
+  const int v = sf_tune().wsyrk_variant;
+  if (xt_f64) return wsyrk_go<double, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);   // (float64 rows: 96-band tiles fit the registers)
+  if (v == 2) return wsyrk_go<float, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
+  if (v == 3) return wsyrk_go<float, 3, 3>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
+  return wsyrk_go<float, 4, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
 }
 
 // the sweep of columns c0 .. c0 + nb - 1: operands into `opnd` (sf_wgemm_operand_bytes of the nb-column geometry), partials

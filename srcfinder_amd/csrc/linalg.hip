@@ -482,7 +482,9 @@ __global__ void k_argmin_nan_first(const double *__restrict__ nll, const int32_t
 constexpr int DET_SLOTS = 512;   // matrices factorised per launch (two rounds of 256 CUs) ...
 constexpr size_t DET_SLOT_BYTES = (size_t)1 << 30;     // ... within this many bytes of p x p float64 work matrices (p = 425: all 512, p = 512: 512;
                                                        // 290 slots at p = 425 cost the pass 13.4 instead of 9.1 ms per launch: the workgroups pair up on a CU)
-constexpr int DET_GROUP = 4;     // grid points per side and round of the deepening rule (k_det_round)
+constexpr int DET_GROUP = 4;     // grid points per side and round of the deepening rule (k_det_round), windows of <= 96 bands
+constexpr int DET_GROUP_WIDE = 2;   // wide windows (an LU of 425 x 425 is 3 ms of a workgroup): the misclassified points are a run of
+                                    // 1-2 next to the crossing; a side closes after two unchanged points, in twice as many (mostly empty) rounds
 // The job list holds every grid point of every column whatever the window: a column whose lost points are not two runs at
 // the ends of the grid takes the plain window rule in round 0 and may push up to nalpha jobs (with ncols x 2 x
 // window entries such a column overflowed the list and which jobs survived depended on the order of the atomics).  An int
@@ -517,14 +519,15 @@ int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *s
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_det_grid_blocked), lb_lds_bytes(g.p))) return rc;
   // window > 0: rounds of DET_GROUP points per open side (k_det_round); det_variant 1 = the plain window rule in one round
   const bool rounds = window > 0 && sf_tune().det_variant == 0;
-  const int nrounds = rounds ? sf_cdiv(window, DET_GROUP) : 1;
+  const int group = g.p > SF_MAX_ACTIVE_FUSED ? DET_GROUP_WIDE : DET_GROUP;
+  const int nrounds = rounds ? sf_cdiv(window, group) : 1;
   for (int r = 0; r < nrounds; ++r) {
     // round 0 may hold every grid point of a plain-window column, later rounds at most 2 x DET_GROUP per column
-    const size_t cap = (r == 0) ? maxjobs : std::min(maxjobs, (size_t)g.ncols * 2 * DET_GROUP);
+    const size_t cap = (r == 0) ? maxjobs : std::min(maxjobs, (size_t)g.ncols * 2 * group);
     SF_HIP(hipMemsetAsync(njobs, 0, sizeof(int32_t), st));
     if (rounds)
       hipLaunchKernelGGL(k_det_round, dim3(g.ncols), dim3(64), 0, st, nll, rest, status, g.ncols, g.nalpha, window,
-                         DET_GROUP, r, jobs, njobs, (int)maxjobs, state);
+                         group, r, jobs, njobs, (int)maxjobs, state);
     else
       hipLaunchKernelGGL(k_det_jobs, dim3(sf_cdiv(g.ncols, 128)), dim3(128), 0, st, nll, rest, status, g.ncols, g.nalpha, window, jobs,
                          njobs, (int)maxjobs);

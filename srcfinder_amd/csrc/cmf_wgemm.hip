@@ -86,13 +86,15 @@ __global__ __launch_bounds__(256, OCC) void k_wsyrk(const XT *__restrict__ xt, c
     nv[u] = min(max(p - gb, 0), 4);
   }
   XT pre[NIT][4];   // raw values of the next chunk (promoted when they are stored)
-  bool prok[NIT];
+  unsigned char pmk[NIT];   // the rows' validity bytes, as loaded: NOTHING in a fetch depends on loaded data (a compare here made
+  bool pin[NIT];            // every item wait for all the loads in flight -- vmcnt(0) four times per chunk)
   auto gload = [&](int r0) {
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
       const int row = r0 + max(irow[u], 0);
       const int rr = row < L ? row : L - 1;
-      prok[u] = (irow[u] >= 0) && (row < L) && (mp[rr] != 0);
+      pin[u] = (irow[u] >= 0) && (row < L);
+      pmk[u] = mp[rr];
       sy_load4(xc + (size_t)rr * ps + ioff[u], pre[u]);
     }
   };
@@ -100,9 +102,10 @@ __global__ __launch_bounds__(256, OCC) void k_wsyrk(const XT *__restrict__ xt, c
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
       if (irow[u] < 0) continue;
+      const bool ok = pin[u] && pmk[u] != 0;
       double *dst = sm + (size_t)buf * SY_KC * LD + lslot[u];
-      const double *mq = (prok[u] ? mus : zeros) + (lslot[u] - irow[u] * LD);
-      const int nvu = prok[u] ? nv[u] : 0;
+      const double *mq = (ok ? mus : zeros) + (lslot[u] - irow[u] * LD);
+      const int nvu = ok ? nv[u] : 0;
       double o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -276,6 +279,8 @@ __global__ __launch_bounds__(256, OCC) void k_wsweep(const XT *__restrict__ xt, 
   constexpr int CCD = WS_CA * LDW;             // doubles per C chunk
   constexpr int NPIECE = WCD * 8 / 1024, NPIECE_C = CCD * 8 / 1024;   // 1 KB wave-pieces (LDW is a multiple of 16)
   // chunk s of the stream -> Bs[s & 1]: s < NKC: rows 16 s .. of W; else alpha chunk s - NKC of C.  Lane-linear copies.
+  // (tried: the pieces of chunk s + 1 issued one at a time between the MFMAs of chunk s instead of in a row after the barrier --
+  //  the Y phase went from 292 k to 427 k cycles per tile: an LDS-DMA between ds_reads and MFMAs stalls the stream)
   auto glds = [&](int s) {
     const char *src = (s < NKC ? Wc + (size_t)s * WCD * 8 : Cc + (size_t)(s - NKC) * CCD * 8) + lane * 16;
     char *dst = reinterpret_cast<char *>(Bs + (size_t)(s & 1) * CHD);
@@ -527,13 +532,13 @@ static int wsyrk_go(const void *xt, const uint8_t *mask_t, const int32_t *nuse, 
 }
 int sf_launch_wsyrk(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
                     int c0, int nb, double *cov, hipStream_t st) {
-  // 128-band tiles by default; 96-band tiles (16 % fewer MFMAs at p = 425, more operand traffic per MFMA) with two or three
-  // workgroups per CU measured within 1 % of it on the full-band flightline (sf_debug_set(25, 2 / 3))
+  // 96-band tiles, three workgroups per CU by default (16 % fewer MFMAs at p = 425 than 128-band tiles; full-band flightline
+  // 484 ms against 488 with sf_debug_set(25, 1) = 128-band tiles; 2 = 96-band tiles, two workgroups per CU)
   const int v = sf_tune().wsyrk_variant;
   if (xt_f64) return wsyrk_go<double, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);   // (float64 rows: 96-band tiles fit the registers)
   if (v == 2) return wsyrk_go<float, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
-  if (v == 3) return wsyrk_go<float, 3, 3>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
-  return wsyrk_go<float, 4, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
+  if (v == 1) return wsyrk_go<float, 4, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
+  return wsyrk_go<float, 3, 3>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
 }
 
 // the sweep of columns c0 .. c0 + nb - 1: operands into `opnd` (sf_wgemm_operand_bytes of the nb-column geometry), partials

@@ -200,7 +200,12 @@ def robust_mf(cube_bil, library, *, gas="ch4", reflectance=False, kmeans=1, pcad
         host = cube_bil.numpy() if torch.is_tensor(cube_bil) else cube_bil
         if getattr(host, "ndim", 0) != 3:
             raise TypeError("cube must be float32 [lines, bands, samples]")
-        compact = ingest.stage_cube(host, (a0, a1), rgb_bands)
+        # (a column shard of a host cube: only those columns are staged, and they become columns 0 .. of the compact cube)
+        compact = ingest.stage_cube(host, (a0, a1), rgb_bands, columns=columns)
+        if columns is not None:
+            if labels is not None:                 # injected labels are full width: keep the shard's columns
+                labels = labels[:, int(columns[0]):int(columns[1])]
+            columns = (0, int(columns[1]) - int(columns[0]))
     if compact is not None:
         cube_bil = compact.tensor
         b0 = 0                                         # the window starts at band 0 of the compact cube

@@ -23,7 +23,7 @@ struct SfTune {
   int wsyrk_variant = 0;      // key 25: 2 / 3 = 96-band tiles in the fused wide covariance with two / three workgroups per CU (default: 128-band tiles)
   int score_wgs = 0;          // key 12: workgroups per CU k_score_blk2 is sized for (0 = occupancy query)
   int cnn_pool_variant = 0;   // key 18: 1 = branch-4 pool taken inside the 1x1 convolution's tile fetch (sf_cnn_pool_conv; slower)
-  int cnn_conv_variant = 0;   // key 17: 1 = pointer-form tile loads in k_conv_igemm (cnn_kernels.hip)
+  int cnn_conv_variant = 0;   // key 17: 1 = pointer-form tile loads in k_conv_igemm (cnn_kernels.hip), 2 = two LDS buffers / one barrier per chunk
   int cnn_variant = 0;        // key 16: 1 = the 8 x 8 conv1+pool kernel (cnn_kernels.hip)
   int det_variant = 0;        // key 15: 1 = the plain window rule of the exact-determinant pass in one round, 2 = no pass in sf_cmf_run's narrow branch
   int lu_variant = 0;         // key 14: 1 = the unblocked LU in the determinant passes (linalg.hip)

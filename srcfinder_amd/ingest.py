@@ -68,14 +68,15 @@ def _as_bil_view(src, interleave):
     raise ValueError("unknown interleave %r" % (interleave,))
 
 
-def _fill(dst, bil, l0, l1, a0, a1, rgb, pool, nthreads):
-    """dst[:l1-l0] <- the active window and the RGB bands of lines l0..l1 (host copy; numpy releases the GIL for it)."""
+def _fill(dst, bil, l0, l1, a0, a1, rgb, pool, nthreads, s0=0, s1=None):
+    """dst[:l1-l0] <- the active window and the RGB bands of lines l0..l1, samples s0..s1 (host copy; numpy releases the
+    GIL for it)."""
     n, p = l1 - l0, a1 - a0 + 1
 
     def part(i0, i1):
-        np.copyto(dst[i0:i1, :p, :], bil[l0 + i0:l0 + i1, a0 - 1:a1, :], casting="unsafe")
+        np.copyto(dst[i0:i1, :p, :], bil[l0 + i0:l0 + i1, a0 - 1:a1, s0:s1], casting="unsafe")
         for i, b in enumerate(rgb):
-            np.copyto(dst[i0:i1, p + i, :], bil[l0 + i0:l0 + i1, b, :], casting="unsafe")
+            np.copyto(dst[i0:i1, p + i, :], bil[l0 + i0:l0 + i1, b, s0:s1], casting="unsafe")
 
     if pool is None or n < 2 * nthreads:
         part(0, n)
@@ -108,8 +109,11 @@ def _default_threads():
 
 
 def stage_cube(src, active, rgb_bands=(60, 42, 24), *, interleave="bil", device=None, chunk_bytes=96 << 20, pinned=True,
-               threads=None):
+               threads=None, columns=None):
     """Host array / memmap (any ENVI interleave) -> :class:`CompactCube` on ``device``.
+
+    columns=(s0, s1): only that sample range -- what one rank of a column-sharded run needs (in a BIL file the
+    shard is a 4 (s1 - s0)-byte fragment of every band row; the other ranks' columns are never read).
 
     pinned=True : two page-locked chunk buffers, asynchronous copies on a private stream, host fill of chunk i+1
                   overlapped with the copy of chunk i.
@@ -124,7 +128,11 @@ def stage_cube(src, active, rgb_bands=(60, 42, 24), *, interleave="bil", device=
     bil = _as_bil_view(src, interleave)
     if bil.ndim != 3:
         raise TypeError("cube must be [lines, bands, samples]")
-    lines, bands, samples = bil.shape
+    lines, bands, samples_all = bil.shape
+    s0, s1 = (0, samples_all) if columns is None else (int(columns[0]), int(columns[1]))
+    if not 0 <= s0 < s1 <= samples_all:
+        raise ValueError("bad column shard [%d,%d) of %d samples" % (s0, s1, samples_all))
+    samples = s1 - s0
     a0, a1 = int(active[0]), int(active[1])
     plan = band_plan((a0, a1), rgb_bands, bands)
     rgb = plan[a1 - a0 + 1:]
@@ -148,7 +156,7 @@ def stage_cube(src, active, rgb_bands=(60, 42, 24), *, interleave="bil", device=
                 if events[k] is not None:
                     events[k].synchronize()              # the copy that last read this buffer has finished
                 t0 = time.perf_counter()
-                _fill(views[k], bil, l0, l1, a0, a1, rgb, pool, nthreads)
+                _fill(views[k], bil, l0, l1, a0, a1, rgb, pool, nthreads, s0, s1)
                 t_fill += time.perf_counter() - t0
                 if pinned:
                     with torch.cuda.stream(copy_stream):
@@ -169,7 +177,7 @@ def stage_cube(src, active, rgb_bands=(60, 42, 24), *, interleave="bil", device=
     dt = time.perf_counter() - t_begin
     nbytes = lines * line_bytes
     stats = {"bytes": nbytes, "seconds": dt, "host_fill_seconds": t_fill, "GBps": nbytes / dt / 1e9 if dt > 0 else 0.0,
-             "pinned": bool(pinned), "chunk_lines": chunk, "bands_moved": nb, "bands_total": bands}
+             "pinned": bool(pinned), "chunk_lines": chunk, "bands_moved": nb, "bands_total": bands, "columns": (s0, s1)}
     return CompactCube(out, (a0, a1), rgb, bands, stats)
 
 

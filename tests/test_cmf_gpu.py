@@ -521,6 +521,13 @@ def test_host_cube_is_staged_compact_and_bit_identical(torch_cuda, library):
     assert np.array_equal(host, want.out.cpu().numpy())
     with pytest.raises(IndexError):
         ingest.stage_cube(cube, (a0, a1), (60, 42, 999))
+    # a rank's column shard: only its samples are read and moved
+    sh = ingest.stage_cube(cube, (a0, a1), (60, 42, 24), columns=(13, 40), chunk_bytes=1 << 19)
+    assert sh.shape == (300, 75, 27) and sh.stats["columns"] == (13, 40)
+    assert torch.equal(bits(sh.tensor[:, :72]), bits(dev_cube[:, a0 - 1:a1, 13:40]))
+    want = cmf.robust_mf(dev_cube, library, metadata=True, columns=(13, 40))
+    for got in (cmf.robust_mf(sh, library, metadata=True), cmf.robust_mf(cube, library, metadata=True, columns=(13, 40))):
+        assert torch.equal(got.out, want.out) and torch.equal(got.bgmeta, want.bgmeta) and torch.equal(got.alphaidx, want.alphaidx)
 
 
 def test_full_flightline_shard_is_bit_identical(torch_cuda, library, full_flightline):

@@ -21,11 +21,16 @@ def main():
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--no-fuse", action="store_true", help="conv1 and maxpool1 as two kernels (A/B of the fused kernel)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--knob", action="append", default=[], help="key=value for sf_debug_set (repeatable)")
     args = ap.parse_args()
     import torch
     from srcfinder_amd import cnn
     from srcfinder_amd.cnn_weights import synthetic_plane, synthetic_state_dict
 
+    from srcfinder_amd import _ffi
+    for kv in args.knob:
+        k, v = kv.split("=")
+        _ffi.lib().sf_debug_set(int(k), int(v))
     sd = synthetic_state_dict(2024)
     net = cnn.GoogLeNetHIP(sd, precision=args.precision)
     net.fuse_conv1 = not args.no_fuse

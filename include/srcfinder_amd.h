@@ -191,8 +191,9 @@ int sf_debug_lowrank(const double *lam, const int32_t *nuse, const int32_t *stat
 /* Test / tuning hook: phase clocks of the wide-window Jacobi visits (cmf_wjac.hip), accumulated while
  * sf_debug_set(22, 1) is on: out8 = visits, load, Gram, rotations, update, store ticks, early exits, 0. */
 int sf_debug_wjac_stamps(unsigned long long *out8, int reset);
-/* the same for the tiles of the fused wide-window sweep (cmf_wgemm.hip): out4 = tiles, X tile load, Y = X~ W, r = Z C + rows */
-int sf_debug_wsweep_stamps(unsigned long long *out4, int reset);
+/* the same for the tiles of the fused wide-window sweep (cmf_wgemm.hip): out8 = tiles, Y = X~ W, r = Z C + rows, then (k_wsweep8) the r
+ * phase's MFMAs, row reductions, first barrier, exchange + second barrier, 0 */
+int sf_debug_wsweep_stamps(unsigned long long *out8, int reset);
 
 /* Timing hook for bench.py's roofline line: while enabled, every sf_cmf_score launch (direct or
  * inside sf_cmf_run) is bracketed by a fresh pair of HIP events on the launch stream.

@@ -213,7 +213,7 @@ __device__ __forceinline__ double ws_dpp(double v) {
 }
 
 // phase clocks of the sweep's tiles (sf_debug_set(22, 1); sf_debug_wsweep_stamps): [0] tiles, [1] Y = X~ W, [2] r = Z C + rows
-__device__ unsigned long long g_ws_stamps[4];
+__device__ unsigned long long g_ws_stamps[8];   // k_wsweep8 also: [3] the r phase's MFMAs, [4] row reductions, [5] first barrier, [6] exchange + second barrier
 
 constexpr int WS_CA = 8;    // alphas per C chunk (two groups of four: their row reductions are interleaved)
 
@@ -224,23 +224,30 @@ constexpr int WS_CA = 8;    // alphas per C chunk (two groups of four: their row
 // streamed beside W (16 bands x the tile's rows), centred and promoted when it is read as an operand.
 // CH: bands per W chunk (16: 55 KB chunks, one workgroup per CU; 8: half that, two workgroups per CU -- or one beside a
 // workgroup of another kernel, e.g. the eigensolver of another column group).  OCC: workgroups per CU the registers allow.
-template <typename XT, int NI, int NJW, int CH, int OCC>
-__global__ __launch_bounds__(256, OCC) void k_wsweep(const XT *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+// NW: waves per workgroup.  4: one wave per SIMD, a quarter of Y's columns each (NJW 4-column groups).  8: two waves per SIMD
+// (<= 256 registers each), an eighth each -- LDW / 4 groups dealt NJW to waves 0-3 and NJL = LDW / 16 - NJW to waves 4-7 (14 + 13
+// of the 108 groups at LDW = 432), so that one wave's operand reads, barriers and row reductions run under the other's MFMAs.
+template <typename XT, int NI, int NJW, int CH, int OCC, int NW = 4, int LDWT = 16 * NJW>
+__global__ __launch_bounds__(64 * NW, OCC) void k_wsweep(const XT *__restrict__ xt, const uint8_t *__restrict__ mask_t,
                                                  const int32_t *__restrict__ nloo, const double *__restrict__ mu,
                                                  const double *__restrict__ Wp, const double *__restrict__ Ct,
                                                  const int32_t *__restrict__ status, const double *__restrict__ alphas, int nalpha,
                                                  int NA, int L, int p, int ps, int P16, int rows_per_wg, int nsplit, int ncols,
                                                  double *__restrict__ part, int stamp) {
   constexpr int RT = 16 * NI;        // rows per tile
-  constexpr int LDW = 16 * NJW;
+  constexpr int LDW = LDWT;
+  constexpr int NJL = NW == 4 ? NJW : LDW / 16 - NJW;   // groups of waves 4-7
+  constexpr int NT = 64 * NW;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert((NW == 4 ? 4 * NJW : 4 * NJW + 4 * NJL) == LDW / 4 && NJL <= NJW && NJL > 0, "column groups");
   constexpr int WS_CH = CH;
   constexpr int CHD = (CH > WS_CA ? CH : WS_CA) * LDW;   // doubles per chunk buffer
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   // ---- LDS carve (ws_lds_bytes below)
   double *Bs = reinterpret_cast<double *>(smraw);                 // [2][CHD]
   double *mus = Bs + 2 * CHD;                                      // [P16]
-  double *red = mus + P16;                                         // [2][4][NI][64]
-  double *Pacc = red + 2 * 4 * NI * 64;                            // [NA]
+  double *red = mus + P16;                                         // [2][NW][NI][64]
+  double *Pacc = red + 2 * NW * NI * 64;                           // [NA]
   double *Sacc = Pacc + NA;                                        // [NA]
   double *betas = Sacc + NA;                                       // [NA]
   XT *Xs = reinterpret_cast<XT *>(betas + NA);                     // [2][WS_CH][RT]
@@ -256,25 +263,26 @@ __global__ __launch_bounds__(256, OCC) void k_wsweep(const XT *__restrict__ xt, 
   const int q = lane >> 4, m = (lane >> 2) & 3, n = lane & 3;
   double *po = part + ((size_t)c * nsplit + split) * 2 * NA;
   if (status[c] != 0) {
-    for (int i = tid; i < 2 * NA; i += 256) po[i] = 0.0;
+    for (int i = tid; i < 2 * NA; i += NT) po[i] = 0.0;
     return;
   }
   const double nn = (double)nloo[c];
-  for (int i = tid; i < NA; i += 256) {
+  for (int i = tid; i < NA; i += NT) {
     Pacc[i] = 1.0;
     Sacc[i] = 0.0;
     Eacc[i] = 0;
     Nacc[i] = 0;
     betas[i] = (i < nalpha) ? (1.0 - alphas[i]) / (nn - 1.0) : 0.0;
   }
-  for (int i = tid; i < P16; i += 256) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
+  for (int i = tid; i < P16; i += NT) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
   const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
   const XT *xc = xt + (size_t)c * L * ps;
   const uint8_t *mp = mask_t + (size_t)c * L;
   const char *Wc = reinterpret_cast<const char *>(Wp + (size_t)c * P16 * LDW);
   const int NKC = P16 / WS_CH, NCC = NA / WS_CA, NS = NKC + NCC;
   const char *Cc = reinterpret_cast<const char *>(Ct + (size_t)c * NCC * LDW * WS_CA);
-  const int j0w = 4 * NJW * wave;              // first Y column of this wave
+  const int j0w = 4 * (wave < 4 ? NJW * wave : 4 * NJW + NJL * (wave - 4));   // first Y column of this wave
+  const int njw = wave < 4 ? NJW : NJL;                                        // its 4-column groups (wave-uniform)
   constexpr int WCD = CH * LDW;                // doubles per W chunk
   constexpr int CCD = WS_CA * LDW;             // doubles per C chunk
   constexpr int NPIECE = WCD * 8 / 1024, NPIECE_C = CCD * 8 / 1024;   // 1 KB wave-pieces (LDW is a multiple of 16)
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256, OCC) void k_wsweep(const XT *__restrict__ xt, 
     const char *src = (s < NKC ? Wc + (size_t)s * WCD * 8 : Cc + (size_t)(s - NKC) * CCD * 8) + lane * 16;
     char *dst = reinterpret_cast<char *>(Bs + (size_t)(s & 1) * CHD);
     const int npc = s < NKC ? NPIECE : NPIECE_C;
-    for (int pc = wave; pc < npc; pc += 4)
+    for (int pc = wave; pc < npc; pc += NW)
       __builtin_amdgcn_global_load_lds((ws_glb_void *)(src + (size_t)pc * 1024), (ws_lds_void *)(dst + (size_t)pc * 1024), 16, 0, 0);
   };
   // the X chunk of W chunk s: lane item = (row, band quad) of [RT rows][4 quads]
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(256, OCC) void k_wsweep(const XT *__restrict__ xt, 
       const int row = rr + lane;
       if (row < RT) {
         const int I = row >> 4, src = 16 * (row & 3) + 4 * ((row >> 2) & 3) + wave;
-        const double *rp0 = red, *rp1 = red + 4 * NI * 64;
+        const double *rp0 = red, *rp1 = red + NW * NI * 64;
         const double r0v = (rp0[(0 * NI + I) * 64 + src] + rp0[(1 * NI + I) * 64 + src]) +
                            (rp0[(2 * NI + I) * 64 + src] + rp0[(3 * NI + I) * 64 + src]);
         const double r1v = (rp1[(0 * NI + I) * 64 + src] + rp1[(1 * NI + I) * 64 + src]) +
@@ -378,6 +386,48 @@ __global__ __launch_bounds__(256, OCC) void k_wsweep(const XT *__restrict__ xt, 
     }
   };
 
+  // eight waves: one alpha per wave (group t = wave / 4, slot n = wave % 4 of the chunk), eight partials per row
+  auto nll_rows1 = [&](int ai) {
+    if (ai >= nalpha) return;   // wave-uniform
+    const double beta0 = betas[ai];
+    const double *rp = red + (size_t)(wave >> 2) * NW * NI * 64;
+    double prod0 = 1.0, ssum0 = 0.0;
+    int neg = 0;
+#pragma unroll
+    for (int rr = 0; rr < RT; rr += 64) {
+      const int row = rr + lane;
+      if (row < RT) {
+        const int I = row >> 4, src = 16 * (row & 3) + 4 * ((row >> 2) & 3) + (wave & 3);
+        const double r0v = ((rp[(0 * NI + I) * 64 + src] + rp[(1 * NI + I) * 64 + src]) +
+                            (rp[(2 * NI + I) * 64 + src] + rp[(3 * NI + I) * 64 + src])) +
+                           ((rp[(4 * NI + I) * 64 + src] + rp[(5 * NI + I) * 64 + src]) +
+                            (rp[(6 * NI + I) * 64 + src] + rp[(7 * NI + I) * 64 + src]));
+        const bool ok = rowok[row] != 0;
+        const double q0 = __builtin_fma(-beta0, r0v, 1.0);
+        double y0 = __builtin_amdgcn_rcp(q0);
+        y0 = __builtin_fma(y0, __builtin_fma(-q0, y0, 1.0), y0);
+        y0 = __builtin_fma(y0, __builtin_fma(-q0, y0, 1.0), y0);
+        neg |= (ok && q0 < 0.0) ? 1 : 0;
+        prod0 *= ok ? q0 : 1.0;
+        ssum0 += ok ? r0v * y0 : 0.0;
+      }
+    }
+    prod0 *= ws_dpp<0xB1>(prod0);  ssum0 += ws_dpp<0xB1>(ssum0);
+    prod0 *= ws_dpp<0x4E>(prod0);  ssum0 += ws_dpp<0x4E>(ssum0);
+    prod0 *= ws_dpp<0x141>(prod0); ssum0 += ws_dpp<0x141>(ssum0);
+    prod0 *= ws_dpp<0x140>(prod0); ssum0 += ws_dpp<0x140>(ssum0);
+    const double pw0 = (rdl(prod0, 0) * rdl(prod0, 16)) * (rdl(prod0, 32) * rdl(prod0, 48));
+    const double sw0 = (rdl(ssum0, 0) + rdl(ssum0, 16)) + (rdl(ssum0, 32) + rdl(ssum0, 48));
+    const int n0 = __any(neg & 1) ? 1 : 0;
+    if (lane == 0) {
+      const double pm0 = Pacc[ai] * pw0;
+      Eacc[ai] += __builtin_amdgcn_frexp_exp(pm0);
+      Pacc[ai] = __builtin_amdgcn_frexp_mant(pm0);
+      Sacc[ai] += sw0;
+      Nacc[ai] |= n0;
+    }
+  };
+
   for (int r0 = rbeg; r0 < rend; r0 += RT) {
     __syncthreads();   // the previous tile's readers of Bs / Xs / rowok / red are done
     unsigned long long tk0 = 0, tk1 = 0;
@@ -408,9 +458,11 @@ __global__ __launch_bounds__(256, OCC) void k_wsweep(const XT *__restrict__ xt, 
           const double *brow = bs + (size_t)(4 * k4 + q) * LDW + j0w + n;
 #pragma unroll
           for (int J = 0; J < NJW; ++J) {
-            const double wr = brow[4 * J];
+            if (NJL == NJW || J < njw) {
+              const double wr = brow[4 * J];
 #pragma unroll
-            for (int I = 0; I < NI; ++I) acc[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(wr, xr[I], acc[I][J], 0, 0, 0);
+              for (int I = 0; I < NI; ++I) acc[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(wr, xr[I], acc[I][J], 0, 0, 0);
+            }
           }
         }
         if (s + 1 < NKC) xstore(s + 1);
@@ -431,21 +483,24 @@ __global__ __launch_bounds__(256, OCC) void k_wsweep(const XT *__restrict__ xt, 
         const double *bcol = bs + (size_t)(j0w + q) * WS_CA + n;
 #pragma unroll
         for (int J = 0; J < NJW; ++J) {
-          const double ca = bcol[(size_t)4 * WS_CA * J], cb = bcol[(size_t)4 * WS_CA * J + 4];
+          if (NJL == NJW || J < njw) {
+            const double ca = bcol[(size_t)4 * WS_CA * J], cb = bcol[(size_t)4 * WS_CA * J + 4];
 #pragma unroll
-          for (int I = 0; I < NI; ++I) {
-            ra[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[I][J], ca, ra[I], 0, 0, 0);
-            rb[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[I][J], cb, rb[I], 0, 0, 0);
+            for (int I = 0; I < NI; ++I) {
+              ra[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[I][J], ca, ra[I], 0, 0, 0);
+              rb[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[I][J], cb, rb[I], 0, 0, 0);
+            }
           }
         }
         // lane (q, m, n): r[row 16 I + 4 m + q][alpha 8 ch + 4 t + n] -> red[t][wave][I][lane]
 #pragma unroll
         for (int I = 0; I < NI; ++I) {
           red[(wave * NI + I) * 64 + lane] = ra[I];
-          red[4 * NI * 64 + (wave * NI + I) * 64 + lane] = rb[I];
+          red[NW * NI * 64 + (wave * NI + I) * 64 + lane] = rb[I];
         }
-        __syncthreads();   // the four partials of both alpha groups are in red (rewritten after the next chunk barrier)
-        nll_rows2(WS_CA * ch + wave, WS_CA * ch + 4 + wave);
+        __syncthreads();   // the waves' partials of both alpha groups are in red (rewritten after the next chunk barrier)
+        if constexpr (NW == 4) nll_rows2(WS_CA * ch + wave, WS_CA * ch + 4 + wave);
+        else nll_rows1(WS_CA * ch + wave);
       }
     }
     if (stamp && tid == 0) {
@@ -456,7 +511,7 @@ __global__ __launch_bounds__(256, OCC) void k_wsweep(const XT *__restrict__ xt, 
     }
   }
   __syncthreads();
-  for (int i = tid; i < NA; i += 256) {
+  for (int i = tid; i < NA; i += NT) {
     if (i < nalpha) {
       po[i] = log(Pacc[i]) + (double)Eacc[i] * 0.6931471805599453094;
       po[NA + i] = Nacc[i] ? __builtin_nan("") : Sacc[i];
@@ -467,32 +522,409 @@ __global__ __launch_bounds__(256, OCC) void k_wsweep(const XT *__restrict__ xt, 
   }
 }
 
-template <typename XT, int NI, int NJW, int CH>
+template <typename XT, int NI, int CH, int NW, int LDW>
 size_t ws_lds_bytes(int P16, int NA) {
   const int RT = 16 * NI;
-  size_t b = (size_t)(2 * (CH > WS_CA ? CH : WS_CA) * 16 * NJW + P16 + 2 * 4 * NI * 64 + 3 * NA) * sizeof(double);
+  size_t b = (size_t)(2 * (CH > WS_CA ? CH : WS_CA) * LDW + P16 + 2 * NW * NI * 64 + 3 * NA) * sizeof(double);
   b += (size_t)2 * CH * RT * sizeof(XT);
   b += (size_t)(2 * NA + RT) * sizeof(int);
   return b;
 }
 
-template <typename XT, int NI, int NJW, int CH, int OCC>
+template <typename XT, int NI, int NJW, int CH, int OCC, int NW = 4, int LDWT = 16 * NJW>
 int ws_launch(const void *xt, const uint8_t *mask_t, const int32_t *nloo, const double *mu, const double *Wp, const double *Ct,
               const int32_t *status, const double *alphas, const SfGeom &g, int P16, int NA, int rows, int nsplit, double *part,
               hipStream_t st) {
-  const size_t lds = ws_lds_bytes<XT, NI, NJW, CH>(P16, NA);
+  const size_t lds = ws_lds_bytes<XT, NI, CH, NW, LDWT>(P16, NA);
   if (lds > 160 * 1024) {
     sf_set_error("wide sweep: %d bands need %zu bytes of LDS", g.p, lds);
     return -2;
   }
-  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsweep<XT, NI, NJW, CH, OCC>), lds)) return rc;
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsweep<XT, NI, NJW, CH, OCC, NW, LDWT>), lds)) return rc;
   const int grid = 8 * sf_cdiv(g.ncols, 8) * nsplit;
-  hipLaunchKernelGGL((k_wsweep<XT, NI, NJW, CH, OCC>), dim3(grid), dim3(256), lds, st, reinterpret_cast<const XT *>(xt), mask_t, nloo, mu, Wp,
+  hipLaunchKernelGGL((k_wsweep<XT, NI, NJW, CH, OCC, NW, LDWT>), dim3(grid), dim3(64 * NW), lds, st, reinterpret_cast<const XT *>(xt), mask_t, nloo, mu, Wp,
                      Ct, status, alphas, g.nalpha, NA, g.lines, g.p, g.ps, P16, rows, nsplit, g.ncols, part, sf_tune().wjac_stamps);
   SF_LAUNCH_CHECK("k_wsweep");
   return 0;
 }
 
+
+// --------------------------------------------------------------------------------------------------------------------
+// k_wsweep8: the sweep with two waves per SIMD and NO workgroup barrier in the Y phase.  Each of the eight waves owns a
+// slice of Y's columns (NJW 4-column groups for waves 0-3, NJL for waves 4-7: 14 + 13 of the 108 groups at p <= 432) and
+// streams ITS slice of W -- and later of C -- through its own two LDS buffers by global_load_lds; the operand images are laid
+// out per (chunk, wave) by k_wmat_p8 / k_cmat_t8, so nothing a wave reads was written by another wave and its only
+// synchronisation is its own s_waitcnt vmcnt.  The rows of X~ go from global memory straight to the B-operand registers:
+// MFMA step k4 of a 16-band chunk takes band 16 s + 4 q + k4 from lane quarter q (any bijection of the chunk's bands onto
+// (k4, q) is a valid K order as long as the W operand uses the same one), so one float4 per 16-row group is everything the
+// lane needs of the chunk.  The waves drift apart; one's waits and address work run under the other's MFMAs.  The r phase
+// keeps one exchange per 8-alpha chunk (the eight K-slices' partial r meet in `red`), with the row reductions of chunk
+// ch - 1 placed beside the MFMAs of chunk ch.
+// --------------------------------------------------------------------------------------------------------------------
+constexpr int W8_NW = 8;
+template <int NJW, int NJL>
+__global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+                                                       const int32_t *__restrict__ nloo, const double *__restrict__ mu,
+                                                       const double *__restrict__ W8, const double *__restrict__ C8,
+                                                       const int32_t *__restrict__ status, const double *__restrict__ alphas,
+                                                       int nalpha, int NA, int L, int p, int ps, int P16, int rows_per_wg,
+                                                       int nsplit, int ncols, double *__restrict__ part, int stamp) {
+  constexpr int NI = 4, RT = 64, NW = W8_NW, NT = 64 * NW;
+  constexpr int SW = 4 * NJW;            // columns per wave slot
+  constexpr int WSL = 16 * SW;           // doubles per W slice [16 band rows][SW]
+  constexpr int CSL = WS_CA * SW;        // doubles per C slice [SW][8 alphas]
+  constexpr int NPW = WSL * 8 / 1024, NPC = (CSL * 8 + 1023) / 1024;
+  static_assert(WSL * 8 % 1024 == 0 && NJL <= NJW && NJL > 0 && NJW >= 13, "slice geometry (the row reductions are spread over 13 MFMA groups)");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  double *Bs = reinterpret_cast<double *>(smraw);                 // [2][NW][WSL]
+  double *mus = Bs + 2 * NW * WSL;                                 // [P16]
+  constexpr int RS = 65, RW = NI * RS;   // red: [2 groups][NW][NI][RS]: the 16-row groups one double apart in the banks (the rows'
+                                         // reads are a stride-4 gather inside a group: 8-way conflicts at stride 64, 2-way at 65)
+  double *red = mus + P16;
+  double *betas = red + 2 * NW * RW;                               // [NA]
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int c = 8 * (slot / nsplit) + xcd, split = slot % nsplit;
+  if (c >= ncols) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, m = (lane >> 2) & 3, n = lane & 3;
+  double *po = part + ((size_t)c * nsplit + split) * 2 * NA;
+  if (status[c] != 0) {
+    for (int i = tid; i < 2 * NA; i += NT) po[i] = 0.0;
+    return;
+  }
+  const double nn = (double)nloo[c];
+  for (int i = tid; i < NA; i += NT) betas[i] = (i < nalpha) ? (1.0 - alphas[i]) / (nn - 1.0) : 0.0;
+  for (int i = tid; i < P16; i += NT) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
+  __syncthreads();
+  const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
+  const float *xc = xt + (size_t)c * L * ps;
+  const uint8_t *mp = mask_t + (size_t)c * L;
+  const int NKC = P16 / 16, NCC = NA / WS_CA;
+  // (the SIMD's arbiter favours its older wave: the waves of the lighter slices, 4-7, lagged 15 % behind 0-3 and every
+  //  exchange waited for them; at priority 1 they keep up -- 382 k -> 367 k cycles per tile)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  // the split's running (mantissa, exponent, sum, flag) of alpha 8 ch + wave live in lane ch of this wave's registers
+  double Pv = 1.0, Sv = 0.0;
+  int Ev = 0, Nv = 0;
+  const char *Wc = reinterpret_cast<const char *>(W8 + ((size_t)c * NKC * NW + wave) * WSL);   // (wave-uniform)
+  const char *Cc = reinterpret_cast<const char *>(C8 + ((size_t)c * NCC * NW + wave) * CSL);
+  const unsigned loff = lane * 16;
+  const int njw = wave < 4 ? NJW : NJL;
+  double *bw0 = Bs + wave * WSL;   // this wave's slice of buffer 0 (buffer 1: + NW * WSL; plain arithmetic keeps the pointers in the LDS address space)
+  // chunk s of a tile's stream (running count gs over the tiles: NS is odd, the buffer parity alternates) -> this wave's
+  // buffer gs & 1
+  auto glds = [&](int s, int gs) {
+    char *dst = reinterpret_cast<char *>(bw0 + (gs & 1) * (NW * WSL));
+    // (the instruction's immediate offset moves the global AND the LDS address: one address pair per 4 KB)
+    if (s < NKC) {
+      const char *src = Wc + (size_t)s * NW * WSL * 8;
+#pragma unroll
+      for (int pb = 0; pb < NPW; pb += 4) {
+        ws_glb_void *gp = (ws_glb_void *)(src + pb * 1024 + loff);
+        ws_lds_void *lp = (ws_lds_void *)(dst + pb * 1024);
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+        if (pb + 1 < NPW) __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+        if (pb + 2 < NPW) __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+        if (pb + 3 < NPW) __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+      }
+    } else {
+      const char *src = Cc + (size_t)(s - NKC) * NW * CSL * 8;
+      static_assert(NPC <= 4, "C slice pieces");
+      ws_glb_void *gp = (ws_glb_void *)(src + loff);   // (the last piece runs 512 B past the slice: into the wave's own buffer / the next slice)
+      ws_lds_void *lp = (ws_lds_void *)dst;
+      __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+      if (1 < NPC) __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+      if (2 < NPC) __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+      if (3 < NPC) __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+    }
+  };
+  // this lane's rows of X~, bands 16 s + 4 q .. + 3 (clamped inside the row; bands past the window are zeroed at use)
+  auto xload = [&](float4 (&xv)[NI], int s, int r0) {
+    const int b = min(16 * s + 4 * q, ps - 4);
+#pragma unroll
+    for (int I = 0; I < NI; ++I)
+      xv[I] = *reinterpret_cast<const float4 *>(xc + (size_t)min(r0 + 16 * I + 4 * m + n, L - 1) * ps + b);
+  };
+  auto rdl = [](double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+  };
+  // one alpha per wave (group t = wave / 4, slot wave % 4 of the chunk), lane = row, eight partials per (row, alpha); fixed
+  // reduction tree
+  constexpr int R2OFF = 512;   // red2: doubles into a wave's operand slice (above the 4 KB a C chunk's copy covers)
+  static_assert(R2OFF * 8 >= NPC * 1024 && R2OFF + RW <= WSL, "red2 fits the free part of the slices");
+  auto nll_rows1 = [&](int chi, bool ok, bool live = true) {
+    const int ai = WS_CA * chi + wave;   // (alpha slots past the grid: beta = 0, never stored)
+    const double beta0 = betas[ai];
+    const int t = wave >> 2, odd = chi & 1;
+    const double *rp = odd ? Bs + (size_t)t * NW * WSL + R2OFF : red + (size_t)t * NW * RW;   // partial of wave w: + w * rs
+    const int rs = odd ? WSL : RW;
+    const int I = lane >> 4, src = 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (wave & 3);
+    rp += I * RS + src;
+    const double r0v = ((rp[0 * rs] + rp[1 * rs]) + (rp[2 * rs] + rp[3 * rs])) + ((rp[4 * rs] + rp[5 * rs]) + (rp[6 * rs] + rp[7 * rs]));
+    const double q0 = __builtin_fma(-beta0, r0v, 1.0);
+    double y0 = __builtin_amdgcn_rcp(q0);
+    y0 = __builtin_fma(y0, __builtin_fma(-q0, y0, 1.0), y0);
+    y0 = __builtin_fma(y0, __builtin_fma(-q0, y0, 1.0), y0);
+    const int neg = (ok && q0 < 0.0) ? 1 : 0;
+    double prod0 = ok ? q0 : 1.0, ssum0 = ok ? r0v * y0 : 0.0;
+    prod0 *= ws_dpp<0xB1>(prod0);  ssum0 += ws_dpp<0xB1>(ssum0);
+    prod0 *= ws_dpp<0x4E>(prod0);  ssum0 += ws_dpp<0x4E>(ssum0);
+    prod0 *= ws_dpp<0x141>(prod0); ssum0 += ws_dpp<0x141>(ssum0);
+    prod0 *= ws_dpp<0x140>(prod0); ssum0 += ws_dpp<0x140>(ssum0);
+    const double pw0 = (rdl(prod0, 0) * rdl(prod0, 16)) * (rdl(prod0, 32) * rdl(prod0, 48));
+    const double sw0 = (rdl(ssum0, 0) + rdl(ssum0, 16)) + (rdl(ssum0, 32) + rdl(ssum0, 48));
+    const int n0 = __any(neg) ? 1 : 0;
+    const bool mine = live && lane == chi && ai < nalpha;
+    const double pm0 = Pv * pw0;
+    Ev += mine ? __builtin_amdgcn_frexp_exp(pm0) : 0;
+    Pv = mine ? __builtin_amdgcn_frexp_mant(pm0) : Pv;
+    Sv += mine ? sw0 : 0.0;
+    Nv |= mine ? n0 : 0;
+  };
+
+  int gs = 0;
+  float4 xa[NI], xb[NI];
+  if (rbeg < rend) {
+    glds(0, 0);
+    xload(xa, 0, rbeg);
+  }
+  for (int r0 = rbeg; r0 < rend; r0 += RT) {
+    unsigned long long tk0 = 0, tk1 = 0;
+    if (stamp) tk0 = __builtin_readcyclecounter();
+    const unsigned long long pt0 = tk0;
+    const uint8_t mrow = mp[min(r0 + lane, L - 1)];   // (compared where it is used: nothing waits for it here)
+    const bool rin = r0 + lane < rend;
+    double acc[NI][NJW];
+#pragma unroll
+    for (int I = 0; I < NI; ++I)
+#pragma unroll
+      for (int J = 0; J < NJW; ++J) acc[I][J] = 0.0;
+    // ---- Y^T slice += W^T X~^T, 16 bands a chunk: A operand W[band 16 s + 4 q + k4][col 4 J + n] at slice row 4 k4 + q,
+    //      B operand X~[row 16 I + 4 m + n][the same band]
+    for (int s = 0; s < NKC; ++s, ++gs) {
+      __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);   // vmcnt(0) (expcnt / lgkmcnt untouched): chunk s and its rows have landed
+      asm volatile("" ::: "memory");
+      glds(s + 1, gs + 1);                // (s + 1 == NKC: the first C chunk)
+      if (s + 1 < NKC) xload(xb, s + 1, r0);
+      const double *bs = bw0 + (gs & 1) * (NW * WSL);
+      const double *mq = mus + 16 * s + 4 * q;
+      const double mu4[4] = {mq[0], mq[1], mq[2], mq[3]};
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const bool bok = 16 * s + 4 * q + k4 < p;
+        double xr[NI];
+#pragma unroll
+        for (int I = 0; I < NI; ++I) {
+          const float xe = k4 == 0 ? xa[I].x : k4 == 1 ? xa[I].y : k4 == 2 ? xa[I].z : xa[I].w;
+          xr[I] = bok ? (double)xe - mu4[k4] : 0.0;
+        }
+        const double *brow = bs + (size_t)(4 * k4 + q) * SW + n;
+#pragma unroll
+        for (int J = 0; J < NJW; ++J) {
+          if (NJL == NJW || J < njw) {
+            const double wr = brow[4 * J];
+#pragma unroll
+            for (int I = 0; I < NI; ++I) acc[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(wr, xr[I], acc[I][J], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (keeps the next step's operand reads from being hoisted over this step: registers)
+      }
+#pragma unroll
+      for (int I = 0; I < NI; ++I) xa[I] = xb[I];
+    }
+    if (stamp) tk1 = __builtin_readcyclecounter();
+    // ---- Z = Y.^2: lane (q, m, n) holds Z[row 16 I + 4 m + n][col 4 J + q] of the slice
+#pragma unroll
+    for (int I = 0; I < NI; ++I)
+#pragma unroll
+      for (int J = 0; J < NJW; ++J) acc[I][J] = acc[I][J] * acc[I][J];
+    // ---- r = Z C, eight alphas a chunk.  One exchange per chunk: the waves' partial r go to red (even chunks) or red2 (odd
+    //      chunks: the upper 3 KB of the waves' own operand buffers, free while the 3.5 KB C slices stream through the lower
+    //      4 KB), one barrier, and the row reductions of chunk ch - 1 run beside the MFMAs of chunk ch: waves 0-3 issue their
+    //      MFMAs first, waves 4-7 their row reductions first, so the two waves of a SIMD are in opposite phases.
+    const bool more = r0 + RT < rend;
+    const bool rowok = rin && mrow != 0;
+    // (stamp = 16 + w: wave w's clocks of the chunk loop, summed in registers, one set of atomics per tile:
+    //  [3] wait for the chunk's copy, [4] first half (MFMAs for waves 0-3, row reductions for 4-7), [5] second half, [6] exchange + barrier)
+    const bool probe = stamp >= 16 && wave == stamp - 16;
+    unsigned long long pd0 = 0, pd1 = 0, pd2 = 0, pd3 = 0;
+    for (int ch = 0; ch < NCC; ++ch, ++gs) {
+      unsigned long long pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0;
+      if (probe) pk0 = __builtin_readcyclecounter();
+      __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);
+      asm volatile("" ::: "memory");
+      if (probe) pk1 = __builtin_readcyclecounter();
+      if (ch + 1 < NCC) glds(NKC + ch + 1, gs + 1);
+      double ra[NI], rb[NI];
+      const double *bcol = bw0 + (gs & 1) * (NW * WSL) + q * WS_CA + n;
+      // the slice's operands: the first half up front, the second half while the first is being consumed
+      constexpr int JH = NJW / 2;
+      double ca[NJW], cb[NJW];
+#pragma unroll
+      for (int J = 0; J < JH; ++J) { ca[J] = bcol[(size_t)4 * WS_CA * J]; cb[J] = bcol[(size_t)4 * WS_CA * J + 4]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int I = 0; I < NI; ++I) { ra[I] = 0.0; rb[I] = 0.0; }
+      // The row reductions of chunk ch - 1 (alpha 8 (ch - 1) + wave, lane = row; chunk 0 reduces stale partials into nothing)
+      // are spread BY HAND between the 14 groups of eight MFMAs, one dependent step per group, the order pinned by
+      // sched_barrier: float64 vector instructions of ANOTHER wave are not issued while a wave streams float64 MFMAs (measured:
+      // the reductions of a SIMD's second wave took 3.5 k cycles beside the first wave's MFMAs, 0.9 k alone), and the
+      // scheduler leaves the two parts one after the other even with sched_group_barrier pipelines -- so the overlap is
+      // written into the instruction stream: each step's latency is covered by the next group's 136 cycles of MFMA.
+      const int chi = max(ch - 1, 0), ai = WS_CA * chi + wave;
+      const bool live = ch > 0 && ai < nalpha;
+      const double *rp;
+      int rs;
+      double pr[8], r0v = 0.0, q0 = 1.0, y0 = 0.0, prod0 = 1.0, ssum0 = 0.0, beta0 = 0.0, pw0 = 1.0, sw0 = 0.0;
+      int neg = 0;
+#pragma unroll
+      for (int J = 0; J < NJW; ++J) {   // (a wave of NJL groups runs its last group on zeros: Z = 0 there, C zero-padded)
+#pragma unroll
+        for (int I = 0; I < NI; ++I) {
+          ra[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[I][J], ca[J], ra[I], 0, 0, 0);
+          rb[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[I][J], cb[J], rb[I], 0, 0, 0);
+        }
+        if (J == 0) {
+          const int t = wave >> 2, odd = chi & 1;
+          rp = odd ? Bs + (size_t)t * NW * WSL + R2OFF : red + (size_t)t * NW * RW;   // partial of wave w: + w * rs
+          rs = odd ? WSL : RW;
+          rp += (lane >> 4) * RS + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (wave & 3);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) pr[w] = rp[w * rs];
+          beta0 = betas[ai];
+        } else if (J == 1) {
+#pragma unroll
+          for (int JJ = JH; JJ < NJW; ++JJ) { ca[JJ] = bcol[(size_t)4 * WS_CA * JJ]; cb[JJ] = bcol[(size_t)4 * WS_CA * JJ + 4]; }
+        } else if (J == 2) {
+          pr[0] += pr[1]; pr[2] += pr[3];
+#pragma unroll
+          for (int w = 4; w < 8; ++w) pr[w] = rp[w * rs];
+        } else if (J == 3) {
+          pr[0] += pr[2]; pr[4] += pr[5]; pr[6] += pr[7];
+          r0v = pr[0] + (pr[4] + pr[6]);
+          q0 = __builtin_fma(-beta0, r0v, 1.0);
+          y0 = __builtin_amdgcn_rcp(q0);
+        } else if (J == 4) {
+          y0 = __builtin_fma(y0, __builtin_fma(-q0, y0, 1.0), y0);
+        } else if (J == 5) {
+          y0 = __builtin_fma(y0, __builtin_fma(-q0, y0, 1.0), y0);
+          neg = (rowok && q0 < 0.0) ? 1 : 0;
+          prod0 = rowok ? q0 : 1.0;
+        } else if (J == 6) {
+          ssum0 = rowok ? r0v * y0 : 0.0;
+          prod0 *= ws_dpp<0xB1>(prod0);
+        } else if (J == 7) {
+          ssum0 += ws_dpp<0xB1>(ssum0);
+          prod0 *= ws_dpp<0x4E>(prod0);
+        } else if (J == 8) {
+          ssum0 += ws_dpp<0x4E>(ssum0);
+          prod0 *= ws_dpp<0x141>(prod0);
+        } else if (J == 9) {
+          ssum0 += ws_dpp<0x141>(ssum0);
+          prod0 *= ws_dpp<0x140>(prod0);
+        } else if (J == 10) {
+          ssum0 += ws_dpp<0x140>(ssum0);
+          pw0 = (rdl(prod0, 0) * rdl(prod0, 16)) * (rdl(prod0, 32) * rdl(prod0, 48));
+        } else if (J == 11) {
+          sw0 = (rdl(ssum0, 0) + rdl(ssum0, 16)) + (rdl(ssum0, 32) + rdl(ssum0, 48));
+        } else if (J == 12) {
+          const int n0 = __any(neg) ? 1 : 0;
+          const bool mine = live && lane == chi;
+          const double pm0 = Pv * pw0;
+          Ev += mine ? __builtin_amdgcn_frexp_exp(pm0) : 0;
+          Pv = mine ? __builtin_amdgcn_frexp_mant(pm0) : Pv;
+          Sv += mine ? sw0 : 0.0;
+          Nv |= mine ? n0 : 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      pk2 = pk1;
+      if (probe) { asm volatile("" : "+v"(ra[0]), "+v"(rb[3]), "+v"(Pv), "+v"(Sv)); pk3 = __builtin_readcyclecounter(); }
+      double *wa = (ch & 1) ? Bs + (size_t)wave * WSL + R2OFF : red + (size_t)wave * RW;
+      double *wb = (ch & 1) ? Bs + (size_t)(NW + wave) * WSL + R2OFF : red + (size_t)(NW + wave) * RW;
+#pragma unroll
+      for (int I = 0; I < NI; ++I) {
+        wa[I * RS + lane] = ra[I];
+        wb[I * RS + lane] = rb[I];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (no vmcnt: the next chunk's copy stays in flight)
+      if (probe) {
+        pk4 = __builtin_readcyclecounter();
+        pd0 += pk1 - pk0; pd1 += pk2 - pk1; pd2 += pk3 - pk2; pd3 += pk4 - pk3;
+      }
+    }
+    if (probe && lane == 0) {
+      atomicAdd(&g_ws_stamps[7], __builtin_readcyclecounter() - pt0);   // this wave's whole tile
+      atomicAdd(&g_ws_stamps[3], pd0);
+      atomicAdd(&g_ws_stamps[4], pd1);
+      atomicAdd(&g_ws_stamps[5], pd2);
+      atomicAdd(&g_ws_stamps[6], pd3);
+    }
+    nll_rows1(NCC - 1, rowok);
+    if (more) {   // the next tile's first chunk (not earlier: W slices cover the buffers' upper parts, which held red2)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave has read the last chunk's partials
+      glds(0, gs);
+      xload(xa, 0, r0 + RT);
+    }
+    if (stamp && tid == 0) {
+      const unsigned long long tk2 = __builtin_readcyclecounter();
+      atomicAdd(&g_ws_stamps[0], 1ull);
+      atomicAdd(&g_ws_stamps[1], tk1 - tk0);
+      atomicAdd(&g_ws_stamps[2], tk2 - tk1);
+    }
+  }
+  if (lane < NCC) {
+    const int ai = WS_CA * lane + wave;
+    const bool in = ai < nalpha;
+    po[ai] = in ? log(Pv) + (double)Ev * 0.6931471805599453094 : 0.0;
+    po[NA + ai] = in ? (Nv ? __builtin_nan("") : Sv) : 0.0;
+  }
+}
+
+// the operand images of k_wsweep8: W8 [NKC][8 waves][16 slice rows][SW], slice row 4 k4 + qq = band 16 s + 4 qq + k4;
+// C8 [NCC][8 waves][SW][8 alphas]; a wave's columns: j0(wave) + jl, jl < 4 (NJW or NJL), zero elsewhere
+template <int NJW, int NJL>
+__global__ void k_wmat_p8(const double *__restrict__ evec, const double *__restrict__ d, int p, int NKC, double *__restrict__ W) {
+  constexpr int SW = 4 * NJW, WSL = 16 * SW;
+  const int c = blockIdx.y;
+  const double *ev = evec + (size_t)c * p * p, *dd = d + (size_t)c * p;
+  double *o = W + (size_t)c * NKC * 8 * WSL;
+  const int total = NKC * 8 * WSL;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int s = i / (8 * WSL), r1 = i - s * 8 * WSL, w = r1 / WSL, r2 = r1 - w * WSL, row = r2 / SW, jl = r2 - row * SW;
+    const int b = 16 * s + 4 * (row & 3) + (row >> 2);
+    const int j = 4 * (w < 4 ? NJW * w : 4 * NJW + NJL * (w - 4)) + jl;
+    const bool in = jl < 4 * (w < 4 ? NJW : NJL) && b < p && j < p;
+    o[i] = in ? ev[(size_t)j * p + b] / dd[b] : 0.0;
+  }
+}
+template <int NJW, int NJL>
+__global__ void k_cmat_t8(const double *__restrict__ lam, const int32_t *__restrict__ nloo, const int32_t *__restrict__ status,
+                          const double *__restrict__ alphas, int nalpha, int NCC, int p, double *__restrict__ Ct) {
+  constexpr int SW = 4 * NJW, CSL = WS_CA * SW;
+  const int c = blockIdx.y;
+  const double nn = (double)nloo[c];
+  const bool ok = status[c] == 0;
+  const double *lc = lam + (size_t)c * p;
+  double *o = Ct + (size_t)c * NCC * 8 * CSL;
+  const int total = NCC * 8 * CSL;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int ch = i / (8 * CSL), r1 = i - ch * 8 * CSL, w = r1 / CSL, r2 = r1 - w * CSL, jl = r2 >> 3, a = 8 * ch + (r2 & 7);
+    const int j = 4 * (w < 4 ? NJW * w : 4 * NJW + NJL * (w - 4)) + jl;
+    double v = 0.0;
+    if (ok && a < nalpha && jl < 4 * (w < 4 ? NJW : NJL) && j < p) {
+      const double al = alphas[a];
+      const double beta = (1.0 - al) / (nn - 1.0);
+      v = 1.0 / ((nn * beta) * lc[j] + al);
+    }
+    o[i] = v;
+  }
+}
+template <int NJW>
+size_t ws8_lds_bytes(int P16, int NA) {
+  return (size_t)(2 * W8_NW * 64 * NJW + P16 + 2 * W8_NW * 4 * 65 + NA) * sizeof(double);
+}
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -507,9 +939,10 @@ static int wg_p16(const SfGeom &g) { return (g.p + 15) / 16 * 16; }
 static int wg_ldw(const SfGeom &g) { return g.p <= 256 ? 256 : (g.p <= 432 ? 432 : 512); }   // 16 NJW of the instantiation used
 static int wg_na(const SfGeom &g) { return g.nu * 16; }   // (a multiple of the 8 alphas of a C chunk)   // alpha slots = the stride k_nll reads the partials with
 // scratch of the fused route: W [ncols][P16][LDW], Ct [ncols][NA / 16][LDW][16], the sweep partials [ncols][nsplit][2][NA]
+static size_t wg_ldw_alloc(const SfGeom &g) { const size_t l = wg_ldw(g); return l == 432 ? 448 : l; }   // (k_wsweep8's 8 x 56 slots)
 size_t sf_wgemm_operand_bytes(const SfGeom &g) {
-  const size_t P16 = wg_p16(g), LDW = wg_ldw(g), NA = wg_na(g);
-  return sf_align((size_t)g.ncols * P16 * LDW * sizeof(double)) + sf_align((size_t)g.ncols * NA * LDW * sizeof(double));
+  const size_t P16 = wg_p16(g), LDW = wg_ldw_alloc(g), NA = wg_na(g);
+  return sf_align((size_t)g.ncols * P16 * LDW * sizeof(double)) + sf_align((size_t)g.ncols * NA * LDW * sizeof(double) + 1024);
 }
 size_t sf_wgemm_part_bytes(const SfGeom &g) {
   return sf_align((size_t)g.ncols * sf_wgemm_splits(g) * 2 * wg_na(g) * sizeof(double));
@@ -551,22 +984,43 @@ int sf_launch_wsweep(const void *xt, int xt_f64, const uint8_t *mask_t, const in
   SfGeom gb = g;
   gb.ncols = nb;
   double *Wp = reinterpret_cast<double *>(opnd);
-  double *Ct = reinterpret_cast<double *>(reinterpret_cast<char *>(opnd) + sf_align((size_t)nb * P16 * LDW * sizeof(double)));
+  double *Ct = reinterpret_cast<double *>(reinterpret_cast<char *>(opnd) + sf_align((size_t)nb * P16 * wg_ldw_alloc(g) * sizeof(double)));
   const size_t colx = (size_t)g.lines * g.ps * (xt_f64 ? sizeof(double) : sizeof(float));
   const void *xb = reinterpret_cast<const char *>(xt) + (size_t)c0 * colx;
+  // sf_debug_set(24, v): 0 = k_wsweep8 where it applies (float32 rows, 256 < p <= 432); 1: 32-row tiles, 8-band chunks, two
+  // workgroups per CU; 2: eight waves on shared chunks; 4: round 4's first form (four waves, shared chunks)
+  const int lite = sf_tune().wsweep_variant;
+  if (!xt_f64 && LDW == 432 && lite == 0) {
+    // eight waves, wave-private operand slices, no barrier in the Y phase (k_wsweep8)
+    constexpr int NJW = 14, NJL = 13;
+    const size_t lds = ws8_lds_bytes<NJW>(P16, NA);
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsweep8<NJW, NJL>), lds)) return rc;
+    hipLaunchKernelGGL((k_wmat_p8<NJW, NJL>), dim3(128, nb), dim3(256), 0, st, evec + (size_t)c0 * g.p * g.p, d + (size_t)c0 * g.p, g.p,
+                       P16 / 16, Wp);
+    SF_LAUNCH_CHECK("k_wmat_p8");
+    hipLaunchKernelGGL((k_cmat_t8<NJW, NJL>), dim3(64, nb), dim3(256), 0, st, lam + (size_t)c0 * g.p, nloo + c0, status + c0, alphas,
+                       g.nalpha, NA / 8, g.p, Ct);
+    SF_LAUNCH_CHECK("k_cmat_t8");
+    const int grid = 8 * sf_cdiv(nb, 8) * nsplit;
+    hipLaunchKernelGGL((k_wsweep8<NJW, NJL>), dim3(grid), dim3(64 * W8_NW), lds, st, reinterpret_cast<const float *>(xb),
+                       mask_t + (size_t)c0 * g.lines, nloo + c0, mu + (size_t)c0 * g.p, Wp, Ct, status + c0, alphas, g.nalpha, NA,
+                       g.lines, g.p, g.ps, P16, rows, nsplit, nb, part + (size_t)c0 * nsplit * 2 * NA, sf_tune().wjac_stamps);
+    SF_LAUNCH_CHECK("k_wsweep8");
+    return 0;
+  }
   hipLaunchKernelGGL(k_wmat_p, dim3(128, nb), dim3(256), 0, st, evec + (size_t)c0 * g.p * g.p, d + (size_t)c0 * g.p, g.p, P16, LDW, Wp);
   SF_LAUNCH_CHECK("k_wmat_p");
   hipLaunchKernelGGL(k_cmat_t, dim3(64, nb), dim3(256), 0, st, lam + (size_t)c0 * g.p, nloo + c0, status + c0, alphas, g.nalpha,
                      NA / 8, g.p, LDW, Ct);
   SF_LAUNCH_CHECK("k_cmat_t");
   double *pb = part + (size_t)c0 * nsplit * 2 * NA;
-#define WS_GO(XT, NI, NJW, CH, OCC)                                                                                               \
-  return ws_launch<XT, NI, NJW, CH, OCC>(xb, mask_t + (size_t)c0 * g.lines, nloo + c0, mu + (size_t)c0 * g.p, Wp, Ct, status + c0, alphas, gb, \
+#define WS_GO(XT, NI, NJW, CH, OCC, ...)                                                                                          \
+  return ws_launch<XT, NI, NJW, CH, OCC, ##__VA_ARGS__>(xb, mask_t + (size_t)c0 * g.lines, nloo + c0, mu + (size_t)c0 * g.p, Wp, Ct, status + c0, alphas, gb, \
                                 P16, NA, rows, nsplit, pb, st)
-  const int lite = sf_tune().wsweep_variant;   // 1: 32-row tiles, 8-band chunks, two workgroups per CU
   if (!xt_f64) {
     if (LDW == 256) WS_GO(float, 4, 16, 16, 1);
     if (LDW == 432 && lite == 1) WS_GO(float, 2, 27, 8, 2);
+    if (LDW == 432 && lite == 2) WS_GO(float, 4, 14, 16, 1, 8, 432);
     if (LDW == 432) WS_GO(float, 4, 27, 16, 1);
     WS_GO(float, 2, 32, 16, 1);
   } else {
@@ -577,10 +1031,10 @@ int sf_launch_wsweep(const void *xt, int xt_f64, const uint8_t *mask_t, const in
 #undef WS_GO
 }
 
-extern "C" int sf_debug_wsweep_stamps(unsigned long long *out4, int reset) {
-  if (out4) SF_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_ws_stamps), 4 * sizeof(unsigned long long)));
+extern "C" int sf_debug_wsweep_stamps(unsigned long long *out4 /* [8] */, int reset) {
+  if (out4) SF_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_ws_stamps), 8 * sizeof(unsigned long long)));
   if (reset) {
-    unsigned long long z[4] = {0, 0, 0, 0};
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     SF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ws_stamps), z, sizeof(z)));
   }
   return 0;

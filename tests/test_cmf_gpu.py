@@ -1145,6 +1145,60 @@ def test_wide_eigensolver_variants_agree(torch_cuda, golden_dir, library):
                                    atol=1e-12 * np.abs(b.out[..., 3][~nod]).max())
 
 
+@pytest.mark.parametrize("p", [260, 333, 425, 432])
+def test_wide_sweep_forms_agree(torch_cuda, p):
+    """The sweep kernels of the wide path on float32 rows -- k_wsweep8 (default for 256 < p <= 432: eight waves, wave-private
+    operand slices, a wave's 14 or 13 column groups) against round 4's first form (sf_debug_set(24, 4): four waves, shared
+    chunks) and the 32-row form (1) -- through sf_cmf_wide_stats on odd geometry: a row count that is no multiple of the
+    64-row tile or the 640-row split, invalid rows holding NaN, NaN in the rows' padding, a column without valid rows.
+    NLL curves to 1e-13, alpha indices and the inf pattern exact, a re-run bit-identical."""
+    import torch
+    L = _ffi.lib()
+    dev = torch.device("cuda:0")
+    ncols, rows = 11, 1500 + 37
+    ps = (p + 3) // 4 * 4
+    g = torch.Generator(device=dev); g.manual_seed(100 + p)
+    base = 5.0 * torch.exp(-3.0 * torch.arange(p, device=dev) / (p - 1)) + 0.2
+    xt = torch.full((ncols, rows, ps), float("nan"), dtype=torch.float32, device=dev)
+    for c in range(ncols):
+        lm = torch.randn((5, p), generator=g, device=dev) * 0.1 * base
+        xt[c, :, :p] = base + torch.randn((rows, 5), generator=g, device=dev) @ lm + torch.randn((rows, p), generator=g, device=dev) * 0.01 * base
+    mask = torch.ones((ncols, rows), dtype=torch.uint8, device=dev)
+    mask[:, :5] = 0
+    mask[:, 700] = 0
+    xt[:, 700, :] = float("nan")
+    mask[3, :] = 0                                   # status 1: no valid row
+    mask[5, 64:128] = 0                              # a whole tile of invalid rows
+    al = torch.as_tensor(cmf.alpha_grid(), device=dev); nalpha = al.numel()
+    f64k = dict(dtype=torch.float64, device=dev)
+    nuse = torch.empty(ncols, dtype=torch.int32, device=dev); mu = torch.empty((ncols, p), **f64k)
+    ws = torch.empty(L.sf_cmf_workspace_bytes(rows, p, ncols, nalpha), dtype=torch.uint8, device=dev)
+    P, st = _ffi.ptr, _ffi.stream_ptr()
+    _ffi.check(L.sf_cmf_column_mean(P(xt), 0, P(mask), rows, p, ncols, P(nuse), P(mu), P(ws), st), "mean")
+    out = {}
+    try:
+        for v in (0, 4, 1, 0):
+            L.sf_debug_set(24, v)
+            S = torch.empty((ncols, p, p), **f64k); d = torch.empty((ncols, p), **f64k); lam = torch.empty((ncols, p), **f64k)
+            evec = torch.empty((ncols, p, p), **f64k); status = torch.empty(ncols, dtype=torch.int32, device=dev)
+            nll = torch.empty((ncols, nalpha), **f64k); aidx = torch.empty(ncols, dtype=torch.int32, device=dev)
+            _ffi.check(L.sf_cmf_wide_stats(P(xt), 0, P(mask), P(nuse), P(nuse), P(mu), P(al), nalpha, rows, p, ncols, P(S), P(d),
+                                           P(lam), P(evec), P(status), P(nll), P(aidx), P(ws), st), "wide_stats")
+            cur = dict(nll=nll.cpu().numpy(), aidx=aidx.cpu().numpy(), status=status.cpu().numpy())
+            if v in out:
+                assert np.array_equal(out[v]["nll"], cur["nll"], equal_nan=True)      # re-run bit-identical
+            elif out:
+                ref = out[0]
+                assert np.array_equal(ref["status"], cur["status"]) and np.array_equal(ref["aidx"], cur["aidx"])
+                assert np.array_equal(np.isfinite(ref["nll"]), np.isfinite(cur["nll"]))
+                fin = np.isfinite(ref["nll"])
+                np.testing.assert_allclose(cur["nll"][fin], ref["nll"][fin], rtol=1e-13)
+            out.setdefault(v, cur)
+    finally:
+        L.sf_debug_set(24, 0)
+    assert out[0]["status"][3] == 1 and (np.delete(out[0]["status"], 3) == 0).all()
+
+
 def test_multimodal_return_nll(torch_cuda, golden_dir, library):
     """return_nll with kmeans > 1: one NLL curve per (column, cluster); its argmin is the cluster's alpha index and it
     equals the curve looshrinkage() computes for the cluster's rows with n = the column's valid-row count."""

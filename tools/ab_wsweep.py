@@ -1,18 +1,19 @@
 #!/usr/bin/env python3
-"""Wide-window statistics A/B: round 3's route (k_center + three 16x16x4 GEMMs + k_nllrows; sf_debug_set(23, 1)) against the fused
-4x4x4 kernels of cmf_wgemm.hip (default) through sf_cmf_wide_stats: covariance, eigenvalues, NLL curve, alpha index, ms per call.
-    python tools/ab_wgemm.py [ncols=36] [rows=20000] [p=425] [reps=2] [f64=0]"""
+"""Wide-window sweep A/B: the forms of k_wsweep (sf_debug_set(24, v): 0 = k_wsweep8: eight waves, wave-private operand slices; 4 = four waves, one per SIMD; 2 = eight waves on shared chunks;
+1 = 32-row tiles, two workgroups per CU) through sf_cmf_wide_stats: NLL curve, alpha index, ms per call, phase clocks per form.
+    python tools/ab_wsweep.py [ncols=128] [rows=20000] [p=425] [reps=2] [variants=0,2,0,2]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from srcfinder_amd import _ffi, cmf
 
-ncols = int(sys.argv[1]) if len(sys.argv) > 1 else 36
+ncols = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 rows = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 p = int(sys.argv[3]) if len(sys.argv) > 3 else 425
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
-f64 = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+variants = [int(v) for v in (sys.argv[5] if len(sys.argv) > 5 else "4,0,4,0").split(",")]
+f64 = 0
 L = _ffi.lib()
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(11)
@@ -36,9 +37,11 @@ mu = torch.empty((ncols, p), **f64k)
 ws = torch.empty(L.sf_cmf_workspace_bytes(rows, p, ncols, nalpha), dtype=torch.uint8, device=dev)
 P, st = _ffi.ptr, _ffi.stream_ptr()
 _ffi.check(L.sf_cmf_column_mean(P(xt), f64, P(mask), rows, p, ncols, P(nuse), P(mu), P(ws), st), "mean")
+import ctypes
 res = {}
-for name, variant in (("round 3 (16x16x4, unfused)", 1), ("fused 4x4x4 (r4)", 0), ("round 3 again", 1), ("fused again", 0)):
-    L.sf_debug_set(23, variant)
+buf = (ctypes.c_ulonglong * 8)()
+for variant in variants:
+    L.sf_debug_set(24, variant)
     S = torch.empty((ncols, p, p), **f64k); d = torch.empty((ncols, p), **f64k); lam = torch.empty((ncols, p), **f64k)
     evec = torch.empty((ncols, p, p), **f64k); status = torch.empty(ncols, dtype=torch.int32, device=dev)
     nll = torch.empty((ncols, nalpha), **f64k); aidx = torch.empty(ncols, dtype=torch.int32, device=dev)
@@ -50,23 +53,23 @@ for name, variant in (("round 3 (16x16x4, unfused)", 1), ("fused 4x4x4 (r4)", 0)
     for _ in range(reps): run()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    res[name] = dict(S=S.cpu().numpy(), lam=torch.sort(lam, dim=1).values.cpu().numpy(), nll=nll.cpu().numpy(), aidx=aidx.cpu().numpy(),
-                     status=status.cpu().numpy())
-    print("%-28s %9.2f ms/call   status!=0: %d  S symmetric: %s  alpha idx %s" % (name, ms, int((status != 0).sum()),
-          bool(torch.equal(S, S.transpose(1, 2))), aidx[:6].tolist()))
-L.sf_debug_set(23, 0)
-import ctypes
-buf = (ctypes.c_ulonglong * 8)()
-L.sf_debug_set(22, 1); L.sf_debug_wsweep_stamps(None, 1)
-run(); torch.cuda.synchronize()
-L.sf_debug_wsweep_stamps(buf, 1); L.sf_debug_set(22, 0)
-v = list(buf); nt = max(v[0], 1)
-print("sweep tiles %d: cycles per tile: Y = X W %.0f   r = Z C + rows %.0f" % (v[0], v[1] / nt, v[2] / nt))
-a, b = res["round 3 (16x16x4, unfused)"], res["fused 4x4x4 (r4)"]
-print("covariance: max |dS| / max |S| = %.2e" % (np.abs(a["S"] - b["S"]).max() / np.abs(a["S"]).max()))
-print("eigenvalues: max rel diff %.2e" % np.max(np.abs(a["lam"] - b["lam"]) / np.abs(a["lam"])))
-fin = np.isfinite(a["nll"]) & np.isfinite(b["nll"])
-print("NLL: inf/nan pattern equal %s, max rel diff %.2e, alpha index equal %s"
-      % (np.array_equal(np.isfinite(a["nll"]), np.isfinite(b["nll"])), np.max(np.abs(a["nll"][fin] - b["nll"][fin]) / np.abs(a["nll"][fin])),
-         np.array_equal(a["aidx"], b["aidx"])))
-print("re-run bit-identical: %s" % np.array_equal(res["fused 4x4x4 (r4)"]["nll"], res["fused again"]["nll"], equal_nan=True))
+    L.sf_debug_set(22, int(os.environ.get('WS_STAMP', '1'))); L.sf_debug_wsweep_stamps(None, 1)
+    run(); torch.cuda.synchronize()
+    L.sf_debug_wsweep_stamps(buf, 1); L.sf_debug_set(22, 0)
+    v = list(buf); nt = max(v[0], 1)
+    cur = dict(nll=nll.cpu().numpy(), aidx=aidx.cpu().numpy())
+    line = "variant %d: %9.2f ms/call  status!=0: %d  tiles %d: cycles per tile Y %.0f  r + rows %.0f" % (
+        variant, ms, int((status != 0).sum()), v[0], v[1] / nt, v[2] / nt)
+    if v[3]:
+        line += " (wait %.0f first half %.0f second half %.0f exchange %.0f; the wave's tile %.0f)" % (v[3] / nt, v[4] / nt, v[5] / nt, v[6] / nt, v[7] / nt)
+    if variant in res:
+        line += "   re-run bit-identical: %s" % np.array_equal(res[variant]["nll"], cur["nll"], equal_nan=True)
+    elif res:
+        a = res[variants[0]]
+        fin = np.isfinite(a["nll"]) & np.isfinite(cur["nll"])
+        line += "   vs variant %d: NLL finite pattern equal %s, max rel diff %.2e, alpha index equal %s" % (
+            variants[0], np.array_equal(np.isfinite(a["nll"]), np.isfinite(cur["nll"])),
+            np.max(np.abs(a["nll"][fin] - cur["nll"][fin]) / np.abs(a["nll"][fin])), np.array_equal(a["aidx"], cur["aidx"]))
+    res.setdefault(variant, cur)
+    print(line, flush=True)
+L.sf_debug_set(24, 0)

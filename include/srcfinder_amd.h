@@ -194,6 +194,13 @@ int sf_debug_wjac_stamps(unsigned long long *out8, int reset);
 /* the same for the tiles of the fused wide-window sweep (cmf_wgemm.hip): out8 = tiles, Y = X~ W, r = Z C + rows, then (k_wsweep8) the r
  * phase's MFMAs, row reductions, first barrier, exchange + second barrier, 0 */
 int sf_debug_wsweep_stamps(unsigned long long *out8, int reset);
+/* test entry of the tridiagonal preconditioner of the wide-window eigensolver (csrc/cmf_wtri.hip; the eigendecomposition that
+ * replaces the 201 det / inv of cmf/robust_mf.py:105-117 on windows of more than 96 bands): R [nb][p][p] symmetric positive
+ * definite, Lc [nb][p][p] its lower Cholesky factor in column-major order -> F [nb][p][p] column-major with F F^T = R and nearly
+ * orthogonal columns, tlam [nb][p] the tridiagonal route's eigenvalues, pflag [nb] 0 where the preconditioner was applied */
+size_t sf_debug_wtri_scratch_bytes(int p, int nb);
+int sf_debug_wtri(const double *R, const double *Lc, int p, int nb, double *F, double *tlam, int32_t *pflag, void *scratch,
+                  void *stream);
 
 /* Timing hook for bench.py's roofline line: while enabled, every sf_cmf_score launch (direct or
  * inside sf_cmf_run) is bracketed by a fresh pair of HIP events on the launch stream.

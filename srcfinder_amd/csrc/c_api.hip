@@ -319,6 +319,7 @@ static int *sf_tune_slot(int key) {
     case 23: return &t.wide_gemm_variant;
     case 24: return &t.wsweep_variant;
     case 25: return &t.wsyrk_variant;
+    case 26: return &t.det_slots;
     default: return nullptr;
   }
 }

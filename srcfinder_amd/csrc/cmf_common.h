@@ -158,6 +158,15 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
 int sf_wgemm_splits(const SfGeom &g);
 size_t sf_wgemm_operand_bytes(const SfGeom &g);   // W and C of g.ncols columns
 size_t sf_wgemm_part_bytes(const SfGeom &g);      // the sweep partials of the whole flightline
+// cmf_wtri.hip: the tridiagonal preconditioner of the wide eigensolver; cmf_wide.hip: the batched float64 GEMM it uses
+// (column-major n x n matrices: C = Y X for tb = 0, C = Y^T X ... see the definition), matrices with skip1 / skip2 != 0 untouched
+size_t sf_wtri_small_bytes(int p, int nb);
+int sf_launch_wtri_prepare(double *gv, int p, int p2, int nb, double *B2, double *B3, double *small, const int32_t *cflag,
+                           int32_t *pflag, hipStream_t st);
+int sf_launch_wtri_apply(double *gv, int p, int p2, int nb, double *B2, double *B3, double *small, const int32_t *cflag,
+                         int32_t *pflag, hipStream_t st);
+int sf_wide_dgemm(const double *A, int lda, size_t sA, const double *B, int ldb, size_t sB, int tb, double *C, int ldc, size_t sC,
+                  int n, int nb, const int32_t *skip1, const int32_t *skip2, hipStream_t st);
 int sf_launch_wsyrk(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
                     int c0, int nb, double *cov, hipStream_t st);
 int sf_launch_wsweep(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nloo, const double *mu, const double *d,

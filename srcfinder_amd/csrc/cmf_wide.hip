@@ -35,11 +35,14 @@ __global__ void k_center(const XT *__restrict__ xt, const uint8_t *__restrict__ 
 // SQUARE: C = (A B).^2.  Scalar predicated loads (any size); 64x64 block, 4 waves of 32x32, BK = 16.
 // SYM (the covariance, C = A^T A with B = A, M = N): only the tiles on and below the diagonal are computed, each
 // written to both triangles.
-template <bool TA, bool SQUARE, bool SYM = false>
+// TB: B is stored [N x K] (row-major) instead of [K x N].  skip1 / skip2: per-matrix flags, a non-zero one leaves the matrix alone.
+template <bool TA, bool SQUARE, bool SYM = false, bool TB = false>
 __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, int lda, size_t sA,
                                                 const double *__restrict__ B, int ldb, size_t sB,
                                                 double *__restrict__ Cm, int ldc, size_t sC, int M, int N, int K,
-                                                double scale) {
+                                                double scale, const int32_t *__restrict__ skip1 = nullptr,
+                                                const int32_t *__restrict__ skip2 = nullptr) {
+  if ((skip1 && skip1[blockIdx.z] != 0) || (skip2 && skip2[blockIdx.z] != 0)) return;
   __shared__ double As[WD_BK * WD_LD];
   __shared__ double Bs[WD_BK * WD_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,7 +73,11 @@ __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, int
 #pragma unroll
       for (int j = 0; j < 4; ++j) ra[j] = (m < M && k0 + kq + j < K) ? A[(size_t)m * lda + k0 + kq + j] : 0.0;
     }
-    {
+    if (TB) {  // B[n][k]: thread (n = tid/4, 4 consecutive k)
+      const int n = n0 + (tid >> 2), kq = (tid & 3) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rb[j] = (n < N && k0 + kq + j < K) ? B[(size_t)n * ldb + k0 + kq + j] : 0.0;
+    } else {
       const int k = tid >> 4, nq = (tid & 15) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -88,7 +95,11 @@ __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, int
 #pragma unroll
       for (int j = 0; j < 4; ++j) As[(kq + j) * WD_LD + m] = ra[j];
     }
-    {
+    if (TB) {
+      const int n = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Bs[(kq + j) * WD_LD + n] = rb[j];
+    } else {
       const int k = tid >> 4, nq = (tid & 15) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) Bs[k * WD_LD + nq + j] = rb[j];
@@ -1185,6 +1196,23 @@ static size_t legacy_scratch_bytes(const SfGeom &g) {
 size_t sf_wide_scratch_bytes(const SfGeom &g) {
   const size_t a = fused_scratch_bytes(g), b = legacy_scratch_bytes(g);   // (the round-3 route stays selectable: sf_debug_set(23, 1))
   return a > b ? a : b;
+}
+
+// Batched n x n float64 GEMM on COLUMN-major matrices through k_dgemm (whose operands are row-major: a column-major X is the
+// row-major X^T):  tb = 0: C = Bm Am;  tb = 1: C = Bm^T Am ... with Am / Bm the column-major matrices in A / B -- i.e. the
+// row-major product C^T = A^T-view x B-view.  Used by the tridiagonal preconditioner (cmf_wtri.hip):
+//   W = L^T U:  A = U, B = L, tb = 1      G = W^T W:  A = W, B = W, tb = 1      W' = W M:  A = M, B = W, tb = 0
+int sf_wide_dgemm(const double *A, int lda, size_t sA, const double *B, int ldb, size_t sB, int tb, double *C, int ldc, size_t sC,
+                  int n, int nb, const int32_t *skip1, const int32_t *skip2, hipStream_t st) {
+  const dim3 grid(sf_cdiv(n, WD_BM), sf_cdiv(n, WD_BN), nb);
+  if (tb)
+    hipLaunchKernelGGL((k_dgemm<false, false, false, true>), grid, dim3(256), 0, st, A, lda, sA, B, ldb, sB, C, ldc, sC, n, n, n, 1.0,
+                       skip1, skip2);
+  else
+    hipLaunchKernelGGL((k_dgemm<false, false, false, false>), grid, dim3(256), 0, st, A, lda, sA, B, ldb, sB, C, ldc, sC, n, n, n, 1.0,
+                       skip1, skip2);
+  SF_LAUNCH_CHECK("k_dgemm(wtri)");
+  return 0;
 }
 
 // blocked Cholesky of the nb matrices in gv whose flag is 0 (flag -> 1 where a pivot is not positive)

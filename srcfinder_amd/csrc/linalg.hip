@@ -507,9 +507,10 @@ int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *s
                         int window, const double *rest, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st,
                         const double *target) {
   const size_t maxjobs = det_maxjobs(g);
-  const size_t slots = det_slots(g, maxjobs);
+  const size_t slots_alloc = det_slots(g, maxjobs);
+  const size_t slots = sf_tune().det_slots > 0 ? std::min(slots_alloc, (size_t)sf_tune().det_slots) : slots_alloc;
   char *p = reinterpret_cast<char *>(scratch);
-  double *work = reinterpret_cast<double *>(p); p += sf_align(slots * g.p * g.p * sizeof(double));
+  double *work = reinterpret_cast<double *>(p); p += sf_align(slots_alloc * g.p * g.p * sizeof(double));
   int32_t *jobs = reinterpret_cast<int32_t *>(p); p += sf_align(maxjobs * sizeof(int32_t));
   double *det = reinterpret_cast<double *>(p); p += sf_align(maxjobs * sizeof(double));
   int32_t *njobs = reinterpret_cast<int32_t *>(p); p += sf_align(sizeof(int32_t));

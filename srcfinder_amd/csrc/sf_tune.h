@@ -26,6 +26,7 @@ struct SfTune {
   int cnn_conv_variant = 0;   // key 17: 1 = pointer-form tile loads in k_conv_igemm (cnn_kernels.hip), 2 = two LDS buffers / one barrier per chunk
   int cnn_variant = 0;        // key 16: 1 = the 8 x 8 conv1+pool kernel (cnn_kernels.hip)
   int det_variant = 0;        // key 15: 1 = the plain window rule of the exact-determinant pass in one round, 2 = no pass in sf_cmf_run's narrow branch
+  int det_slots = 0;          // key 26: workgroups (work matrices) of a launch of the exact-determinant pass; 0 = as many as fit (512)
   int lu_variant = 0;         // key 14: 1 = the unblocked LU in the determinant passes (linalg.hip)
   int score_exp = 0;          // key 13: timing experiments of k_score_blk2 (only with -DSF_SCORE_EXPERIMENTS)
 };

@@ -1168,7 +1168,8 @@ static size_t fused_col_bytes(const SfGeom &g) {
   const size_t p = g.p, p2 = g.p + (g.p & 1);
   SfGeom one = g;
   one.ncols = 1;
-  return sf_align(2 * p2 * p2 * sizeof(double)) + sf_wgemm_operand_bytes(one) + sf_align(2 * p * p * sizeof(double)) + 256;
+  return sf_align(2 * p2 * p2 * sizeof(double)) + sf_wgemm_operand_bytes(one) + sf_align(2 * p * p * sizeof(double)) +
+         sf_wtri_small_bytes(g.p, 1) + 256;
 }
 int sf_wide_group(const SfGeom &g) {
   // The eigensolver streams every factor (2 p2^2 doubles are allocated, p2^2 are live) once per Jacobi step: a group whose
@@ -1235,8 +1236,12 @@ static int wide_chol(double *gv, int p, int p2, int nb, int32_t *cflag, hipStrea
 
 // eigendecomposition of a batch of nb correlation matrices (columns c0 .. c0+nb-1)
 // (unit: `cov` = the batch's nb whitened matrices, no diagonal scaling, d untouched -- the full-target route)
+// pre != nullptr: the tridiagonal preconditioner of cmf_wtri.hip between the Cholesky and the sweeps (work matrices and flags of
+// the group: pre->B2, B3 [nb][p^2], small, pflag)
+struct WidePre { double *B2, *B3, *small; int32_t *pflag; };
 static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int c0, int nb, double *d, double *lam, double *evec,
-                     int32_t *status, double *gv, int32_t *cflag, int32_t *done, int32_t *rot, hipStream_t st, int unit = 0) {
+                     int32_t *status, double *gv, int32_t *cflag, int32_t *done, int32_t *rot, hipStream_t st, int unit = 0,
+                     const WidePre *pre = nullptr) {
   if (sf_tune().wide_eigh_variant == 1) {
     hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 0, cflag, unit);
     SF_LAUNCH_CHECK("k_eigh_global");
@@ -1244,7 +1249,12 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
   }
   hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 3, cflag, unit);
   SF_LAUNCH_CHECK("k_eigh_global(prep)");
+  const bool precond = pre && sf_tune().wide_eigh_variant == 0 && p >= 128;
+  if (precond)
+    if (int rc = sf_launch_wtri_prepare(gv, p, p2, nb, pre->B2, pre->B3, pre->small, cflag, pre->pflag, st)) return rc;
   if (int rc = wide_chol(gv, p, p2, nb, cflag, st)) return rc;
+  if (precond)
+    if (int rc = sf_launch_wtri_apply(gv, p, p2, nb, pre->B2, pre->B3, pre->small, cflag, pre->pflag, st)) return rc;
   if (sf_tune().wide_eigh_variant == 3 || sf_tune().wide_eigh_variant == 4) {
     // round 4 experiment (cmf_wjac.hip): the rotations of a visit on its 32 x 32 Gram matrix, applied by MFMA.  Same results,
     // 6 % SLOWER than the scalar kernels below (profiles/r04_wjac_phase_clocks.txt): not the default.
@@ -1327,15 +1337,18 @@ static int wide_stats_fused(const void *xt, int xt_f64, const uint8_t *mask_t, c
     void *opnd = gbase + (size_t)gb * gv_b;
     double *Lc = reinterpret_cast<double *>(gbase + (size_t)gb * (gv_b + op_b));
     double *Bw = Lc + (size_t)gb * p * p;
-    int32_t *flags = reinterpret_cast<int32_t *>(gbase + (size_t)gb * (per - 256));   // cflag | done | rot | tflag, gb each
+    int32_t *flags = reinterpret_cast<int32_t *>(gbase + (size_t)gb * (per - 256));   // cflag | done | rot | tflag | pflag, gb each
     int32_t *tflag = flags + 3 * gb;
     static_assert(sizeof(int32_t) == 4, "flags");
-    if ((size_t)4 * gb * sizeof(int32_t) > (size_t)gb * 256) return -2;   // (16 bytes of flags per column: always true)
+    if ((size_t)5 * gb * sizeof(int32_t) > (size_t)gb * 256) return -2;   // (20 bytes of flags per column: always true)
+    // the preconditioner's work: the full-target route's L / B matrices (free on the unimodal route) and d, e, t, scales
+    double *small = reinterpret_cast<double *>(gbase + (size_t)gb * (per - 256 - sf_wtri_small_bytes(g.p, 1)));
+    const WidePre pre{Lc, Bw, small, flags + 4 * gb};
     // gv of matrix i must sit at gv + i * 2 p2^2 (the eigensolver kernels index it that way): gv_b may be padded, so the
     // group's gv block is addressed densely and simply has to fit
     if (int rc = sf_launch_wsyrk(xt, xt_f64, mask_t, nuse, mu, g, c0, nb, cov, st)) return rc;
     if (!target) {
-      if (int rc = wide_eigh(cov, nuse, p, p2, c0, nb, d, lam, evec, status, gv, flags, flags + gb, flags + 2 * gb, st)) return rc;
+      if (int rc = wide_eigh(cov, nuse, p, p2, c0, nb, d, lam, evec, status, gv, flags, flags + gb, flags + 2 * gb, st, 0, &pre)) return rc;
     } else {
       hipLaunchKernelGGL(k_wg_load, dim3(64, nb), dim3(256), 0, st, target, nuse, p, p2, c0, gv, flags);
       SF_LAUNCH_CHECK("k_wg_load");

@@ -162,7 +162,7 @@ size_t sf_wgemm_part_bytes(const SfGeom &g);      // the sweep partials of the w
 // (column-major n x n matrices: C = Y X for tb = 0, C = Y^T X ... see the definition), matrices with skip1 / skip2 != 0 untouched
 size_t sf_wtri_small_bytes(int p, int nb);
 int sf_launch_wtri_prepare(double *gv, int p, int p2, int nb, double *B2, double *B3, double *small, const int32_t *cflag,
-                           int32_t *pflag, hipStream_t st);
+                           int32_t *pflag, hipStream_t st, int gbn, size_t gstride);   // (nb matrices in groups of gbn, gstride bytes apart; gbn 0: one group)
 int sf_launch_wtri_apply(double *gv, int p, int p2, int nb, double *B2, double *B3, double *small, const int32_t *cflag,
                          int32_t *pflag, hipStream_t st);
 int sf_wide_dgemm(const double *A, int lda, size_t sA, const double *B, int ldb, size_t sB, int tb, double *C, int ldc, size_t sC,

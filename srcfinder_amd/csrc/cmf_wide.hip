@@ -1238,20 +1238,26 @@ static int wide_chol(double *gv, int p, int p2, int nb, int32_t *cflag, hipStrea
 // (unit: `cov` = the batch's nb whitened matrices, no diagonal scaling, d untouched -- the full-target route)
 // pre != nullptr: the tridiagonal preconditioner of cmf_wtri.hip between the Cholesky and the sweeps (work matrices and flags of
 // the group: pre->B2, B3 [nb][p^2], small, pflag)
+static bool wide_precond_on(int p) { return sf_tune().wide_eigh_variant == 0 && p >= 128; }
+// stage: 0 = all of it; 1 = only the work matrices (R, d, flags: k_eigh_global mode 3) -- the caller then runs the preconditioner's
+// first half over ALL groups at once (sf_launch_wtri_prepare) -- and 2 = the rest (Cholesky, second half, sweeps, finish)
 struct WidePre { double *B2, *B3, *small; int32_t *pflag; };
 static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int c0, int nb, double *d, double *lam, double *evec,
                      int32_t *status, double *gv, int32_t *cflag, int32_t *done, int32_t *rot, hipStream_t st, int unit = 0,
-                     const WidePre *pre = nullptr) {
+                     const WidePre *pre = nullptr, int stage = 0) {
   if (sf_tune().wide_eigh_variant == 1) {
     hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 0, cflag, unit);
     SF_LAUNCH_CHECK("k_eigh_global");
     return 0;
   }
-  hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 3, cflag, unit);
-  SF_LAUNCH_CHECK("k_eigh_global(prep)");
-  const bool precond = pre && sf_tune().wide_eigh_variant == 0 && p >= 128;
-  if (precond)
-    if (int rc = sf_launch_wtri_prepare(gv, p, p2, nb, pre->B2, pre->B3, pre->small, cflag, pre->pflag, st)) return rc;
+  if (stage != 2) {
+    hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 3, cflag, unit);
+    SF_LAUNCH_CHECK("k_eigh_global(prep)");
+  }
+  if (stage == 1) return 0;
+  const bool precond = pre && wide_precond_on(p);
+  if (precond && stage == 0)
+    if (int rc = sf_launch_wtri_prepare(gv, p, p2, nb, pre->B2, pre->B3, pre->small, cflag, pre->pflag, st, 0, 0)) return rc;
   if (int rc = wide_chol(gv, p, p2, nb, cflag, st)) return rc;
   if (precond)
     if (int rc = sf_launch_wtri_apply(gv, p, p2, nb, pre->B2, pre->B3, pre->small, cflag, pre->pflag, st)) return rc;
@@ -1329,6 +1335,21 @@ static int wide_stats_fused(const void *xt, int xt_f64, const uint8_t *mask_t, c
   double *part = reinterpret_cast<double *>(base + (size_t)ngr * gb * per);
   double *rest = reinterpret_cast<double *>(reinterpret_cast<char *>(part) + sf_wgemm_part_bytes(g));
   void *det_scratch = reinterpret_cast<char *>(rest) + sf_align((size_t)g.ncols * g.nalpha * sizeof(double));
+  // Unimodal route with the tridiagonal preconditioner: covariances and work matrices of every group first, then the
+  // preconditioner's first half (tridiagonalisation, bisection: latency-bound per workgroup) over ALL columns in one set of
+  // launches, then group by group the Cholesky, the second half, the sweeps and the LOO sweep.  phase 0: one pass as before.
+  const bool phased = !target && wide_precond_on(p) && ngr > 1;
+  for (int phase = phased ? 1 : 0; phase <= (phased ? 2 : 0); ++phase) {
+  if (phase == 2) {
+    char *g0 = base;
+    double *gv0 = reinterpret_cast<double *>(g0);
+    double *Lc0 = reinterpret_cast<double *>(g0 + (size_t)gb * (gv_b + op_b));
+    int32_t *fl0 = reinterpret_cast<int32_t *>(g0 + (size_t)gb * (per - 256));
+    double *small0 = reinterpret_cast<double *>(g0 + (size_t)gb * (per - 256 - sf_wtri_small_bytes(g.p, 1)));
+    if (int rc = sf_launch_wtri_prepare(gv0, p, p2, ngr * gb, Lc0, Lc0 + (size_t)gb * p * p, small0, fl0, fl0 + 4 * gb, st, gb,
+                                        (size_t)gb * per))
+      return rc;
+  }
   for (int gi = 0; gi < ngr; ++gi) {
     const int c0 = gi * gb, nb = (g.ncols - c0 < gb) ? g.ncols - c0 : gb;
     char *gbase = base + (size_t)gi * gb * per;
@@ -1346,9 +1367,15 @@ static int wide_stats_fused(const void *xt, int xt_f64, const uint8_t *mask_t, c
     const WidePre pre{Lc, Bw, small, flags + 4 * gb};
     // gv of matrix i must sit at gv + i * 2 p2^2 (the eigensolver kernels index it that way): gv_b may be padded, so the
     // group's gv block is addressed densely and simply has to fit
-    if (int rc = sf_launch_wsyrk(xt, xt_f64, mask_t, nuse, mu, g, c0, nb, cov, st)) return rc;
+    if (phase != 2)
+      if (int rc = sf_launch_wsyrk(xt, xt_f64, mask_t, nuse, mu, g, c0, nb, cov, st)) return rc;
     if (!target) {
-      if (int rc = wide_eigh(cov, nuse, p, p2, c0, nb, d, lam, evec, status, gv, flags, flags + gb, flags + 2 * gb, st, 0, &pre)) return rc;
+      if (phase == 1 && nb < gb) {   // (the all-groups launches walk gb slots per group: the unused ones of a short group are flagged)
+        SF_HIP(hipMemsetAsync(flags + nb, 0x01, (size_t)(gb - nb) * sizeof(int32_t), st));
+      }
+      if (int rc = wide_eigh(cov, nuse, p, p2, c0, nb, d, lam, evec, status, gv, flags, flags + gb, flags + 2 * gb, st, 0, &pre, phase))
+        return rc;
+      if (phase == 1) continue;
     } else {
       hipLaunchKernelGGL(k_wg_load, dim3(64, nb), dim3(256), 0, st, target, nuse, p, p2, c0, gv, flags);
       SF_LAUNCH_CHECK("k_wg_load");
@@ -1366,6 +1393,7 @@ static int wide_stats_fused(const void *xt, int xt_f64, const uint8_t *mask_t, c
       SF_LAUNCH_CHECK("k_wg_back");
     }
     if (int rc = sf_launch_wsweep(xt, xt_f64, mask_t, nloo, mu, d, lam, evec, status, alphas, g, c0, nb, opnd, part, st)) return rc;
+  }
   }
   if (int rc = sf_launch_nll_finish(part, sf_wgemm_splits(g), nloo, d, lam, status, alphas, g, nll, alphaidx, st, rest)) return rc;
   return sf_launch_exact_det(cov, nloo, status, alphas, g, sf_exact_det_window(g), rest, nll, alphaidx, det_scratch, st, target);

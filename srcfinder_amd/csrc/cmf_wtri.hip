@@ -20,11 +20,14 @@
 // result is still the Jacobi's.  A matrix whose tridiagonal eigenvalues are not all positive and finite keeps F = L.
 // Measured (profiles/r04_wtri_ab.txt): eigensolver of a 598 x 425 x 425 flightline 191 -> see DESIGN.md.
 #include "cmf_common.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int TR_NT = 512;      // threads of k_tridiag (one row each)
 constexpr int TR_NB = 8;        // panel width
+constexpr int TR_MG = TR_NT / 64;   // row groups of 64 a lane may own in the symv
+constexpr int TR_CU = 6;            // columns a wave has in flight there (x 7 row groups: 42 loads per lane)
 
 __device__ __forceinline__ double tr_wave_sum(double v) {
 #pragma unroll
@@ -54,10 +57,19 @@ __device__ __forceinline__ void tr_block_sum(double (&v)[NV], double *red, int n
   __syncthreads();
 }
 
+// Two-level batch: matrix mtx of a launch is matrix mtx % gbn of column group mtx / gbn; a group's buffers sit gstride BYTES behind
+// the previous group's (cmf_wide.hip lays a group's work out in one block) -- so the launches that are latency-bound per
+// workgroup (tridiagonalisation, bisection) can run over all the groups of a flightline at once.
+template <typename T>
+__device__ __forceinline__ T *tr_goff(T *base, int grp, size_t gstride) {
+  return reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(base)) + (size_t)grp * gstride);
+}
+
 // A (column-major, ld) <- copy of the n x n matrix in G (column-major, ldg) for matrices with flag 0
 __global__ void k_tri_copy(const double *__restrict__ G, size_t sG, int ldg, double *__restrict__ A, size_t sA, int lda, int n,
-                           const int32_t *__restrict__ cflag) {
-  const int mtx = blockIdx.y;
+                           const int32_t *__restrict__ cflag, int gbn, size_t gstride) {
+  const int grp = blockIdx.y / gbn, mtx = blockIdx.y - grp * gbn;
+  G = tr_goff(G, grp, gstride); A = tr_goff(A, grp, gstride); cflag = tr_goff(cflag, grp, gstride);
   if (cflag[mtx] != 0) return;
   const double *g = G + (size_t)mtx * sG;
   double *a = A + (size_t)mtx * sA;
@@ -76,9 +88,10 @@ __global__ void k_tri_copy(const double *__restrict__ G, size_t sG, int ldg, dou
 // update A -= V W^T + W V^T is applied to the rows / columns behind it.  Traffic: the trailing matrix once per column (the symv)
 // plus once per panel -- served by the Infinity Cache for a group of ~150 matrices.
 __global__ __launch_bounds__(TR_NT) void k_tridiag(double *__restrict__ Aall, size_t sA, int ld, int n, double *__restrict__ deall,
-                                                   size_t sDE, int pl, const int32_t *__restrict__ cflag) {
+                                                   size_t sDE, int pl, const int32_t *__restrict__ cflag, int gbn, size_t gstride) {
   extern __shared__ __attribute__((aligned(16))) double trs[];
-  const int mtx = blockIdx.x;
+  const int grp = blockIdx.x / gbn, mtx = blockIdx.x - grp * gbn;
+  Aall = tr_goff(Aall, grp, gstride); deall = tr_goff(deall, grp, gstride); cflag = tr_goff(cflag, grp, gstride);
   if (cflag[mtx] != 0) return;
   double *A = Aall + (size_t)mtx * sA;
   double *de = deall + (size_t)mtx * sDE;
@@ -88,7 +101,9 @@ __global__ __launch_bounds__(TR_NT) void k_tridiag(double *__restrict__ Aall, si
   double *W = V + TR_NB * nl;             // [TR_NB][nl]
   double *red = W + TR_NB * nl;           // [2 * TR_NB + 2][8]
   double *bc = red + (2 * TR_NB + 2) * 8; // broadcast scalars
+  double *part = bc + 8;                  // [8 waves][nl]: the symv's partial sums
   const bool rin = r < n;
+  const int mg = (n + 63) >> 6;           // row groups of 64
   for (int j0 = 0; j0 < n - 1; j0 += TR_NB) {
     const int nbp = min(TR_NB, n - 1 - j0);
     for (int i = 0; i < nbp; ++i) {
@@ -121,19 +136,48 @@ __global__ __launch_bounds__(TR_NT) void k_tridiag(double *__restrict__ Aall, si
       }
       __syncthreads();
       // (c) p = A_stale v over rows / columns >= j + 1, and (d) the partial dots W_t . v, V_t . v of the correction
+      //     The symv is latency-bound if a thread walks its row alone (8 loads in flight); so wave w takes the columns
+      //     k = j + 1 + w (mod 8), its lanes the rows lane + 64 m of every row group still alive: 6 x 7 loads in flight per lane,
+      //     the eight partial sums of a row meet in LDS.  (Reading only the lower triangle -- a = A[r][k] serving p_r and p_k --
+      //     halves the traffic and was 45 % SLOWER: the per-column wave reductions cost more than the bytes.)
+      {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int m0 = (j + 1) >> 6;
+        const double *vi = V + i * nl;
+        double ps[TR_MG];
+#pragma unroll
+        for (int m = 0; m < TR_MG; ++m) ps[m] = 0.0;
+        int k = j + 1 + wave;
+        for (; k + 8 * (TR_CU - 1) < n; k += 8 * TR_CU) {
+          double x[TR_CU][TR_MG];
+#pragma unroll
+          for (int u = 0; u < TR_CU; ++u)
+#pragma unroll
+            for (int m = 0; m < TR_MG; ++m)
+              if (m >= m0 && m < mg) x[u][m] = (A + (size_t)(k + 8 * u) * ld + lane)[64 * m];   // (rows past n - 1: the next column's, unused)
+#pragma unroll
+          for (int u = 0; u < TR_CU; ++u) {
+            const double vk = vi[k + 8 * u];
+#pragma unroll
+            for (int m = 0; m < TR_MG; ++m)
+              if (m >= m0 && m < mg) ps[m] = __builtin_fma(x[u][m], vk, ps[m]);
+          }
+        }
+        for (; k < n; k += 8) {
+          const double vk = vi[k];
+#pragma unroll
+          for (int m = 0; m < TR_MG; ++m)
+            if (m >= m0 && m < mg) ps[m] = __builtin_fma((A + (size_t)k * ld + lane)[64 * m], vk, ps[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < TR_MG; ++m)
+          if (m < mg && lane + 64 * m < n) part[wave * nl + lane + 64 * m] = (m >= m0) ? ps[m] : 0.0;
+      }
+      __syncthreads();
       double p = 0.0;
       if (rin && r >= j + 1) {
-        const double *ar = A + r;
-        const double *vi = V + i * nl;
-        int k = j + 1;
-        for (; k + 8 <= n; k += 8) {
-          double x[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) x[u] = ar[(size_t)(k + u) * ld];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) p = __builtin_fma(x[u], vi[k + u], p);
-        }
-        for (; k < n; ++k) p = __builtin_fma(ar[(size_t)k * ld], vi[k], p);
+        for (int w = 0; w < TR_NT / 64; ++w) p += part[w * nl + r];
       }
       double dots[2 * TR_NB];
 #pragma unroll
@@ -167,12 +211,12 @@ __global__ __launch_bounds__(TR_NT) void k_tridiag(double *__restrict__ Aall, si
       if (rin && r >= c1) {
         double *ar = A + r;
         int c = c1;
-        for (; c + 4 <= n; c += 4) {
-          double x[4];
+        for (; c + 8 <= n; c += 8) {
+          double x[8];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) x[u] = ar[(size_t)(c + u) * ld];
+          for (int u = 0; u < 8; ++u) x[u] = ar[(size_t)(c + u) * ld];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < 8; ++u) {
             double acc = x[u];
 #pragma unroll
             for (int t = 0; t < TR_NB; ++t) acc -= vr[t] * W[t * nl + c + u] + wr[t] * V[t * nl + c + u];
@@ -205,11 +249,15 @@ __global__ __launch_bounds__(TR_NT) void k_tridiag(double *__restrict__ Aall, si
 // |gamma|).  D+ goes to row-major scratch Zt (element i of thread k at Zt[i * ldz + k]: coalesced), D- to Dm likewise; the vector
 // overwrites D+ in place.  de[2 pl + k] = t_k, de[3 pl + k] = 1 / (|z_k| sqrt(t_k)); pflag = 1 when some t_k is not positive and finite.
 constexpr int TE_NT = 512;
+constexpr int TE_PF = 8;      // scratch elements fetched together in the twisted-factorisation passes
 __global__ __launch_bounds__(TE_NT) void k_tri_eig(double *__restrict__ deall, size_t sDE, int n, double *__restrict__ Ztall,
                                                    size_t sZ, int ldz, double *__restrict__ Dmall, size_t sD, int ldd,
-                                                   int pl, const int32_t *__restrict__ cflag, int32_t *__restrict__ pflag) {
+                                                   int pl, const int32_t *__restrict__ cflag, int32_t *__restrict__ pflag, int gbn,
+                                                   size_t gstride) {
   extern __shared__ __attribute__((aligned(16))) double tes[];
-  const int mtx = blockIdx.x;
+  const int grp = blockIdx.x / gbn, mtx = blockIdx.x - grp * gbn;
+  deall = tr_goff(deall, grp, gstride); Ztall = tr_goff(Ztall, grp, gstride); Dmall = tr_goff(Dmall, grp, gstride);
+  cflag = tr_goff(cflag, grp, gstride); pflag = tr_goff(pflag, grp, gstride);
   if (cflag[mtx] != 0) return;
   const double *de = deall + (size_t)mtx * sDE;
   double *Zt = Ztall + (size_t)mtx * sZ, *Dm = Dmall + (size_t)mtx * sD;
@@ -243,18 +291,35 @@ __global__ __launch_bounds__(TE_NT) void k_tri_eig(double *__restrict__ deall, s
   const double tnorm = fmax(fabs(gl[0]), fabs(gl[1]));
   const double tiny = 2.220446049250313e-16 * tnorm * 1e-3 + 1e-300;
   if (k < n) {
+    // bisection; the quotient of the Sturm recurrence by reciprocal + two Newton steps (the launch is bound by the vector
+    // pipes: a quadrisection with three independent chains a round does 1.5 x the evaluations and took as long), the last
+    // rounds with the IEEE division
     double lo = gl[0], hi = gl[1];
+    auto rcp = [](double q) {
+      double y = __builtin_amdgcn_rcp(q);
+      y = __builtin_fma(y, __builtin_fma(-q, y, 1.0), y);
+      return __builtin_fma(y, __builtin_fma(-q, y, 1.0), y);
+    };
     for (int it = 0; it < 120; ++it) {
       const double mid = 0.5 * (lo + hi);
-      if (!(mid > lo && mid < hi)) break;   // the interval is two adjacent floats
+      if (!(mid > lo && mid < hi)) break;   // two adjacent floats
+      const bool exact = (hi - lo) <= 64.0 * 2.220446049250313e-16 * fmax(fabs(lo), fabs(hi));
       int cnt = 0;
       double q = dd[0] - mid;
       if (q == 0.0) q = -tiny;
       cnt += q < 0.0;
-      for (int i = 1; i < n; ++i) {
-        q = dd[i] - mid - e2[i - 1] / q;
-        if (q == 0.0) q = -tiny;
-        cnt += q < 0.0;
+      if (exact) {
+        for (int i = 1; i < n; ++i) {
+          q = dd[i] - mid - e2[i - 1] / q;
+          if (q == 0.0) q = -tiny;
+          cnt += q < 0.0;
+        }
+      } else {
+        for (int i = 1; i < n; ++i) {
+          q = __builtin_fma(-e2[i - 1], rcp(q), dd[i] - mid);
+          if (q == 0.0) q = -tiny;
+          cnt += q < 0.0;
+        }
       }
       if (cnt > k) hi = mid; else lo = mid;   // cnt = number of eigenvalues < mid
     }
@@ -269,31 +334,60 @@ __global__ __launch_bounds__(TE_NT) void k_tri_eig(double *__restrict__ deall, s
       if (dp == 0.0) dp = tiny;
       Zt[(size_t)(i + 1) * ldz + k] = dp;
     }
+    // (the three passes below walk this thread's scratch columns in blocks of TE_PF elements, loaded together: a dependent
+    //  global load per recurrence step is 2 us of latency each -- 2.5 ms a launch)
     double dm = dd[n - 1] - lam;
     if (dm == 0.0) dm = tiny;
     Dm[(size_t)(n - 1) * ldd + k] = dm;
     double gbest = fabs(dp + dm - (dd[n - 1] - lam));
     int rtw = n - 1;
-    for (int i = n - 2; i >= 0; --i) {        // D-_i = (d_i - lam) - e_i^2 / D-_{i+1}
-      dm = (dd[i] - lam) - e2[i] / dm;
-      if (dm == 0.0) dm = tiny;
-      Dm[(size_t)i * ldd + k] = dm;
-      const double g = fabs(Zt[(size_t)i * ldz + k] + dm - (dd[i] - lam));
-      if (g < gbest) { gbest = g; rtw = i; }
+    for (int ib = n - 2; ib >= 0; ib -= TE_PF) {          // D-_i = (d_i - lam) - e_i^2 / D-_{i+1}
+      double dpl[TE_PF];
+#pragma unroll
+      for (int u = 0; u < TE_PF; ++u) dpl[u] = Zt[(size_t)max(ib - u, 0) * ldz + k];
+#pragma unroll
+      for (int u = 0; u < TE_PF; ++u) {
+        const int i = ib - u;
+        if (i >= 0) {
+          dm = (dd[i] - lam) - e2[i] / dm;
+          if (dm == 0.0) dm = tiny;
+          Dm[(size_t)i * ldd + k] = dm;
+          const double g = fabs(dpl[u] + dm - (dd[i] - lam));
+          if (g < gbest) { gbest = g; rtw = i; }
+        }
+      }
     }
     // ---- z: z_r = 1, upward z_i = -(e_i / D+_i) z_{i+1}, downward z_{i+1} = -(e_i / D-_{i+1}) z_i; in place of D+
     double z = 1.0, nrm2 = 1.0;
-    for (int i = rtw - 1; i >= 0; --i) {
-      z = -(ee[i] / Zt[(size_t)i * ldz + k]) * z;
-      Zt[(size_t)i * ldz + k] = z;
-      nrm2 += z * z;
+    for (int ib = rtw - 1; ib >= 0; ib -= TE_PF) {
+      double dpl[TE_PF];
+#pragma unroll
+      for (int u = 0; u < TE_PF; ++u) dpl[u] = Zt[(size_t)max(ib - u, 0) * ldz + k];
+#pragma unroll
+      for (int u = 0; u < TE_PF; ++u) {
+        const int i = ib - u;
+        if (i >= 0) {
+          z = -(ee[i] / dpl[u]) * z;
+          Zt[(size_t)i * ldz + k] = z;
+          nrm2 += z * z;
+        }
+      }
     }
     z = 1.0;
     Zt[(size_t)rtw * ldz + k] = 1.0;
-    for (int i = rtw; i < n - 1; ++i) {
-      z = -(ee[i] / Dm[(size_t)(i + 1) * ldd + k]) * z;
-      Zt[(size_t)(i + 1) * ldz + k] = z;
-      nrm2 += z * z;
+    for (int ib = rtw; ib < n - 1; ib += TE_PF) {
+      double dml[TE_PF];
+#pragma unroll
+      for (int u = 0; u < TE_PF; ++u) dml[u] = Dm[(size_t)min(ib + u + 1, n - 1) * ldd + k];
+#pragma unroll
+      for (int u = 0; u < TE_PF; ++u) {
+        const int i = ib + u;
+        if (i < n - 1) {
+          z = -(ee[i] / dml[u]) * z;
+          Zt[(size_t)(i + 1) * ldz + k] = z;
+          nrm2 += z * z;
+        }
+      }
     }
     lamo[k] = lam;
     const double sc = 1.0 / sqrt(nrm2 * fabs(lam));
@@ -327,9 +421,17 @@ __global__ __launch_bounds__(256) void k_tri_transpose(const double *__restrict_
   }
 }
 
-// U0 = H_0 H_1 ... H_{n-2} Z, column by column: 16 lanes per column (row = sub + 16 t), 32 columns per workgroup, the reflectors
-// staged through LDS eight at a time.  Reflector j lives in column j of A (rows j+1.., v[j+1] = 1), tau_j at A[j][j].
-constexpr int TBK_NT = 512, TBK_RM = 32, TBK_CH = 8;
+// U0 = H_0 H_1 ... H_{n-2} Z, column by column: 16 lanes per column (row = sub + 16 t, RM rows a lane), 32 columns per workgroup, the
+// reflectors staged through LDS eight at a time, zero above their first row and padded to 16 RM rows -- so the dot product and
+// the update run over all RM rows without a predicate.  Reflector j lives in column j of A (rows j+1.., v[j+1] = 1), tau_j at A[j][j].
+constexpr int TBK_NT = 512, TBK_CH = 8;
+template <int CTRL>
+__device__ __forceinline__ double tr_dpp_swap(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int RM>
 __global__ __launch_bounds__(TBK_NT) void k_tri_back(const double *__restrict__ Aall, size_t sA, int lda, double *__restrict__ Zall,
                                                      size_t sZ, int ldz, int n, const int32_t *__restrict__ cflag,
                                                      const int32_t *__restrict__ pflag) {
@@ -342,12 +444,15 @@ __global__ __launch_bounds__(TBK_NT) void k_tri_back(const double *__restrict__ 
   const int col = blockIdx.x * 32 + grp;
   const bool creal = col < n;
   const int nr = (n - sub + 15) >> 4;
-  const int nl = (n + 15) & ~15;
+  constexpr int nl = 16 * RM;
   double *taus = tbs + 2 * TBK_CH * nl;
-  double x[TBK_RM];
+  double x[RM];
   double *zc = Z + (size_t)min(col, n - 1) * ldz + sub;
 #pragma unroll
-  for (int t = 0; t < TBK_RM; ++t) x[t] = (t < nr && creal) ? zc[16 * t] : 0.0;
+  for (int t = 0; t < RM; ++t) {
+    const double z = zc[16 * min(t, nr - 1)];
+    x[t] = (t < nr && creal) ? z : 0.0;
+  }
   const int nref = n - 1;                                  // reflectors 0 .. n-2
   const int nch = (nref + TBK_CH - 1) / TBK_CH;
   auto stage = [&](int ch, int buf) {                      // reflectors jhi-1 .. jhi-TBK_CH (descending), jhi = nref - ch * TBK_CH
@@ -365,31 +470,30 @@ __global__ __launch_bounds__(TBK_NT) void k_tri_back(const double *__restrict__ 
     const int buf = ch & 1;
     if (ch + 1 < nch) stage(ch + 1, buf ^ 1);
     const double *vb = tbs + (size_t)buf * TBK_CH * nl + sub;
-    const int jhi = nref - ch * TBK_CH;
-#pragma unroll 1
-    for (int u = 0; u < TBK_CH; ++u) {
-      const int j = jhi - 1 - u;
-      if (j < 0) break;
+#pragma unroll 2
+    for (int u = 0; u < TBK_CH; ++u) {                     // (a reflector past the first is all zeros with tau = 0: harmless)
       const double *vj = vb + (size_t)u * nl;
-      const int t0 = max(0, (j + 1 - sub + 15) >> 4);      // first t with row sub + 16 t >= j + 1
-      double dot = 0.0;
+      double vv[RM];
 #pragma unroll
-      for (int t = 0; t < TBK_RM; ++t)
-        if (t >= t0 && t < nr) dot = __builtin_fma(vj[16 * t], x[t], dot);
-      dot += __shfl_xor(dot, 1, 64);
-      dot += __shfl_xor(dot, 2, 64);
-      dot += __shfl_xor(dot, 4, 64);
-      dot += __shfl_xor(dot, 8, 64);
+      for (int t = 0; t < RM; ++t) vv[t] = vj[16 * t];
+      double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+      for (int t = 0; t + 1 < RM; t += 2) { d0 = __builtin_fma(vv[t], x[t], d0); d1 = __builtin_fma(vv[t + 1], x[t + 1], d1); }
+      if (RM & 1) d0 = __builtin_fma(vv[RM - 1], x[RM - 1], d0);
+      double dot = d0 + d1;
+      dot += tr_dpp_swap<0xB1>(dot);
+      dot += tr_dpp_swap<0x4E>(dot);
+      dot += tr_dpp_swap<0x141>(dot);
+      dot += tr_dpp_swap<0x140>(dot);
       const double f = -taus[buf * TBK_CH + u] * dot;
 #pragma unroll
-      for (int t = 0; t < TBK_RM; ++t)
-        if (t >= t0 && t < nr) x[t] = __builtin_fma(f, vj[16 * t], x[t]);
+      for (int t = 0; t < RM; ++t) x[t] = __builtin_fma(f, vv[t], x[t]);
     }
     __syncthreads();
   }
   if (creal) {
 #pragma unroll
-    for (int t = 0; t < TBK_RM; ++t)
+    for (int t = 0; t < RM; ++t)
       if (t < nr) zc[16 * t] = x[t];
   }
 }
@@ -443,20 +547,21 @@ __global__ void k_tri_check(const double *__restrict__ Fall, size_t sF, int ldf,
 size_t sf_wtri_small_bytes(int p, int nb) { return sf_align((size_t)nb * 4 * ((p + 15) & ~15) * sizeof(double)); }
 
 int sf_launch_wtri_prepare(double *gv, int p, int p2, int nb, double *B2, double *B3, double *small, const int32_t *cflag,
-                           int32_t *pflag, hipStream_t st) {
+                           int32_t *pflag, hipStream_t st, int gbn, size_t gstride) {
+  if (gbn <= 0) { gbn = nb; gstride = 0; }
   if (p > TR_NT || p < 4) { sf_set_error("tridiagonal preconditioner: %d bands unsupported", p); return -2; }
   const size_t sG = (size_t)2 * p2 * p2, sB = (size_t)p * p;
   const int pl = (p + 15) & ~15;
   const size_t sS = (size_t)4 * pl;
   double *A1 = gv + (size_t)p2 * p2;
-  hipLaunchKernelGGL(k_tri_copy, dim3(64, nb), dim3(256), 0, st, gv, sG, p2, A1, sG, p2, p, cflag);
+  hipLaunchKernelGGL(k_tri_copy, dim3(64, nb), dim3(256), 0, st, gv, sG, p2, A1, sG, p2, p, cflag, gbn, gstride);
   SF_LAUNCH_CHECK("k_tri_copy");
-  const size_t lds1 = ((size_t)2 * TR_NB * p + (2 * TR_NB + 2) * 8 + 8) * sizeof(double);
+  const size_t lds1 = ((size_t)2 * TR_NB * p + (2 * TR_NB + 2) * 8 + 8 + (size_t)(TR_NT / 64) * p) * sizeof(double);
   if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_tridiag), lds1)) return rc;
-  hipLaunchKernelGGL(k_tridiag, dim3(nb), dim3(TR_NT), lds1, st, A1, sG, p2, p, small, sS, pl, cflag);
+  hipLaunchKernelGGL(k_tridiag, dim3(nb), dim3(TR_NT), lds1, st, A1, sG, p2, p, small, sS, pl, cflag, gbn, gstride);
   SF_LAUNCH_CHECK("k_tridiag");
   const size_t lds2 = (size_t)3 * pl * sizeof(double);
-  hipLaunchKernelGGL(k_tri_eig, dim3(nb), dim3(TE_NT), lds2, st, small, sS, p, B3, sB, p, B2, sB, p, pl, cflag, pflag);
+  hipLaunchKernelGGL(k_tri_eig, dim3(nb), dim3(TE_NT), lds2, st, small, sS, p, B3, sB, p, B2, sB, p, pl, cflag, pflag, gbn, gstride);
   SF_LAUNCH_CHECK("k_tri_eig");
   return 0;
 }
@@ -471,9 +576,16 @@ int sf_launch_wtri_apply(double *gv, int p, int p2, int nb, double *B2, double *
   const int nt = sf_cdiv(p, 32);
   hipLaunchKernelGGL(k_tri_transpose, dim3(nt, nt, nb), dim3(256), 0, st, B3, sB, p, B2, sB, p, p, small, sS, pl, cflag, pflag);
   SF_LAUNCH_CHECK("k_tri_transpose");
-  const size_t lds3 = ((size_t)2 * TBK_CH * pl + 2 * TBK_CH) * sizeof(double);
-  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_tri_back), lds3)) return rc;
-  hipLaunchKernelGGL(k_tri_back, dim3(sf_cdiv(p, 32), nb), dim3(TBK_NT), lds3, st, A1, sG, p2, B2, sB, p, p, cflag, pflag);
+#define TBK_GO(RM)                                                                                                              \
+  {                                                                                                                             \
+    const size_t lds3 = ((size_t)2 * TBK_CH * 16 * RM + 2 * TBK_CH) * sizeof(double);                                           \
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_tri_back<RM>), lds3)) return rc;                                  \
+    hipLaunchKernelGGL(k_tri_back<RM>, dim3(sf_cdiv(p, 32), nb), dim3(TBK_NT), lds3, st, A1, sG, p2, B2, sB, p, p, cflag, pflag); \
+  }
+  const int rm = sf_cdiv(p, 16);
+  if (rm <= 12) TBK_GO(12) else if (rm <= 16) TBK_GO(16) else if (rm <= 20) TBK_GO(20) else if (rm <= 24) TBK_GO(24)
+  else if (rm <= 27) TBK_GO(27) else TBK_GO(32)
+#undef TBK_GO
   SF_LAUNCH_CHECK("k_tri_back");
   // W (B3) = L^T U0s
   if (int rc = sf_wide_dgemm(B2, p, sB, gv, p2, sG, 1, B3, p, sB, p, nb, cflag, pflag, st)) return rc;
@@ -540,7 +652,7 @@ int sf_debug_wtri(const double *R, const double *Lc, int p, int nb, double *F, d
   SF_HIP(hipMemsetAsync(cflag, 0, (size_t)2 * nb * sizeof(int32_t), st));
   const size_t sG = (size_t)2 * p2 * p2;
   hipLaunchKernelGGL(k_tri_load, dim3(64, nb), dim3(256), 0, st, R, p, gv, sG, p2);
-  if (int rc = sf_launch_wtri_prepare(gv, p, p2, nb, B2, B3, small, cflag, pflag, st)) return rc;
+  if (int rc = sf_launch_wtri_prepare(gv, p, p2, nb, B2, B3, small, cflag, pflag, st, 0, 0)) return rc;
   hipLaunchKernelGGL(k_tri_load, dim3(64, nb), dim3(256), 0, st, Lc, p, gv, sG, p2);
   if (int rc = sf_launch_wtri_apply(gv, p, p2, nb, B2, B3, small, cflag, pflag, st)) return rc;
   hipLaunchKernelGGL(k_tri_store, dim3(64, nb), dim3(256), 0, st, gv, sG, p2, p, F);

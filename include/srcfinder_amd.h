@@ -198,6 +198,9 @@ int sf_debug_wsweep_stamps(unsigned long long *out8, int reset);
  * replaces the 201 det / inv of cmf/robust_mf.py:105-117 on windows of more than 96 bands): R [nb][p][p] symmetric positive
  * definite, Lc [nb][p][p] its lower Cholesky factor in column-major order -> F [nb][p][p] column-major with F F^T = R and nearly
  * orthogonal columns, tlam [nb][p] the tridiagonal route's eigenvalues, pflag [nb] 0 where the preconditioner was applied */
+/* phase clocks of the tridiagonalisation's workgroup 0: out8 = cycles in the reflector, the symv, the corrections, the trailing
+ * update, then the number of columns */
+int sf_debug_wtri_stamps(unsigned long long *out8, int reset);
 size_t sf_debug_wtri_scratch_bytes(int p, int nb);
 int sf_debug_wtri(const double *R, const double *Lc, int p, int nb, double *F, double *tlam, int32_t *pflag, void *scratch,
                   void *stream);

@@ -1285,7 +1285,7 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac<RM>), lds)) return rc;                                    \
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac_x<RM>), ldsx)) return rc;                                 \
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac_q<RM>), lds)) return rc;                                  \
-    for (int sweep = 0; sweep < 16; ++sweep) { /* converged matrices drop out by their flag; no host round trip */               \
+    for (int sweep = 0; sweep < nsweeps; ++sweep) { /* converged matrices drop out by their flag; no host round trip */          \
       /* (10-12 sweeps on flightline-like spectra; a matrix still rotating after 16 is redone by k_eigh_global, mode 2) */        \
       hipLaunchKernelGGL(k_blockjac<RM>, dim3(mblk / 2 > 0 ? mblk / 2 : 1, nb), dim3(BJ_NT), lds, st, gv, p2, LDr, nblk,         \
                          mblk > 1 ? mblk : 2, 0, cflag, done, rot);                                                              \
@@ -1301,6 +1301,10 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
       hipLaunchKernelGGL(k_blockjac_flags, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, done, rot);                             \
     }                                                                                                                            \
   }
+  // behind the preconditioner a matrix needs one sweep (two or three if its preconditioner was poor); one without it -- a flagged
+  // preconditioner -- 11-12: the launches of the sweeps nobody needs are ~4.5 us each, 15 a sweep; a matrix still rotating after
+  // the last sweep is redone by k_eigh_global (mode 2)
+  const int nsweeps = precond ? 12 : 16;
   // quad visits (k_blockjac_q): the default whenever there are at least two super-blocks; sf_debug_set(10, 5): the pair visits
   const int msb = mblk / 2, msbE = msb + (msb & 1);
   const bool quad = msb >= 2 && sf_tune().wide_eigh_variant != 5;

@@ -87,6 +87,7 @@ __global__ void k_tri_copy(const double *__restrict__ G, size_t sG, int ldg, dou
 // turn comes, p = A v reads the stale trailing matrix and is corrected by V (W^T v) + W (V^T v); after the panel the rank-16
 // update A -= V W^T + W V^T is applied to the rows / columns behind it.  Traffic: the trailing matrix once per column (the symv)
 // plus once per panel -- served by the Infinity Cache for a group of ~150 matrices.
+__device__ unsigned long long g_tr_stamps[8];   // phase clocks of workgroup 0 (sf_debug_wtri_stamps): reflector, symv, corrections, update
 __global__ __launch_bounds__(TR_NT) void k_tridiag(double *__restrict__ Aall, size_t sA, int ld, int n, double *__restrict__ deall,
                                                    size_t sDE, int pl, const int32_t *__restrict__ cflag, int gbn, size_t gstride) {
   extern __shared__ __attribute__((aligned(16))) double trs[];
@@ -108,6 +109,9 @@ __global__ __launch_bounds__(TR_NT) void k_tridiag(double *__restrict__ Aall, si
     const int nbp = min(TR_NB, n - 1 - j0);
     for (int i = 0; i < nbp; ++i) {
       const int j = j0 + i;
+      unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
+      const bool stampw = blockIdx.x == 0 && tid == 0;
+      if (stampw) tq0 = __builtin_readcyclecounter();
       // (a) column j brought up to date (rows >= j)
       double a = 0.0;
       if (rin && r >= j) {
@@ -136,6 +140,7 @@ __global__ __launch_bounds__(TR_NT) void k_tridiag(double *__restrict__ Aall, si
       }
       __syncthreads();
       // (c) p = A_stale v over rows / columns >= j + 1, and (d) the partial dots W_t . v, V_t . v of the correction
+      if (stampw) tq1 = __builtin_readcyclecounter();
       //     The symv is latency-bound if a thread walks its row alone (8 loads in flight); so wave w takes the columns
       //     k = j + 1 + w (mod 8), its lanes the rows lane + 64 m of every row group still alive: 6 x 7 loads in flight per lane,
       //     the eight partial sums of a row meet in LDS.  (Reading only the lower triangle -- a = A[r][k] serving p_r and p_k --
@@ -179,6 +184,7 @@ __global__ __launch_bounds__(TR_NT) void k_tridiag(double *__restrict__ Aall, si
 #pragma unroll
         for (int w = 0; w < TR_NT / 64; ++w) p += part[w * nl + r];
       }
+      if (stampw) tq2 = __builtin_readcyclecounter();
       double dots[2 * TR_NB];
 #pragma unroll
       for (int t = 0; t < TR_NB; ++t) {
@@ -198,10 +204,43 @@ __global__ __launch_bounds__(TR_NT) void k_tridiag(double *__restrict__ Aall, si
       const double al2 = -0.5 * tau * s2[0];
       if (rin) W[i * nl + r] = (r >= j + 1) ? p + al2 * v : 0.0;
       __syncthreads();
+      if (stampw) {
+        tq3 = __builtin_readcyclecounter();
+        g_tr_stamps[0] += tq1 - tq0; g_tr_stamps[1] += tq2 - tq1; g_tr_stamps[2] += tq3 - tq2; g_tr_stamps[4] += 1;
+      }
     }
-    // the rank-2nb update of what lies behind the panel: rows and columns >= j0 + nbp (both triangles)
+    unsigned long long tu0 = 0;
+    if (blockIdx.x == 0 && tid == 0) tu0 = __builtin_readcyclecounter();
+    // the rank-2nb update of what lies behind the panel: rows and columns >= j0 + nbp (both triangles).  On the matrix cores:
+    // as scalar code every multiply-add fetched a broadcast value of V / W from LDS and the update -- 16 flops per element --
+    // was LDS-issue-bound at 360 k cycles a panel, 85 % of the kernel.  A 16 x 16 tile of A^T (the block is symmetric: rows
+    // and columns swap roles so that a lane's four elements are 16-lane contiguous runs of a column) takes four
+    // v_mfma_f64_16x16x4 with operands X = [V W], Y = [W V] read conflict-free from the t-major LDS panels.
     const int c1 = j0 + nbp;
-    if (c1 < n) {
+    if (c1 < n && nbp == TR_NB && n - c1 > 16) {
+      typedef double d4_t __attribute__((ext_vector_type(4)));
+      const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+      const int nt = (n - c1 + 15) >> 4;
+      for (int q = wave; q < nt * nt; q += TR_NT / 64) {
+        const int tc = q / nt, trw = q - tc * nt;
+        const int C0 = c1 + 16 * tc, R0 = c1 + 16 * trw;
+        const int row = R0 + li;
+        d4_t acc;
+        double *ap = A + (size_t)(C0 + g) * ld + row;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = (row < n && C0 + g + 4 * e < n) ? ap[(size_t)4 * e * ld] : 0.0;
+        const int ci = min(C0 + li, n - 1), ri = min(row, n - 1);
+        // D'[m = column g + 4 e][n = row li] -= sum_k Y[C0 + m][k] X[R0 + n][k]; A' operand: lane (g, li) = -Y[C0 + li][k0 + g],
+        // B' operand: lane (g, li) = X[R0 + li][k0 + g]; X[r][k] = k < 8 ? V[k][r] : W[k - 8][r], Y[c][k] = k < 8 ? W[k][c] : V[k - 8][c]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[g * nl + ci], V[g * nl + ri], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[(4 + g) * nl + ci], V[(4 + g) * nl + ri], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-V[g * nl + ci], W[g * nl + ri], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-V[(4 + g) * nl + ci], W[(4 + g) * nl + ri], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (row < n && C0 + g + 4 * e < n) ap[(size_t)4 * e * ld] = acc[e];
+      }
+    } else if (c1 < n) {
       double vr[TR_NB], wr[TR_NB];
 #pragma unroll
       for (int t = 0; t < TR_NB; ++t) {
@@ -210,20 +249,7 @@ __global__ __launch_bounds__(TR_NT) void k_tridiag(double *__restrict__ Aall, si
       }
       if (rin && r >= c1) {
         double *ar = A + r;
-        int c = c1;
-        for (; c + 8 <= n; c += 8) {
-          double x[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) x[u] = ar[(size_t)(c + u) * ld];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            double acc = x[u];
-#pragma unroll
-            for (int t = 0; t < TR_NB; ++t) acc -= vr[t] * W[t * nl + c + u] + wr[t] * V[t * nl + c + u];
-            ar[(size_t)(c + u) * ld] = acc;
-          }
-        }
-        for (; c < n; ++c) {
+        for (int c = c1; c < n; ++c) {
           double acc = ar[(size_t)c * ld];
 #pragma unroll
           for (int t = 0; t < TR_NB; ++t) acc -= vr[t] * W[t * nl + c] + wr[t] * V[t * nl + c];
@@ -233,6 +259,7 @@ __global__ __launch_bounds__(TR_NT) void k_tridiag(double *__restrict__ Aall, si
     }
     __syncthreads();
     __threadfence_block();
+    if (blockIdx.x == 0 && tid == 0) g_tr_stamps[3] += __builtin_readcyclecounter() - tu0;
   }
   // the last diagonal element (no reflector past column n - 2; its column was updated as part of the last panel's trailing
   // block, or, when the last panel ended at n - 1, is row n - 1 of the stale matrix corrected here)
@@ -628,6 +655,14 @@ __global__ void k_tri_store_small(const double *__restrict__ small, size_t sS, i
 }
 }  // namespace
 
+extern "C" int sf_debug_wtri_stamps(unsigned long long *out8, int reset) {
+  if (out8) SF_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tr_stamps), 8 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    SF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tr_stamps), z, sizeof(z)));
+  }
+  return 0;
+}
 extern "C" {
 /* Test entry of the tridiagonal preconditioner (tests/test_cmf_gpu.py): R [nb][p][p] symmetric positive definite, Lc [nb][p][p] its
  * lower Cholesky factor in COLUMN-major order (zeros above the diagonal); F [nb][p][p] column-major <- the preconditioned factor

@@ -96,11 +96,20 @@ __device__ void lu_factor(double *A, int n, int *piv, double *det_out, int *info
 // system for its column of U in registers and applies the rank-16 update to its column, reading the L rows as LDS
 // broadcasts.  Neither L nor the rows of U are written back: only the running product of the pivots is wanted.
 // Same pivoting rule (first row of maximal magnitude) and the same left-to-right product as lu_factor.
-constexpr int LB_NT = 512, LB_NB = 16, LB_LD = 18;
-static size_t lb_lds_bytes(int n) { return (size_t)n * LB_LD * sizeof(double) + (size_t)n * sizeof(int) + 64 * sizeof(int); }
+// MF (n <= LB_MF_MAX: the 16 rows of U fit LDS beside the panel): the rank-16 update on the matrix cores.  As scalar code every
+// multiply-add fetched a broadcast L value from LDS -- 16 per element: the update was LDS-issue-bound and the pass one LU per
+// 1.5 ms and CU.  Here a thread still permutes and solves its column of U, puts it into LDS, and the waves then take 16 x 16 tiles
+// of the trailing block with four v_mfma_f64_16x16x4 each (A operand -L, B operand U).
+constexpr int LB_NT = 512, LB_NB = 16, LB_LD = 18, LB_MF_MAX = 560;
+static size_t lb_lds_bytes(int n) {
+  return (size_t)n * LB_LD * sizeof(double) + (n <= LB_MF_MAX ? (size_t)LB_NB * n * sizeof(double) : 0) + (size_t)n * sizeof(int) +
+         64 * sizeof(int);
+}
 static bool lb_fits(int n) { return lb_lds_bytes(n) <= 150 * 1024; }
 
-__device__ void lu_det_blocked(double *__restrict__ A, int n, double *det_out, double *pan, int *rowof, int *plist) {
+template <bool MF>
+__device__ void lu_det_blocked(double *__restrict__ A, int n, double *det_out, double *pan, int *rowof, int *plist,
+                               double *Us = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int info = 0, nswap = 0;
   double det = 1.0;
@@ -174,6 +183,11 @@ __device__ void lu_det_blocked(double *__restrict__ A, int n, double *det_out, d
 #pragma unroll
         for (int sx = 0; sx < t; ++sx)
           if (t < nc) u[t] = __builtin_fma(-pan[t * LB_LD + sx], u[sx], u[t]);
+      if (MF) {
+#pragma unroll
+        for (int t = 0; t < LB_NB; ++t) Us[t * n + jc] = u[t];
+        continue;
+      }
       int r = nc;
       for (; r + 4 <= H; r += 4) {
         double a0 = col[(size_t)r * n], a1 = col[(size_t)(r + 1) * n], a2 = col[(size_t)(r + 2) * n], a3 = col[(size_t)(r + 3) * n];
@@ -193,6 +207,27 @@ __device__ void lu_det_blocked(double *__restrict__ A, int n, double *det_out, d
         col[(size_t)r * n] = a0;
       }
     }
+    if (MF && rest > 0 && H > nc) {
+      __syncthreads();   // U's rows are in LDS, the right part's rows are permuted
+      typedef double d4_t __attribute__((ext_vector_type(4)));
+      const int g = lane >> 4, li = lane & 15;
+      const int nrt = (H - nc + 15) >> 4, nct = (rest + 15) >> 4;
+      for (int q = wave; q < nrt * nct; q += LB_NT / 64) {
+        const int tr = q / nct, tc = q - tr * nct;
+        const int R0 = nc + 16 * tr, C0 = 16 * tc, cc = C0 + li;
+        double *ap = A + (size_t)(k0 + R0 + g) * n + k1 + cc;
+        d4_t acc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = (R0 + g + 4 * e < H && cc < rest) ? ap[(size_t)4 * e * n] : 0.0;
+        const double *lp = pan + (size_t)min(R0 + li, H - 1) * LB_LD + g;
+        const double *up = Us + (size_t)g * n + min(cc, rest - 1);
+#pragma unroll
+        for (int kk = 0; kk < LB_NB; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lp[kk], up[(size_t)kk * n], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (R0 + g + 4 * e < H && cc < rest) ap[(size_t)4 * e * n] = acc[e];
+      }
+    }
     __syncthreads();
   }
   if (tid == 0 && det_out) *det_out = info ? 0.0 : ((nswap & 1) ? -det : det);
@@ -210,12 +245,15 @@ __global__ __launch_bounds__(LU_NT) void k_lu_det(const double *__restrict__ A, 
 __global__ __launch_bounds__(LB_NT) void k_lu_det_blocked(const double *__restrict__ A, int n, double *__restrict__ work,
                                                           double *__restrict__ det) {
   extern __shared__ __attribute__((aligned(16))) double lb_lds[];
-  int *rowof = reinterpret_cast<int *>(lb_lds + (size_t)n * LB_LD);
+  const bool mf = n <= LB_MF_MAX;
+  double *Us = lb_lds + (size_t)n * LB_LD;
+  int *rowof = reinterpret_cast<int *>(Us + (mf ? (size_t)LB_NB * n : 0));
   const int b = blockIdx.x, tid = threadIdx.x;
   double *W = work + (size_t)b * n * n;
   for (size_t e = tid; e < (size_t)n * n; e += LB_NT) W[e] = A[(size_t)b * n * n + e];
   __syncthreads();
-  lu_det_blocked(W, n, det + b, lb_lds, rowof, rowof + n);
+  if (mf) lu_det_blocked<true>(W, n, det + b, lb_lds, rowof, rowof + n, Us);
+  else lu_det_blocked<false>(W, n, det + b, lb_lds, rowof, rowof + n);
 }
 
 // inverse from the factors: solve (P A) X = P I column by column (forward with unit L, backward with U)
@@ -417,7 +455,9 @@ __global__ __launch_bounds__(LB_NT) void k_det_grid_blocked(const double *__rest
                                                             int job0, double *__restrict__ work, double *__restrict__ det,
                                                             const double *__restrict__ target) {
   extern __shared__ __attribute__((aligned(16))) double lb_lds[];
-  int *rowof = reinterpret_cast<int *>(lb_lds + (size_t)p * LB_LD);
+  const bool mf = p <= LB_MF_MAX;
+  double *Us = lb_lds + (size_t)p * LB_LD;
+  int *rowof = reinterpret_cast<int *>(Us + (mf ? (size_t)LB_NB * p : 0));
   const int slot = blockIdx.x, tid = threadIdx.x;
   const int nj = min(*njobs, job0);                  // (job0 carries the capacity of the job list)
   double *G = work + (size_t)slot * p * p;
@@ -436,7 +476,8 @@ __global__ __launch_bounds__(LB_NT) void k_det_grid_blocked(const double *__rest
       G[e] = gij;
     }
     __syncthreads();
-    lu_det_blocked(G, p, det + jb, lb_lds, rowof, rowof + p);
+    if (mf) lu_det_blocked<true>(G, p, det + jb, lb_lds, rowof, rowof + p, Us);
+    else lu_det_blocked<false>(G, p, det + jb, lb_lds, rowof, rowof + p);
     __syncthreads();
   }
 }

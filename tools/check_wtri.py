@@ -31,7 +31,14 @@ for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     _ffi.check(L.sf_debug_wtri(P(Rt), P(Lt), p, nb, P(F), P(tl), P(pf), P(ws), st), "wtri")
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print("p = %d, %d matrices: %.2f ms per call; flags %s" % (p, nb, dt * 1e3, pf.cpu().numpy().tolist()))
+print("p = %d, %d matrices: %.2f ms per call; flags %s" % (p, nb, dt * 1e3, pf.cpu().numpy().tolist()[:8]))
+import ctypes
+buf = (ctypes.c_ulonglong * 8)()
+L.sf_debug_wtri_stamps(buf, 1)
+_ffi.check(L.sf_debug_wtri(P(Rt), P(Lt), p, nb, P(F), P(tl), P(pf), P(ws), st), "wtri"); torch.cuda.synchronize()
+L.sf_debug_wtri_stamps(buf, 1)
+v = list(buf)
+print("tridiagonalisation, workgroup 0: cycles in reflector %d  symv %d  corrections %d  trailing updates %d  (%d columns)" % (v[0], v[1], v[2], v[3], v[4]))
 Fh = F.cpu().numpy(); tlh = tl.cpu().numpy()
 for m in range(min(nb, 4)):
     Fm = Fh[m].T                                # column-major buffer -> matrix

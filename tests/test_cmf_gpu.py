@@ -1126,13 +1126,14 @@ def test_cli_multimodal_flags_reach_the_device_path(torch_cuda, tmp_path, librar
 
 
 def test_wide_eigensolver_variants_agree(torch_cuda, golden_dir, library):
-    """The blocked eigensolver of the wide path (default), the single-workgroup kernel it replaced (debug key 10 = 1) and
-    the Gram-space / MFMA forms of round 4 (cmf_wjac.hip, key 10 = 3 / 4) give the same product on the reference's
-    reflectance configuration (p = 416): alpha indices exact, scores 1e-9."""
+    """The blocked eigensolver of the wide path behind its tridiagonal preconditioner (default), the same sweeps from the plain
+    Cholesky factor (debug key 10 = 6), the single-workgroup kernel it replaced (1) and the Gram-space / MFMA forms of round 4
+    (cmf_wjac.hip, 3 / 4) give the same product on the reference's reflectance configuration (p = 416): alpha indices exact,
+    scores 1e-9."""
     L = _ffi.lib()
     cube = make_cube_numpy(300, 5, seed=4, abscf_full=library[:, 2], nodata_column=2)
     a = cmf.robust_mf(cube, library, reflectance=True, to_numpy=True)
-    for variant in (1, 3, 4, 5):          # (5: round 3's pair visits instead of the quad visits)
+    for variant in (1, 3, 4, 5, 6):       # (5: round 3's pair visits instead of the quad visits; 6: no tridiagonal preconditioner)
         L.sf_debug_set(10, variant)
         try:
             b = cmf.robust_mf(cube, library, reflectance=True, to_numpy=True)
@@ -1197,6 +1198,46 @@ def test_wide_sweep_forms_agree(torch_cuda, p):
     finally:
         L.sf_debug_set(24, 0)
     assert out[0]["status"][3] == 1 and (np.delete(out[0]["status"], 3) == 0).all()
+
+
+@pytest.mark.parametrize("p,decades", [(130, 2.0), (425, 2.0), (300, 6.0), (512, 3.0)])
+def test_wide_tridiagonal_preconditioner(torch_cuda, p, decades):
+    """csrc/cmf_wtri.hip through its test entry: for correlation matrices R = L L^T (benchmark-like and with a spectrum spread over
+    `decades` more orders of magnitude) the preconditioned factor F satisfies F F^T = R to rounding (what keeps the eigensolver's
+    accuracy the Jacobi's: F = L W' with W' orthogonal to rounding) and has nearly orthogonal columns (what saves the sweeps);
+    the tridiagonal route's eigenvalues agree with numpy's to ~1e-9 (their own accuracy is not part of the product)."""
+    import torch
+    L = _ffi.lib()
+    rng = np.random.default_rng(1000 + p)
+    nb, n = 3, 3000
+    Rs, Ls = [], []
+    for m in range(nb):
+        b = (5.0 * np.exp(-3.0 * np.arange(p) / (p - 1)) + 0.2) * 10.0 ** (-0.5 * decades * np.arange(p) / (p - 1))
+        lm = rng.standard_normal((5, p)) * 0.1 * b
+        x = b + rng.standard_normal((n, 5)) @ lm + rng.standard_normal((n, p)) * 0.01 * b
+        x = np.float64(np.float32(x)); x -= x.mean(0)
+        S = x.T @ x / (n - 1); d = np.sqrt(np.diag(S)); R = S / np.outer(d, d); R = 0.5 * (R + R.T)
+        Rs.append(R); Ls.append(np.linalg.cholesky(R))
+    R = np.stack(Rs); Lc = np.stack([l.T.copy() for l in Ls])
+    dev = torch.device("cuda:0")
+    Rt = torch.as_tensor(R, device=dev); Lt = torch.as_tensor(Lc, device=dev)
+    F = torch.empty((nb, p, p), dtype=torch.float64, device=dev); tl = torch.empty((nb, p), dtype=torch.float64, device=dev)
+    pf = torch.empty(nb, dtype=torch.int32, device=dev)
+    ws = torch.empty(L.sf_debug_wtri_scratch_bytes(p, nb), dtype=torch.uint8, device=dev)
+    _ffi.check(L.sf_debug_wtri(_ffi.ptr(Rt), _ffi.ptr(Lt), p, nb, _ffi.ptr(F), _ffi.ptr(tl), _ffi.ptr(pf), _ffi.ptr(ws),
+                               _ffi.stream_ptr()), "wtri")
+    torch.cuda.synchronize()
+    assert (pf.cpu().numpy() == 0).all()
+    Fh, tlh = F.cpu().numpy(), tl.cpu().numpy()
+    for m in range(nb):
+        Fm = Fh[m].T
+        assert np.abs(Fm @ Fm.T - R[m]).max() <= 5e-14
+        M = Fm.T @ Fm
+        nn = np.sqrt(np.diag(M))
+        C = M / np.outer(nn, nn) - np.eye(p)
+        assert np.abs(C).max() <= 1e-7, np.abs(C).max()          # (measured: 1e-11 .. 1e-9)
+        ref = np.linalg.eigvalsh(R[m])
+        np.testing.assert_allclose(tlh[m], ref, rtol=1e-7, atol=1e-13 * ref[-1])
 
 
 def test_multimodal_return_nll(torch_cuda, golden_dir, library):

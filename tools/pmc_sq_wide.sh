@@ -23,7 +23,7 @@ def load(path):
 sq, mf = load(sys.argv[1]), load(sys.argv[2])
 print("# rocprofv3 --pmc (two passes: SQ wave-cycle counters; MFMA busy) -- python3 bench.py --active 1,425 --steps 1 --warmup 1 --in-flight 1 ...")
 for k in sorted(sq):
-    if not any(x in k for x in ("k_wsweep", "k_wsyrk", "k_blockjac", "k_det_grid")): continue
+    if not any(x in k for x in ("k_wsweep", "k_wsyrk", "k_blockjac", "k_det_grid", "k_tri", "k_dgemm")): continue
     per = {c: sum(v.values()) / len(v) for c, v in sq[k].items()}
     wc = per.get("SQ_WAVE_CYCLES", 0.0)
     if wc < 1e6: continue

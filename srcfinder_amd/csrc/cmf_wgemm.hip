@@ -601,9 +601,6 @@ __global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restri
   const float *xc = xt + (size_t)c * L * ps;
   const uint8_t *mp = mask_t + (size_t)c * L;
   const int NKC = P16 / 16, NCC = NA / WS_CA;
-  // (the SIMD's arbiter favours its older wave: the waves of the lighter slices, 4-7, lagged 15 % behind 0-3 and every
-  //  exchange waited for them; at priority 1 they keep up -- 382 k -> 367 k cycles per tile)
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
   // the split's running (mantissa, exponent, sum, flag) of alpha 8 ch + wave live in lane ch of this wave's registers
   double Pv = 1.0, Sv = 0.0;
   int Ev = 0, Nv = 0;
@@ -705,6 +702,9 @@ __global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restri
     for (int s = 0; s < NKC; ++s, ++gs) {
       __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);   // vmcnt(0) (expcnt / lgkmcnt untouched): chunk s and its rows have landed
       asm volatile("" ::: "memory");
+      // (the SIMD's arbiter favours one of its two waves for as long as both are ready: the priority alternates chunk by chunk,
+      //  so both reach the end of the phase together)
+      if (((s ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
       glds(s + 1, gs + 1);                // (s + 1 == NKC: the first C chunk)
       if (s + 1 < NKC) xload(xb, s + 1, r0);
       const double *bs = bw0 + (gs & 1) * (NW * WSL);
@@ -755,6 +755,7 @@ __global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restri
       __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);
       asm volatile("" ::: "memory");
       if (probe) pk1 = __builtin_readcyclecounter();
+      if (wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (first half of the chunk; see J == JH below)
       if (ch + 1 < NCC) glds(NKC + ch + 1, gs + 1);
       double ra[NI], rb[NI];
       const double *bcol = bw0 + (gs & 1) * (NW * WSL) + q * WS_CA + n;
@@ -785,6 +786,8 @@ __global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restri
           ra[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[I][J], ca[J], ra[I], 0, 0, 0);
           rb[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[I][J], cb[J], rb[I], 0, 0, 0);
         }
+        if (J == JH) __builtin_amdgcn_s_setprio(0);   // every exchange waits for the SIMD's slower wave: the younger wave leads the
+                                                      // first half of a chunk, the older one the second, and they finish together
         if (J == 0) {
           const int t = wave >> 2, odd = chi & 1;
           rp = odd ? Bs + (size_t)t * NW * WSL + R2OFF : red + (size_t)t * NW * RW;   // partial of wave w: + w * rs

@@ -1206,7 +1206,10 @@ size_t sf_wide_scratch_bytes(const SfGeom &g) {
 int sf_wide_dgemm(const double *A, int lda, size_t sA, const double *B, int ldb, size_t sB, int tb, double *C, int ldc, size_t sC,
                   int n, int nb, const int32_t *skip1, const int32_t *skip2, hipStream_t st) {
   const dim3 grid(sf_cdiv(n, WD_BM), sf_cdiv(n, WD_BN), nb);
-  if (tb)
+  if (tb && A == B)   // C = Am^T Am: symmetric, the tiles above the diagonal are mirrored
+    hipLaunchKernelGGL((k_dgemm<false, false, true, true>), grid, dim3(256), 0, st, A, lda, sA, B, ldb, sB, C, ldc, sC, n, n, n, 1.0,
+                       skip1, skip2);
+  else if (tb)
     hipLaunchKernelGGL((k_dgemm<false, false, false, true>), grid, dim3(256), 0, st, A, lda, sA, B, ldb, sB, C, ldc, sC, n, n, n, 1.0,
                        skip1, skip2);
   else

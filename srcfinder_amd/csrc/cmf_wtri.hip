@@ -29,10 +29,23 @@ constexpr int TR_NB = 8;        // panel width
 constexpr int TR_MG = TR_NT / 64;   // row groups of 64 a lane may own in the symv
 constexpr int TR_CU = 6;            // columns a wave has in flight there (x 7 row groups: 42 loads per lane)
 
+template <int CTRL>
+__device__ __forceinline__ double tr_dpp_swap(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, the same value in every lane: DPP butterflies inside the rows of 16, the four rows by readlane (no
+// LDS crossbar round trips: the corrections of a tridiagonalisation step reduce up to 18 values)
 __device__ __forceinline__ double tr_wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += tr_dpp_swap<0xB1>(v);
+  v += tr_dpp_swap<0x4E>(v);
+  v += tr_dpp_swap<0x141>(v);
+  v += tr_dpp_swap<0x140>(v);
+  auto rdl = [](double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+  };
+  return (rdl(v, 0) + rdl(v, 16)) + (rdl(v, 32) + rdl(v, 48));
 }
 
 // block-wide sums of NV values per thread: partial sums per wave in red[NV][8], every thread gets the totals
@@ -452,12 +465,6 @@ __global__ __launch_bounds__(256) void k_tri_transpose(const double *__restrict_
 // reflectors staged through LDS eight at a time, zero above their first row and padded to 16 RM rows -- so the dot product and
 // the update run over all RM rows without a predicate.  Reflector j lives in column j of A (rows j+1.., v[j+1] = 1), tau_j at A[j][j].
 constexpr int TBK_NT = 512, TBK_CH = 8;
-template <int CTRL>
-__device__ __forceinline__ double tr_dpp_swap(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
 template <int RM>
 __global__ __launch_bounds__(TBK_NT) void k_tri_back(const double *__restrict__ Aall, size_t sA, int lda, double *__restrict__ Zall,
                                                      size_t sZ, int ldz, int n, const int32_t *__restrict__ cflag,
@@ -497,25 +504,37 @@ __global__ __launch_bounds__(TBK_NT) void k_tri_back(const double *__restrict__ 
     const int buf = ch & 1;
     if (ch + 1 < nch) stage(ch + 1, buf ^ 1);
     const double *vb = tbs + (size_t)buf * TBK_CH * nl + sub;
+    // the reflectors of this chunk are zero in rows 0 .. jlo: the row slots below (jlo + 1) / 16 are skipped, in steps of RM / 4
+    // (compile-time loop bounds: the column stays in registers)
+    const int jlo = max(nref - (ch + 1) * TBK_CH, 0);
+    auto run = [&](auto t0c) {
+      constexpr int T0 = decltype(t0c)::value;
 #pragma unroll 2
-    for (int u = 0; u < TBK_CH; ++u) {                     // (a reflector past the first is all zeros with tau = 0: harmless)
-      const double *vj = vb + (size_t)u * nl;
-      double vv[RM];
+      for (int u = 0; u < TBK_CH; ++u) {                   // (a reflector past the first is all zeros with tau = 0: harmless)
+        const double *vj = vb + (size_t)u * nl;
+        double vv[RM];
 #pragma unroll
-      for (int t = 0; t < RM; ++t) vv[t] = vj[16 * t];
-      double d0 = 0.0, d1 = 0.0;
+        for (int t = T0; t < RM; ++t) vv[t] = vj[16 * t];
+        double d0 = 0.0, d1 = 0.0;
 #pragma unroll
-      for (int t = 0; t + 1 < RM; t += 2) { d0 = __builtin_fma(vv[t], x[t], d0); d1 = __builtin_fma(vv[t + 1], x[t + 1], d1); }
-      if (RM & 1) d0 = __builtin_fma(vv[RM - 1], x[RM - 1], d0);
-      double dot = d0 + d1;
-      dot += tr_dpp_swap<0xB1>(dot);
-      dot += tr_dpp_swap<0x4E>(dot);
-      dot += tr_dpp_swap<0x141>(dot);
-      dot += tr_dpp_swap<0x140>(dot);
-      const double f = -taus[buf * TBK_CH + u] * dot;
+        for (int t = T0; t + 1 < RM; t += 2) { d0 = __builtin_fma(vv[t], x[t], d0); d1 = __builtin_fma(vv[t + 1], x[t + 1], d1); }
+        if ((RM - T0) & 1) d0 = __builtin_fma(vv[RM - 1], x[RM - 1], d0);
+        double dot = d0 + d1;
+        dot += tr_dpp_swap<0xB1>(dot);
+        dot += tr_dpp_swap<0x4E>(dot);
+        dot += tr_dpp_swap<0x141>(dot);
+        dot += tr_dpp_swap<0x140>(dot);
+        const double f = -taus[buf * TBK_CH + u] * dot;
 #pragma unroll
-      for (int t = 0; t < RM; ++t) x[t] = __builtin_fma(f, vv[t], x[t]);
-    }
+        for (int t = T0; t < RM; ++t) x[t] = __builtin_fma(f, vv[t], x[t]);
+      }
+    };
+    constexpr int Q = RM / 4;
+    const int tz = (jlo + 1) >> 4;
+    if (tz >= 3 * Q) run(std::integral_constant<int, 3 * Q>{});
+    else if (tz >= 2 * Q) run(std::integral_constant<int, 2 * Q>{});
+    else if (tz >= Q) run(std::integral_constant<int, Q>{});
+    else run(std::integral_constant<int, 0>{});
     __syncthreads();
   }
   if (creal) {

@@ -201,6 +201,9 @@ int sf_debug_wsweep_stamps(unsigned long long *out8, int reset);
 /* phase clocks of the tridiagonalisation's workgroup 0: out8 = cycles in the reflector, the symv, the corrections, the trailing
  * update, then the number of columns */
 int sf_debug_wtri_stamps(unsigned long long *out8, int reset);
+/* phase clocks of the blocked LU of the exact-determinant pass, workgroup 0: out8 = cycles in panel load, panel factorisation,
+ * permutation + triangular solve, rank-16 update, then the number of factorisations */
+int sf_debug_lu_stamps(unsigned long long *out8, int reset);
 size_t sf_debug_wtri_scratch_bytes(int p, int nb);
 int sf_debug_wtri(const double *R, const double *Lc, int p, int nb, double *F, double *tlam, int32_t *pflag, void *scratch,
                   void *stream);

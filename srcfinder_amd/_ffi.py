@@ -67,6 +67,7 @@ SIGNATURES = {
     "sf_debug_wtri_scratch_bytes": (sz, [i32, i32]),
     "sf_debug_wtri": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "sf_debug_wtri_stamps": (i32, [vp, i32]),
+    "sf_debug_lu_stamps": (i32, [vp, i32]),
     "sf_cmf_column_profile_robust": (i32, [vp, i32, i32, i32, i32, f64, f64, vp, vp]),
     "sf_cmf_column_profile": (i32, [vp, i32, i32, i32, i32, f64, vp, vp, vp]),
     "sf_masks_pixel": (i32, [vp, i32, i32, i32, i32, i32, f32, i32, i32, f32, f32, i32, f32, i32, f32, i32,

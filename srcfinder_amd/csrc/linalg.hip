@@ -96,6 +96,9 @@ __device__ void lu_factor(double *A, int n, int *piv, double *det_out, int *info
 // system for its column of U in registers and applies the rank-16 update to its column, reading the L rows as LDS
 // broadcasts.  Neither L nor the rows of U are written back: only the running product of the pivots is wanted.
 // Same pivoting rule (first row of maximal magnitude) and the same left-to-right product as lu_factor.
+// (A 425 x 425 factorisation alone on the chip, sf_debug_lu_stamps: 3.9 M cycles = panel 1.8 M -- 425 columns of pivot search by
+// wave 0 + elimination between two barriers --, permutation + solve 0.8 M, update 1.3 M.  A panel form with a thread per row, the
+// row in registers and a block-wide argmax was measured SLOWER (2.0 M) and dropped.)
 // MF (n <= LB_MF_MAX: the 16 rows of U fit LDS beside the panel): the rank-16 update on the matrix cores.  As scalar code every
 // multiply-add fetched a broadcast L value from LDS -- 16 per element: the update was LDS-issue-bound and the pass one LU per
 // 1.5 ms and CU.  Here a thread still permutes and solves its column of U, puts it into LDS, and the waves then take 16 x 16 tiles
@@ -107,6 +110,7 @@ static size_t lb_lds_bytes(int n) {
 }
 static bool lb_fits(int n) { return lb_lds_bytes(n) <= 150 * 1024; }
 
+__device__ unsigned long long g_lu_stamps[8];   // phase clocks of workgroup 0's factorisations: panel load, panel, solve, update, count
 template <bool MF>
 __device__ void lu_det_blocked(double *__restrict__ A, int n, double *det_out, double *pan, int *rowof, int *plist,
                                double *Us = nullptr) {
@@ -115,12 +119,16 @@ __device__ void lu_det_blocked(double *__restrict__ A, int n, double *det_out, d
   double det = 1.0;
   for (int k0 = 0; k0 < n; k0 += LB_NB) {
     const int nc = min(LB_NB, n - k0), H = n - k0, k1 = k0 + nc, rest = n - k1;
+    const bool stw = blockIdx.x == 0 && tid == 0;
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (stw) q0 = __builtin_readcyclecounter();
     for (int e = tid; e < H * LB_NB; e += LB_NT) {
       const int r = e >> 4, c = e & 15;
       pan[r * LB_LD + c] = (c < nc) ? A[(size_t)(k0 + r) * n + k0 + c] : 0.0;
     }
     for (int r = tid; r < H; r += LB_NT) rowof[r] = r;
     __syncthreads();
+    if (stw) q1 = __builtin_readcyclecounter();
     for (int j = 0; j < nc; ++j) {
       if (wave == 0) {
         double best = -1.0;
@@ -163,6 +171,7 @@ __device__ void lu_det_blocked(double *__restrict__ A, int n, double *det_out, d
       }
       __syncthreads();
     }
+    if (stw) q2 = __builtin_readcyclecounter();
     for (int jc = tid; jc < rest; jc += LB_NT) {
       double *col = A + (size_t)k0 * n + k1 + jc;        // column jc of the right part, panel row 0
       double u[LB_NB], moved[LB_NB];
@@ -209,6 +218,7 @@ __device__ void lu_det_blocked(double *__restrict__ A, int n, double *det_out, d
     }
     if (MF && rest > 0 && H > nc) {
       __syncthreads();   // U's rows are in LDS, the right part's rows are permuted
+      if (stw) q3 = __builtin_readcyclecounter();
       typedef double d4_t __attribute__((ext_vector_type(4)));
       const int g = lane >> 4, li = lane & 15;
       const int nrt = (H - nc + 15) >> 4, nct = (rest + 15) >> 4;
@@ -229,7 +239,12 @@ __device__ void lu_det_blocked(double *__restrict__ A, int n, double *det_out, d
       }
     }
     __syncthreads();
+    if (stw) {
+      const unsigned long long q4 = __builtin_readcyclecounter();
+      g_lu_stamps[0] += q1 - q0; g_lu_stamps[1] += q2 - q1; g_lu_stamps[2] += (q3 ? q3 : q4) - q2; g_lu_stamps[3] += q3 ? q4 - q3 : 0;
+    }
   }
+  if (blockIdx.x == 0 && tid == 0) g_lu_stamps[4] += 1;
   if (tid == 0 && det_out) *det_out = info ? 0.0 : ((nswap & 1) ? -det : det);
 }
 
@@ -586,6 +601,15 @@ int sf_launch_exact_det(const double *cov, const int32_t *nloo, const int32_t *s
   }
   hipLaunchKernelGGL(k_argmin_nan_first, dim3(g.ncols), dim3(64), 0, st, nll, status, g.ncols, g.nalpha, alphaidx);
   SF_LAUNCH_CHECK("k_argmin_nan_first");
+  return 0;
+}
+
+extern "C" int sf_debug_lu_stamps(unsigned long long *out8, int reset) {
+  if (out8) SF_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lu_stamps), 8 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    SF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_lu_stamps), z, sizeof(z)));
+  }
   return 0;
 }
 

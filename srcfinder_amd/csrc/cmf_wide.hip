@@ -1241,7 +1241,12 @@ static int wide_chol(double *gv, int p, int p2, int nb, int32_t *cflag, hipStrea
 // (unit: `cov` = the batch's nb whitened matrices, no diagonal scaling, d untouched -- the full-target route)
 // pre != nullptr: the tridiagonal preconditioner of cmf_wtri.hip between the Cholesky and the sweeps (work matrices and flags of
 // the group: pre->B2, B3 [nb][p^2], small, pflag)
-static bool wide_precond_on(int p) { return sf_tune().wide_eigh_variant == 0 && p >= 128; }
+// The preconditioner pays from ~32 matrices a call: its tridiagonalisation is 9 ms of LATENCY for any number of matrices up to ~150
+// (one workgroup each), the plain sweeps of a handful of matrices are launch-bound at ~6 ms.  sf_debug_set(10, 7) forces it.
+static bool wide_precond_on(int p, int ncols) {
+  const int v = sf_tune().wide_eigh_variant;
+  return p >= 128 && (v == 7 || (v == 0 && ncols >= 32));
+}
 // stage: 0 = all of it; 1 = only the work matrices (R, d, flags: k_eigh_global mode 3) -- the caller then runs the preconditioner's
 // first half over ALL groups at once (sf_launch_wtri_prepare) -- and 2 = the rest (Cholesky, second half, sweeps, finish)
 struct WidePre { double *B2, *B3, *small; int32_t *pflag; };
@@ -1258,7 +1263,7 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
     SF_LAUNCH_CHECK("k_eigh_global(prep)");
   }
   if (stage == 1) return 0;
-  const bool precond = pre && wide_precond_on(p);
+  const bool precond = pre && (stage == 2 || wide_precond_on(p, nb));
   if (precond && stage == 0)
     if (int rc = sf_launch_wtri_prepare(gv, p, p2, nb, pre->B2, pre->B3, pre->small, cflag, pre->pflag, st, 0, 0)) return rc;
   if (int rc = wide_chol(gv, p, p2, nb, cflag, st)) return rc;
@@ -1345,7 +1350,7 @@ static int wide_stats_fused(const void *xt, int xt_f64, const uint8_t *mask_t, c
   // Unimodal route with the tridiagonal preconditioner: covariances and work matrices of every group first, then the
   // preconditioner's first half (tridiagonalisation, bisection: latency-bound per workgroup) over ALL columns in one set of
   // launches, then group by group the Cholesky, the second half, the sweeps and the LOO sweep.  phase 0: one pass as before.
-  const bool phased = !target && wide_precond_on(p) && ngr > 1;
+  const bool phased = !target && wide_precond_on(p, g.ncols) && ngr > 1;
   for (int phase = phased ? 1 : 0; phase <= (phased ? 2 : 0); ++phase) {
   if (phase == 2) {
     char *g0 = base;

@@ -16,7 +16,7 @@ struct SfTune {
   int eigh_lpp = 0;           // key 7: lanes per column pair of the Jacobi eigensolver
   int sweep4r_waves = 8;      // key 8: waves per workgroup of the rank-factored sweep (k_sweep4r, form 1)
   int sweep4_form = 0;        // key 20: rank-28 sweep kernel: 0 = k_sweep4s (round 3: one streamed ring), 1 = k_sweep4r (round 2, both ranks), 3 = k_sweep4r for the rank-36 columns only, 4 = k_sweep4s renormalising after every tile; 100 + bits = timing experiments (-DSF_SWEEP_EXPERIMENTS)
-  int wide_eigh_variant = 0;  // key 10: 0 = blocked Jacobi behind the tridiagonal preconditioner (cmf_wtri.hip); 6 = the same sweeps from the Cholesky factor (round 4's first form: 11-12 sweeps); 1 = the single-workgroup eigensolver for every wide matrix, 5 = pair visits (k_blockjac_x, round 3) instead of the quad visits of round 4 (k_blockjac_q), 3 / 4 = the Gram-space / MFMA form of the blocked Jacobi with four / eight waves (cmf_wjac.hip; measured slower)
+  int wide_eigh_variant = 0;  // key 10: 0 = blocked Jacobi behind the tridiagonal preconditioner (cmf_wtri.hip) for calls of 32 columns or more; 7 = the preconditioner for any number of columns; 6 = the sweeps from the Cholesky factor (round 4's first form: 11-12 sweeps); 1 = the single-workgroup eigensolver for every wide matrix, 5 = pair visits (k_blockjac_x, round 3) instead of the quad visits of round 4 (k_blockjac_q), 3 / 4 = the Gram-space / MFMA form of the blocked Jacobi with four / eight waves (cmf_wjac.hip; measured slower)
   int wjac_stamps = 0;        // key 22: 1 = the wide Jacobi kernels accumulate their phase clocks (sf_debug_wjac_stamps)
   int wide_gemm_variant = 0;  // key 23: 1 = round 3's wide-window route (k_center + three k_dgemm + k_nllrows, 36-column batches) instead of the fused 4x4x4 kernels of cmf_wgemm.hip
   int wsweep_variant = 0;     // key 24: the fused wide sweep: 0 = k_wsweep8 (eight waves, wave-private operand slices) where it applies; 1 = 32-row tiles, two workgroups per CU; 2 = eight waves on shared chunks; 4 = four waves on shared chunks (round 4's first form)

@@ -14,8 +14,11 @@
 //                 Z = Y.^2                      -> the same registers, already in the A-operand layout of the next product
 //                 r = Z C    (C[j][a] = 1 / (n beta_a lam_j + alpha_a))   four alphas at a time, summed over the waves
 //                 sum_k log(1 - beta r), sum_k r / (1 - beta r)            -> per (column, row split) partials for k_nll
-//             W and C stream through LDS in 4-band / 4-alpha chunks (L2-resident: 1.5 + 0.7 MB per column); nothing
+//             W and C stream through LDS in 16-band / 8-alpha chunks (L2-resident: 1.5 + 0.7 MB per column); nothing
 //             but the 2 x 208 partial sums per (column, split) is written.  No float64 scratch per column any more.
+//   k_wsweep8 the same sweep with eight waves (two per SIMD), wave-private operand slices and no workgroup barrier in the
+//             first product: the form that runs for float32 rows and 256 < p <= 432 (the reflectance window, the full-band
+//             shape); 483 k -> 367-380 k cycles per 64-row tile.
 //
 // MFMA operand roles (validated by cmf_cov4.hip / cmf_wjac.hip): D_m[i][j] += sum_k A_m[i][k] B_m[k][j] for the four
 // blocks m, lane = 16 q + 4 m + n, A[i][k] at (q = k, n = i), B[k][j] at (q = k, n = j), D[i][j] at (q = i, n = j).
@@ -741,12 +744,11 @@ __global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restri
       for (int J = 0; J < NJW; ++J) acc[I][J] = acc[I][J] * acc[I][J];
     // ---- r = Z C, eight alphas a chunk.  One exchange per chunk: the waves' partial r go to red (even chunks) or red2 (odd
     //      chunks: the upper 3 KB of the waves' own operand buffers, free while the 3.5 KB C slices stream through the lower
-    //      4 KB), one barrier, and the row reductions of chunk ch - 1 run beside the MFMAs of chunk ch: waves 0-3 issue their
-    //      MFMAs first, waves 4-7 their row reductions first, so the two waves of a SIMD are in opposite phases.
+    //      4 KB), one barrier, and the row reductions of chunk ch - 1 are spread between the MFMAs of chunk ch (below).
     const bool more = r0 + RT < rend;
     const bool rowok = rin && mrow != 0;
     // (stamp = 16 + w: wave w's clocks of the chunk loop, summed in registers, one set of atomics per tile:
-    //  [3] wait for the chunk's copy, [4] first half (MFMAs for waves 0-3, row reductions for 4-7), [5] second half, [6] exchange + barrier)
+    //  [3] wait for the chunk's copy, [5] MFMAs + row reductions, [6] exchange + barrier, [7] the wave's whole tile)
     const bool probe = stamp >= 16 && wave == stamp - 16;
     unsigned long long pd0 = 0, pd1 = 0, pd2 = 0, pd3 = 0;
     for (int ch = 0; ch < NCC; ++ch, ++gs) {

@@ -18,7 +18,8 @@
 // last (k_blockjac_flags).  Whatever the preconditioner gets wrong -- a tight pair of eigenvalues, a poor inverse-iteration
 // vector -- costs Jacobi sweeps, never accuracy: F F^T = R holds to rounding because W' is orthogonal to rounding, and the
 // result is still the Jacobi's.  A matrix whose tridiagonal eigenvalues are not all positive and finite keeps F = L.
-// Measured (profiles/r04_wtri_ab.txt): eigensolver of a 598 x 425 x 425 flightline 191 -> see DESIGN.md.
+// Measured (profiles/r04_wtri_ab.txt): the eigensolver of a 598 x 425 x 425 flightline 198 -> 85-92 ms, the flightline 450 -> 334 ms,
+// alpha indices identical.  Used from 32 columns a call (cmf_wide.hip: below that its latency exceeds the plain sweeps').
 #include "cmf_common.h"
 #include <type_traits>
 

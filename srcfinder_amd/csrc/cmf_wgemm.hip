@@ -26,10 +26,15 @@
 
 namespace {
 
+__device__ unsigned long long g_ws_stamps[8];   // phase clocks (sf_debug_wsweep_stamps)
+
 // --------------------------------------------------------------------------------------------------------------------
 // k_wsyrk
 // --------------------------------------------------------------------------------------------------------------------
 constexpr int SY_KC = 16;              // rows per LDS chunk
+#ifndef SY_STAMPS
+#define SY_STAMPS 0
+#endif
 
 __device__ __forceinline__ void sy_load4(const float *p, float (&v)[4]) {
   const float4 f = *reinterpret_cast<const float4 *>(p);
@@ -48,6 +53,7 @@ __global__ __launch_bounds__(256, OCC) void k_wsyrk(const XT *__restrict__ xt, c
                                                      const int32_t *__restrict__ nuse, const double *__restrict__ mu, int L, int p,
                                                      int ps, int ntile, double *__restrict__ cov) {
   constexpr int TJ = 4 * TI;           // 4-band groups per wave along J
+  constexpr bool SY_IL = TI <= 3;      // the loader's store half interleaved with the MFMA groups (the 128-band tile has no registers for it)
   constexpr int T = 32 * TI;           // band tile
   constexpr int LD = 2 * T + 16;       // doubles per chunk row: [I bands | J bands] + pad (= 16 mod 32)
   constexpr int NQ = 2 * T / 4;        // 4-band quads per chunk row
@@ -88,23 +94,36 @@ __global__ __launch_bounds__(256, OCC) void k_wsyrk(const XT *__restrict__ xt, c
     lslot[u] = r * LD + 4 * qd;
     nv[u] = min(max(p - gb, 0), 4);
   }
+  unsigned voff[NIT];   // the item's byte offset from the chunk's first row (scalar base + this: no address arithmetic per chunk)
+#pragma unroll
+  for (int u = 0; u < NIT; ++u) voff[u] = (unsigned)((max(irow[u], 0) * ps + ioff[u]) * (int)sizeof(XT));
   XT pre[NIT][4];   // raw values of the next chunk (promoted when they are stored)
   unsigned char pmk[NIT];   // the rows' validity bytes, as loaded: NOTHING in a fetch depends on loaded data (a compare here made
   bool pin[NIT];            // every item wait for all the loads in flight -- vmcnt(0) four times per chunk)
   auto gload = [&](int r0) {
+    if (r0 + SY_KC <= L) {   // (uniform) a whole chunk: scalar base of the chunk + the item's constant offset
+      const char *xb = reinterpret_cast<const char *>(xc + (size_t)r0 * ps);
+      const uint8_t *mb = mp + r0;
 #pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-      const int row = r0 + max(irow[u], 0);
-      const int rr = row < L ? row : L - 1;
-      pin[u] = (irow[u] >= 0) && (row < L);
-      pmk[u] = mp[rr];
-      sy_load4(xc + (size_t)rr * ps + ioff[u], pre[u]);
+      for (int u = 0; u < NIT; ++u) {
+        pin[u] = irow[u] >= 0;
+        pmk[u] = mb[max(irow[u], 0)];
+        sy_load4(reinterpret_cast<const XT *>(xb + voff[u]), pre[u]);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NIT; ++u) {
+        const int row = r0 + max(irow[u], 0);
+        const int rr = row < L ? row : L - 1;
+        pin[u] = (irow[u] >= 0) && (row < L);
+        pmk[u] = mp[rr];
+        sy_load4(xc + (size_t)rr * ps + ioff[u], pre[u]);
+      }
     }
   };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-      if (irow[u] < 0) continue;
+  auto lstore_item = [&](int buf, int u) {
+    {
+      if (irow[u] < 0) return;
       const bool ok = pin[u] && pmk[u] != 0;
       double *dst = sm + (size_t)buf * SY_KC * LD + lslot[u];
       const double *mq = (ok ? mus : zeros) + (lslot[u] - irow[u] * LD);
@@ -123,6 +142,10 @@ __global__ __launch_bounds__(256, OCC) void k_wsyrk(const XT *__restrict__ xt, c
       *reinterpret_cast<double2 *>(dst + 2) = make_double2(o[2], o[3]);
     }
   };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) lstore_item(buf, u);
+  };
   double acc[TI][TJ];
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -132,26 +155,56 @@ __global__ __launch_bounds__(256, OCC) void k_wsyrk(const XT *__restrict__ xt, c
   gload(0);
   lstore(0);
   const int nchunk = (L + SY_KC - 1) / SY_KC;
+  const bool stw = SY_STAMPS && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+  unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
   for (int ch = 0; ch < nchunk; ++ch) {
     const int buf = ch & 1;
+    if (stw) s0 = __builtin_readcyclecounter();
     if (ch + 1 < nchunk) gload((ch + 1) * SY_KC);
+    if (stw) s1 = __builtin_readcyclecounter();
     __syncthreads();   // chunk ch is in sm[buf]; everybody is done with sm[buf ^ 1] (chunk ch - 1)
+    if (stw) s2 = __builtin_readcyclecounter();
     const double *xs = sm + (size_t)buf * SY_KC * LD;
+    // operands of MFMA step k4 + 1 are fetched before the MFMAs of step k4 (the pinned order below would otherwise expose the LDS
+    // latency four times a chunk)
+    double a[2][TI], b[2][TJ];
+    auto opload = [&](int k4, int slot) {
+      const double *row = xs + (size_t)(4 * k4 + q) * LD;
+#pragma unroll
+      for (int I = 0; I < TI; ++I) a[slot][I] = row[16 * TI * wi + 16 * I + 4 * m + n];
+#pragma unroll
+      for (int J = 0; J < TJ; ++J) b[slot][J] = row[T + 16 * TI * wj + 4 * J + n];
+    };
+    opload(0, 0);
 #pragma unroll
     for (int k4 = 0; k4 < SY_KC / 4; ++k4) {
-      const double *row = xs + (size_t)(4 * k4 + q) * LD;
-      double a[TI], b[TJ];
-#pragma unroll
-      for (int I = 0; I < TI; ++I) a[I] = row[16 * TI * wi + 16 * I + 4 * m + n];
-#pragma unroll
-      for (int J = 0; J < TJ; ++J) b[J] = row[T + 16 * TI * wj + 4 * J + n];
+      if (k4 + 1 < SY_KC / 4) opload(k4 + 1, (k4 + 1) & 1);
+      if (SY_IL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int I = 0; I < TI; ++I)
 #pragma unroll
-        for (int J = 0; J < TJ; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[I], b[J], acc[I][J], 0, 0, 0);
+        for (int J = 0; J < TJ; ++J) acc[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[k4 & 1][I], b[k4 & 1][J], acc[I][J], 0, 0, 0);
+      // The next chunk's rows are promoted and stored (into the other buffer: nobody reads it before the next barrier) BETWEEN
+      // the MFMA groups of this chunk, an item a group: a vector instruction of a wave that is NOT streaming MFMAs waits for a gap
+      // in the other waves' MFMA streams (~40 cycles each; the store phase alone was 4.3 k cycles of a 13.8 k-cycle chunk, the
+      // load phase's address arithmetic 4.7 k: sf_debug_wsweep_stamps with -DSY_STAMPS=1), inside the stream it costs ~6.
+      if (SY_IL && ch + 1 < nchunk) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (k4 >= 1 && k4 - 1 < NIT) lstore_item(buf ^ 1, k4 - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    if (ch + 1 < nchunk) lstore(buf ^ 1);
+    if (stw) { asm volatile("" : "+v"(acc[0][0])); s3 = __builtin_readcyclecounter(); }
+    if (ch + 1 < nchunk) {
+      if (!SY_IL) lstore(buf ^ 1);
+      else {
+#pragma unroll
+        for (int u = SY_KC / 4 - 1; u < NIT; ++u) lstore_item(buf ^ 1, u);
+      }
+    }
+    if (stw) { const unsigned long long s4 = __builtin_readcyclecounter(); d0 += s1 - s0; d1 += s2 - s1; d2 += s3 - s2; d3 += s4 - s3; }
   }
+  if (stw) { g_ws_stamps[3] = d0; g_ws_stamps[4] = d1; g_ws_stamps[5] = d2; g_ws_stamps[6] = d3; g_ws_stamps[7] = nchunk; }
   const double inv = 1.0 / ((double)nuse[c] - 1.0);
   double *co = cov + (size_t)c * p * p;
 #pragma unroll
@@ -216,7 +269,7 @@ __device__ __forceinline__ double ws_dpp(double v) {
 }
 
 // phase clocks of the sweep's tiles (sf_debug_set(22, 1); sf_debug_wsweep_stamps): [0] tiles, [1] Y = X~ W, [2] r = Z C + rows
-__device__ unsigned long long g_ws_stamps[8];   // k_wsweep8 also: [3] the r phase's MFMAs, [4] row reductions, [5] first barrier, [6] exchange + second barrier
+// (declared near the top of the file) g_ws_stamps: k_wsweep8 also: [3] the r phase's MFMAs, [4] row reductions, [5] first barrier, [6] exchange + second barrier
 
 constexpr int WS_CA = 8;    // alphas per C chunk (two groups of four: their row reductions are interleaved)
 
@@ -970,13 +1023,13 @@ static int wsyrk_go(const void *xt, const uint8_t *mask_t, const int32_t *nuse, 
 }
 int sf_launch_wsyrk(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
                     int c0, int nb, double *cov, hipStream_t st) {
-  // 96-band tiles, three workgroups per CU by default (16 % fewer MFMAs at p = 425 than 128-band tiles; full-band flightline
-  // 484 ms against 488 with sf_debug_set(25, 1) = 128-band tiles; 2 = 96-band tiles, two workgroups per CU)
+  // 96-band tiles (16 % fewer MFMAs at p = 425 than 128-band tiles: sf_debug_set(25, 1)), two workgroups per CU: with the store
+  // half of the loader inside the MFMA stream and the operands of the next MFMA step prefetched the kernel wants 216 registers
+  // (three workgroups per CU at 168 registers spilled: 435 ms a flightline against 332)
   const int v = sf_tune().wsyrk_variant;
-  if (xt_f64) return wsyrk_go<double, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);   // (float64 rows: 96-band tiles fit the registers)
-  if (v == 2) return wsyrk_go<float, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
+  if (xt_f64) return wsyrk_go<double, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
   if (v == 1) return wsyrk_go<float, 4, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
-  return wsyrk_go<float, 3, 3>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
+  return wsyrk_go<float, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
 }
 
 // the sweep of columns c0 .. c0 + nb - 1: operands into `opnd` (sf_wgemm_operand_bytes of the nb-column geometry), partials

@@ -163,7 +163,7 @@ size_t sf_wgemm_part_bytes(const SfGeom &g);      // the sweep partials of the w
 size_t sf_wtri_small_bytes(int p, int nb);
 int sf_launch_wtri_prepare(double *gv, int p, int p2, int nb, double *B2, double *B3, double *small, const int32_t *cflag,
                            int32_t *pflag, hipStream_t st, int gbn, size_t gstride);   // (nb matrices in groups of gbn, gstride bytes apart; gbn 0: one group)
-int sf_launch_wtri_apply(double *gv, int p, int p2, int nb, double *B2, double *B3, double *small, const int32_t *cflag,
+int sf_launch_wtri_apply(double *gv, int p, int p2, int nb, double *B2, double *B3, double *small, int32_t *cflag,
                          int32_t *pflag, hipStream_t st);
 int sf_wide_dgemm(const double *A, int lda, size_t sA, const double *B, int ldb, size_t sB, int tb, double *C, int ldc, size_t sC,
                   int n, int nb, const int32_t *skip1, const int32_t *skip2, hipStream_t st);

@@ -1245,7 +1245,7 @@ static int wide_chol(double *gv, int p, int p2, int nb, int32_t *cflag, hipStrea
 // (one workgroup each), the plain sweeps of a handful of matrices are launch-bound at ~6 ms.  sf_debug_set(10, 7) forces it.
 static bool wide_precond_on(int p, int ncols) {
   const int v = sf_tune().wide_eigh_variant;
-  return p >= 128 && (v == 7 || (v == 0 && ncols >= 32));
+  return p >= 128 && (v == 7 || v == 8 || (v == 0 && ncols >= 32));   // (8: as 7, but every preconditioner is refused afterwards: the fallback's test)
 }
 // stage: 0 = all of it; 1 = only the work matrices (R, d, flags: k_eigh_global mode 3) -- the caller then runs the preconditioner's
 // first half over ALL groups at once (sf_launch_wtri_prepare) -- and 2 = the rest (Cholesky, second half, sweeps, finish)
@@ -1309,10 +1309,11 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
       hipLaunchKernelGGL(k_blockjac_flags, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, done, rot);                             \
     }                                                                                                                            \
   }
-  // behind the preconditioner a matrix needs one sweep (two or three if its preconditioner was poor); one without it -- a flagged
-  // preconditioner -- 11-12: the launches of the sweeps nobody needs are ~4.5 us each, 15 a sweep; a matrix still rotating after
-  // the last sweep is redone by k_eigh_global (mode 2)
-  const int nsweeps = precond ? 12 : 16;
+  // behind the preconditioner a matrix needs ONE sweep (two or three if its preconditioner was poor: measured cosines 1e-11, a
+  // 6-decade spectrum 1e-9); the launches of sweeps nobody needs are ~4.5 us each, 15 a sweep and group.  A matrix still rotating
+  // after the last sweep -- one whose preconditioner was refused (pflag) and whose Cholesky still succeeded -- is redone by
+  // k_eigh_global (mode 2), as after 16 sweeps without the preconditioner.
+  const int nsweeps = precond ? 5 : 16;
   // quad visits (k_blockjac_q): the default whenever there are at least two super-blocks; sf_debug_set(10, 5): the pair visits
   const int msb = mblk / 2, msbE = msb + (msb & 1);
   const bool quad = msb >= 2 && sf_tune().wide_eigh_variant != 5;

@@ -21,6 +21,7 @@
 // Measured (profiles/r04_wtri_ab.txt): the eigensolver of a 598 x 425 x 425 flightline 198 -> 85-92 ms, the flightline 450 -> 334 ms,
 // alpha indices identical.  Used from 32 columns a call (cmf_wide.hip: below that its latency exceeds the plain sweeps').
 #include "cmf_common.h"
+#include "sf_tune.h"
 #include <type_traits>
 
 namespace {
@@ -571,6 +572,13 @@ __global__ void k_tri_select(const double *__restrict__ Fall, size_t sF, int ldf
   }
 }
 
+// a matrix whose preconditioner was refused goes the way of one whose Cholesky failed: the single-workgroup eigensolver from
+// the covariance itself (k_eigh_global, mode 2) -- the few sweeps launched behind the preconditioner would not finish it
+__global__ void k_tri_demote(int nb, int32_t *__restrict__ cflag, const int32_t *__restrict__ pflag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb && cflag[i] == 0 && pflag[i] != 0) cflag[i] = 1;
+}
+
 // pflag |= 1 where F has a non-finite entry (checked before the copy)
 __global__ void k_tri_check(const double *__restrict__ Fall, size_t sF, int ldf, int n, const int32_t *__restrict__ cflag,
                             int32_t *__restrict__ pflag) {
@@ -614,7 +622,7 @@ int sf_launch_wtri_prepare(double *gv, int p, int p2, int nb, double *B2, double
 }
 
 // after the Cholesky (gv half 0 = L): Z -> U0 S^-1 -> W -> W' -> F -> gv half 0 where everything stayed finite
-int sf_launch_wtri_apply(double *gv, int p, int p2, int nb, double *B2, double *B3, double *small, const int32_t *cflag,
+int sf_launch_wtri_apply(double *gv, int p, int p2, int nb, double *B2, double *B3, double *small, int32_t *cflag,
                          int32_t *pflag, hipStream_t st) {
   const size_t sG = (size_t)2 * p2 * p2, sB = (size_t)p * p;
   const int pl = (p + 15) & ~15;
@@ -645,6 +653,8 @@ int sf_launch_wtri_apply(double *gv, int p, int p2, int nb, double *B2, double *
   if (int rc = sf_wide_dgemm(B2, p, sB, gv, p2, sG, 0, B3, p, sB, p, nb, cflag, pflag, st)) return rc;
   hipLaunchKernelGGL(k_tri_check, dim3(64, nb), dim3(256), 0, st, B3, sB, p, p, cflag, pflag);
   hipLaunchKernelGGL(k_tri_select, dim3(64, nb), dim3(256), 0, st, B3, sB, p, gv, sG, p2, p, cflag, pflag);
+  if (sf_tune().wide_eigh_variant == 8) SF_HIP(hipMemsetAsync(pflag, 0x01, (size_t)nb * sizeof(int32_t), st));   // (test: every preconditioner refused)
+  hipLaunchKernelGGL(k_tri_demote, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, cflag, pflag);
   SF_LAUNCH_CHECK("k_tri_select");
   return 0;
 }

@@ -1133,7 +1133,8 @@ def test_wide_eigensolver_variants_agree(torch_cuda, golden_dir, library):
     L = _ffi.lib()
     cube = make_cube_numpy(300, 5, seed=4, abscf_full=library[:, 2], nodata_column=2)
     a = cmf.robust_mf(cube, library, reflectance=True, to_numpy=True)
-    for variant in (1, 3, 4, 5, 6, 7):    # (5: pair visits instead of quad visits; 6: never / 7: always the tridiagonal preconditioner --
+    for variant in (1, 3, 4, 5, 6, 7, 8): # (5: pair visits instead of quad visits; 6: never / 7: always the tridiagonal preconditioner, 8: always
+                                           #  and every one refused afterwards: the single-workgroup fallback --
                                            #  by default it is used from 32 columns a call, i.e. not on this 5-column cube)
         L.sf_debug_set(10, variant)
         try:

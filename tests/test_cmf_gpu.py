@@ -1202,6 +1202,28 @@ def test_wide_sweep_forms_agree(torch_cuda, p):
     assert out[0]["status"][3] == 1 and (np.delete(out[0]["status"], 3) == 0).all()
 
 
+def test_wide_preconditioner_over_column_groups(torch_cuda, library):
+    """170 columns of a full-band window (p = 425): two column groups of 85, the second phase of the preconditioner's first half
+    running over both groups in one set of launches (cmf_wide.hip: `phased`).  Against the same sweeps without the
+    preconditioner (sf_debug_set(10, 6)): statuses and alpha indices exact, scores 1e-9; and a re-run is bit-identical."""
+    L = _ffi.lib()
+    cube = make_cube_numpy(700, 170, seed=11, abscf_full=library[:, 2], nodata_column=40)
+    a = cmf.robust_mf(cube, library, active=(1, 425), to_numpy=True)
+    a2 = cmf.robust_mf(cube, library, active=(1, 425), to_numpy=True)
+    assert np.array_equal(a.out, a2.out, equal_nan=True) and np.array_equal(a.alphaidx, a2.alphaidx)
+    L.sf_debug_set(10, 6)
+    try:
+        b = cmf.robust_mf(cube, library, active=(1, 425), to_numpy=True)
+    finally:
+        L.sf_debug_set(10, 0)
+    assert np.array_equal(a.alphaidx, b.alphaidx) and np.array_equal(a.status, b.status)
+    assert (a.status[np.arange(170) != 40] == 0).all()
+    nod = a.out[..., 3] == -9999.0
+    assert np.array_equal(nod, b.out[..., 3] == -9999.0)
+    # (700 rows for 425 bands: an ill-conditioned covariance -- the two eigensolver routes agree to 1e-11 of the largest score)
+    np.testing.assert_allclose(a.out[..., 3][~nod], b.out[..., 3][~nod], rtol=1e-9, atol=1e-10 * np.abs(b.out[..., 3][~nod]).max())
+
+
 @pytest.mark.parametrize("p,decades", [(130, 2.0), (425, 2.0), (300, 6.0), (512, 3.0)])
 def test_wide_tridiagonal_preconditioner(torch_cuda, p, decades):
     """csrc/cmf_wtri.hip through its test entry: for correlation matrices R = L L^T (benchmark-like and with a spectrum spread over

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, OCC) void k_wsyrk(const XT *__restrict__ xt, c
                                                      const int32_t *__restrict__ nuse, const double *__restrict__ mu, int L, int p,
                                                      int ps, int ntile, double *__restrict__ cov) {
   constexpr int TJ = 4 * TI;           // 4-band groups per wave along J
-  constexpr bool SY_IL = TI <= 3;      // the loader's store half interleaved with the MFMA groups (the 128-band tile has no registers for it)
+  constexpr bool SY_IL = true;         // the loader's store half interleaved with the MFMA groups
   constexpr int T = 32 * TI;           // band tile
   constexpr int LD = 2 * T + 16;       // doubles per chunk row: [I bands | J bands] + pad (= 16 mod 32)
   constexpr int NQ = 2 * T / 4;        // 4-band quads per chunk row
@@ -1023,12 +1023,10 @@ static int wsyrk_go(const void *xt, const uint8_t *mask_t, const int32_t *nuse, 
 }
 int sf_launch_wsyrk(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
                     int c0, int nb, double *cov, hipStream_t st) {
-  // 96-band tiles (16 % fewer MFMAs at p = 425 than 128-band tiles: sf_debug_set(25, 1)), two workgroups per CU: with the store
-  // half of the loader inside the MFMA stream and the operands of the next MFMA step prefetched the kernel wants 216 registers
-  // (three workgroups per CU at 168 registers spilled: 435 ms a flightline against 332)
-  const int v = sf_tune().wsyrk_variant;
+  // 96-band tiles (16 % fewer MFMAs at p = 425 than the 128-band tiles of the round's first half), two workgroups per CU: with the
+  // store half of the loader inside the MFMA stream and the operands of the next MFMA step prefetched the kernel wants 216
+  // registers (three workgroups per CU at 168 registers spilled: 435 ms a flightline against 332)
   if (xt_f64) return wsyrk_go<double, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
-  if (v == 1) return wsyrk_go<float, 4, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
   return wsyrk_go<float, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
 }
 

@@ -20,7 +20,7 @@ struct SfTune {
   int wjac_stamps = 0;        // key 22: 1 = the wide Jacobi kernels accumulate their phase clocks (sf_debug_wjac_stamps)
   int wide_gemm_variant = 0;  // key 23: 1 = round 3's wide-window route (k_center + three k_dgemm + k_nllrows, 36-column batches) instead of the fused 4x4x4 kernels of cmf_wgemm.hip
   int wsweep_variant = 0;     // key 24: the fused wide sweep: 0 = k_wsweep8 (eight waves, wave-private operand slices) where it applies; 1 = 32-row tiles, two workgroups per CU; 2 = eight waves on shared chunks; 4 = four waves on shared chunks (round 4's first form)
-  int wsyrk_variant = 0;      // key 25: 1 = 128-band tiles in the fused wide covariance (default: 96-band tiles, two workgroups per CU)
+  int wsyrk_variant = 0;      // key 25: (unused since the 128-band tile variant of the fused wide covariance was removed)
   int score_wgs = 0;          // key 12: workgroups per CU k_score_blk2 is sized for (0 = occupancy query)
   int cnn_pool_variant = 0;   // key 18: 1 = branch-4 pool taken inside the 1x1 convolution's tile fetch (sf_cnn_pool_conv; slower)
   int cnn_conv_variant = 0;   // key 17: 1 = pointer-form tile loads in k_conv_igemm (cnn_kernels.hip), 2 = two LDS buffers / one barrier per chunk

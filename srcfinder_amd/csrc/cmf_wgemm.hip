@@ -7,8 +7,9 @@
 // 4x4x4 form reaches 71 (tools/microbench/mfma64.hip).  Here:
 //
 //   k_wsyrk   S = X~^T X~ / (n - 1)  (numpy.cov as called by looshrinkage, robust_mf.py:52-70, :98, :130) straight from
-//             the extracted float32 rows: centring, validity mask and promotion happen on the way into LDS, 128 x 128
-//             band tiles (upper triangle of tiles), four waves of 64 x 64, K = all rows of the column.
+//             the extracted float32 rows: centring, validity mask and promotion happen on the way into LDS (interleaved by
+//             hand with the MFMA groups), 96 x 96 band tiles (upper triangle of tiles), four waves of 48 x 48, K = all
+//             rows of the column.
 //   k_wsweep  the LOO sweep of robust_mf.py:105-117 in its eigen form: per 64-row tile
 //                 Y = X~ W   (W = D^-1 V)      -> registers (each wave a quarter of the columns of Y)
 //                 Z = Y.^2                      -> the same registers, already in the A-operand layout of the next product

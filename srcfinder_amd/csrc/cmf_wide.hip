@@ -442,11 +442,16 @@ __global__ __launch_bounds__(512) void k_eigh_global(const double *__restrict__ 
 // solves the rows below it, then k_chol_trail applies the rank-16 update to the trailing lower triangle with one
 // workgroup per 64 x 64 tile and matrix.  A non-positive pivot flags the matrix (cflag = 1 -> k_eigh_global, mode 2).
 constexpr int CH_B = 16;
+// (gbn, gstride: matrix mtx of the launch is matrix mtx % gbn of column group mtx / gbn, whose buffers sit gstride bytes behind the
+//  previous group's -- the ~850 launches of a flightline's four groups become ~210 over all its matrices)
+__device__ __forceinline__ char *ch_goff(void *base, int grp, size_t gstride) { return reinterpret_cast<char *>(base) + (size_t)grp * gstride; }
 __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ gscratch, int p, int p2, int kb,
-                                                     int32_t *__restrict__ cflag) {
+                                                     int32_t *__restrict__ cflag, int gbn, size_t gstride) {
   extern __shared__ __attribute__((aligned(16))) double pan[];   // [CH_B][H]: column j of the panel, rows k0 .. p-1
   __shared__ int bad;
-  const int mtx = blockIdx.x, tid = threadIdx.x;
+  const int grp = blockIdx.x / gbn, mtx = blockIdx.x - grp * gbn, tid = threadIdx.x;
+  gscratch = reinterpret_cast<double *>(ch_goff(gscratch, grp, gstride));
+  cflag = reinterpret_cast<int32_t *>(ch_goff(cflag, grp, gstride));
   if (cflag[mtx] != 0) return;
   double *G = gscratch + (size_t)mtx * 2 * p2 * p2;
   const int k0 = kb * CH_B, nc = min(CH_B, p - k0), H = p - k0;
@@ -484,9 +489,11 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ gscratc
 
 // A[i][j] -= sum_k L[i][k] L[j][k] for i >= j in the trailing block (rows / columns >= k1 = (kb + 1) * 16)
 __global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ gscratch, int p, int p2, int kb,
-                                                     const int32_t *__restrict__ cflag) {
+                                                     const int32_t *__restrict__ cflag, int gbn, size_t gstride) {
   __shared__ double Li[64][CH_B + 1], Lj[64][CH_B + 1];
-  const int mtx = blockIdx.z, tid = threadIdx.x;
+  const int grp = blockIdx.z / gbn, mtx = blockIdx.z - grp * gbn, tid = threadIdx.x;
+  gscratch = reinterpret_cast<double *>(ch_goff(gscratch, grp, gstride));
+  cflag = reinterpret_cast<const int32_t *>(ch_goff(const_cast<int32_t *>(cflag), grp, gstride));
   if (cflag[mtx] != 0) return;
   const int k0 = kb * CH_B, k1 = k0 + CH_B;
   const int ti = blockIdx.y, tj = blockIdx.x;
@@ -519,8 +526,11 @@ __global__ __launch_bounds__(256) void k_chol_trail(double *__restrict__ gscratc
 }
 
 // after the factorisation: zero the strict upper triangle and the padding (G = L)
-__global__ void k_chol_clean(double *__restrict__ gscratch, int p, int p2, const int32_t *__restrict__ cflag) {
-  const int mtx = blockIdx.y;
+__global__ void k_chol_clean(double *__restrict__ gscratch, int p, int p2, const int32_t *__restrict__ cflag, int gbn,
+                             size_t gstride) {
+  const int grp = blockIdx.y / gbn, mtx = blockIdx.y - grp * gbn;
+  gscratch = reinterpret_cast<double *>(ch_goff(gscratch, grp, gstride));
+  cflag = reinterpret_cast<const int32_t *>(ch_goff(const_cast<int32_t *>(cflag), grp, gstride));
   if (cflag[mtx] != 0) return;
   double *G = gscratch + (size_t)mtx * 2 * p2 * p2;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p2 * p2; i += gridDim.x * blockDim.x) {
@@ -1220,19 +1230,20 @@ int sf_wide_dgemm(const double *A, int lda, size_t sA, const double *B, int ldb,
 }
 
 // blocked Cholesky of the nb matrices in gv whose flag is 0 (flag -> 1 where a pivot is not positive)
-static int wide_chol(double *gv, int p, int p2, int nb, int32_t *cflag, hipStream_t st) {
+static int wide_chol(double *gv, int p, int p2, int nb, int32_t *cflag, hipStream_t st, int gbn = 0, size_t gstride = 0) {
+  if (gbn <= 0) { gbn = nb > 0 ? nb : 1; gstride = 0; }
   const size_t plds = (size_t)CH_B * p * sizeof(double);
   if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_chol_panel), plds)) return rc;
   const int npan = sf_cdiv(p, CH_B);
   for (int kb = 0; kb < npan; ++kb) {
-    hipLaunchKernelGGL(k_chol_panel, dim3(nb), dim3(256), plds, st, gv, p, p2, kb, cflag);
+    hipLaunchKernelGGL(k_chol_panel, dim3(nb), dim3(256), plds, st, gv, p, p2, kb, cflag, gbn, gstride);
     const int rem = p - (kb + 1) * CH_B;
     if (rem > 0) {
       const int nt = sf_cdiv(rem, 64);
-      hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt, nb), dim3(256), 0, st, gv, p, p2, kb, cflag);
+      hipLaunchKernelGGL(k_chol_trail, dim3(nt, nt, nb), dim3(256), 0, st, gv, p, p2, kb, cflag, gbn, gstride);
     }
   }
-  hipLaunchKernelGGL(k_chol_clean, dim3(64, nb), dim3(256), 0, st, gv, p, p2, cflag);
+  hipLaunchKernelGGL(k_chol_clean, dim3(64, nb), dim3(256), 0, st, gv, p, p2, cflag, gbn, gstride);
   SF_LAUNCH_CHECK("k_chol");
   return 0;
 }
@@ -1248,7 +1259,7 @@ static bool wide_precond_on(int p, int ncols) {
   return p >= 128 && (v == 7 || v == 8 || (v == 0 && ncols >= 32));   // (8: as 7, but every preconditioner is refused afterwards: the fallback's test)
 }
 // stage: 0 = all of it; 1 = only the work matrices (R, d, flags: k_eigh_global mode 3) -- the caller then runs the preconditioner's
-// first half over ALL groups at once (sf_launch_wtri_prepare) -- and 2 = the rest (Cholesky, second half, sweeps, finish)
+// first half and the Cholesky over ALL groups at once (sf_launch_wtri_prepare, wide_chol) -- and 2 = the rest (second half, sweeps, finish)
 struct WidePre { double *B2, *B3, *small; int32_t *pflag; };
 static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int c0, int nb, double *d, double *lam, double *evec,
                      int32_t *status, double *gv, int32_t *cflag, int32_t *done, int32_t *rot, hipStream_t st, int unit = 0,
@@ -1266,7 +1277,8 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
   const bool precond = pre && (stage == 2 || wide_precond_on(p, nb));
   if (precond && stage == 0)
     if (int rc = sf_launch_wtri_prepare(gv, p, p2, nb, pre->B2, pre->B3, pre->small, cflag, pre->pflag, st, 0, 0)) return rc;
-  if (int rc = wide_chol(gv, p, p2, nb, cflag, st)) return rc;
+  if (stage != 2)
+    if (int rc = wide_chol(gv, p, p2, nb, cflag, st)) return rc;
   if (precond)
     if (int rc = sf_launch_wtri_apply(gv, p, p2, nb, pre->B2, pre->B3, pre->small, cflag, pre->pflag, st)) return rc;
   if (sf_tune().wide_eigh_variant == 3 || sf_tune().wide_eigh_variant == 4) {
@@ -1362,6 +1374,7 @@ static int wide_stats_fused(const void *xt, int xt_f64, const uint8_t *mask_t, c
     if (int rc = sf_launch_wtri_prepare(gv0, p, p2, ngr * gb, Lc0, Lc0 + (size_t)gb * p * p, small0, fl0, fl0 + 4 * gb, st, gb,
                                         (size_t)gb * per))
       return rc;
+    if (int rc = wide_chol(gv0, p, p2, ngr * gb, fl0, st, gb, (size_t)gb * per)) return rc;
   }
   for (int gi = 0; gi < ngr; ++gi) {
     const int c0 = gi * gb, nb = (g.ncols - c0 < gb) ? g.ncols - c0 : gb;

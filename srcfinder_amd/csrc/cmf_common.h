@@ -166,7 +166,7 @@ int sf_launch_wtri_prepare(double *gv, int p, int p2, int nb, double *B2, double
 int sf_launch_wtri_apply(double *gv, int p, int p2, int nb, double *B2, double *B3, double *small, int32_t *cflag,
                          int32_t *pflag, hipStream_t st);
 int sf_wide_dgemm(const double *A, int lda, size_t sA, const double *B, int ldb, size_t sB, int tb, double *C, int ldc, size_t sC,
-                  int n, int nb, const int32_t *skip1, const int32_t *skip2, hipStream_t st);
+                  int n, int nb, const int32_t *skip1, const int32_t *skip2, hipStream_t st, int lower = 0);
 int sf_launch_wsyrk(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
                     int c0, int nb, double *cov, hipStream_t st);
 int sf_launch_wsweep(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nloo, const double *mu, const double *d,

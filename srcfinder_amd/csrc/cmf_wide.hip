@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, int
                                                 const double *__restrict__ B, int ldb, size_t sB,
                                                 double *__restrict__ Cm, int ldc, size_t sC, int M, int N, int K,
                                                 double scale, const int32_t *__restrict__ skip1 = nullptr,
-                                                const int32_t *__restrict__ skip2 = nullptr) {
+                                                const int32_t *__restrict__ skip2 = nullptr, int tri = 0) {
   if ((skip1 && skip1[blockIdx.z] != 0) || (skip2 && skip2[blockIdx.z] != 0)) return;
   __shared__ double As[WD_BK * WD_LD];
   __shared__ double Bs[WD_BK * WD_LD];
@@ -59,7 +59,11 @@ __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, int
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
 
-  for (int k0 = 0; k0 < K; k0 += WD_BK) {
+  // tri: the B operand is triangular -- 1: B'[k][n] = 0 for k > n (the K loop ends with the tile's last column), 2: B'[k][n] = 0 for
+  // k < n (it starts at the tile's first column): the products with the Cholesky factor skip their zero half
+  const int kbeg = (tri == 2) ? (blockIdx.y * WD_BN) / WD_BK * WD_BK : 0;
+  const int kend = (tri == 1) ? min(K, (int)(blockIdx.y * WD_BN + WD_BN)) : K;
+  for (int k0 = kbeg; k0 < kend; k0 += WD_BK) {
     double ra[4], rb[4];
     if (TA) {  // A[k][m]: thread (k = tid/16, 4 consecutive m)
       const int k = tid >> 4, mq = (tid & 15) * 4;
@@ -1214,9 +1218,16 @@ size_t sf_wide_scratch_bytes(const SfGeom &g) {
 // row-major product C^T = A^T-view x B-view.  Used by the tridiagonal preconditioner (cmf_wtri.hip):
 //   W = L^T U:  A = U, B = L, tb = 1      G = W^T W:  A = W, B = W, tb = 1      W' = W M:  A = M, B = W, tb = 0
 int sf_wide_dgemm(const double *A, int lda, size_t sA, const double *B, int ldb, size_t sB, int tb, double *C, int ldc, size_t sC,
-                  int n, int nb, const int32_t *skip1, const int32_t *skip2, hipStream_t st) {
+                  int n, int nb, const int32_t *skip1, const int32_t *skip2, hipStream_t st, int lower) {
+  // lower: Bm is lower-triangular (the Cholesky factor): its zero half is skipped (tb = 0: C = Bm Am; tb = 1: C = Bm^T Am)
   const dim3 grid(sf_cdiv(n, WD_BM), sf_cdiv(n, WD_BN), nb);
-  if (tb && A == B)   // C = Am^T Am: symmetric, the tiles above the diagonal are mirrored
+  if (lower && tb)
+    hipLaunchKernelGGL((k_dgemm<false, false, false, true>), grid, dim3(256), 0, st, A, lda, sA, B, ldb, sB, C, ldc, sC, n, n, n, 1.0,
+                       skip1, skip2, 2);
+  else if (lower)
+    hipLaunchKernelGGL((k_dgemm<false, false, false, false>), grid, dim3(256), 0, st, A, lda, sA, B, ldb, sB, C, ldc, sC, n, n, n, 1.0,
+                       skip1, skip2, 1);
+  else if (tb && A == B)   // C = Am^T Am: symmetric, the tiles above the diagonal are mirrored
     hipLaunchKernelGGL((k_dgemm<false, false, true, true>), grid, dim3(256), 0, st, A, lda, sA, B, ldb, sB, C, ldc, sC, n, n, n, 1.0,
                        skip1, skip2);
   else if (tb)

@@ -643,14 +643,14 @@ int sf_launch_wtri_apply(double *gv, int p, int p2, int nb, double *B2, double *
 #undef TBK_GO
   SF_LAUNCH_CHECK("k_tri_back");
   // W (B3) = L^T U0s
-  if (int rc = sf_wide_dgemm(B2, p, sB, gv, p2, sG, 1, B3, p, sB, p, nb, cflag, pflag, st)) return rc;
+  if (int rc = sf_wide_dgemm(B2, p, sB, gv, p2, sG, 1, B3, p, sB, p, nb, cflag, pflag, st, 1)) return rc;
   // G (A1) = W^T W, M = 1.5 I - 0.5 G
   if (int rc = sf_wide_dgemm(B3, p, sB, B3, p, sB, 1, A1, p2, sG, p, nb, cflag, pflag, st)) return rc;
   hipLaunchKernelGGL(k_tri_nsm, dim3(64, nb), dim3(256), 0, st, A1, sG, p2, p, cflag, pflag);
   SF_LAUNCH_CHECK("k_tri_nsm");
   // W' (B2) = W M;  F (B3) = L W'
   if (int rc = sf_wide_dgemm(A1, p2, sG, B3, p, sB, 0, B2, p, sB, p, nb, cflag, pflag, st)) return rc;
-  if (int rc = sf_wide_dgemm(B2, p, sB, gv, p2, sG, 0, B3, p, sB, p, nb, cflag, pflag, st)) return rc;
+  if (int rc = sf_wide_dgemm(B2, p, sB, gv, p2, sG, 0, B3, p, sB, p, nb, cflag, pflag, st, 1)) return rc;
   hipLaunchKernelGGL(k_tri_check, dim3(64, nb), dim3(256), 0, st, B3, sB, p, p, cflag, pflag);
   hipLaunchKernelGGL(k_tri_select, dim3(64, nb), dim3(256), 0, st, B3, sB, p, gv, sG, p2, p, cflag, pflag);
   if (sf_tune().wide_eigh_variant == 8) SF_HIP(hipMemsetAsync(pflag, 0x01, (size_t)nb * sizeof(int32_t), st));   // (test: every preconditioner refused)

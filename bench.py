@@ -44,6 +44,8 @@ def main():
                     help="skip the pure-traffic microbenchmark child process (always skipped under a profiler)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the file -> HBM -> product section (SURVEY 8(f) N3)")
     ap.add_argument("--no-routes", action="store_true", help="skip the sweep-route histogram and the hard-spectrum line")
+    ap.add_argument("--no-windows", action="store_true",
+                    help="skip the CO2 (p = 83) and reflectance (-R, p = 416) window sections (cmf/robust_mf.py:186-191)")
     ap.add_argument("--cpu-columns", type=int, default=12)    # ~7 s of one host core (+ the all-cores sample)
     ap.add_argument("--active", type=str, default="", help="a0,a1 (1-based inclusive) override of the active window, e.g. 1,425")
     ap.add_argument("--in-flight", type=int, default=0,
@@ -221,6 +223,10 @@ def main():
             # which sweep kernel each column took (the step's cost depends on it) and the same step on a hard spectrum
             line["sweep_routes"] = cmf.sweep_routes(cube, lib, active=(a0, a1))
             line["hard_spectrum"] = hard_spectrum_section(cube, lib, (a0, a1), depth)
+        if full and not args.no_windows:
+            # the reference's other two windows (cmf/robust_mf.py:186-191): CO2 radiance 309..391 (p = 83) at the headline's
+            # depth, and the -R reflectance window 5..420 (p = 416, the wide route) one flightline at a time
+            line["co2"] = window_section(cube, lib, cmf.active_window("co2", False), False, depth, 10, ms_per_step)
         if full and not args.no_ingest:
             line["ingest"] = ingest_section(cube, lib, res)
         if full and not args.no_e2e:
@@ -229,6 +235,8 @@ def main():
         if full and not args.no_wide:
             # SURVEY 8(d) lists the full-band window among the configs: the batched-GEMM path, bounded to three flightlines
             del main, solo
+            if not args.no_windows:
+                line["reflectance"] = window_section(cube, lib, cmf.active_window("ch4", True), True, 1, 2, ms_per_step)
             line["wide"] = wide_section(cube, lib, with_cpu=not args.no_cpu_baseline)
     if world > 1 or force_dist:
         dist.barrier()
@@ -236,6 +244,36 @@ def main():
     flush_c_stdio()
     if rank == 0:
         print(json.dumps(line), flush=True)      # the last line of the job's output
+
+
+def window_section(cube, lib, active, reflectance, depth, steps, ch4_ms):
+    """The same flightline through another of the reference's active windows (cmf/robust_mf.py:186-191): `steps` passes with
+    `depth` flightlines in flight, after one untimed pass per slot.  `per_pixel_vs_ch4` = this step's time over the CH4
+    headline step's (the same pixel count)."""
+    import torch
+    from srcfinder_amd import cmf
+    from srcfinder_amd.inflight import FlightlinePipeline
+    lines, bands, ncols = cube.shape
+    a0, a1 = active
+    p = a1 - a0 + 1
+    outs = [torch.empty((lines, ncols, 4), dtype=torch.float64, device=cube.device) for _ in range(depth)]
+    with FlightlinePipeline(depth, cube.device) as pipe:
+        for i in range(depth):
+            pipe.submit(cube, lib, out=outs[i], out_column0=0, active=active, reflectance=reflectance)
+        pipe.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            pipe.submit(cube, lib, out=outs[i % depth], out_column0=0, active=active, reflectance=reflectance)
+        pipe.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    del outs
+    cmf._Workspace._bufs.clear()
+    torch.cuda.empty_cache()
+    return {"metric": "CMF Mpixels/s, %s window" % ("reflectance (-R)" if reflectance else "CO2"),
+            "value": round(lines * ncols / dt / 1e6, 3), "unit": "Mpixel/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+            "in_flight": depth, "dtype": "f64", "per_pixel_vs_ch4": round(dt * 1e3 / ch4_ms, 3),
+            "workload": "the benchmark flightline, active window %d..%d (p = %d)%s, 201-point sweep, unimodal"
+                        % (a0, a1, p, ", reflectance target abscf - mu" if reflectance else "")}
 
 
 def wide_section(cube, lib, steps=2, with_cpu=True):

@@ -27,6 +27,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the ABI is exactly the names declared between this push and its pop. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define SF_MAX_ACTIVE_FUSED 96   /* largest active window of the LDS-resident statistics path */
 #define SF_NALPHA_MAX 208        /* alpha grid is padded to a multiple of 16 (201 -> 208) */
@@ -202,7 +206,8 @@ int sf_debug_wsweep_stamps(unsigned long long *out8, int reset);
  * update, then the number of columns */
 int sf_debug_wtri_stamps(unsigned long long *out8, int reset);
 /* phase clocks of the blocked LU of the exact-determinant pass, workgroup 0: out8 = cycles in panel load, panel factorisation,
- * permutation + triangular solve, rank-16 update, then the number of factorisations */
+ * permutation + triangular solve, rank-16 update, then the number of factorisations.  The clocks are OFF unless asked for:
+ * reset = 1 zeroes them and turns them on, reset = 2 (after the read into out8) zeroes them and turns them off */
 int sf_debug_lu_stamps(unsigned long long *out8, int reset);
 size_t sf_debug_wtri_scratch_bytes(int p, int nb);
 int sf_debug_wtri(const double *R, const double *Lc, int p, int nb, double *F, double *tlam, int32_t *pflag, void *scratch,
@@ -372,6 +377,9 @@ int sf_cnn_conv_split3_f16(const void *in, int N, int H, int W, int Cin, int ld_
 int sf_cnn_head_f16(const void *in, int ntiles, int HW, int C, const float *fcw, const float *fcb, const float *plane,
                     long long tile0, float nodata, float *out, void *stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

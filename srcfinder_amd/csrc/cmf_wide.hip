@@ -1263,11 +1263,14 @@ static int wide_chol(double *gv, int p, int p2, int nb, int32_t *cflag, hipStrea
 // (unit: `cov` = the batch's nb whitened matrices, no diagonal scaling, d untouched -- the full-target route)
 // pre != nullptr: the tridiagonal preconditioner of cmf_wtri.hip between the Cholesky and the sweeps (work matrices and flags of
 // the group: pre->B2, B3 [nb][p^2], small, pflag)
-// The preconditioner pays from ~32 matrices a call: its tridiagonalisation is 9 ms of LATENCY for any number of matrices up to ~150
-// (one workgroup each), the plain sweeps of a handful of matrices are launch-bound at ~6 ms.  sf_debug_set(10, 7) forces it.
+// The route is a function of p ONLY: the preconditioned and the plain sweeps apply different rotation sequences, so a
+// column's eigenvectors -- and with them its NLL and scores -- must not depend on how many columns share the call (cmf_common.h:
+// a column is bit-identical as part of the flightline or of any shard, however narrow).  A call of a handful of matrices pays the
+// tridiagonalisation's ~9 ms of latency where the plain sweeps would be launch-bound at ~6 ms.  sf_debug_set(10, 6) = plain sweeps.
 static bool wide_precond_on(int p, int ncols) {
+  (void)ncols;
   const int v = sf_tune().wide_eigh_variant;
-  return p >= 128 && (v == 7 || v == 8 || (v == 0 && ncols >= 32));   // (8: as 7, but every preconditioner is refused afterwards: the fallback's test)
+  return p >= 128 && (v == 0 || v == 7 || v == 8);   // (8: every preconditioner is refused afterwards: the fallback's test)
 }
 // stage: 0 = all of it; 1 = only the work matrices (R, d, flags: k_eigh_global mode 3) -- the caller then runs the preconditioner's
 // first half and the Cholesky over ALL groups at once (sf_launch_wtri_prepare, wide_chol) -- and 2 = the rest (second half, sweeps, finish)

@@ -111,6 +111,9 @@ static size_t lb_lds_bytes(int n) {
 static bool lb_fits(int n) { return lb_lds_bytes(n) <= 150 * 1024; }
 
 __device__ unsigned long long g_lu_stamps[8];   // phase clocks of workgroup 0's factorisations: panel load, panel, solve, update, count
+// Off in production: the accumulation is a non-atomic read-modify-write of a device global, racing across the streams
+// of the in-flight pipeline.  sf_debug_lu_stamps(out, 1) zeroes the clocks and turns them on, (out, 2) reads and turns them off.
+__device__ int g_lu_stamps_on = 0;
 template <bool MF>
 __device__ void lu_det_blocked(double *__restrict__ A, int n, double *det_out, double *pan, int *rowof, int *plist,
                                double *Us = nullptr) {
@@ -119,7 +122,7 @@ __device__ void lu_det_blocked(double *__restrict__ A, int n, double *det_out, d
   double det = 1.0;
   for (int k0 = 0; k0 < n; k0 += LB_NB) {
     const int nc = min(LB_NB, n - k0), H = n - k0, k1 = k0 + nc, rest = n - k1;
-    const bool stw = blockIdx.x == 0 && tid == 0;
+    const bool stw = blockIdx.x == 0 && tid == 0 && g_lu_stamps_on;
     unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     if (stw) q0 = __builtin_readcyclecounter();
     for (int e = tid; e < H * LB_NB; e += LB_NT) {
@@ -244,7 +247,7 @@ __device__ void lu_det_blocked(double *__restrict__ A, int n, double *det_out, d
       g_lu_stamps[0] += q1 - q0; g_lu_stamps[1] += q2 - q1; g_lu_stamps[2] += (q3 ? q3 : q4) - q2; g_lu_stamps[3] += q3 ? q4 - q3 : 0;
     }
   }
-  if (blockIdx.x == 0 && tid == 0) g_lu_stamps[4] += 1;
+  if (blockIdx.x == 0 && tid == 0 && g_lu_stamps_on) g_lu_stamps[4] += 1;
   if (tid == 0 && det_out) *det_out = info ? 0.0 : ((nswap & 1) ? -det : det);
 }
 
@@ -608,7 +611,9 @@ extern "C" int sf_debug_lu_stamps(unsigned long long *out8, int reset) {
   if (out8) SF_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lu_stamps), 8 * sizeof(unsigned long long)));
   if (reset) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int on = reset == 1 ? 1 : 0;
     SF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_lu_stamps), z, sizeof(z)));
+    SF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_lu_stamps_on), &on, sizeof(on)));
   }
   return 0;
 }

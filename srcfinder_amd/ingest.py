@@ -146,6 +146,11 @@ def stage_cube(src, active, rgb_bands=(60, 42, 24), *, interleave="bil", device=
         views = [b.numpy() for b in bufs]
         events = [None, None]
         copy_stream = torch.cuda.Stream(device=dev) if pinned else None
+        if pinned:
+            # `out` may be a block the caching allocator just took back from the previous call's compact cube, whose score /
+            # sweep kernels can still be reading it on the caller's stream (robust_mf does not synchronise on return): the
+            # private stream must not write it before the allocating stream has reached this point
+            copy_stream.wait_stream(torch.cuda.current_stream(dev))
         nthreads = max(1, int(threads if threads is not None else _default_threads()))
         pool = ThreadPoolExecutor(nthreads) if nthreads > 1 else None
         t_fill = 0.0

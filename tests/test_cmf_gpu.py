@@ -530,6 +530,25 @@ def test_host_cube_is_staged_compact_and_bit_identical(torch_cuda, library):
         assert torch.equal(got.out, want.out) and torch.equal(got.bgmeta, want.bgmeta) and torch.equal(got.alphaidx, want.alphaidx)
 
 
+def test_host_cubes_back_to_back_without_a_sync(torch_cuda, library):
+    """robust_mf(host) does not synchronise on return, and the next call's compact cube may reuse the block the
+    previous one just freed -- its staging copies (a private stream) must wait for the allocating stream, or the second
+    flightline's H2D copies overwrite a cube whose score kernel is still reading it.  Two DIFFERENT cubes of the same shape
+    back to back, large enough that the first call's kernels are still in flight when the second stages."""
+    torch = torch_cuda
+    a = make_cube_numpy(3000, 96, seed=41, abscf_full=library[:, 2])
+    b = make_cube_numpy(3000, 96, seed=42, abscf_full=library[:, 2])
+    want_a = cmf.robust_mf(torch.as_tensor(a).cuda(), library).out.clone()
+    want_b = cmf.robust_mf(torch.as_tensor(b).cuda(), library).out.clone()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        ra = cmf.robust_mf(a, library)
+        rb = cmf.robust_mf(b, library)               # no synchronisation in between
+        oa, ob = ra.out, rb.out
+        del ra, rb
+        assert torch.equal(oa, want_a) and torch.equal(ob, want_b)
+
+
 def test_full_flightline_shard_is_bit_identical(torch_cuda, library, full_flightline):
     """What one rank of 8 does with the same flightline: a COMPACT 75-column cube (its own allocation, flat extract
     kernel, three flightlines in flight on three streams) must reproduce columns 224..298 of the single-GPU product

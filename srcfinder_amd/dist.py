@@ -4,9 +4,9 @@ Cross-track columns are independent in the reference's loop (``for col in arange
 cmf/robust_mf.py:297), so rank r processes the contiguous sample range ``shard_columns(samples, world, r)``
 with exactly the arithmetic of a single-GPU run (results are bit-identical for every column), and the only
 exchange is ONE gather of the finished score blocks to the destination rank (``gather_columns``; the library call
-``robust_mf_sharded`` that also returns the per-column records and the metadata image packs them into two): ``torch.distributed.gather`` on the
+``robust_mf_sharded`` adds one <= 5 KB gather of the per-column records): ``torch.distributed.gather`` on the
 ``nccl`` backend is RCCL over xGMI; every peer sends its block straight to the root (7 links in parallel,
-<= 48 MB per rank for the float64 4-band product of a 598 x 20000 flightline).  The helper is backend
+12 MB per rank for the float64 score band of a 598 x 20000 flightline; 48 MB with ``gather="product"``).  The helper is backend
 agnostic -- the CPU tests drive it with ``gloo``.
 """
 from __future__ import annotations
@@ -154,30 +154,41 @@ def gather_packed(fields, samples: int, *, lead: int = 1, group=None, dst: int =
     return out
 
 
-def robust_mf_sharded(cube_shard, library, samples: int, *, group=None, dst: int = 0, compute=None, **kw):
+def robust_mf_sharded(cube_shard, library, samples: int, *, group=None, dst: int = 0, compute=None, gather: str = "score",
+                      **kw):
     """Run the matched filter on this rank's column slice ``cube_shard`` [lines, bands, ncols_r] and gather.
 
-    Returns on ``dst`` a dict with the full ``out`` [lines, samples, nb], ``alphaidx``, ``nuse``, ``status``
-    [samples] ([samples, k] for alphaidx / status of a multimodal run), ``colstats`` [3, samples] (and ``bgmeta``,
-    ``labels`` [lines, samples], ``nll`` when the run produced them); ``None`` elsewhere.
-    TWO collectives whatever the run produced (``gather_packed``): the image-like fields (product, background metadata,
-    labels) as one byte slab per rank, the per-column records as a second, small one.
-    ``compute`` defaults to :func:`srcfinder_amd.cmf.robust_mf`; tests inject a CPU stand-in to exercise the
-    sharding and the collective without a GPU.
-    """
+    ``gather="score"`` (default; the north star's "single gather of the final score image"): the image
+    collective carries the float64 CMF band only -- 8 B/pixel, 12 MB per rank of a 598 x 20000 flightline (plus the 4 B/pixel
+    of the int16 metadata image and 8 B/pixel of a label image when the run produced them, in the SAME collective).  ``dst``
+    gets ``score`` [lines, samples] float64; the RGB quick-look bands of the 4-band product are a copy of three cube bands
+    and stay with the rank that read those columns (``out`` of this rank's own block is returned as ``out_local`` on every
+    rank).  ``gather="product"``: the whole [lines, samples, nb] float64 product (32 B/pixel, 48 MB per rank) as ``out`` too.
+
+    Either way TWO collectives: the image slab above, and ONE small record slab (``alphaidx``, ``nuse``, ``status`` [samples]
+    -- [samples, k] for a multimodal run --, ``colstats`` [3, samples], ``nll`` when asked for: <= 5 KB per rank for the
+    unimodal product).  Returns the dict on ``dst`` and ``None`` elsewhere (``{"out_local": ...}`` is attached to the dict
+    on ``dst`` only).  ``compute`` defaults to :func:`srcfinder_amd.cmf.robust_mf`; tests inject a CPU stand-in to exercise
+    the sharding and the collectives without a GPU."""
     import torch.distributed as dist
+    if gather not in ("score", "product"):
+        raise ValueError("gather must be 'score' or 'product'")
     if compute is None:
         from .cmf import robust_mf as compute
     res = compute(cube_shard, library, **kw)
     get = (lambda n: res.get(n)) if isinstance(res, dict) else (lambda n: getattr(res, n, None))
-    lines = get("out").shape[0]
+    out = get("out")
+    lines = out.shape[0]
     images, records = {}, {}
     for name, axis in _COLUMN_AXIS.items():
         v = get(name)
         if v is None:
             continue
         if axis == 1 and v.ndim >= 2 and v.shape[0] == lines and name != "colstats":
-            images[name] = (v, axis)
+            if name == "out" and gather == "score":
+                images["score"] = (out[..., out.shape[2] - 1], 1)      # the CMF band is the LAST band (robust_mf.py:212-228)
+            else:
+                images[name] = (v, axis)
         else:
             records[name] = (v, axis)
     full = gather_packed(images, samples, lead=lines, group=group, dst=dst)
@@ -185,6 +196,10 @@ def robust_mf_sharded(cube_shard, library, samples: int, *, group=None, dst: int
     if dist.get_rank(group) != dst:
         return None
     full.update(rec)
+    if gather == "product":
+        full["score"] = full["out"][..., full["out"].shape[2] - 1]
+    else:
+        full["out_local"] = out
     return full
 
 

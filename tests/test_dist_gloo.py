@@ -33,7 +33,27 @@ def _worker(rank, world, port, lines, samples, q):
         r = O.robust_mf_oracle(shard, library)
         return {k: torch.as_tensor(v) for k, v in r.items()}
 
+    # count the collectives and their payload: the default call is ONE image gather of the score band (+ the metadata bytes
+    # of this run) and ONE small record gather
+    calls = []
+    real_gather = dist.gather
+
+    def counting_gather(t, *a, **k):
+        calls.append(t.numel() * t.element_size())
+        return real_gather(t, *a, **k)
+
+    dist.gather = counting_gather
     got = sd.robust_mf_sharded(np.ascontiguousarray(cube[:, :, s0:s1]), lib, samples, compute=compute)
+    ncalls_score, bytes_score = len(calls), list(calls)
+    del calls[:]
+    prod = sd.robust_mf_sharded(np.ascontiguousarray(cube[:, :, s0:s1]), lib, samples, compute=compute, gather="product")
+    ncalls_prod, bytes_prod = len(calls), list(calls)
+    dist.gather = real_gather
+    maxc = max(b - a for a, b in (sd.shard_columns(samples, world, r) for r in range(world)))
+    assert ncalls_score == 2 and ncalls_prod == 2
+    assert bytes_score[0] == lines * maxc * (8 + 4)            # float64 score + int16 x 2 metadata per pixel, nothing else
+    assert bytes_prod[0] == lines * maxc * (32 + 4)
+    assert bytes_score[1] <= 64 * maxc                         # the per-column records: a few dozen bytes per column
     # the overlapped form bench.py uses: two gathers in flight, waited in order
     mine = O.robust_mf_oracle(np.ascontiguousarray(cube[:, :, s0:s1]), lib)
     h1 = sd.gather_columns(torch.as_tensor(mine["out"][..., 3]), samples, dst=0, async_op=True)
@@ -42,11 +62,15 @@ def _worker(rank, world, port, lines, samples, q):
     if rank == 0:
         ref = O.robust_mf_oracle(cube, lib)
         ok = all(np.array_equal(got[k].numpy(), ref[k], equal_nan=True)
-                 for k in ("out", "alphaidx", "nuse", "status", "colstats", "bgmeta"))
+                 for k in ("alphaidx", "nuse", "status", "colstats", "bgmeta"))
+        ok = ok and np.array_equal(got["score"].numpy(), ref["out"][..., 3]) and "out" not in got
+        ok = ok and np.array_equal(got["out_local"].numpy(), ref["out"][:, s0:s1])
+        ok = ok and all(np.array_equal(prod[k].numpy(), ref[k], equal_nan=True)
+                        for k in ("out", "alphaidx", "nuse", "status", "colstats", "bgmeta"))
         ok = ok and np.array_equal(a1.numpy(), ref["out"][..., 3]) and np.array_equal(a2.numpy(), ref["bgmeta"])
         q.put(bool(ok))
     else:
-        assert got is None and a1 is None and a2 is None
+        assert got is None and prod is None and a1 is None and a2 is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -91,7 +115,7 @@ def _mm_worker(rank, world, port, q):
         return {name: torch.as_tensor(np.ascontiguousarray(np.take(v, np.arange(s0, s1), axis=sd._COLUMN_AXIS[name])))
                 for name, v in full.items()}
 
-    got = sd.robust_mf_sharded(None, None, samples, compute=compute)
+    got = sd.robust_mf_sharded(None, None, samples, compute=compute, gather="product")
     # a block whose column axis disagrees with the rank's shard is refused, not silently mis-assembled
     try:
         sd.gather_columns(torch.zeros(s1 - s0 + 1, k), samples, axis=0)
@@ -100,6 +124,7 @@ def _mm_worker(rank, world, port, q):
         raised = True
     if rank == 0:
         ok = raised and all(np.array_equal(got[name].numpy(), v) for name, v in full.items())
+        ok = ok and np.array_equal(got["score"].numpy(), full["out"][..., 3])
         q.put(bool(ok))
     else:
         assert got is None and raised

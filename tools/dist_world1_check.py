@@ -13,9 +13,11 @@ os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
 cube = make_cube_torch(400, 9, seed=3, abscf_full=lib[:, 2])
-got = sd.robust_mf_sharded(cube, lib, 9, metadata=True)
+got = sd.robust_mf_sharded(cube, lib, 9, metadata=True, gather="product")
+sc = sd.robust_mf_sharded(cube, lib, 9, metadata=True)
 ref = cmf.robust_mf(cube, lib, metadata=True)
-ok1 = all(torch.equal(got[k], getattr(ref, k)) for k in ("out", "alphaidx", "nuse", "status", "bgmeta")) and torch.equal(got["colstats"], ref.colstats)
+ok1 = all(torch.equal(got[k], getattr(ref, k)) for k in ("out", "alphaidx", "nuse", "status", "bgmeta")) and torch.equal(got["colstats"], ref.colstats) \
+    and torch.equal(sc["score"], ref.out[..., 3]) and torch.equal(sc["bgmeta"], ref.bgmeta) and "out" not in sc
 net = cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024))
 plane = torch.as_tensor(synthetic_plane(6, 5, seed=1)).cuda()
 a = sd.predict_flightline_sharded(plane, net=net, batch=8)

@@ -195,6 +195,12 @@ int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0,
                        const int32_t *status, double nodata, double *colstats, hipStream_t st);
 // cmf_loocv4.hip: the production-window sweep (p in 69..72, 201-point grid) on the 4x4x4 fp64 MFMA
 constexpr int SF_SW4_NJ = 18, SF_SW4_NM = 13;
+// windows the 4x4x4 kernels serve: band groups of four (a lane group of the MFMA holds NJ consecutive bands, 4 NJ = the row
+// stride of xt, and at most the last three lie beyond the window): 18 (p 69..72: CH4), 21 (81..84: CO2, p = 83), 24 (93..96)
+static inline int sf_sw4_groups(int p) {
+  const int s4 = (p + 3) / 4;
+  return (s4 == 18 || s4 == 21 || s4 == 24) ? s4 : 0;
+}
 constexpr int SF_LR_K = 28, SF_LR_K2 = 36;   // ranks of the factored sweep coefficients (cmf_lowrank.hip); fragments use the K2 layout
 size_t sf_lowrank_bytes(const SfGeom &g);
 int sf_launch_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas, const SfGeom &g,
@@ -206,5 +212,6 @@ int sf_launch_cov4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
 int sf_launch_wfrag4(const double *evec, const double *d, const SfGeom &g, size_t wstride, double *wfrag, hipStream_t st);
 int sf_launch_sweep4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
                      const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,
-                     int nsplit, double *part, int variant, void *lr_scratch, hipStream_t st);
+                     int nsplit, double *part, int variant, void *lr_scratch, hipStream_t st,
+                     const int32_t **lrok_out = nullptr);   // lrok_out: where the rank factorisation left its verdict per column
 

@@ -174,7 +174,7 @@ size_t sf_cov_scratch_bytes(const SfGeom &g) {
 
 int sf_launch_cov(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu,
                   const SfGeom &g, double *cov, void *scratch, hipStream_t st) {
-  if (!xt_f64 && sf_tune().cov_variant != 1 && g.s4 == SF_SW4_NJ)   // production window: p in 69..72
+  if (!xt_f64 && sf_tune().cov_variant != 1 && sf_sw4_groups(g.p))   // p in 69..72 (CH4), 81..84 (CO2), 93..96
     return sf_launch_cov4((const float *)xt, mask_t, nuse, mu, g, cov, scratch, st);
   switch (g.nt) {
     case 1: return launch_cov_nt<1>(xt, xt_f64, mask_t, nuse, mu, g, cov, scratch, st);

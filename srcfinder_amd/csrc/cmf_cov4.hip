@@ -267,14 +267,180 @@ __global__ __launch_bounds__(256) void k_syrk4_reduce(const double *__restrict__
   }
 }
 
+// ---- windows of 81..84 and 93..96 bands (NG = 21 / 24 band groups; the CO2 window is 309..391, p = 83: robust_mf.py:190-191)
+// 231 (300) upper-triangular tiles are 462 (600) accumulator registers: more than a wave's 512.  A 16-row tile is therefore
+// taken by TWO waves, each with half of the tiles (116 / 150 accumulators, pinned to the AGPR file as far as it reaches), on
+// different SIMDs: waves (2 rg, 2 rg + 1) share row group rg of the workgroup's 32 rows per step.  Both convert the rows (3 NG
+// vector instructions per NTRI / 2 MFMAs instead of per NTRI); everything else -- operand layout band(I, n) = NG n + I, the
+// depth-2 row prefetch whose addresses do not depend on loaded data, exact zeros for invalid rows and for bands beyond the
+// window (only the last three of lane group n = 3 can be: p >= 4 NG - 3), the split-wise partial sums -- is k_syrk4's.
+template <int NG>
+struct Cov4H {
+  static constexpr int NTRI = NG * (NG + 1) / 2, HALF = (NTRI + 1) / 2;
+  static constexpr int NACC_A = HALF < 120 ? HALF : 120;           // accumulators in AGPRs; the rest in VGPRs
+  static constexpr int tri(int I, int J) { return I * NG - I * (I - 1) / 2 + (J - I); }
+};
+template <int T, int NA>
+__device__ __forceinline__ void mfma_acc_h(double &acc, double a, double b) {
+  if constexpr (T < NA) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <int I, int N>
+__device__ __forceinline__ void tie_operands(double (&f)[N]) {   // one empty volatile asm per operand: it is computed before what follows
+  if constexpr (I < N) {
+    asm volatile("" : "+v"(f[I]));
+    tie_operands<I + 1, N>(f);
+  }
+}
+template <int NG, int H>
+__device__ __forceinline__ void syrk4h_tile(double (&acc)[Cov4H<NG>::HALF], const double (&f)[NG]) {
+  using C = Cov4H<NG>;
+  static_for<0, NG>([&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    static_for<I, NG>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      constexpr int t = C::tri(I, J);
+      if constexpr ((t < C::HALF) == (H == 0)) mfma_acc_h<t - H * C::HALF, C::NACC_A>(acc[t - H * C::HALF], f[I], f[J]);
+    });
+  });
+}
+
+template <int NG>
+__global__ __launch_bounds__(256, 1) void k_syrk4h(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
+                                                    const double *__restrict__ mu, int L, int p, int rows_per_wg,
+                                                    double *__restrict__ part) {
+  using C = Cov4H<NG>;
+  constexpr int PS = 4 * NG, NTRI = C::NTRI, HALF = C::HALF;
+  extern __shared__ __attribute__((aligned(16))) double c4h_lds[];
+  double *red = c4h_lds;                       // [2 row groups][NTRI][16]: the waves' tiles before the final sum
+  double *mus = red + 2 * NTRI * 16;           // [PS]
+  double *zeros = mus + PS;                    // [NG]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = wave & 1, rg = wave >> 1;
+  const int q = lane >> 4, m = (lane >> 2) & 3, n = lane & 3;
+  const int c = blockIdx.x, split = blockIdx.y;
+  for (int i = tid; i < PS; i += 256) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
+  if (tid < NG) zeros[tid] = 0.0;
+  __syncthreads();
+  const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
+  const uint8_t *mp = mask_t + (size_t)c * L;
+  const float *xc = xt + (size_t)c * L * PS + NG * n;
+  const int rlane = 4 * m + q;   // this lane's row inside a 16-row tile
+
+  double acc[HALF];
+#pragma unroll
+  for (int t = 0; t < HALF; ++t) acc[t] = 0.0;
+
+  constexpr int DEPTH = 2;
+  float xraw[DEPTH][NG];
+  uint8_t mk[DEPTH];
+  auto fetch = [&](int r0, auto sc) {
+    constexpr int sl = decltype(sc)::value;
+    const int row = r0 + rlane;
+    const int rr = row < rend ? row : rbeg;
+    mk[sl] = mp[rr];
+    const float *xp = xc + (size_t)rr * PS;
+#pragma unroll
+    for (int s = 0; s + 1 < NG; s += 2) sf_load2(xp + s, xraw[sl][s], xraw[sl][s + 1]);
+    if constexpr (NG & 1) xraw[sl][NG - 1] = xp[NG - 1];
+  };
+  unsigned colm[3];   // lane n = 3 holds bands 3 NG .. 4 NG - 1: those beyond the window are switched off
+#pragma unroll
+  for (int i = 0; i < 3; ++i) colm[i] = (NG * n + (NG - 3) + i < p) ? 0xffffffffu : 0u;
+  int r0 = rbeg + 16 * rg;
+  static_for<0, DEPTH>([&](auto sc) { fetch(r0 + 32 * decltype(sc)::value, sc); });
+  for (; r0 < rend; r0 += 32 * DEPTH) {
+    static_for<0, DEPTH>([&](auto sc) {
+      constexpr int sl = decltype(sc)::value;
+      const int rt = r0 + 32 * sl;
+      const bool ok = (rt + rlane < rend) && mk[sl] != 0;
+      int opq = 0;
+      asm volatile("" : "+v"(opq));   // keep the mean reads inside the iteration (see k_sweep)
+      const double *musl = (ok ? mus + NG * n : zeros) + opq;
+      unsigned okm = ok ? 0xffffffffu : 0u;
+      asm volatile("" : "+v"(okm));   // opaque: otherwise the and is turned back into a select of the CONVERTED value
+      double f[NG];
+#pragma unroll
+      for (int I = 0; I < NG; ++I) {
+        unsigned msk = okm;
+        if (I >= NG - 3) msk &= colm[I - (NG - 3)];
+        f[I] = (double)__uint_as_float(__float_as_uint(xraw[sl][I]) & msk) - musl[I];
+      }
+      fetch(rt + 32 * DEPTH, sc);
+      // the asm MFMAs are invisible to the hazard recogniser: every operand is tied down first, then the wait states a VALU
+      // result needs before an MFMA may read it (volatile asm statements keep their order)
+      tie_operands<0, NG>(f);
+      asm volatile("s_nop 4");
+      if (half == 0) syrk4h_tile<NG, 0>(acc, f);   // (wave-uniform)
+      else syrk4h_tile<NG, 1>(acc, f);
+    });
+  }
+  // ---- sum the 4 blocks (row groups of the MFMA) of every tile, then the two row groups of the workgroup
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // let the last asm MFMAs retire
+#pragma unroll
+  for (int t = 0; t < HALF; ++t) {
+    double v = acc[t];
+    v += dpp_row<0x124>(v);   // row_ror:4
+    v += dpp_row<0x128>(v);   // row_ror:8
+    const int tt = t + half * HALF;
+    if (m == 0 && tt < NTRI) red[(rg * NTRI + tt) * 16 + 4 * q + n] = v;
+  }
+  __syncthreads();
+  double *po = part + ((size_t)c * gridDim.y + split) * (NTRI * 16);
+  for (int i = tid; i < NTRI * 16; i += 256) po[i] = red[i] + red[NTRI * 16 + i];
+}
+
+// part[c][split][tile][4 i + j] -> cov[c][band(I,i)][band(J,j)] (and its mirror), band(I, i) = NG i + I
+template <int NG>
+__global__ __launch_bounds__(256) void k_syrk4h_reduce(const double *__restrict__ part, int nsplit,
+                                                        const int32_t *__restrict__ nuse, int p, double *__restrict__ cov) {
+  constexpr int NTRI = NG * (NG + 1) / 2;
+  const int c = blockIdx.x;
+  const double denom = (double)nuse[c] - 1.0;
+  for (int idx = blockIdx.y * 256 + threadIdx.x; idx < NTRI * 16; idx += 256 * gridDim.y) {
+    const int t = idx >> 4, i = (idx >> 2) & 3, j = idx & 3;
+    int I = 0, rem = t, rowlen = NG;
+    while (rem >= rowlen) { rem -= rowlen; ++I; --rowlen; }
+    const int J = I + rem;
+    double s = 0;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[((size_t)c * nsplit + sp) * (NTRI * 16) + idx];
+    s /= denom;
+    const int a = NG * i + I, b = NG * j + J;
+    if (a < p && b < p && (I != J || i <= j)) {
+      cov[((size_t)c * p + a) * p + b] = s;
+      cov[((size_t)c * p + b) * p + a] = s;
+    }
+  }
+}
+
+template <int NG>
+int launch_cov4h(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g, double *cov,
+                 void *scratch, hipStream_t st) {
+  using C = Cov4H<NG>;
+  const int nsplit = sf_sweep_splits(g.lines, g.ncols);
+  int rows = sf_cdiv(g.lines, nsplit);
+  rows = (rows + 63) / 64 * 64;   // whole prefetch rings: 2 row groups x 16 rows x depth 2
+  double *part = reinterpret_cast<double *>(scratch);
+  const size_t lds = ((size_t)2 * C::NTRI * 16 + 4 * NG + NG) * sizeof(double);
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_syrk4h<NG>), lds)) return rc;
+  hipLaunchKernelGGL(k_syrk4h<NG>, dim3(g.ncols, nsplit), dim3(256), lds, st, xt, mask_t, mu, g.lines, g.p, rows, part);
+  SF_LAUNCH_CHECK("k_syrk4h");
+  hipLaunchKernelGGL(k_syrk4h_reduce<NG>, dim3(g.ncols, 4), dim3(256), 0, st, part, nsplit, nuse, g.p, cov);
+  SF_LAUNCH_CHECK("k_syrk4h_reduce");
+  return 0;
+}
+
 }  // namespace
 
 size_t sf_cov4_scratch_bytes(const SfGeom &g) {
-  return sf_align((size_t)g.ncols * sf_sweep_splits(g.lines, g.ncols) * C4_NTRI * 16 * sizeof(double));
+  const int ng = sf_sw4_groups(g.p) ? sf_sw4_groups(g.p) : C4_NG;
+  return sf_align((size_t)g.ncols * sf_sweep_splits(g.lines, g.ncols) * (ng * (ng + 1) / 2) * 16 * sizeof(double));
 }
 
 int sf_launch_cov4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
                    double *cov, void *scratch, hipStream_t st) {
+  if (g.s4 == 21) return launch_cov4h<21>(xt, mask_t, nuse, mu, g, cov, scratch, st);
+  if (g.s4 == 24) return launch_cov4h<24>(xt, mask_t, nuse, mu, g, cov, scratch, st);
   const int nsplit = sf_sweep_splits(g.lines, g.ncols);
   int rows = sf_cdiv(g.lines, nsplit);
   rows = (rows + 127) / 128 * 128;   // whole prefetch rings: 4 waves x 16 rows x depth 2

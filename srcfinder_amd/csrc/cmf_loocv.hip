@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256, 1) void k_sweep(const XT *__restrict__ xt, con
                                                    const double *__restrict__ lam, const double *__restrict__ wfrag,
                                                    size_t wstride, const int32_t *__restrict__ status,
                                                    const double *__restrict__ alphas, int nalpha, int L, int p,
-                                                   int PS, int rows_per_wg, double *__restrict__ part) {
+                                                   int PS, int rows_per_wg, double *__restrict__ part,
+                                                   const int32_t *__restrict__ taken) {
   constexpr int NS = S4C ? S4C : 4 * NT;
   constexpr int NUM = NUC ? NUC : SW_NUMAX;
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256, 1) void k_sweep(const XT *__restrict__ xt, con
   const int NA16 = NU * 16;
   double *po = part + ((size_t)c * nsplit + split) * 2 * NA16;
 
+  if (taken && taken[c] != 0) return;   // a rank-factored 4x4x4 sweep serves this column (cmf_loocv4.hip)
   if (status[c] != 0) {  // no valid rows / singular: every NLL is +inf, nothing to accumulate
     for (int i = tid; i < 2 * NA16; i += 256) po[i] = 0.0;
     return;
@@ -260,9 +262,9 @@ template <bool TBL>
 __global__ __launch_bounds__(1024) void k_nll(const double *__restrict__ part, int nsplit, const int32_t *__restrict__ nuse,
                                               const double *__restrict__ d, const double *__restrict__ lam,
                                               const int32_t *__restrict__ status, const double *__restrict__ alphas,
-                                              int nalpha, int p, int NA16, int rq_scaled,
+                                              int nalpha, int p, int NA16, int rq_scaled_all,
                                               double *__restrict__ nll_out, int32_t *__restrict__ alphaidx,
-                                              double *__restrict__ rest_out) {
+                                              double *__restrict__ rest_out, const int32_t *__restrict__ rq_col) {
   extern __shared__ double tbl[];   // TBL: [nalpha][p] log(n beta_i lam_j + alpha_i), then [p] log(100 d_j)
   __shared__ double snll[SF_NALPHA_MAX];
   __shared__ double slogd;
@@ -270,6 +272,9 @@ __global__ __launch_bounds__(1024) void k_nll(const double *__restrict__ part, i
   const int st = status[c];
   const double n = (double)nuse[c];
   const double inf = __builtin_inf();
+  // which sweep wrote this column's partial sums: the 4x4x4 kernels hand over beta sum r/q (and count their rows), the
+  // 16x16x4 kernel sum r/q; rq_col (the rank-factorisation's verdict per column) when the two share a launch
+  const int rq_scaled = rq_col ? (rq_col[c] != 0) : rq_scaled_all;
   if (TBL && st == 0) {
     double *tld = tbl + (size_t)nalpha * p;
     for (int j = tid; j < p; j += nthr) tld[j] = log(d[(size_t)c * p + j] * 100.0);
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(1024) void k_nll(const double *__restrict__ part, i
 template <int NT, int S4C, int NUC, bool WREG, typename XT>
 int launch_sweep_t(const XT *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
                    const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,
-                   int nsplit, double *part, hipStream_t st) {
+                   int nsplit, double *part, hipStream_t st, const int32_t *taken = nullptr) {
   const size_t lds = ((size_t)g.nu * g.s4 * 64 + g.ps + g.nu * 16) * sizeof(double);
   const size_t lds_red = (size_t)4 * g.nu * 16 * (2 * sizeof(double) + sizeof(int));
   const size_t need = lds > lds_red ? lds : lds_red;
@@ -369,16 +374,16 @@ int launch_sweep_t(const XT *xt, const uint8_t *mask_t, const int32_t *nuse, con
   int rows = sf_cdiv(g.lines, nsplit);
   rows = (rows + 63) / 64 * 64;
   hipLaunchKernelGGL((k_sweep<NT, S4C, NUC, WREG, XT>), dim3(g.ncols, nsplit), dim3(256), need, st, xt, mask_t, nuse, mu,
-                     lam, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part);
+                     lam, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part, taken);
   SF_LAUNCH_CHECK("k_sweep");
   return 0;
 }
 
-#define SW_ARGS xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part, st
+#define SW_ARGS xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part, st, taken
 template <typename XT>
 int launch_sweep(const XT *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
                  const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,
-                 int nsplit, double *part, hipStream_t st) {
+                 int nsplit, double *part, hipStream_t st, const int32_t *taken = nullptr) {
   if constexpr (sizeof(XT) == 4) {
     const bool std_grid = g.nu == 13;
     // production windows get fully specialised kernels (CH4 radiance p = 72; CO2 p = 83)
@@ -401,15 +406,15 @@ int launch_sweep(const XT *xt, const uint8_t *mask_t, const int32_t *nuse, const
 
 int launch_nll(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam, const int32_t *status,
                const double *alphas, const SfGeom &g, int rq_scaled, double *nll, int32_t *alphaidx, hipStream_t st,
-               double *rest = nullptr) {
+               double *rest = nullptr, const int32_t *rq_col = nullptr) {
   const size_t lds = ((size_t)g.nalpha * g.p + g.p) * sizeof(double);
   if (lds <= 150 * 1024 && g.ncols <= 256) {   // one 116 KB workgroup per CU: only worth it when the launch is a single round
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_nll<true>), lds)) return rc;
     hipLaunchKernelGGL(k_nll<true>, dim3(g.ncols), dim3(1024), lds, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha,
-                       g.p, g.nu * 16, rq_scaled, nll, alphaidx, rest);
+                       g.p, g.nu * 16, rq_scaled, nll, alphaidx, rest, rq_col);
   } else {
     hipLaunchKernelGGL(k_nll<false>, dim3(g.ncols), dim3(256), 0, st, part, nsplit, nuse, d, lam, status, alphas, g.nalpha,
-                       g.p, g.nu * 16, rq_scaled, nll, alphaidx, rest);
+                       g.p, g.nu * 16, rq_scaled, nll, alphaidx, rest, rq_col);
   }
   SF_LAUNCH_CHECK("k_nll");
   return 0;
@@ -425,11 +430,15 @@ int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, co
 }
 
 static bool sweep4_ok(const SfGeom &g, int xt_f64) {
-  return !xt_f64 && sf_tune().sweep_variant != 1 && g.nu == SF_SW4_NM && g.s4 == SF_SW4_NJ;
+  return !xt_f64 && sf_tune().sweep_variant != 1 && g.nu == SF_SW4_NM && sf_sw4_groups(g.p) != 0;
 }
 
+// per column: the W fragments of the 16x16x4 sweep ([nt][s4][64]) or of the 4x4x4 sweeps ([nj][nje][16], nje = nj rounded up
+// to even); windows of 21 / 24 band groups keep BOTH (the columns whose rank factorisation is refused take the 16x16x4 kernel)
 size_t sf_wfrag_elems(const SfGeom &g) {
-  const size_t a = (size_t)g.nt * g.s4 * 64, b = (size_t)SF_SW4_NJ * SF_SW4_NJ * 16;
+  const int nj = sf_sw4_groups(g.p);
+  const size_t a = (size_t)g.nt * g.s4 * 64, b = (size_t)nj * (nj + (nj & 1)) * 16;
+  if (nj > SF_SW4_NJ) return a + b;
   return a > b ? a : b;
 }
 
@@ -454,6 +463,22 @@ int sf_launch_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int
   if (sweep4_ok(g, xt_f64)) {
     if (int rcw = sf_launch_wfrag4(evec, d, g, wstride, wfrag, st)) return rcw;
     void *lr = reinterpret_cast<char *>(part) + sf_align((size_t)g.ncols * nsplit * 2 * g.nu * 16 * sizeof(double));
+    const int nj = sf_sw4_groups(g.p);
+    if (nj > SF_SW4_NJ) {
+      // 21 / 24 band groups (CO2: p = 83): the streamed rank-factored kernels; a column whose factorisation is refused (lrok == 0)
+      // is swept by the 16x16x4 kernel from its own fragments (behind the 4x4x4 ones in the column's slot), and k_nll reads the
+      // factorisation's verdict to tell the two forms of partial sums apart
+      const int32_t *lrok = nullptr;
+      int rc4 = sf_launch_sweep4((const float *)xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part, 0, lr, st,
+                                 &lrok);
+      if (rc4) return rc4;
+      double *wfragG = wfrag + (size_t)nj * (nj + (nj & 1)) * 16;
+      hipLaunchKernelGGL(k_wfrag, dim3(g.ncols), dim3(256), 0, st, evec, d, g.p, g.s4, g.nt, wstride, wfragG);
+      SF_LAUNCH_CHECK("k_wfrag");
+      if (int rc = launch_sweep((const float *)xt, mask_t, nuse, mu, lam, wfragG, wstride, status, alphas, g, nsplit, part, st, lrok))
+        return rc;
+      return launch_nll(part, nsplit, nuse, d, lam, status, alphas, g, 1, nll, alphaidx, st, nullptr, lrok);
+    }
     int rc4 = sf_launch_sweep4((const float *)xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part,
                                sf_tune().sweep_variant, sf_tune().sweep_variant == 2 ? nullptr : lr, st);
     if (rc4) return rc4;

@@ -39,17 +39,18 @@ constexpr int sw4_reads(int t) {
   return left <= 0 ? 0 : (left < 4 ? left : 4);
 }
 
-__global__ void k_wfrag4(const double *__restrict__ evec, const double *__restrict__ d, int p, size_t stride,
+__global__ void k_wfrag4(const double *__restrict__ evec, const double *__restrict__ d, int p, int nj, int nje, size_t stride,
                          double *__restrict__ wfrag) {
-  // wfrag[c][(ig*18 + jg)*16 + 4 q + n] = V[b][j] / d[b],   b = 18 q + ig,   j = 4 jg + n
+  // wfrag[c][(ig*nje + jg)*16 + 4 q + n] = V[b][j] / d[b],   b = nj q + ig,   j = 4 jg + n   (nje = nj rounded up to even: the
+  // streamed sweep reads the blocks of two eigen groups as one pair; the padding group is zero)
   const int c = blockIdx.x;
   const double *ev = evec + (size_t)c * p * p;
   const double *dd = d + (size_t)c * p;
   double *w = wfrag + (size_t)c * stride;
-  for (int i = threadIdx.x; i < S4J * S4J * 16; i += blockDim.x) {
+  for (int i = threadIdx.x; i < nj * nje * 16; i += blockDim.x) {
     const int n = i & 3, q = (i >> 2) & 3, blk = i >> 4;
-    const int ig = blk / S4J, jg = blk - ig * S4J;
-    const int b = S4J * q + ig, j = 4 * jg + n;
+    const int ig = blk / nje, jg = blk - ig * nje;
+    const int b = nj * q + ig, j = 4 * jg + n;
     w[i] = (j < p && b < p) ? ev[(size_t)j * p + b] / dd[b] : 0.0;
   }
 }
@@ -714,16 +715,19 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
 //   and validity selects 0.03 + 0.05 ms; with every one of them gone the launch is 4.9 ms, not 4.2: profiles/r03_sweep_ablation.txt.
 //   (The hardware's A-block broadcast -- cbsz / abid, which would replace the three DPP-rotated copies of t -- assembles
 //   for v_mfma_f64_4x4x4_4b_f64 but is ignored by gfx950: tools/microbench/mfma4_layout.hip modes 1-3.)
-template <int NK>
+template <int NK, int NJT = S4J>
 struct SwS {
-  static constexpr int NJ = S4J, NM = S4M, NKP = (NK + 1) / 2, NG = NM / 4;   // NG full groups of 4 alpha tiles + one tile
-  static constexpr int R1 = NJ * (NJ / 2);   // W block pairs (GEMM1 A operands), ds_read_b128
-  static constexpr int R2 = NJ * NKP;        // -U block pairs (GEMM2a A operands), ds_read_b128 (odd NK: last pair half empty)
+  // NJ band steps (= band groups of four: a lane group holds NJ consecutive bands), NJE eigen groups (NJ rounded up to even:
+  // the W blocks of two eigen groups travel as one 16-byte pair; the padding group of an odd NJ is zero)
+  static constexpr int NJ = NJT, NJE = NJT + (NJT & 1), NM = S4M, NKP = (NK + 1) / 2, NG = NM / 4;   // NG full groups of 4 alpha tiles + one tile
+  static constexpr int NMU = (NJ + 1) / 2;   // 16-byte pairs of the column mean per lane group
+  static constexpr int R1 = NJ * (NJE / 2);  // W block pairs (GEMM1 A operands), ds_read_b128
+  static constexpr int R2 = NJE * NKP;       // -U block pairs (GEMM2a A operands), ds_read_b128 (odd NK: last pair half empty)
   static constexpr int R3 = NG * NK * 2;     // W fragment pairs of the full alpha-tile groups (GEMM2b B operands), ds_read_b128
   static constexpr int R4 = NK;              // W fragments of the 13th alpha tile, ds_read_b64
   static constexpr int NR = R1 + R2 + R3 + R4;
   static constexpr int LEAD12 = 8, LEAD3 = 4, RING = 10;
-  static_assert(NM == 4 * NG + 1 && NJ % 2 == 0, "tile structure");
+  static_assert(NM == 4 * NG + 1, "tile structure");
   static constexpr int lead(int c) { return c < R1 + R2 ? LEAD12 : LEAD3; }
   // reads issued when unit c (= read c and the MFMAs it feeds) is awaited
   static constexpr int issued(int c) {
@@ -740,9 +744,9 @@ struct SwS {
   static constexpr int OU = OW + R1 * 32;                    // [R2][16][2]
   static constexpr int OF = OU + R2 * 32;                    // [R3][64][2]
   static constexpr int OL = OF + R3 * 128;                   // [R4][64]
-  static constexpr int OM = OL + R4 * 64;                    // mu [72]
-  static constexpr int OS = OM + 4 * NJ;                     // 1/sqrt(lam) [72] (prologue only)
-  static constexpr int TOTAL = OS + 4 * NJ;
+  static constexpr int OM = OL + R4 * 64;                    // mu [4 lane groups][2 NMU] (16-byte aligned slices)
+  static constexpr int OS = OM + 8 * NMU;                    // 1/sqrt(lam) [4 NJE] (prologue only)
+  static constexpr int TOTAL = OS + 4 * NJE;
   static constexpr size_t lds_bytes() { return (size_t)TOTAL * sizeof(double); }
 };
 
@@ -765,11 +769,18 @@ template <int CNT>
 __device__ __forceinline__ void lds_await(d2_t &a, d2_t &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT)); }
 template <int CNT>
 __device__ __forceinline__ void lds_await(double &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(CNT)); }
-template <int CNT>
-__device__ __forceinline__ void lds_await9(d2_t (&m)[9]) {
-  asm volatile("s_waitcnt lgkmcnt(%9)"
-               : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8])
-               : "n"(CNT));
+template <int I, int N>
+__device__ __forceinline__ void lds_tie(d2_t (&m)[N]) {
+  if constexpr (I < N) {
+    asm volatile("" : "+v"(m[I]));
+    lds_tie<I + 1, N>(m);
+  }
+}
+// wait, then tie every register of the group to a point behind the wait (volatile asm statements keep their order)
+template <int CNT, int N>
+__device__ __forceinline__ void lds_await_all(d2_t (&m)[N]) {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT));
+  lds_tie<0, N>(m);
 }
 
 // EXP (timing experiments, wrong results, -DSF_SWEEP_EXPERIMENTS): bit 0 no row reduction, 1 no conversion / centring,
@@ -778,7 +789,7 @@ __device__ __forceinline__ void lds_await9(d2_t (&m)[9]) {
 // RN: the running products are renormalised (mantissa / exponent split) after every RN-th tile of a wave.  A nonzero finite q of this
 // sweep lies in [~1e-17, ~1e3] (1 + a sum of O(1) terms in fp64), so the product of the 4 RN = 16 values a lane folds in between two
 // splits stays inside [1e-272, 1e48]: scaling by powers of two is exact there, the results are bit-identical to RN = 1.
-template <int NK, int EXP = 0, int RN = 4>
+template <int NK, int EXP = 0, int RN = 4, int NJT = S4J>
 __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
                                                     const int32_t *__restrict__ nuse, const double *__restrict__ mu,
                                                     const double *__restrict__ ufrag_g, const double *__restrict__ wfrag2_g,
@@ -787,8 +798,8 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
                                                     size_t wstride, const int32_t *__restrict__ status,
                                                     const double *__restrict__ alphas, int nalpha, int L, int p,
                                                     int PS, int rows_per_wg, double *__restrict__ part, int split_fastest) {
-  using S = SwS<NK>;
-  constexpr int NJ = S::NJ, NM = S::NM, NA16 = NM * 16, NW = 8, NKP = S::NKP, NG = S::NG;
+  using S = SwS<NK, NJT>;
+  constexpr int NJ = S::NJ, NJE = S::NJE, NMU = S::NMU, NM = S::NM, NA16 = NM * 16, NW = 8, NKP = S::NKP, NG = S::NG;
   constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, NR = S::NR, RING = S::RING;
   constexpr int NK2 = SF_LR_K2 / 4;          // stride of the global fragment layout (shared by both ranks)
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -805,12 +816,12 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
   // nothing else runs on the CU meanwhile, and a load-store loop paid one L2 round trip per iteration
   if constexpr ((EXP & 64) == 0) {
     constexpr int NT = 64 * NW;
-    constexpr int NW2 = NJ * NJ * 8, NU2 = NJ * NKP * 16, NF2 = R3 * 64, NL2 = NK * 32;   // 16-byte pieces of the four tables
+    constexpr int NW2 = NJ * NJE * 8, NU2 = NJE * NKP * 16, NF2 = R3 * 64, NL2 = NK * 32;   // 16-byte pieces of the four tables
     constexpr int IW = (NW2 + NT - 1) / NT, IU = (NU2 + NT - 1) / NT, IF = (NF2 + NT - 1) / NT, IL = (NL2 + NT - 1) / NT;
-    static_assert(IL == 1 && 4 * NJ <= NT, "one piece per thread");
+    static_assert(IL == 1 && 4 * NJE <= NT, "one piece per thread");
     double *mus = sm + S::OM, *scl = sm + S::OS;
-    const d2_t *wsrc = reinterpret_cast<const d2_t *>(wfrag + (size_t)c * wstride);            // [(s*18 + jg)*16 + 4q + n]
-    const d2_t *us = reinterpret_cast<const d2_t *>(ufrag_g + (size_t)c * (NJ * NK2 * 16));    // [(jg*NK2 + mg)*16 + 4q + n]
+    const d2_t *wsrc = reinterpret_cast<const d2_t *>(wfrag + (size_t)c * wstride);            // [(s*NJE + jg)*16 + 4q + n]
+    const d2_t *us = reinterpret_cast<const d2_t *>(ufrag_g + (size_t)c * (NJE * NK2 * 16));   // [(jg*NK2 + mg)*16 + 4q + n]
     const double *ws = wfrag2_g + (size_t)c * (NM * NK2 * 64);                                 // [(M*NK2 + mg)*64 + lane]
     const d2_t zero2 = {0.0, 0.0};
     d2_t vw[IW], vu[IU], vf[IF], vl;
@@ -832,14 +843,18 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
     vl = (tid < NL2) ? *reinterpret_cast<const d2_t *>(ws + ((NM - 1) * NK2 + (tid >> 5)) * 64 + 2 * (tid & 31)) : zero2;
     // W blocks scaled by 1/sqrt(lam_j): GEMM1 then yields the whitened coordinates y_j/sqrt(lam_j) (unit variance) and
     // z their squares, which is what the row-scaled factorisation of cmf_lowrank.hip multiplies
-    if (tid < 4 * NJ) { scl[tid] = (tid < p) ? 1.0 / sqrt(lamv) : 1.0; mus[tid] = muv; }
+    // (band b = NJ g + s of lane group g sits at mus[2 NMU g + s]: every group's slice starts on a 16-byte boundary)
+    if (tid < 4 * NJE) {
+      scl[tid] = (tid < p) ? 1.0 / sqrt(lamv) : 1.0;
+      if (tid < 4 * NJ) mus[2 * NMU * (tid / NJ) + tid % NJ] = muv;
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < IW; ++k) {
       const int i = tid + k * NT;
       if (i < NW2) {
-        const int blk = i >> 3, sl = 2 * (i & 7), s = blk / NJ, jg = blk - s * NJ;
-        double *dst = sm + S::OW + ((s * (NJ / 2) + (jg >> 1)) * 16 + sl) * 2 + (jg & 1);
+        const int blk = i >> 3, sl = 2 * (i & 7), s = blk / NJE, jg = blk - s * NJE;
+        double *dst = sm + S::OW + ((s * (NJE / 2) + (jg >> 1)) * 16 + sl) * 2 + (jg & 1);
         dst[0] = vw[k].x * scl[4 * jg + (sl & 3)];
         dst[2] = vw[k].y * scl[4 * jg + (sl & 3) + 1];
       }
@@ -881,7 +896,7 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
   const unsigned uadr = smb + S::OU * 8 + (4 * g + (lane & 3)) * 16;
   const unsigned fadr = smb + S::OF * 8 + lane * 16;
   const unsigned ladr = smb + S::OL * 8 + lane * 8;
-  const unsigned madr = smb + S::OM * 8 + g * (NJ * 8);
+  const unsigned madr = smb + S::OM * 8 + g * (NMU * 16);
   const double qnan = __builtin_nan("");
 
   float xraw[NJ];
@@ -891,7 +906,8 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
     ok = (mp[rowc] != 0) && (row < rend);
     const float *xp = xc + (size_t)rowc * PS;
 #pragma unroll
-    for (int s = 0; s < NJ; s += 2) sf_load2(xp + s, dst[s], dst[s + 1]);
+    for (int s = 0; s + 1 < NJ; s += 2) sf_load2(xp + s, dst[s], dst[s + 1]);
+    if constexpr (NJ & 1) dst[NJ - 1] = xp[NJ - 1];
   };
   int r0 = rbeg + 16 * wave;
   if (r0 < rend) fetch(r0, xraw, rowok_next);
@@ -902,11 +918,12 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
     nrowok += (rowok && g == 0) ? 1 : 0;
     d2_t ring[RING];
     double ringl[RING];
-    double x[NJ], z[NJ], t[4][NK], acc[4][4];
-    d2_t mur[NJ / 2];
+    double x[NJ], z[NJE], t[4][NK], acc[4][4];
+    d2_t mur[NMU];
     auto issue = [&](auto rc) {   // read r of the tile's stream into its ring slot
       constexpr int r = decltype(rc)::value;
-      if constexpr (r < R1) ring[r % RING] = lds_ld128<r * 256>(wadr);
+      if constexpr (r < R1 && r * 256 >= 65536) ring[r % RING] = lds_ld128<r * 256 - 32768>(wadr + 32768);   // (16-bit offset field)
+      else if constexpr (r < R1) ring[r % RING] = lds_ld128<r * 256>(wadr);
       else if constexpr (r < R1 + R2) ring[r % RING] = lds_ld128<(r - R1) * 256>(uadr);
       else if constexpr (r < R1 + R2 + R3) ring[r % RING] = lds_ld128<(r - R1 - R2) * 1024>(fadr);
       else ringl[r % RING] = lds_ld64<(r - R1 - R2 - R3) * 512>(ladr);
@@ -921,9 +938,9 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
       if constexpr (3 * NJ + s >= 4 * NJ - 3) v = (NJ * g + s < p) ? v : 0.0;   // p >= 69: only bands 69..71 can lie beyond the window
       x[s] = v;
     };
-    static_for<0, NJ / 2>([&](auto ic) { mur[decltype(ic)::value] = lds_ld128<decltype(ic)::value * 16>(madr); });
+    static_for<0, NMU>([&](auto ic) { mur[decltype(ic)::value] = lds_ld128<decltype(ic)::value * 16>(madr); });
     static_for<0, S::issued(0)>(issue);
-    lds_await9<S::issued(0)>(mur);
+    lds_await_all<S::issued(0)>(mur);
     cvt(std::integral_constant<int, 0>{});
     cvt(std::integral_constant<int, 1>{});
 
@@ -978,7 +995,7 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
         else lds_await<S::issued(u) - u - 2>(ring[slot], ring[(u + 1) % RING]);   // R1, R2 are even: u + 1 is in the same phase
       }
       if constexpr (u < R1) {
-        constexpr int s = u / (NJ / 2), jg = 2 * (u % (NJ / 2));
+        constexpr int s = u / (NJE / 2), jg = 2 * (u % (NJE / 2));
         if constexpr (s == 0) {
           z[jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].x, x[s], 0.0, 0, 0, 0);
           z[jg + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].y, x[s], 0.0, 0, 0, 0);
@@ -987,7 +1004,7 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
           z[jg + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].y, x[s], z[jg + 1], 0, 0, 0);
         }
         if constexpr (jg == 0 && s + 2 < NJ) cvt(std::integral_constant<int, s + 2>{});   // two band steps ahead
-        if constexpr (u == (NJ - 2) * (NJ / 2)) {   // every raw value is converted: the next tile's rows may land in xraw
+        if constexpr (u == (NJ - 2) * (NJE / 2)) {   // every raw value is converted: the next tile's rows may land in xraw
           if (r0 + 16 * NW < rend) fetch(r0 + 16 * NW, xraw, rowok_next);
         }
         if constexpr (u == R1 - 1 && (EXP & 8) == 0) z[0] = z[0] * z[0];
@@ -1000,7 +1017,7 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
           t[0][mg] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].x, z[jg], t[0][mg], 0, 0, 0);
           if constexpr (mg + 1 < NK) t[0][mg + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[slot].y, z[jg], t[0][mg + 1], 0, 0, 0);
         }
-        if constexpr (mg == 2 && jg + 1 < NJ && (EXP & 8) == 0) z[jg + 1] = z[jg + 1] * z[jg + 1];   // the square the next eigen group multiplies
+        if constexpr (mg == 2 && jg + 1 < NJE && (EXP & 8) == 0) z[jg + 1] = z[jg + 1] * z[jg + 1];   // the square the next eigen group multiplies
         if constexpr (u == R1 + R2 - 1) {   // an invalid row leaves every q of the tile at 1
           if constexpr ((EXP & 16) == 0) {
 #pragma unroll
@@ -1179,27 +1196,62 @@ int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
   return 0;
 }
 
+// windows of 21 / 24 band groups (CO2: p = 83): the streamed kernel only -- rank 28, and rank 36 where its tables fit the LDS
+// (NJ = 21: 145 KB; NJ = 24: 162 KB + the mean: does not fit, k_lowrank<24> refuses those columns).  The full-rank 4x4x4
+// kernel has no room for its 13 x NJ x 64 coefficient fragments beside the W blocks beyond NJ = 18: a refused column is
+// swept by the 16x16x4 kernel (sf_launch_loocv).
+template <int NJ>
+int launch_sweep4s_nj(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *ufrag,
+                      const double *wfrag2, const int32_t *lrok, const double *lam, const double *wfrag, size_t wstride,
+                      const int32_t *status, const double *alphas, const SfGeom &g, int nsplit, double *part, hipStream_t st) {
+  constexpr int NK1 = SF_LR_K / 4, NK2 = SF_LR_K2 / 4;
+  int rows = sf_cdiv(g.lines, nsplit);
+  rows = (rows + 127) / 128 * 128;
+  const dim3 grid(nsplit, g.ncols);
+  using S1 = SwS<NK1, NJ>;
+  if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK1, 0, 4, NJ>), S1::lds_bytes())) return rc;
+  hipLaunchKernelGGL((k_sweep4s<NK1, 0, 4, NJ>), grid, dim3(512), S1::lds_bytes(), st, xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam,
+                     wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part, 1);
+  SF_LAUNCH_CHECK("k_sweep4s");
+  if constexpr (SwS<NK2, NJ>::lds_bytes() <= 160 * 1024) {
+    using S2 = SwS<NK2, NJ>;
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK2, 0, 4, NJ>), S2::lds_bytes())) return rc;
+    hipLaunchKernelGGL((k_sweep4s<NK2, 0, 4, NJ>), grid, dim3(512), S2::lds_bytes(), st, xt, mask_t, nuse, mu, ufrag, wfrag2, lrok,
+                       lam, wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part, 1);
+    SF_LAUNCH_CHECK("k_sweep4s(rank 36)");
+  }
+  return 0;
+}
+
 }  // namespace
 
 int sf_launch_wfrag4(const double *evec, const double *d, const SfGeom &g, size_t wstride, double *wfrag, hipStream_t st) {
-  hipLaunchKernelGGL(k_wfrag4, dim3(g.ncols), dim3(256), 0, st, evec, d, g.p, wstride, wfrag);
+  const int nj = sf_sw4_groups(g.p), nje = nj + (nj & 1);
+  hipLaunchKernelGGL(k_wfrag4, dim3(g.ncols), dim3(256), 0, st, evec, d, g.p, nj, nje, wstride, wfrag);
   SF_LAUNCH_CHECK("k_wfrag4");
   return 0;
 }
 
 int sf_launch_sweep4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
                      const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,
-                     int nsplit, double *part, int variant, void *lr_scratch, hipStream_t st) {
+                     int nsplit, double *part, int variant, void *lr_scratch, hipStream_t st, const int32_t **lrok_out) {
 #define SW4_ARGS xt, mask_t, nuse, mu, lam, wfrag, wstride, status, alphas, g, nsplit, part, st
-  if (variant == 0 && lr_scratch) {
+  const int nj = sf_sw4_groups(g.p), nje = nj + (nj & 1);
+  if ((variant == 0 && lr_scratch) || nj > S4J) {
     // rank-factored sweep for the columns whose factorisation is accepted, the full-rank kernel for the rest
     // (it returns at once for the others: a column is swept by exactly one of the two)
+    if (!lr_scratch) { sf_set_error("sf_launch_sweep4: windows of 21 / 24 band groups need the rank-factorisation scratch"); return -2; }
     char *base = reinterpret_cast<char *>(lr_scratch);
     double *ufrag = reinterpret_cast<double *>(base);
-    double *wfrag2 = reinterpret_cast<double *>(base + sf_align((size_t)g.ncols * S4J * (SF_LR_K2 / 4) * 16 * sizeof(double)));
+    double *wfrag2 = reinterpret_cast<double *>(base + sf_align((size_t)g.ncols * nje * (SF_LR_K2 / 4) * 16 * sizeof(double)));
     int32_t *lrok = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(wfrag2) +
                                                 sf_align((size_t)g.ncols * S4M * (SF_LR_K2 / 4) * 64 * sizeof(double)));
+    if (lrok_out) *lrok_out = lrok;
     if (int rc = sf_launch_lowrank(lam, nuse, status, alphas, g, ufrag, wfrag2, lrok, st)) return rc;
+    if (nj == 21)
+      return launch_sweep4s_nj<21>(xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam, wfrag, wstride, status, alphas, g, nsplit, part, st);
+    if (nj == 24)
+      return launch_sweep4s_nj<24>(xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam, wfrag, wstride, status, alphas, g, nsplit, part, st);
     if (int rc = launch_sweep4r(xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam, wfrag, wstride, status, alphas, g, nsplit, part, st))
       return rc;
     return launch_sweep4_t<0>(SW4_ARGS, lrok);

@@ -19,13 +19,12 @@
 
 namespace {
 
-constexpr int LR_P = 4 * SF_SW4_NJ;        // 72
 constexpr int LR_NA = 16 * SF_SW4_NM;      // 208
 constexpr int LR_K = SF_LR_K;              // 28: the fast rank
 constexpr int LR_K2 = SF_LR_K2;            // 36: second chance for spectra with a wider eigenvalue range
 constexpr int LR_NK2 = LR_K2 / 4;          // fragment layout stride (both ranks share the 36-wide layout)
 constexpr int LR_TPC = 8;                  // lanes per column in the update (8-lane DPP reductions, no LDS partials)
-constexpr int LR_NT = 576;                 // 72 columns x 8 lanes = 9 waves
+// threads: 8 lanes per column of B^T (4 NJ columns: 576 at NJ = 18, 672 at 21, 768 at 24); the Q_K phase uses the first 576
 constexpr int LR_PK = 5;                   // row slots (of 8 rows) that can touch the diagonal: 8 * 5 = 40 > K2
 static_assert(LR_TPC * LR_PK >= LR_K2 + 1 && LR_NA % LR_TPC == 0, "row slots");
 
@@ -62,11 +61,14 @@ __device__ __forceinline__ double lr_sum16(double v) {
 // 120 KB matrix: two workgroups per CU, 598 columns in two rounds instead of three, and a step moves a third of the
 // LDS bytes it used to).  Q_K is formed in registers as well (16 lanes per column, reflectors read from V).  Same
 // arithmetic in the same order as the LDS-resident form of round 2: the fragments are bit-identical.
-__global__ __launch_bounds__(LR_NT)
+template <int NJ>
+__global__ __launch_bounds__(32 * NJ)
 void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
                const int32_t *__restrict__ status, const double *__restrict__ alphas,
                int nalpha, int p, double *__restrict__ ufrag, double *__restrict__ wfrag,
                int32_t *__restrict__ lrok) {
+  constexpr int LR_P = 4 * NJ, LR_NT = 8 * LR_P, NJE = NJ + (NJ & 1);   // NJE: eigen groups of the sweep's pair layout (even)
+  static_assert(LR_NT >= 576 && LR_NT <= 1024, "the Q_K phase needs 36 x 16 threads");
   __shared__ double V[LR_K2][LR_NA];            // reflector s: 0 above row s, 1 at row s, x_i * scale below
   __shared__ double cnorm[LR_P];                // squared norms of the remaining columns, rows >= current (-1: pivoted)
   __shared__ double cnorm2[LR_P];               // the same over the rows below the current one
@@ -142,9 +144,10 @@ void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
     double bv = cnorm[sub];
     int bi = sub;
 #pragma unroll
-    for (int k = 1; k < LR_P / LR_TPC; ++k) {
-      const double v2 = cnorm[sub + LR_TPC * k];
-      if (v2 > bv) { bv = v2; bi = sub + LR_TPC * k; }
+    for (int k = 1; k < (LR_P + LR_TPC - 1) / LR_TPC; ++k) {
+      const int jc = sub + LR_TPC * k;
+      const double v2 = (LR_P % LR_TPC == 0 || jc < LR_P) ? cnorm[jc < LR_P ? jc : 0] : -2.0;
+      if (v2 > bv) { bv = v2; bi = jc; }
     }
     lr_argmax_step<0xB1>(bv, bi);
     lr_argmax_step<0x4E>(bv, bi);
@@ -237,12 +240,15 @@ void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
     if (sqrt(bn) <= 1e-14 * r00 && r00 > 0.0) kuse = LR_K2;
   }
   if (!lam_ok) kuse = 0;   // (near-)singular or indefinite correlation matrix: the full-rank kernel
+  if (NJ == 24 && kuse == LR_K2) kuse = 0;   // the rank-36 tables of 24 band groups do not fit the LDS (cmf_loocv4.hip)
   if (tid == 0) lrok[c] = (kuse == LR_K) ? 1 : ((kuse == LR_K2) ? 2 : 0);
   if (kuse == 0) return;
   // ---- U fragments: ufrag[(jg*NK + mg)*16 + 4q + n] = -U[4jg+q][4mg+n];  U[j][m] = R[m][column j]: rows m <= its step
   //      of a pivoted column (below them sat its reflector), all K rows of the others -- straight from the registers
   {
-    double *uo = ufrag + (size_t)c * (SF_SW4_NJ * LR_NK2 * 16);
+    double *uo = ufrag + (size_t)c * (NJE * LR_NK2 * 16);
+    if (NJE > NJ)                                  // the padding eigen group of an odd NJ multiplies nothing
+      for (int i = tid; i < LR_NK2 * 16; i += LR_NT) uo[NJ * LR_NK2 * 16 + i] = 0.0;
     const int jg = col >> 2, q = col & 3;
 #pragma unroll
     for (int k = 0; k < LR_PK; ++k) {
@@ -260,7 +266,7 @@ void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
   double qv[NQ];
 #pragma unroll
   for (int k = 0; k < NQ; ++k) qv[k] = (qsub + 16 * k == qcol) ? 1.0 : 0.0;
-  if (qcol < kuse) {
+  if (qcol < kuse && tid < 576) {
     for (int s = kuse - 1; s >= 0; --s) {
       const double tau = tau_s[s];
       double vv[NQ];
@@ -281,7 +287,7 @@ void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
     }
   }
   // ---- W fragments: wfrag[(M*NK + mg)*64 + lane], lane = 16q + 4mm + n  ->  W[4mg+q][16M + 4mm + n] = Q[alpha][m]
-  {
+  if (tid < 576) {
     double *wo = wfrag + (size_t)c * (SF_SW4_NM * LR_NK2 * 64);
     const int mg = qcol >> 2, q = qcol & 3;
 #pragma unroll
@@ -293,13 +299,19 @@ void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
 }  // namespace
 
 size_t sf_lowrank_bytes(const SfGeom &g) {
-  return sf_align((size_t)g.ncols * SF_SW4_NJ * LR_NK2 * 16 * sizeof(double)) +
+  const int nj = sf_sw4_groups(g.p) ? sf_sw4_groups(g.p) : SF_SW4_NJ, nje = nj + (nj & 1);
+  return sf_align((size_t)g.ncols * nje * LR_NK2 * 16 * sizeof(double)) +
          sf_align((size_t)g.ncols * SF_SW4_NM * LR_NK2 * 64 * sizeof(double)) + sf_align((size_t)g.ncols * sizeof(int32_t));
 }
 
 int sf_launch_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas, const SfGeom &g,
                       double *ufrag, double *wfrag, int32_t *lrok, hipStream_t st) {
-  hipLaunchKernelGGL(k_lowrank, dim3(g.ncols), dim3(LR_NT), 0, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok);
+  if (g.s4 == 21)
+    hipLaunchKernelGGL(k_lowrank<21>, dim3(g.ncols), dim3(32 * 21), 0, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok);
+  else if (g.s4 == 24)
+    hipLaunchKernelGGL(k_lowrank<24>, dim3(g.ncols), dim3(32 * 24), 0, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok);
+  else
+    hipLaunchKernelGGL(k_lowrank<18>, dim3(g.ncols), dim3(32 * 18), 0, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok);
   SF_LAUNCH_CHECK("k_lowrank");
   return 0;
 }
@@ -308,6 +320,6 @@ int sf_launch_lowrank(const double *lam, const int32_t *nuse, const int32_t *sta
 extern "C" int sf_debug_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas,
                                 int nalpha, int p, int ncols, double *ufrag, double *wfrag, int32_t *lrok, void *stream) {
   const SfGeom g = sf_geom(64, p, ncols, nalpha);
-  if (g.s4 != SF_SW4_NJ || g.nu != SF_SW4_NM) { sf_set_error("sf_debug_lowrank: production window only"); return -2; }
+  if (!sf_sw4_groups(p) || g.nu != SF_SW4_NM) { sf_set_error("sf_debug_lowrank: windows of 69..72, 81..84, 93..96 bands only"); return -2; }
   return sf_launch_lowrank(lam, nuse, status, alphas, g, ufrag, wfrag, lrok, (hipStream_t)stream);
 }

@@ -597,6 +597,179 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in
   }
 }
 
+// ---- inception branch 4 in ONE launch: 3x3 stride-1 pad-1 max pool + 1x1 convolution (googlenet1.py:213-214) -----------
+// The separate pool kernel reads the block input and writes a pooled copy that the convolution reads back: nine launches,
+// 1.08 of a batch's 18 ms, all of it HBM traffic (the tensors are 0.1-0.4 GB).  Taking the nine taps inside the tile fetch
+// (k_conv_igemm<POOL>) was slower still -- nine tile reads through the L1 per chunk.  Here the tile's pixels PLUS one image row
+// above and below are staged raw in LDS once per chunk (row-major, 16 KQ bytes per pixel, linear 16-byte stores), every thread
+// pools its (pixel, channel quad) items from there -- nine ds_read_b128 and eight maxima -- and writes the result into the
+// transposed A image of k_conv_igemm; the multiply loop, the chunk order and the epilogue are k_conv_igemm's, so the
+// convolution sums in the same order: bit-identical to pool-then-convolve.  A tile of 128 pixels is whole image rows (W
+// divides 128: 32, 16, 8), so the halo is W pixels on either side of the tile in the flattened pixel index; taps outside
+// the image are masked per output pixel (the zero they are replaced by is the identity: activations are ReLU outputs).
+// The pooling phase maps lanes to pixels so that the sixteen lanes of each ds_read_b128 lane group fall on distinct banks
+// of the unpadded rows: pixel order [0 2 1 3 4 6 5 7] per eight lanes-blocks at KQ = 8, [0 4 5 1 6 2 3 7] at KQ = 4.
+template <int BK, int BN>
+__global__ __launch_bounds__(256) void k_poolconv(const float *__restrict__ in, int M, int H, int W, int Cin,
+                                                   const float *__restrict__ wt, const float *__restrict__ bias, int Cout,
+                                                   ConvDst dst) {
+  constexpr int BM = 128, LDA = BM + 1, LDB = BN + 1, KQ = BK / 4, NT = BN / 32;
+  constexpr int RMAX = BM + 2 * 32;                         // raw pixels at W = 32
+  constexpr int NRAW = (RMAX * KQ + 255) / 256;             // raw float4 items per thread
+  constexpr int NPOOL = BM * KQ / 256;                      // pooled items per thread
+  constexpr int TPP = BK / 4, PPP = 256 / TPP, NPB = (BN + PPP - 1) / PPP;   // weight tile: as k_conv_igemm
+  static_assert(BK == 32 || BK == 16, "pooled convolution: 32- or 16-channel chunks");
+  __shared__ __attribute__((aligned(16))) float raw[RMAX * BK];
+  __shared__ float As[BK * LDA];
+  __shared__ float Bs[BK * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int R = BM + 2 * W, nchunk = Cin / BK;
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (unsigned)((size_t)M * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wt), 0, (unsigned)((size_t)Cout * Cin * 4), 0x00020000);
+  // ---- raw items: idx = tid + 256 r = rpx * KQ + quad (linear in LDS: byte idx * 16)
+  unsigned rawoff[NRAW];
+#pragma unroll
+  for (int r = 0; r < NRAW; ++r) {
+    const int idx = tid + 256 * r, rpx = idx / KQ, quad = idx - rpx * KQ;
+    const long long m = (long long)m0 - W + rpx;
+    rawoff[r] = (rpx < R && m >= 0 && m < M) ? (unsigned)(((size_t)m * Cin + 4 * quad) * 4) : OOB;
+  }
+  // ---- weight items (as k_conv_igemm's buffer form)
+  const int q = tid % TPP, ri = tid / TPP;
+  unsigned woff[NPB];
+#pragma unroll
+  for (int b = 0; b < NPB; ++b) {
+    const int co = n0 + ri + PPP * b;
+    woff[b] = ((ri + PPP * b < BN) && co < Cout) ? (unsigned)(((size_t)co * Cin + 4 * q) * 4) : OOB;
+  }
+  // ---- pooled items: quad = tid % KQ, pixel = 256 / KQ * a + permuted block
+  const int pq = tid % KQ, pblk = tid / KQ;                                   // 32 (KQ = 8) or 64 (KQ = 4) blocks
+  int ppx[NPOOL];
+  unsigned pmask[NPOOL];
+#pragma unroll
+  for (int a = 0; a < NPOOL; ++a) {
+    const int b8 = pblk & 7;
+    const int perm = (KQ == 8) ? ((b8 & 4) | ((b8 & 1) << 1) | ((b8 >> 1) & 1))             // 0 2 1 3 4 6 5 7
+                               : ((0x73261540u >> (4 * b8)) & 7);                            // 0 4 5 1 6 2 3 7
+    const int px = (256 / KQ) * a + (pblk & ~7) + perm;
+    ppx[a] = px;
+    const int m = m0 + px;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int x = mm % W, y = (mm / W) % H;
+    unsigned vm = 0;
+    for (int tp = 0; tp < 9; ++tp) {
+      const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+      if (ok && yy >= 0 && yy < H && xx >= 0 && xx < W) vm |= 1u << tp;
+    }
+    pmask[a] = vm;
+  }
+
+  f16_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  u4_t rr[NRAW];
+  float4 rb[NPB];
+  auto gload = [&](int it) {
+    const unsigned sb = (unsigned)(it * BK * 4);
+#pragma unroll
+    for (int r = 0; r < NRAW; ++r) rr[r] = __builtin_amdgcn_raw_buffer_load_b128(rsA, rawoff[r], sb, 0);
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+      const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsB, woff[b], sb, 0);
+      rb[b] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+  };
+  auto stage = [&]() {            // raw pixels and the weight tile into LDS
+#pragma unroll
+    for (int r = 0; r < NRAW; ++r)
+      if (tid + 256 * r < RMAX * KQ) *reinterpret_cast<u4_t *>(raw + 4 * (tid + 256 * r)) = rr[r];
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+      if (ri + PPP * b < BN) {
+        float *d = Bs + (4 * q) * LDB + ri + PPP * b;
+        d[0] = rb[b].x; d[LDB] = rb[b].y; d[2 * LDB] = rb[b].z; d[3 * LDB] = rb[b].w;
+      }
+    }
+  };
+  auto pool = [&]() {             // A image = max over the 3 x 3 neighbourhood, transposed as k_conv_igemm stores it
+#pragma unroll
+    for (int a = 0; a < NPOOL; ++a) {
+      const float *c = raw + ((ppx[a] + W) * KQ + pq) * 4;
+      float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int d = ((tp / 3 - 1) * W + (tp % 3 - 1)) * KQ * 4;
+        if ((pmask[a] >> tp) & 1u) mx = max4(mx, *reinterpret_cast<const float4 *>(c + d));   // (a masked tap is never read)
+      }
+      float *d = As + (4 * pq) * LDA + ppx[a];
+      d[0] = mx.x; d[LDA] = mx.y; d[2 * LDA] = mx.z; d[3 * LDA] = mx.w;
+    }
+  };
+
+  gload(0);
+  stage();
+  __syncthreads();
+  pool();
+  __syncthreads();
+  const float *ap = As + (lane >> 5) * LDA + 32 * wave + (lane & 31);
+  const float *bp = Bs + (lane >> 5) * LDB + (lane & 31);
+  for (int it = 0; it < nchunk; ++it) {
+    if (it + 1 < nchunk) gload(it + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const float a = ap[2 * kk * LDA];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float b = bp[2 * kk * LDB + 32 * t];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (it + 1 < nchunk) {
+      stage();
+      __syncthreads();
+      pool();
+      __syncthreads();
+    }
+  }
+  // epilogue: acc[t][r] = D[row = (r&3) + 8(r>>2) + 4(lane>>5)][col = lane&31]
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int co = n0 + 32 * t + (lane & 31);
+    if (co < Cout) {
+      const float bb = bias[co];
+      float *op = dst.p[0] + dst.off[0] + co;
+      const int ld = dst.ld[0];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M) op[(size_t)m * ld] = fmaxf(acc[t][r] + bb, 0.f);
+      }
+    }
+  }
+}
+
+template <int BK>
+static int launch_poolconv(const float *in, int M, int H, int W, int Cin, const float *wt, const float *bias, int Cout,
+                           const ConvDst &dst, hipStream_t st) {
+  // the N tile of conv_dispatch (the same choice: the same summation order and the same tiles as pool-then-convolve)
+  const int bn = Cout < 48 ? 32 : ((sf_cdiv(Cout, 96) * 96 <= sf_cdiv(Cout, 64) * 64) ? 96 : 64);
+  const dim3 grid(sf_cdiv(M, 128), sf_cdiv(Cout, bn));
+  if (bn == 96) hipLaunchKernelGGL((k_poolconv<BK, 96>), grid, dim3(256), 0, st, in, M, H, W, Cin, wt, bias, Cout, dst);
+  else if (bn == 64) hipLaunchKernelGGL((k_poolconv<BK, 64>), grid, dim3(256), 0, st, in, M, H, W, Cin, wt, bias, Cout, dst);
+  else hipLaunchKernelGGL((k_poolconv<BK, 32>), grid, dim3(256), 0, st, in, M, H, W, Cin, wt, bias, Cout, dst);
+  SF_LAUNCH_CHECK("k_poolconv");
+  return 0;
+}
+
 // ---- head: global average pool -> FC(1024 -> 2) -> softmax[:,1]; NODATA where the input plane is NODATA ------------
 // (googlenet1.py:87-89,:156-161; cnn_pred_pipeline.py:177-189)
 __global__ __launch_bounds__(256) void k_head(const float *__restrict__ in, int HW, int C, const float *__restrict__ fcw,
@@ -762,6 +935,15 @@ int sf_cnn_pool_conv(const float *in, int N, int H, int W, int Cin, int ld_in, c
   d.ld[0] = d.ld[1] = d.ld[2] = ld_out;
   d.off[0] = d.off[1] = d.off[2] = ch_off;
   d.end[0] = d.end[1] = d.end[2] = Cout;
+  // round 5: the pool taken from the tile staged in LDS (k_poolconv), where the geometry allows -- whole image rows per
+  // 128-pixel tile, 16- or 32-channel chunks, operands below 2 GB; key 18 = 3: pool into the scratch tensor, then convolve
+  // (the form every other geometry takes, and the tests' cross-check: bit-identical)
+  const long long Ml = (long long)N * H * W;
+  if (sf_tune().cnn_pool_variant == 0 && W >= 1 && W <= 32 && 128 % W == 0 &&
+      (Cin % 16) == 0 && Ml * Cin * 4 < 0x7ff00000LL && (long long)Cout * Cin * 4 < 0x7ff00000LL) {
+    if (Cin % 32 == 0) return launch_poolconv<32>(in, (int)Ml, H, W, Cin, w, bias, Cout, d, (hipStream_t)stream);
+    return launch_poolconv<16>(in, (int)Ml, H, W, Cin, w, bias, Cout, d, (hipStream_t)stream);
+  }
   if (sf_tune().cnn_pool_variant == 1) {     // measured slower (27.2 k vs 28.0 k tiles/s): nine tile reads through the L1
     const int rc = conv_dispatch<true>(in, N, H, W, Cin, ld_in, w, bias, Cout, 1, d, (hipStream_t)stream);
     if (rc <= 0) return rc;

@@ -140,9 +140,10 @@ def test_c_driver_equals_the_python_sequenced_graph(gold):
 
 
 def test_kernel_forms_of_the_tile_scorer_agree_bit_for_bit(gold):
-    """The production kernels against their earlier forms (sf_debug_set keys 16-18): the 8 x 8 conv1+pool kernel with the
-    conv tile in LDS, the pointer-form tile fetch of the convolutions, the branch-4 pool taken inside the 1x1
-    convolution's fetch or by the general pool kernel.  Max and the per-output summation order are the same in every form: equal saliency maps."""
+    """The production kernels against their other forms (sf_debug_set keys 16-18): the 8 x 8 conv1+pool kernel with the
+    conv tile in LDS, the pointer-form tile fetch of the convolutions, the branch-4 pool as its own launch (strip kernel /
+    general kernel: production takes it from the tile staged in LDS, k_poolconv) or inside the 1x1 convolution's fetch.
+    Max and the per-output summation order are the same in every form: equal saliency maps."""
     import torch
     from srcfinder_amd import _ffi
     net = cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024))
@@ -150,7 +151,7 @@ def test_kernel_forms_of_the_tile_scorer_agree_bit_for_bit(gold):
     plane[4, 1] = -9999.0
     ref = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=27)
     L = _ffi.lib()
-    for key, val in ((16, 1), (17, 1), (18, 1), (18, 2)):
+    for key, val in ((16, 1), (17, 1), (18, 1), (18, 2), (18, 3)):
         L.sf_debug_set(key, val)
         try:
             got = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=27)

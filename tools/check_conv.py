@@ -46,6 +46,33 @@ def main():
               % (N, H, W, Cin, ldi, Cout, ks, ldo, off, err, untouched))
         assert err < 2e-6 and untouched
     print("conv ok, worst %.2e" % worst)
+    # ---- inception branch 4: 3x3 s1 p1 max pool + 1x1 convolution in one launch (k_poolconv) against pool-then-convolve
+    #      (sf_debug_set(18, 3): bit-identical) and against float64
+    for (N, H, W, Cin, Cout, ldo, off) in [(3, 32, 32, 192, 32, 256, 224), (2, 32, 32, 256, 64, 480, 416), (5, 16, 16, 480, 64, 512, 448),
+                                            (3, 16, 16, 528, 128, 832, 704), (9, 8, 8, 832, 128, 1024, 896), (1, 16, 16, 512, 64, 64, 0),
+                                            (7, 8, 8, 32, 40, 40, 0)]:
+        x = torch.relu(torch.randn((N, H, W, Cin), generator=g))
+        w = torch.randn((Cout, 1, Cin), generator=g) / np.sqrt(Cin)
+        b = torch.randn((Cout,), generator=g)
+        pooled = F.max_pool2d(x.permute(0, 3, 1, 2).double(), 3, 1, 1)
+        ref = F.conv2d(pooled, w.view(Cout, 1, 1, Cin).permute(0, 3, 1, 2).double(), b.double()).relu().permute(0, 2, 3, 1)
+        xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+        scratch = torch.empty_like(xd)
+        outs = []
+        for variant in (0, 3):
+            L.sf_debug_set(18, variant)
+            out = torch.full((N, H, W, ldo), -7.0, device="cuda")
+            _ffi.check(L.sf_cnn_pool_conv(_ffi.ptr(xd), N, H, W, Cin, Cin, _ffi.ptr(wd), _ffi.ptr(bd), Cout, _ffi.ptr(out), ldo, off,
+                                          _ffi.ptr(scratch), _ffi.stream_ptr()), "pool_conv")
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+        L.sf_debug_set(18, 0)
+        got = outs[0].double()
+        err = (got[..., off:off + Cout] - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+        same = bool(torch.equal(outs[0], outs[1]))
+        print("pool+conv N%d %dx%d Cin %d Cout %d -> ld %d off %d: max err %.2e  == pool-then-convolve: %s" % (N, H, W, Cin, Cout, ldo, off, err, same))
+        assert err < 2e-6 and same
+    print("pool_conv ok")
 
 
 if __name__ == "__main__":

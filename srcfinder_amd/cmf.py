@@ -463,9 +463,10 @@ def _multimodal(torch, L, cube, lines, bands, samples, s0, s1, a0, p, abscf, alp
 def sweep_routes(cube_bil, library=None, *, gas="ch4", reflectance=False, active=None, columns=None):
     """Which sweep kernel each column of a flightline takes (diagnostic; bench.py reports it beside the step time).
 
-    The production-window sweep multiplies by the rank-28 or rank-36 factorisation of its coefficient matrix when the
-    column's eigenvalue spectrum allows it (cmf_lowrank.hip) and by the full matrix otherwise: 814 / 954 / 1260 MFMAs per
-    16-row tile -- the reference pays one cost for any data (robust_mf.py:105-117).  Runs stages 1-4 through the C ABI and
+    The sweep of the 4x4x4 windows (69..72 bands: CH4; 81..84: CO2; 93..96) multiplies by the rank-28 or rank-36
+    factorisation of its coefficient matrix when the column's eigenvalue spectrum allows it (cmf_lowrank.hip) and by the full
+    matrix otherwise (at 72 bands: 814 / 954 / 1260 MFMAs per 16-row tile; "full" columns of the wider windows take the
+    16x16x4 kernel) -- the reference pays one cost for any data (robust_mf.py:105-117).  Runs stages 1-4 through the C ABI and
     the factorisation's test hook; returns counts {"rank28", "rank36", "full", "skipped"} (skipped: status != 0)."""
     torch = _torch()
     if not (torch.is_tensor(cube_bil) and cube_bil.is_cuda):
@@ -474,8 +475,10 @@ def sweep_routes(cube_bil, library=None, *, gas="ch4", reflectance=False, active
     lines, bands, samples = cube_bil.shape
     a0, a1 = active if active is not None else active_window(gas, reflectance)
     p = a1 - a0 + 1
-    if not 69 <= p <= 72:
-        return {"note": "windows other than 69..72 bands take one route (p = %d)" % p}
+    nj = (p + 3) // 4
+    if nj not in (18, 21, 24):
+        return {"note": "windows other than 69..72, 81..84 and 93..96 bands take one route (p = %d)" % p}
+    nje = nj + (nj & 1)
     s0, s1 = (0, samples) if columns is None else (int(columns[0]), int(columns[1]))
     ncols = s1 - s0
     L = _ffi.lib()
@@ -498,7 +501,7 @@ def sweep_routes(cube_bil, library=None, *, gas="ch4", reflectance=False, active
         check(L.sf_cmf_column_mean(P(xt), 0, P(mask), lines, p, ncols, P(nuse), P(mu), P(ws), st), "sf_cmf_column_mean")
         check(L.sf_cmf_covariance(P(xt), 0, P(mask), P(nuse), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
         check(L.sf_cmf_eigh(P(S), P(nuse), p, ncols, P(d), P(lam), P(evec), P(status), P(ws), st), "sf_cmf_eigh")
-        ufrag = torch.empty((ncols, 18 * 9 * 16), **f64)
+        ufrag = torch.empty((ncols, nje * 9 * 16), **f64)
         wfrag = torch.empty((ncols, 13 * 9 * 64), **f64)
         lrok = torch.empty(ncols, dtype=torch.int32, device=dev)
         check(L.sf_debug_lowrank(P(lam), P(nuse), P(status), P(al), nalpha, p, ncols, P(ufrag), P(wfrag), P(lrok), st),

@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int XT_PBMAX = 80;  // band chunk held in LDS at once
+constexpr int XT_PBMAX = 84;  // band chunk held in LDS at once (84: the CO2 window, p = 83, is one chunk and its column sums are fused)
 constexpr int XT_NB = 18;     // loads in flight per wave
 
 // LDS: tile[64 columns][cs] floats, cs odd -> both the column-strided writes (lane = column) and the
@@ -158,9 +158,9 @@ __global__ __launch_bounds__(256) void k_extract_pipe(const float *__restrict__ 
                                                        int nchunk, double *__restrict__ sum_part, int *__restrict__ cnt_part) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   __shared__ uint8_t vf[64][4];
-  static_assert((TL * P) % 4 == 0, "rows of a tile split evenly over the four waves");
   constexpr int NSUM = (P + 3) / 4;
-  constexpr int NLD = TL * P / 4;                          // rows per wave per tile: row = wave + 4 u
+  constexpr int NLD = (TL * P + 3) / 4;                    // rows per wave per tile: row = wave + 4 u (the last u may be short)
+  constexpr bool EVEN = (TL * P) % 4 == 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int cbi, chunk;
   if (!sf_xcd_map(blockIdx.x, ncb, nchunk, cbi, chunk)) return;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_extract_pipe(const float *__restrict__ 
   auto request = [&](int l0) {
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-      const int rr = wave + 4 * u;
+      const int rr = EVEN ? wave + 4 * u : min(wave + 4 * u, TL * P - 1);   // (a short last round re-reads the last row)
       const int l = rr / P, b = rr - l * P;                // wave-uniform
       const int line = min(l0 + l, lend - 1);
       v[u] = (cbase + ((size_t)line * B + b) * C)[lanec];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_extract_pipe(const float *__restrict__ 
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
       const int rr = wave + 4 * u;
-      if (FULL || rr < nl * P) tile[lane * cs + rr] = v[u];
+      if ((FULL && (EVEN || rr < TL * P)) || rr < nl * P) tile[lane * cs + rr] = v[u];
     }
     xt_lds_barrier();
     if (l0 + TL < lend) request(l0 + TL);                 // in flight until the top of the next iteration
@@ -223,12 +223,26 @@ __global__ __launch_bounds__(256) void k_extract_pipe(const float *__restrict__ 
           }
       }
     } else {
+      // rows padded to PS = P rounded up to four: the nl lines of a column are still one contiguous run of nl * PS floats
+      // (element e = band e % PS of line e / PS; the padding bands are written as zeros)
+      constexpr int PSC = (P + 3) / 4 * 4;
+      const int nel = nl * PSC;
+      constexpr int NST = (TL * PSC + 63) / 64;
       for (int c = wave; c < ncol; c += 4) {
-        for (int l = 0; l < nl; ++l) {
-          float *dst = xt + ((size_t)(colbase + c) * L + l0 + l) * PS;
-          const float *src = tile + c * cs + l * P;
-          for (int b = lane; b < PS; b += 64) dst[b] = (b < P) ? src[b] : 0.f;
+        float *dst = xt + ((size_t)(colbase + c) * L + l0) * PSC;
+        const float *src = tile + c * cs;
+        float r[NST];
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+          const int e = min(lane + 64 * j, nel - 1), l = e / PSC, b = e - l * PSC;
+          r[j] = (b < P) ? src[l * P + b] : 0.f;
         }
+#pragma unroll
+        for (int j = 0; j < NST; ++j)
+          if (lane + 64 * j < nel) {
+            if (NTS) __builtin_nontemporal_store(r[j], dst + lane + 64 * j);
+            else dst[lane + 64 * j] = r[j];
+          }
       }
     }
     {
@@ -537,6 +551,14 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
       hipLaunchKernelGGL((k_extract_pipe<4, 72>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), ldsx, st, cube, lines, bands, samples,
                          s0, ncols, b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);
     }
+  } else if (fuse && sf_tune().extract_variant == 0 && p == 83) {
+    // the CO2 window (robust_mf.py:190-191): the same kernel, three lines per tile (64 KB of LDS: two workgroups per CU;
+    // four lines would be 85 KB and one), rows padded to 84 floats, non-temporal stores
+    const int csx = (3 * 83) | 1;
+    const size_t ldsx = (size_t)64 * csx * sizeof(float);
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_pipe<3, 83, true>), ldsx)) return rc;
+    hipLaunchKernelGGL((k_extract_pipe<3, 83, true>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), ldsx, st, cube, lines, bands, samples,
+                       s0, ncols, b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);
   } else if (fuse && sf_tune().extract_variant != 2 && p == 72) {     // variant 5 (any other value): two lines per tile, round 1's form
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_pipe<TL, 72>), maxlds)) return rc;
     hipLaunchKernelGGL((k_extract_pipe<TL, 72>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), lds, st, cube, lines, bands, samples,

@@ -244,6 +244,37 @@ def test_fewer_valid_rows_than_bands(torch_cuda, library):
     assert score_close(res.out[..., 3][~nod], o["out"][..., 3][~nod], rel=1e-4).all()
 
 
+@pytest.mark.parametrize("active,decades", [((309, 391), (1.5, 3.0, 3.6, 5.5)), ((320, 415), (1.5, 3.6, 6.0)), ((331, 411), (2.0, 5.5)),
+                                            ((300, 392), (2.0, 3.6))])
+def test_sweep_routes_of_the_co2_and_96_band_windows(torch_cuda, library, active, decades):
+    """windows of 81..84 (CO2: 309..391, p = 83) and 93..96 bands run the 4x4x4 kernels (k_syrk4h, k_lowrank<NJ>,
+    k_sweep4s<NK, NJ>).  One cube holds benchmark-like columns (rank 28) and columns whose correlation spectra span 3 to 6
+    decades (rank 36 where its tables fit the LDS, else refused -> the 16x16x4 kernel): every route of the launch against
+    the faithful oracle -- alpha index exact, NODATA placement exact, scores 1e-4."""
+    torch = torch_cuda
+    a0, a1 = active
+    p = a1 - a0 + 1
+    lines, samples = 1800, 4 + 3 * len(decades)
+    cube = make_cube_numpy(lines, samples, seed=61 + p, abscf_full=library[:, 2], active=active, nodata_column=2, nodata_lines=3)
+    rng = np.random.default_rng(p)
+    for k, dec in enumerate(decades):
+        for c in range(4 + 3 * k, 7 + 3 * k):
+            qmat, _ = np.linalg.qr(rng.standard_normal((p, p)))
+            sd = np.sqrt(np.exp(np.linspace(0.0, -dec * np.log(10.0), p)))
+            x = 10.0 + 0.5 * (rng.standard_normal((lines, p)) * sd) @ qmat.T
+            cube[3:, a0 - 1:a1, c] = x[3:].astype(np.float32)
+    routes = cmf.sweep_routes(torch.as_tensor(cube).cuda(), library, active=active)
+    assert routes["rank28"] >= 3 and routes["rank36"] + routes["full"] >= 1, routes
+    res = cmf.robust_mf(cube, library, active=active, metadata=True, to_numpy=True)
+    o = O.robust_mf_oracle(cube, library, active=active)
+    _compare_run(res, o, lines, samples)
+    assert np.array_equal(res.nuse, o["nuse"]) and np.array_equal(res.status, o["status"])
+    # a 3-column shard of the same cube: bit-identical columns (every float64 sum in an order that depends on the lines only)
+    sh = cmf.robust_mf(cube, library, active=active, metadata=True, to_numpy=True, columns=(3, 6))
+    assert np.array_equal(sh.out, res.out[:, 3:6]) and np.array_equal(sh.alphaidx, res.alphaidx[3:6])
+    print("p = %d routes %s" % (p, routes))
+
+
 @pytest.mark.parametrize("active", [(351, 421), (360, 366), (340, 422)])
 def test_odd_and_unusual_windows(torch_cuda, library, active):
     """p = 71 (odd: the eigensolver pads a dummy column), p = 7 (single MFMA tile), p = 83 with another offset."""
@@ -450,6 +481,44 @@ def test_full_flightline_598x20000x425(torch_cuda, library, full_flightline):
     want_bg = np.where(nod | ~so[None, :], 0, o["alphaidx"][None, :]).astype(np.int16)
     assert np.array_equal(bg[..., 1], want_bg)
     print("full-size parity: %d oracle columns on %d workers in %.1f s" % (len(cols), o["workers"], o["seconds"]))
+
+
+def test_full_flightline_co2_window_against_oracle(torch_cuda, library, full_flightline):
+    """The CO2 window (309..391, p = 83: robust_mf.py:190-191) at the benchmark's size, on the 4x4x4 kernels: validity == NODATA
+    placement over all 11.96 Mpixel, idempotent, and evenly spaced columns against the faithful oracle (alpha index exact,
+    scores 1e-4) -- at least 48 columns, 4 per usable core."""
+    torch = torch_cuda
+    cube, _ = full_flightline
+    lines, _, samples = cube.shape
+    a0, a1 = cmf.active_window("co2", False)
+    r1 = cmf.robust_mf(cube, library, gas="co2", metadata=True)
+    r2 = cmf.robust_mf(cube, library, gas="co2", metadata=True)
+    assert torch.equal(r1.out, r2.out) and torch.equal(r1.alphaidx, r2.alphaidx)
+    del r2
+    valid = torch.ones((lines, samples), dtype=torch.bool, device=cube.device)
+    for b in range(a0 - 1, a1):
+        x = cube[:, b, :]
+        valid &= (x >= 0) & torch.isfinite(x)
+    assert torch.equal(r1.out[..., 3] != -9999.0, valid)
+    assert torch.equal(r1.nuse.long(), valid.sum(dim=0))
+    from oracle import pool as OP
+    ncheck = min(samples - 1, max(48, 4 * OP.usable_cores()))
+    cols = sorted(set([int(round(i * (samples - 1) / (ncheck - 1))) for i in range(ncheck)] + [samples // 3]))
+    host = cube[:, a0 - 1:a1, :].index_select(2, torch.as_tensor(cols, device=cube.device)).cpu().numpy()
+    o = OP.oracle_columns(host, library[a0 - 1:a1, 2], per_job=2)
+    got = r1.out[:, cols, 3].cpu().numpy()
+    nod = o["score"] == -9999.0
+    assert np.array_equal(got == -9999.0, nod)
+    assert score_close(got[~nod], o["score"][~nod]).all()
+    so = o["status"] == 0
+    assert np.array_equal(r1.status.cpu().numpy()[cols], o["status"])
+    assert np.array_equal(r1.alphaidx.cpu().numpy()[cols][so], o["alphaidx"][so])
+    assert np.array_equal(r1.nuse.cpu().numpy()[cols], o["nuse"])
+    print("CO2 window, full size: %d oracle columns on %d workers in %.1f s; routes %s"
+          % (len(cols), o["workers"], o["seconds"], cmf.sweep_routes(cube, library, gas="co2")))
+    del r1
+    cmf._Workspace._bufs.clear()
+    torch.cuda.empty_cache()
 
 
 def test_full_flightline_wide_window_against_oracle(torch_cuda, library, full_flightline):

@@ -59,6 +59,7 @@ Ws carve(void *base, const SfGeom &g) {
     if (sf_exact_det_scratch_bytes(g, SF_NARROW_DET_WINDOW) > s) s = sf_exact_det_scratch_bytes(g, SF_NARROW_DET_WINDOW);
   } else {
     if (sf_wide_scratch_bytes(g) > s) s = sf_wide_scratch_bytes(g);
+    if (sf_extract_sum_bytes(g) > s) s = sf_extract_sum_bytes(g);   // (the fused column sums of the 416- / 425-band windows)
   }
   if (sf_score_scratch_bytes(g.lines, g.ncols) > s) s = sf_score_scratch_bytes(g.lines, g.ncols);
   w.scratch_bytes = s;
@@ -260,9 +261,14 @@ int sf_cmf_run(const float *cube, int lines, int bands, int samples, int s0, int
   int rc;
   double *nll = nll_out ? nll_out : w.nll;
   if (p > SF_MAX_ACTIVE_FUSED) {  // wide window (e.g. reflectance 5..420): batched-GEMM statistics path
-    if ((rc = sf_launch_extract(cube, lines, bands, samples, s0, ncols, b0, p, w.xt, w.mask_t, nullptr, nullptr, st)))
-      return rc;
-    if ((rc = sf_launch_mean(w.xt, 0, w.mask_t, g, nuse, w.mu, w.scratch, st))) return rc;
+    if (sf_extract_fuses_sum(p)) {   // 1..425 and the -R window: the column sums ride along with the transpose (round 5)
+      if ((rc = sf_launch_extract_fused(cube, lines, bands, samples, s0, b0, g, w.xt, w.mask_t, w.scratch, st))) return rc;
+      if ((rc = sf_launch_mean_from_partials(g, nuse, w.mu, w.scratch, st))) return rc;
+    } else {
+      if ((rc = sf_launch_extract(cube, lines, bands, samples, s0, ncols, b0, p, w.xt, w.mask_t, nullptr, nullptr, st)))
+        return rc;
+      if ((rc = sf_launch_mean(w.xt, 0, w.mask_t, g, nuse, w.mu, w.scratch, st))) return rc;
+    }
     if ((rc = sf_launch_wide_stats(w.xt, 0, w.mask_t, nuse, nullptr, w.mu, alphas, g, w.cov, w.d, w.lam, w.evec, status, nll,
                                    alphaidx, w.scratch, st)))
       return rc;

@@ -151,11 +151,12 @@ __global__ __launch_bounds__(256) void k_extract(const float *__restrict__ cube,
 __device__ __forceinline__ void xt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // (152 VGPRs: three workgroups per CU; forcing four -- 128 VGPRs -- spills and is slower: 1.96 against 1.43 ms)
-template <int TL, int P, bool NTS = false>
-__global__ __launch_bounds__(256) void k_extract_pipe(const float *__restrict__ cube, int L, int B, int C, int s0,
-                                                       int Cs, int b0, int PS, float *__restrict__ xt,
-                                                       uint8_t *__restrict__ mask_t, int lines_per_wg, int cs, int ncb,
-                                                       int nchunk, double *__restrict__ sum_part, int *__restrict__ cnt_part) {
+// (at least two waves per SIMD for the kernel below: left alone the CO2 instantiation took 270 registers and one workgroup per CU)
+template <int TL, int P, bool NTS>
+__device__ __forceinline__ void extract_pipe_body(const float *__restrict__ cube, int L, int B, int C, int s0,
+                                                  int Cs, int b0, int PS, float *__restrict__ xt,
+                                                  uint8_t *__restrict__ mask_t, int lines_per_wg, int cs, int ncb,
+                                                  int nchunk, double *__restrict__ sum_part, int *__restrict__ cnt_part) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   __shared__ uint8_t vf[64][4];
   constexpr int NSUM = (P + 3) / 4;
@@ -178,12 +179,26 @@ __global__ __launch_bounds__(256) void k_extract_pipe(const float *__restrict__ 
   float v[NLD];
   // rows of the tile starting at line l0 -> registers; lines past the chunk alias its last line (loaded, not stored)
   auto request = [&](int l0) {
+    if constexpr (TL == 1) {
+      // one line, rows wave, wave + 4, ...: ONE running pointer per lane (left to itself the compiler keeps an address per
+      // load: 107 loads x 64 bits do not fit beside 107 float64 sums)
+      const float *pp = cbase + ((size_t)min(l0, lend - 1) * B + wave) * C + lanec;
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        if (!EVEN && u == NLD - 1) pp -= (size_t)max(wave + 4 * u - (P - 1), 0) * C;   // (a short last round re-reads the last row)
+        v[u] = *pp;
+        pp += 4 * (size_t)C;
+        asm volatile("" : "+v"(pp));
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
       const int rr = EVEN ? wave + 4 * u : min(wave + 4 * u, TL * P - 1);   // (a short last round re-reads the last row)
       const int l = rr / P, b = rr - l * P;                // wave-uniform
       const int line = min(l0 + l, lend - 1);
       v[u] = (cbase + ((size_t)line * B + b) * C)[lanec];
+      if constexpr (P > 72) __builtin_amdgcn_sched_barrier(0);   // one address at a time (63 row addresses do not fit the scalar file)
     }
   };
   auto body = [&](int l0, auto fullc) {
@@ -196,7 +211,22 @@ __global__ __launch_bounds__(256) void k_extract_pipe(const float *__restrict__ 
     }
     xt_lds_barrier();
     if (l0 + TL < lend) request(l0 + TL);                 // in flight until the top of the next iteration
-    if (FULL || wave < nl) {
+    if constexpr (TL == 1) {
+      // one line per tile (the wide windows): every wave tests the bands it sums (wave, wave + 4, ...); the four partial
+      // verdicts meet in vf[lane][0..3] and are combined after the barrier
+      bool ok = true;
+      const float *tp = tile + lane * cs;
+#pragma unroll 8
+      for (int i = 0; i < NSUM; ++i) {
+        const int b = wave + 4 * i;
+        if (b < P) ok = ok & sf_valid(tp[b]);
+      }
+      vf[lane][wave] = ok ? 1 : 0;
+      xt_lds_barrier();
+      const bool all = vf[lane][0] & vf[lane][1] & vf[lane][2] & vf[lane][3];
+      xt_lds_barrier();                                   // everybody has read the partial verdicts
+      if (wave == 0) vf[lane][0] = all ? 1 : 0;
+    } else if (FULL || wave < nl) {
       if (wave < TL) {
         bool ok = true;
         const float *tp = tile + lane * cs + wave * P;
@@ -290,6 +320,23 @@ __global__ __launch_bounds__(256) void k_extract_pipe(const float *__restrict__ 
       for (int b = P; b < PS; ++b) o[b] = 0.0;
     }
   }
+}
+
+template <int TL, int P, bool NTS = false>
+__global__ __launch_bounds__(256, 2) void k_extract_pipe(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs, int b0,
+                                                          int PS, float *__restrict__ xt, uint8_t *__restrict__ mask_t,
+                                                          int lines_per_wg, int cs, int ncb, int nchunk,
+                                                          double *__restrict__ sum_part, int *__restrict__ cnt_part) {
+  extract_pipe_body<TL, P, NTS>(cube, L, B, C, s0, Cs, b0, PS, xt, mask_t, lines_per_wg, cs, ncb, nchunk, sum_part, cnt_part);
+}
+// the wide windows: ONE line per tile, one wave per SIMD (the whole register file: 107 row loads in flight and 107 float64
+// column sums per lane)
+template <int P>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_extract_wide(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs, int b0, int PS, float *__restrict__ xt,
+                    uint8_t *__restrict__ mask_t, int lines_per_wg, int cs, int ncb, int nchunk, double *__restrict__ sum_part,
+                    int *__restrict__ cnt_part) {
+  extract_pipe_body<1, P, true>(cube, L, B, C, s0, Cs, b0, PS, xt, mask_t, lines_per_wg, cs, ncb, nchunk, sum_part, cnt_part);
 }
 
 // Masked column sums over a chunk of lines.  One workgroup = (column, line chunk); thread (sub, q4)
@@ -513,7 +560,7 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
   constexpr int TL = 2;
   const int cs = (TL * pbmax) | 1;
   const size_t lds = (size_t)64 * cs * sizeof(float);
-  const bool fuse = sum_part != nullptr && p <= XT_PBMAX;
+  const bool fuse = sum_part != nullptr && sf_extract_fuses_sum(p);
   const size_t maxlds = (size_t)64 * ((TL * XT_PBMAX) | 1) * sizeof(float);
   if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract<TL, true>), maxlds)) return rc;
   if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract<TL, false>), maxlds)) return rc;
@@ -551,6 +598,22 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
       hipLaunchKernelGGL((k_extract_pipe<4, 72>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), ldsx, st, cube, lines, bands, samples,
                          s0, ncols, b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);
     }
+  } else if (fuse && sf_tune().extract_variant == 0 && (p == 425 || p == 416)) {
+    // the full-band window of the benchmark (1..425) and the reference's -R window (5..420: robust_mf.py:186-187): ONE line per
+    // tile (64 columns x p bands = 109 KB of LDS, one workgroup per CU with the whole register file: 107 row loads in flight
+    // and 107 float64 column sums per lane), the column sums fused as on the narrow windows -- round 4 ran the blocked kernel
+    // (2.7 TB/s) and re-read the 20.5 GB of xt for the sums (k_colsum)
+    const int csx = p | 1;
+    const size_t ldsx = (size_t)64 * csx * sizeof(float);
+    if (p == 425) {
+      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_wide<425>), ldsx)) return rc;
+      hipLaunchKernelGGL((k_extract_wide<425>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), ldsx, st, cube, lines, bands,
+                         samples, s0, ncols, b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);
+    } else {
+      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_wide<416>), ldsx)) return rc;
+      hipLaunchKernelGGL((k_extract_wide<416>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), ldsx, st, cube, lines, bands,
+                         samples, s0, ncols, b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);
+    }
   } else if (fuse && sf_tune().extract_variant == 0 && p == 83) {
     // the CO2 window (robust_mf.py:190-191): the same kernel, three lines per tile (64 KB of LDS: two workgroups per CU;
     // four lines would be 85 KB and one), rows padded to 84 floats, non-temporal stores
@@ -563,7 +626,7 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_pipe<TL, 72>), maxlds)) return rc;
     hipLaunchKernelGGL((k_extract_pipe<TL, 72>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), lds, st, cube, lines, bands, samples,
                        s0, ncols, b0, PS, xt, mask_t, lpw, cs, ncb, nchunk, sum_part, cnt_part);
-  } else if (fuse)
+  } else if (fuse && p <= XT_PBMAX)
     hipLaunchKernelGGL((k_extract<TL, true>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), lds, st, cube, lines, bands,
                        samples, s0, ncols, b0, p, PS, xt, mask_t, lpw, pbmax, cs, ncb, nchunk, sum_part, cnt_part);
   else
@@ -579,7 +642,7 @@ size_t sf_extract_sum_bytes(const SfGeom &g) {
   const int nchunk = extract_chunks(g.lines, g.ncols, &lpw);
   return sf_align((size_t)nchunk * g.ncols * g.ps * sizeof(double)) + sf_align((size_t)nchunk * g.ncols * sizeof(int));
 }
-bool sf_extract_fuses_sum(int p) { return p <= XT_PBMAX; }
+bool sf_extract_fuses_sum(int p) { return p <= XT_PBMAX || ((p == 425 || p == 416) && sf_tune().extract_variant == 0); }
 
 int sf_launch_extract_fused(const float *cube, int lines, int bands, int samples, int s0, int b0, const SfGeom &g,
                             float *xt, uint8_t *mask_t, void *scratch, hipStream_t st) {

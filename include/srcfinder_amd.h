@@ -192,10 +192,8 @@ int sf_cmf_column_profile_robust(const double *img, int lines, int samples, int 
 int sf_debug_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas,
                      int nalpha, int p, int ncols, double *ufrag, double *wfrag, int32_t *lrok, void *stream);
 
-/* Test / tuning hook: phase clocks of the wide-window Jacobi visits (cmf_wjac.hip), accumulated while
- * sf_debug_set(22, 1) is on: out8 = visits, load, Gram, rotations, update, store ticks, early exits, 0. */
-int sf_debug_wjac_stamps(unsigned long long *out8, int reset);
-/* the same for the tiles of the fused wide-window sweep (cmf_wgemm.hip): out8 = tiles, Y = X~ W, r = Z C + rows, then (k_wsweep8) the r
+/* Test / tuning hook: phase clocks of the tiles of the fused wide-window sweep (cmf_wgemm.hip), accumulated while
+ * sf_debug_set(22, 1) is on: out8 = tiles, Y = X~ W, r = Z C + rows, then (k_wsweep8) the r
  * phase's MFMAs, row reductions, first barrier, exchange + second barrier, 0 */
 int sf_debug_wsweep_stamps(unsigned long long *out8, int reset);
 /* test entry of the tridiagonal preconditioner of the wide-window eigensolver (csrc/cmf_wtri.hip; the eigendecomposition that

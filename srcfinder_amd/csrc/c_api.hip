@@ -311,8 +311,6 @@ static int *sf_tune_slot(int key) {
     case 7: return &t.eigh_lpp;
     case 8: return &t.sweep4r_waves;
     case 10: return &t.wide_eigh_variant;
-    case 12: return &t.score_wgs;
-    case 13: return &t.score_exp;
     case 14: return &t.lu_variant;
     case 15: return &t.det_variant;
     case 16: return &t.cnn_variant;
@@ -322,9 +320,7 @@ static int *sf_tune_slot(int key) {
     case 20: return &t.sweep4_form;
     case 21: return &t.sweep_grid;
     case 22: return &t.wjac_stamps;
-    case 23: return &t.wide_gemm_variant;
     case 24: return &t.wsweep_variant;
-    case 25: return &t.wsyrk_variant;
     case 26: return &t.det_slots;
     default: return nullptr;
   }

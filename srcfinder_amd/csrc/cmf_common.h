@@ -172,9 +172,6 @@ int sf_launch_wsyrk(const void *xt, int xt_f64, const uint8_t *mask_t, const int
 int sf_launch_wsweep(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nloo, const double *mu, const double *d,
                      const double *lam, const double *evec, const int32_t *status, const double *alphas, const SfGeom &g, int c0,
                      int nb, void *opnd, double *part, hipStream_t st);
-// cmf_wjac.hip: the sweeps of the blocked one-sided Jacobi with its rotations on the matrix cores
-int sf_launch_wide_blockjac_mfma(double *gv, int p2, int nb, const int32_t *cflag, int32_t *done, int32_t *rot, int sweeps,
-                                 hipStream_t st);
 int sf_launch_nll_finish(const double *part, int nsplit, const int32_t *nuse, const double *d, const double *lam,
                          const int32_t *status, const double *alphas, const SfGeom &g, double *nll, int32_t *alphaidx,
                          hipStream_t st, double *rest = nullptr);   // rest: the NLL without its determinant term

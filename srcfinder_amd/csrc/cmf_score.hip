@@ -11,7 +11,8 @@
 // CU with 64 loads each in flight (256 KB per CU), XCD-aware block order.  Round 2 added the staged stores: a wave's
 // 64 records of a line (2 KB of contiguous output) pass through 1 KB of LDS and leave as 1 KB contiguous store
 // instructions instead of 16-byte pieces at a 32-byte stride (-0 .. -3 % per launch, never slower).
-// k_score_blk2 (sf_debug_set(1, 10); measured alternative): 128-sample blocks, a lane owns two adjacent samples.
+// (k_score_blk2, round 2's measured alternative -- 128-sample blocks, a lane owns two adjacent samples -- was removed in round 5:
+//  tools/experiments/score_blk2_r02.hip.txt.)
 //
 // What round 2 measured about this kernel (profiles/r02_score_kernel_experiments.md; tools/microbench/readbw*.hip,
 // tools/tune_score.py with -DSF_SCORE_EXPERIMENTS): the launch is NOT limited by its load geometry.  With the stores
@@ -238,244 +239,6 @@ __global__ __launch_bounds__(256 * CW) void k_score(const float *__restrict__ cu
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// helpers of k_score_blk2
-// ---------------------------------------------------------------------------------------------------------------
-typedef float f2a_t __attribute__((ext_vector_type(2)));
-typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-typedef double sc_d2_t __attribute__((ext_vector_type(2)));
-
-// Cube loads are raw buffer loads: one descriptor per LPI-line batch (base = the batch's first line at the shard's
-// first sample; the range ends with the batch's last line, reads past it return 0), the lane's byte offset in a
-// VGPR and the (line, band) offset in an SGPR -- no 64-bit VALU address arithmetic and no per-line pointer registers.
-template <bool NT>
-__device__ __forceinline__ f2a_t sc_ld2(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-  const u2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, NT ? 2 : 0);   // aux 2 = nt
-  f2a_t r;
-  r.x = __uint_as_float(v.x);
-  r.y = __uint_as_float(v.y);
-  return r;
-}
-// Row validity ((~(x<0)) & isfinite(x), robust_mf.py:282) as ONE running unsigned maximum per pixel: x + 0.0f turns
-// -0.0 (valid: not < 0) into +0.0 and leaves every other value alone, and then the valid values are exactly the bit
-// patterns <= 0x7F7FFFFF (+0 .. FLT_MAX); negatives, infinities and NaNs of either sign are larger as unsigned integers.
-__device__ __forceinline__ uint32_t sc_vkey(float x) { return __float_as_uint(x + 0.0f); }
-constexpr uint32_t SC_VKEY_MAX = 0x7F7FFFFFu;
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_score_blk2: 128-sample column blocks, two samples per lane (a measured alternative, not the default)
-// ---------------------------------------------------------------------------------------------------------------
-// Measured on the benchmark cube, loads only (tools/microbench/readbw2.hip, 598 x 20000 x 425, bands 350..421, every
-// form with >= 256 KB in flight per CU): 64-sample blocks with 4-byte loads 5.3 TB/s, 128-sample blocks with 8-byte
-// loads 6.0, 256-sample blocks with 16-byte loads 6.0, whole rows 6.0 -- and 7.0 for one contiguous run, which a
-// strided window of a BIL cube is not.  What a form needs is (a) wide enough pieces and (b) bytes in flight, i.e.
-// registers: whole rows per workgroup (git history: e35b16f) put the filter of ALL columns on the path (344 KB: LDS
-// tiles with barriers, or L2 reads through registers) and lose (b); column blocks keep the block's filter resident in LDS for
-// the workgroup's lifetime, with no barrier after the prologue.  So: 128-sample blocks, a lane owns two adjacent
-// samples (8-byte loads, 512 contiguous bytes per wave instruction), [p][128] float64 filter tile (73.7 KB at p = 72:
-// two workgroups = 8 waves per CU), 8 lines x 4 bands x 2 batches = 64 loads = 32 KB in flight per wave.
-// A workgroup is persistent: one column block, a balanced contiguous range of 8-line batches dealt to its 4 waves;
-// the grid is sized to be resident at once and all column blocks of a line range sit on one XCD (sf_xcd_map), so
-// the 128-byte lines that straddle block boundaries are fetched by neighbours on the same L2 at about the same time.
-// Validity is one running unsigned maximum per pixel (sc_vkey), the wave's records leave through a 2 KB LDS staging
-// block as 1 KB contiguous stores, the statistics partials are per 8-line batch (independent of the launch shape).
-constexpr int SB_LPI = 8, SB_UB = 4, SB_CB = 128;
-static_assert(SB_UB >= 3, "the RGB rows reuse a load buffer");
-// one 16-byte piece of the product.  mode (timing experiments only): 1 = nt, 2 = sc1 (write-through), 3 = sc0 sc1
-__device__ __forceinline__ void sc_store16(sc_d2_t *p, sc_d2_t v, int mode) {
-#ifdef SF_SCORE_EXPERIMENTS
-  if (mode == 1) { __builtin_nontemporal_store(v, p); return; }
-  if (mode == 2) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); return; }
-  if (mode == 3) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); return; }
-#endif
-  (void)mode;
-  *p = v;
-}
-static size_t sb_lds_bytes(int p) { return ((size_t)(p + 2 * SB_UB - 1) / (2 * SB_UB) * (2 * SB_UB) * SB_CB + 4 * 256) * sizeof(double); }
-template <bool RGB, bool NT>
-__global__ __launch_bounds__(256, 2) void k_score_blk2(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs,
-                                                        int b0, int p, const double *__restrict__ filt,
-                                                        const double *__restrict__ bias,
-                                                        const int32_t *__restrict__ status,
-                                                        const int32_t *__restrict__ alphaidx, int rgb0, int rgb1,
-                                                        int rgb2, double nodata, double *__restrict__ out, int oS,
-                                                        int os0, int16_t *__restrict__ bgmeta,
-                                                        double *__restrict__ stat_part, int ncb, int nk, int nbatch,
-                                                        int expf) {
-#ifndef SF_SCORE_EXPERIMENTS
-  expf = 0;
-#endif
-  constexpr int LPI = SB_LPI, UB = SB_UB;
-  extern __shared__ __attribute__((aligned(16))) double tile[];      // [pr][128] filter tile, then 4 x 2 KB staging
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int cbi, kk;
-  if (!sf_xcd_map(blockIdx.x, ncb, nk, cbi, kk)) return;
-  const int colbase = cbi * SB_CB, ncol = min(SB_CB, Cs - colbase);
-  // the lane's pair: local columns 2 lane, 2 lane + 1.  A pair (half) past the block's last column is never written;
-  // its loads stay inside the batch's buffer range (or return 0 past it) and its tile weights are 0.
-  const int lc0 = 2 * lane;
-  const bool own0 = lc0 < ncol, own1 = lc0 + 1 < ncol;
-  const int c0 = colbase + lc0;
-  const int pr = (p + 2 * UB - 1) / (2 * UB) * (2 * UB);      // tile rows: the window padded to whole load batches
-  for (int idx = tid; idx < pr * SB_CB; idx += 256) {
-    const int cl = idx / pr, b = idx - cl * pr;
-    tile[b * SB_CB + cl] = (cl < ncol && b < p) ? filt[(size_t)(colbase + cl) * p + b] : 0.0;
-  }
-  const int c0c = min(c0, Cs - 1), c1c = min(c0 + 1, Cs - 1);
-  const double bias0 = bias[c0c], bias1 = bias[c1c];
-  const int st0 = status[c0c], st1 = status[c1c];
-  const int ai0 = alphaidx[c0c], ai1 = alphaidx[c1c];
-  const size_t lstride = (size_t)B * C;
-  const unsigned lstride4 = (unsigned)lstride * 4u, C4 = (unsigned)C * 4u;
-  const unsigned coff = (unsigned)lc0 * 4u;
-  const double *wp = tile + lc0;
-  sc_d2_t *stg = reinterpret_cast<sc_d2_t *>(tile + (size_t)pr * SB_CB) + 128 * wave;   // 2 KB per wave
-  __syncthreads();
-
-  const int bat_beg = (int)((long)kk * nbatch / nk), bat_end = (int)((long)(kk + 1) * nbatch / nk);
-  auto batch_rsrc = [&](int sbx) {   // from the batch's first line at the block's first sample to the end of its last line
-    const int lx = sbx * LPI, nlx = min(LPI, L - lx);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cube + (size_t)lx * lstride + (size_t)s0 + colbase), 0,
-                                             (unsigned)nlx * lstride4 - (unsigned)(s0 + colbase) * 4u, 0x00020000);
-  };
-  auto load = [&](f2a_t (&x)[LPI][UB], __amdgpu_buffer_rsrc_t rs, int bs) {
-#pragma unroll
-    for (int bb = 0; bb < UB; ++bb) {
-      const unsigned boff = (unsigned)(b0 + min(bs + bb, p - 1)) * C4;   // bands past the window: duplicates, weight 0
-#pragma unroll
-      for (int j = 0; j < LPI; ++j) x[j][bb] = sc_ld2<NT>(rs, coff, boff + (unsigned)j * lstride4);
-    }
-  };
-  int sb = bat_beg + wave;
-  if (sb >= bat_end) return;
-  __amdgpu_buffer_rsrc_t rsrc = batch_rsrc(sb);
-  f2a_t xa[LPI][UB], xb[LPI][UB];
-  load(xa, rsrc, 0);
-
-  // One line batch.  On entry P holds the batch's first band batch (in flight); on exit Q holds the NEXT line batch's
-  // first band batch: it is issued BEFORE this batch's epilogue, because vmcnt retires in order -- loads issued after
-  // the epilogue's 32 stores could not be consumed until every one of those stores had been acknowledged (~10 us
-  // behind the CU's queue), and the wave's stream would stand still that long once per batch.
-  auto batch = [&](f2a_t (&P)[LPI][UB], f2a_t (&Q)[LPI][UB]) -> bool {
-    const int l0 = sb * LPI;
-    const int nl = min(LPI, L - l0);
-    double acc[LPI][2];
-    uint32_t vk[LPI][2];
-#pragma unroll
-    for (int j = 0; j < LPI; ++j) { acc[j][0] = acc[j][1] = 0.0; vk[j][0] = vk[j][1] = 0u; }
-    auto fma = [&](const f2a_t (&x)[LPI][UB], int bs) {
-      if (expf & 4) { acc[0][0] += (double)x[0][0].x + (double)x[LPI - 1][UB - 1].y; return; }
-#pragma unroll
-      for (int bb = 0; bb < UB; ++bb) {
-        const double w0 = wp[(size_t)(bs + bb) * SB_CB], w1 = wp[(size_t)(bs + bb) * SB_CB + 1];   // rows >= p are zero
-#pragma unroll
-        for (int j = 0; j < LPI; ++j) {
-          vk[j][0] = max(vk[j][0], sc_vkey(x[j][bb].x));
-          vk[j][1] = max(vk[j][1], sc_vkey(x[j][bb].y));
-          acc[j][0] = __builtin_fma((double)x[j][bb].x, w0, acc[j][0]);
-          acc[j][1] = __builtin_fma((double)x[j][bb].y, w1, acc[j][1]);
-        }
-      }
-    };
-    for (int bc = 0; bc < pr; bc += 2 * UB) {
-      load(Q, rsrc, bc + UB);
-      fma(P, bc);
-      if (bc + 2 * UB < pr) {
-        load(P, rsrc, bc + 2 * UB);
-      } else if (RGB) {
-        // the last band batch is in flight and P is free: the three RGB rows of the batch's lines (whole-row pieces
-        // again) queue up right behind it, in P's registers
-#pragma unroll
-        for (int j = 0; j < LPI; ++j) {
-          P[j][0] = sc_ld2<NT>(rsrc, coff, (unsigned)rgb0 * C4 + (unsigned)j * lstride4);
-          P[j][1] = sc_ld2<NT>(rsrc, coff, (unsigned)rgb1 * C4 + (unsigned)j * lstride4);
-          P[j][2] = sc_ld2<NT>(rsrc, coff, (unsigned)rgb2 * C4 + (unsigned)j * lstride4);
-        }
-      }
-      fma(Q, bc + UB);
-    }
-    const int sbn = sb + 4;
-    const bool more = sbn < bat_end;
-    if (more) {
-      rsrc = batch_rsrc(sbn);
-      load(Q, rsrc, 0);
-    }
-    if (!((expf & 1) && acc[0][0] != 1.2345e300)) {
-      double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
-      {
-        const f2a_t (&rgbv)[LPI][UB] = P;
-#pragma unroll
-        for (int jj = 0; jj < LPI; ++jj) {
-          const int j = jj;
-          if (j >= nl) break;                                   // (wave-uniform)
-          // status 2 (singular C): filt = bias = 0 -> the valid rows get exactly 0 (robust_mf.py:373)
-          const bool ok0 = vk[j][0] <= SC_VKEY_MAX, ok1 = vk[j][1] <= SC_VKEY_MAX;
-          const double sc0 = ok0 ? ((st0 == 2) ? 0.0 : (acc[j][0] - bias0)) : nodata;
-          const double sc1 = ok1 ? ((st1 == 2) ? 0.0 : (acc[j][1] - bias1)) : nodata;
-          if (ok0) { s1[0] += sc0; s2[0] += sc0 * sc0; }
-          if (ok1) { s1[1] += sc1; s2[1] += sc1 * sc1; }
-          const size_t pix = (size_t)(l0 + j) * oS + os0 + c0;
-          if (expf & 8) continue;
-          if (RGB) {
-            // the wave's 128 records [R, G, B, CMF] of this line are 4 KB of contiguous output; they pass through the wave's
-            // 2 KB staging block in two halves (32 lanes each) and leave as 1 KB contiguous store instructions.
-            // Layout: 16-byte piece m of lane s' at 4 s' + (m ^ ((s' >> 2) & 3)) -- conflict-free both ways.
-            // columns without a valid row are skipped before the RGB copy (:303-304)
-            const bool cp0 = st0 != 1, cp1 = st1 != 1;
-            const sc_d2_t r0a = {cp0 ? (double)rgbv[jj][0].x : 0.0, cp0 ? (double)rgbv[jj][1].x : 0.0};
-            const sc_d2_t r0b = {cp0 ? (double)rgbv[jj][2].x : 0.0, sc0};
-            const sc_d2_t r1a = {cp1 ? (double)rgbv[jj][0].y : 0.0, cp1 ? (double)rgbv[jj][1].y : 0.0};
-            const sc_d2_t r1b = {cp1 ? (double)rgbv[jj][2].y : 0.0, sc1};
-            sc_d2_t *orow = reinterpret_cast<sc_d2_t *>(out + ((size_t)(l0 + j) * oS + os0 + colbase) * 4);
-            if (expf & 32)   // (experiment: the same bytes, but each wave's batch as ONE contiguous 32 KB run)
-              orow = reinterpret_cast<sc_d2_t *>(out) + (((size_t)sb * ncb + cbi) * LPI + j) * 256;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              if ((lane >> 5) == h) {
-                const int s = lane & 31, sw = (s >> 2) & 3;
-                stg[4 * s + (0 ^ sw)] = r0a;
-                stg[4 * s + (1 ^ sw)] = r0b;
-                stg[4 * s + (2 ^ sw)] = r1a;
-                stg[4 * s + (3 ^ sw)] = r1b;
-              }
-#pragma unroll
-              for (int k = 0; k < 2; ++k) {
-                const int P = 64 * k + lane;                    // 16-byte piece of this half's 2 KB
-                const int s = P >> 2;
-                const sc_d2_t v = stg[4 * s + ((P & 3) ^ ((s >> 2) & 3))];
-                const int lcol = 64 * h + (P >> 1);
-                if (lcol < ncol && !((expf & 64) && v.x != 1.2345e300)) sc_store16(orow + (size_t)lcol * 2 + (P & 1), v, expf >> 8);
-              }
-            }
-          } else {
-            if (own0) out[pix] = sc0;
-            if (own1) out[pix + 1] = sc1;
-          }
-          if (bgmeta) {
-            // int16 pair (cluster id = 0, alpha index); written only on valid rows of solved columns (:365)
-            uint32_t *bm = reinterpret_cast<uint32_t *>(bgmeta) + pix;
-            if (own0) bm[0] = (ok0 && st0 == 0) ? ((uint32_t)(uint16_t)(int16_t)ai0 << 16) : 0u;
-            if (own1) bm[1] = (ok1 && st1 == 0) ? ((uint32_t)(uint16_t)(int16_t)ai1 << 16) : 0u;
-          }
-        }
-      }
-      if (stat_part) {
-        double2 *o = reinterpret_cast<double2 *>(stat_part) + (size_t)sb * Cs + c0;
-        if (own0) o[0] = make_double2(s1[0], s2[0]);
-        if (own1) o[1] = make_double2(s1[1], s2[1]);
-      }
-    }
-    sb = sbn;
-    return more;
-  };
-  for (;;) {
-    if (!batch(xa, xb)) break;
-    if (!batch(xb, xa)) break;
-  }
-}
-
 // npix / mean / std (ddof 0) of the written scores per column (robust_mf.py:388-392).  One 1024-thread
 // workgroup per 64 columns: lane = column, the 16 waves split the chunk list (a shard has few columns but
 // hundreds of chunks: the kernel is a chain of dependent-latency loads), fixed combination order.
@@ -605,35 +368,13 @@ int launch_score_t(const float *cube, int lines, int bands, int samples, int s0,
 // A function of the geometry and the calling thread's tuning knobs only (sf_launch_colstats must agree with it).
 namespace {
 struct ScorePlan {
-  int kernel;                        // 0: k_score_blk2, 2: k_score (production)
   int lpw;                           // lines per statistics partial
 };
 ScorePlan score_plan(int lines, int ncols, int p) {
-  const int v = sf_tune().score_variant;
+  (void)p;
   ScorePlan pl;
-  pl.kernel = ((v == 10 || v == 11) && sb_lds_bytes(p) <= 160 * 1024) ? 0 : 2;
-  pl.lpw = pl.kernel == 0 ? SB_LPI : (sf_tune().score_lpw > 0 ? sf_tune().score_lpw : sf_score_lines_per_wg(lines, ncols));
+  pl.lpw = sf_tune().score_lpw > 0 ? sf_tune().score_lpw : sf_score_lines_per_wg(lines, ncols);
   return pl;
-}
-
-// workgroups of `fn` (nthr threads, lds bytes of dynamic LDS) that are resident at once on the current device
-int resident_wgs(const void *fn, int nthr, size_t lds, int *out) {
-  static std::mutex mu;
-  static std::map<std::tuple<int, const void *, int, size_t>, int> have;
-  int dev = 0;
-  SF_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(mu);
-  auto key = std::make_tuple(dev, fn, nthr, lds);
-  auto it = have.find(key);
-  if (it == have.end()) {
-    int per_cu = 0, cus = 0;
-    SF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nthr, lds));
-    SF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (per_cu < 1) per_cu = 1;
-    it = have.emplace(key, per_cu * cus).first;
-  }
-  *out = it->second;
-  return 0;
 }
 
 }  // namespace
@@ -652,37 +393,6 @@ int sf_launch_score(const float *cube, int lines, int bands, int samples, int s0
   double *stat_part = (scratch && want_stats) ? reinterpret_cast<double *>(scratch) : nullptr;
   double *wT = scratch ? reinterpret_cast<double *>(reinterpret_cast<char *>(scratch) + score_stat_bytes(lines, ncols)) : nullptr;
   const bool rgb = out_bands == 4;
-  if (pl.kernel == 0 && (size_t)bands * samples * 4 * SB_LPI >= ((size_t)1 << 32)) {
-    sf_set_error("score kernel: %d lines of %d x %d values exceed a buffer descriptor", SB_LPI, bands, samples);
-    return -2;
-  }
-  if (pl.kernel == 0) {
-    const size_t lds = sb_lds_bytes(p);
-    const bool nt = sf_tune().score_variant == 11;            // (experiment: non-temporal loads)
-    const void *fn = rgb ? (nt ? (const void *)k_score_blk2<true, true> : (const void *)k_score_blk2<true, false>)
-                         : (nt ? (const void *)k_score_blk2<false, true> : (const void *)k_score_blk2<false, false>);
-    if (int rc = sf_lds_attr(fn, lds)) return rc;
-    int slots = 0;
-    if (int rc = resident_wgs(fn, 256, lds, &slots)) return rc;
-    if (sf_tune().score_wgs > 0) slots = sf_tune().score_wgs * 256;
-    const int ncb = sf_cdiv(ncols, SB_CB), nbatch = sf_cdiv(lines, SB_LPI);
-    int nk = slots / (8 * ncb) * 8;                           // every workgroup resident, whole XCD rounds
-    if (nk < 8) nk = 8;
-    if (nk > sf_cdiv(nbatch, 4)) nk = sf_cdiv(nbatch, 4);     // at least one batch per wave
-    if (nk < 1) nk = 1;
-    const int grid = sf_xcd_grid(ncb, nk);
-    if (ea) SF_HIP(hipEventRecord(ea, st));
-#define SB_LAUNCH(RGBV, NTV)                                                                                          \
-    hipLaunchKernelGGL((k_score_blk2<RGBV, NTV>), dim3(grid), dim3(256), lds, st, cube, lines, bands, samples, s0, ncols,  \
-                       b0, p, filt, bias, status, alphaidx, rgb0, rgb1, rgb2, nodata, out, out_samples, out_s0, bgmeta,     \
-                       stat_part, ncb, nk, nbatch, sf_tune().score_exp)
-    if (rgb) { if (nt) SB_LAUNCH(true, true); else SB_LAUNCH(true, false); }
-    else { if (nt) SB_LAUNCH(false, true); else SB_LAUNCH(false, false); }
-#undef SB_LAUNCH
-    SF_LAUNCH_CHECK("k_score_blk2");
-    if (eb) SF_HIP(hipEventRecord(eb, st));
-    return 0;
-  }
   // ---- column-block kernel (round 1)
   if ((size_t)p * 64 * sizeof(double) > 100 * 1024) {  // wide window: filter from a transposed global copy
     if (!scratch) { sf_set_error("score kernel: a window of %d bands needs scratch", p); return -1; }

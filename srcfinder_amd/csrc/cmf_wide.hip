@@ -1,35 +1,18 @@
 // Wide-window statistics path (active window of more than 96 bands, e.g. the reference's reflectance window
-// 5..420, p = 416, cmf/robust_mf.py:186-187).  Same algorithm as the LDS-resident path (DESIGN.md §3), but the
-// per-column matrices no longer fit LDS / registers, so the stages become batched float64 GEMMs over
-// global-memory operands plus a global-memory Jacobi:
-//   X~ = valid rows - mean                      k_center     (float64 copy, zero rows where masked)
-//   S  = X~^T X~ / (n-1)                        k_dgemm<TA>  (robust_mf.py:52-70)
-//   R  = D^-1 S D^-1 = V diag(lam) V^T          k_eigh_global (Cholesky + one-sided Jacobi, fallback with V)
-//   Z  = (X~ W)^2,  W = D^-1 V                  k_dgemm<SQUARE>
-//   r  = Z C,  C[j][i] = 1/(n beta_i lam_j + a_i)   k_dgemm
-//   sum_k log q, sum_k r/q                      k_nllrows -> k_nll (shared with the fused path)
-// Columns are processed in batches so the float64 scratch (X~, Z, r: 166 MB per column at 20000 x 416) stays a
-// few GB.  Correctness-first: v_mfma_f64_16x16x4_f64 64x64 block tiles without software pipelining.
+// 5..420, p = 416, cmf/robust_mf.py:186-187).  Same algorithm as the LDS-resident path (DESIGN.md section 4), but the
+// per-column matrices no longer fit LDS / registers:
+//   S = X~^T X~ / (n-1)                  k_wsyrk   (cmf_wgemm.hip: fused centring / promotion, 4x4x4 fp64 MFMA; robust_mf.py:52-70)
+//   R = D^-1 S D^-1 = V diag(lam) V^T    this file + cmf_wtri.hip: blocked Cholesky, tridiagonal preconditioner, blocked one-sided
+//                                        Jacobi on the factor in global memory (k_blockjac / k_blockjac_q), k_eigh_global as the
+//                                        single-workgroup fallback
+//   NLL(alpha)                           k_wsweep8 (cmf_wgemm.hip) -> k_nll, exact determinants where the total leaves the range (linalg.hip)
+// k_dgemm (below) is the batched float64 GEMM of the preconditioner.  Round 3's route (float64 copies of X~, Z and r in
+// batches of 36 columns: k_center, three k_dgemm, k_nllrows) was removed in round 5 together with its ~3 GB larger scratch.
 #include "cmf_common.h"
 
 namespace {
 
 constexpr int WD_BM = 64, WD_BN = 64, WD_BK = 16, WD_LD = 80;  // LDS row stride 16 (mod 32) doubles
-
-template <typename XT>
-__global__ void k_center(const XT *__restrict__ xt, const uint8_t *__restrict__ mask_t, const double *__restrict__ mu,
-                         int L, int p, int PS, int c0, double *__restrict__ xc) {
-  const int c = blockIdx.y;  // column within the batch
-  const size_t tot = (size_t)L * p;
-  const XT *xs = xt + (size_t)(c0 + c) * L * PS;
-  const uint8_t *mp = mask_t + (size_t)(c0 + c) * L;
-  const double *m = mu + (size_t)(c0 + c) * p;
-  double *o = xc + (size_t)c * tot;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / p), b = (int)(i - (size_t)r * p);
-    o[i] = mp[r] ? (double)xs[(size_t)r * PS + b] - m[b] : 0.0;
-  }
-}
 
 // C[M x N] = op(A) B, float64, batched over blockIdx.z.  TA: A is stored [K x M] (row-major) instead of [M x K].
 // SQUARE: C = (A B).^2.  Scalar predicated loads (any size); 64x64 block, 4 waves of 32x32, BK = 16.
@@ -139,79 +122,6 @@ __global__ __launch_bounds__(256) void k_dgemm(const double *__restrict__ A, int
       }
 }
 
-// cov = XtX / (n - 1)  (in place, per column of the batch)
-__global__ void k_scale_cov(double *__restrict__ cov, const int32_t *__restrict__ nuse, int p, int c0) {
-  const int c = blockIdx.y;
-  const double inv = 1.0 / ((double)nuse[c0 + c] - 1.0);
-  double *o = cov + (size_t)(c0 + c) * p * p;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p * p; i += gridDim.x * blockDim.x) o[i] *= inv;
-}
-
-// W[b][j] = V_j[b] / d_b  (row-major p x p, the B operand of Y = X~ W)
-__global__ void k_wmat(const double *__restrict__ evec, const double *__restrict__ d, int p, int c0,
-                       double *__restrict__ W) {
-  const int c = blockIdx.y;
-  const double *ev = evec + (size_t)(c0 + c) * p * p, *dd = d + (size_t)(c0 + c) * p;
-  double *o = W + (size_t)c * p * p;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p * p; i += gridDim.x * blockDim.x) {
-    const int b = i / p, j = i - b * p;
-    o[i] = ev[(size_t)j * p + b] / dd[b];
-  }
-}
-
-// C[j][i] = 1 / (n beta_i lam_j + alpha_i)   (p x NA16, zero-padded alpha columns)
-__global__ void k_cmat(const double *__restrict__ lam, const int32_t *__restrict__ nuse, const int32_t *__restrict__ status,
-                       const double *__restrict__ alphas, int nalpha, int NA16, int p, int c0, double *__restrict__ Cm) {
-  const int c = blockIdx.y;
-  const double n = (double)nuse[c0 + c];
-  const bool ok = status[c0 + c] == 0;
-  const double *lc = lam + (size_t)(c0 + c) * p;
-  double *o = Cm + (size_t)c * p * NA16;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p * NA16; i += gridDim.x * blockDim.x) {
-    const int j = i / NA16, a = i - j * NA16;
-    double v = 0.0;
-    if (ok && a < nalpha) {
-      const double al = alphas[a];
-      const double beta = (1.0 - al) / (n - 1.0);
-      v = 1.0 / ((n * beta) * lc[j] + al);
-    }
-    o[i] = v;
-  }
-}
-
-// per (column, row chunk): sum_k log q_ki and sum_k r_ki / q_ki for every alpha, q = 1 - beta r
-// (robust_mf.py:115-117); same partial layout as the fused sweep so k_nll finishes both paths.
-__global__ __launch_bounds__(256) void k_nllrows(const double *__restrict__ Rm, const int32_t *__restrict__ nuse,
-                                                  const int32_t *__restrict__ status, const double *__restrict__ alphas,
-                                                  int nalpha, int NA16, int L, int rows_per_wg, int c0, int nsplit,
-                                                  double *__restrict__ part) {
-  const int c = blockIdx.x, split = blockIdx.y, i = threadIdx.x;
-  double *po = part + ((size_t)(c0 + c) * nsplit + split) * 2 * NA16;
-  if (i >= NA16) return;
-  if (status[c0 + c] != 0 || i >= nalpha) {
-    po[i] = 0.0;
-    po[NA16 + i] = 0.0;
-    return;
-  }
-  const double n = (double)nuse[c0 + c];
-  const double beta = (1.0 - alphas[i]) / (n - 1.0);
-  const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
-  const double *rp = Rm + (size_t)c * L * NA16 + i;
-  double P = 1.0, S = 0.0;
-  int E = 0;
-  bool neg = false;
-  for (int k = rbeg; k < rend; ++k) {
-    const double r = rp[(size_t)k * NA16];
-    const double q = __builtin_fma(-beta, r, 1.0);
-    neg = neg | (q < 0.0);
-    S += r / q;
-    const double pm = P * q;
-    E += __builtin_amdgcn_frexp_exp(pm);
-    P = __builtin_amdgcn_frexp_mant(pm);
-  }
-  po[i] = log(P) + (double)E * 0.6931471805599453094;
-  po[NA16 + i] = neg ? __builtin_nan("") : S;
-}
 
 // ---- one-sided Jacobi with the matrix in global memory (one 1024-thread workgroup per column) -------------------
 // Same method as k_eigh (cmf_eigh.hip): Cholesky R = L L^T, Jacobi on the columns of L, eigenvectors = normalised
@@ -733,120 +643,6 @@ __global__ __launch_bounds__(BJ_NT) void k_blockjac(double *__restrict__ gscratc
   if (tid == 0 && any) atomicMax(&rot[mtx], any);
 }
 
-// Steps > 0 of a sweep: cross pairs only.  Group i of 16 lanes takes column a_i straight from global memory into
-// registers (rows sub, sub + 16, ...: 128-byte segments) and puts it back at the end; only the b block goes through
-// LDS (55 KB at p = 425) -- two workgroups per CU, so one's copies run under the other's rotations.
-template <int RM>
-__global__ __launch_bounds__(BJ_NT) void k_blockjac_x(double *__restrict__ gscratch, int p2, int LDr, int nblk, int mblk, int step,
-                                                       const int32_t *__restrict__ cflag, const int32_t *__restrict__ done,
-                                                       int32_t *__restrict__ rot) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];   // [BJ_B][LDr] (the b block), then nrm[BJ_B]
-  double *nrm = sm + (size_t)BJ_B * LDr;
-  __shared__ int any;
-  const int mtx = blockIdx.y;
-  if (cflag[mtx] != 0 || done[mtx]) return;
-  int ba, bb;
-  rr_pair_w(step, blockIdx.x, mblk - 1, ba, bb);
-  if (ba >= nblk || bb >= nblk) return;          // a lone block has nothing to do outside step 0
-  const int tid = threadIdx.x, grp = tid >> 4, sub = tid & 15;
-  double *G = gscratch + (size_t)mtx * 2 * p2 * p2;
-  const int nr = (p2 - sub + 15) >> 4;
-  const double tol = (double)p2 * 2.220446049250313e-16, tol2 = tol * tol;
-  if (tid == 0) any = 0;
-  constexpr int BJ_U = 8;
-  const int half = p2 >> 1;
-  {
-    const int c0 = bb * BJ_B;
-    const int n2 = min(BJ_B, p2 - c0) * half;
-    const double2 *src = reinterpret_cast<const double2 *>(G + (size_t)c0 * p2);
-    for (int base = tid; base < BJ_B * half; base += BJ_NT * BJ_U) {
-      double2 v[BJ_U];
-#pragma unroll
-      for (int u = 0; u < BJ_U; ++u) {
-        const int idx = base + BJ_NT * u;
-        v[u] = (idx < n2) ? src[idx] : make_double2(0.0, 0.0);
-      }
-#pragma unroll
-      for (int u = 0; u < BJ_U; ++u) {
-        const int idx = base + BJ_NT * u;
-        if (idx < BJ_B * half) {
-          const int cc = idx / half, r2 = idx - cc * half;
-          *reinterpret_cast<double2 *>(sm + (size_t)cc * LDr + 2 * r2) = v[u];
-        }
-      }
-    }
-  }
-  // this group's a column (zero past the last real column)
-  const int acol = ba * BJ_B + grp;
-  double *ga = G + (size_t)min(acol, p2 - 1) * p2 + sub;
-  double xa[RM];
-#pragma unroll
-  for (int i = 0; i < RM; ++i) {
-    const int ii = min(i, nr - 1);
-    const double u = ga[16 * ii];
-    xa[i] = (i < nr && acol < p2) ? u : 0.0;
-  }
-  double aa = 0.0;
-#pragma unroll
-  for (int i = 0; i < RM; ++i) aa = __builtin_fma(xa[i], xa[i], aa);
-  aa = dpp_sum16(aa);
-  __syncthreads();
-  {
-    double sacc = 0.0;                            // exact squared norm of b column grp
-    for (int i = 0; i < nr; ++i) { const double x = sm[(size_t)grp * LDr + sub + 16 * i]; sacc = __builtin_fma(x, x, sacc); }
-    sacc = dpp_sum16(sacc);
-    if (sub == 0) nrm[grp] = sacc;
-  }
-  __syncthreads();
-  bool rotated = false, big = false;
-  for (int t = 0; t < BJ_B; ++t) {
-    const int j = (grp + t) & (BJ_B - 1);
-    double *gb = sm + (size_t)j * LDr + sub;
-    double xb[RM];
-#pragma unroll
-    for (int i = 0; i < RM; ++i) { const int ii = min(i, nr - 1); const double v = gb[16 * ii]; xb[i] = i < nr ? v : 0.0; }
-    double ab = 0.0;
-#pragma unroll
-    for (int i = 0; i < RM; ++i) ab = __builtin_fma(xa[i], xb[i], ab);
-    ab = dpp_sum16(ab);
-    const double bbn = nrm[j];
-    double cs, sn;
-    if (bj_rotation(aa, bbn, ab, tol2, cs, sn)) {
-      rotated = true;
-      big = big || (ab * ab > BJ_TINY2 * (aa * bbn));
-#pragma unroll
-      for (int i = 0; i < RM; ++i) {
-        const double na = cs * xa[i] - sn * xb[i], nb = sn * xa[i] + cs * xb[i];
-        xa[i] = na;
-        if (i < nr) gb[16 * i] = nb;
-      }
-      const double cc = cs * cs, ss = sn * sn, x2 = 2.0 * cs * sn * ab;
-      if (sub == 0) nrm[j] = ss * aa + x2 + cc * bbn;
-      aa = cc * aa - x2 + ss * bbn;
-    }
-    __syncthreads();
-  }
-  if (rotated) any = 1;
-  __syncthreads();   // (a workgroup's "1" must not land on another lane's "2")
-  if (big) any = 2;
-  if (acol < p2) {
-#pragma unroll
-    for (int i = 0; i < RM; ++i) if (i < nr) ga[16 * i] = xa[i];
-  }
-  __syncthreads();
-  {
-    const int c0 = bb * BJ_B;
-    const int n2 = min(BJ_B, p2 - c0) * half;
-    double2 *dst = reinterpret_cast<double2 *>(G + (size_t)c0 * p2);
-#pragma unroll 4
-    for (int idx = tid; idx < n2; idx += BJ_NT) {
-      const int cc = idx / half, r2 = idx - cc * half;
-      dst[idx] = *reinterpret_cast<const double2 *>(sm + (size_t)cc * LDr + 2 * r2);
-    }
-  }
-  if (tid == 0 && any) atomicMax(&rot[mtx], any);
-}
-
 // Round 4: TWO block pairs per workgroup, four blocks per visit.  The blocks of step 0's pairs form "super-blocks" K = (a_K, b_K)
 // (their inner and mutual pairs are k_blockjac's, the first launch of a sweep); the remaining pairs are those between
 // super-blocks, and a circle method over the SUPER-blocks schedules them: a visit of the super-pair (K, L) holds a_K and b_K
@@ -1138,44 +934,11 @@ __global__ void k_wg_back_out(const double *__restrict__ B, int p, int c0, const
 
 }  // namespace
 
-// scratch per column of a batch: X~ + Z (L x p each), r (L x NA16), W (p x p), C (p x NA16), G|V (2 p2^2)
-static size_t wide_col_bytes(const SfGeom &g) {
-  const size_t L = g.lines, p = g.p, na = (size_t)g.nu * 16, p2 = g.p + (g.p & 1);
-  return sf_align((2 * L * p + L * na + p * p + p * na + 2 * p2 * p2) * sizeof(double) + 64);   // + 3 flag words per column
-}
-int sf_wide_batch(const SfGeom &g) {
-  const size_t per = wide_col_bytes(g);
-  size_t b = ((size_t)8 << 30) / per;
-  if (b < 1) b = 1;
-  if (b > (size_t)g.ncols) b = g.ncols;
-  if (b < (size_t)g.ncols && b >= 8) {
-    // the blocked Jacobi runs one 111 KB workgroup per CU, (block pairs) x (matrices of the batch) workgroups per
-    // launch: pick the batch in [b/2, b] whose launches fill their last round of 256 CUs best (p = 425: 36 columns
-    // -> 504 workgroups = 1.97 rounds, against 47 -> 658 = 2.57 rounds paid as 3)
-    const int p2 = g.p + (g.p & 1);
-    const int nblk = sf_cdiv(p2, 16), npair = (nblk + (nblk & 1)) / 2;
-    double best = 0.0;
-    size_t pick = b;
-    for (size_t c = b; c >= b / 2 && c >= 1; --c) {
-      const double wg = (double)npair * (double)c;
-      const double rounds = (double)((long long)((wg + 255.0) / 256.0));
-      const double fill = wg / (256.0 * rounds);
-      if (fill > best + 1e-9) { best = fill; pick = c; }
-    }
-    b = pick;
-  }
-  return (int)b;
-}
-static int wide_nll_splits(const SfGeom &g) { return sf_cdiv(g.lines, 512) > 64 ? 64 : sf_cdiv(g.lines, 512); }
 // Exact determinants (linalg.hip): every grid point while that is cheap (the function-level looshrinkage(): one
 // column, 201 factorisations side by side on 256 CUs), else the 24 grid points on the finite side of each crossing of
 // the float64 range (the prefix products of p <= 512 pivots were never seen to run further ahead of the total than 16
 // grid points, tests/test_cmf_gpu.py::test_looshrinkage_function_512_band_golden).
 int sf_exact_det_window(const SfGeom &g) { return ((size_t)g.ncols * g.nalpha <= 2048) ? 0 : 24; }
-// the full-target route's extra per batch column: L, B (p^2 each) and a flag word
-static size_t wide_target_bytes(const SfGeom &g) {
-  return sf_align((size_t)sf_wide_batch(g) * (2 * (size_t)g.p * g.p * sizeof(double) + sizeof(int32_t)));
-}
 // ---- the fused route of round 4 (cmf_wgemm.hip): no float64 copies of X~, Z, r -- a column needs its eigensolver work
 // matrices (2 p2^2), the sweep operands W and C, and, on the full-target route, L and B.  All columns of a flightline in one group when 8 GB hold them.
 static size_t fused_col_bytes(const SfGeom &g) {
@@ -1203,15 +966,7 @@ static size_t fused_scratch_bytes(const SfGeom &g) {
   return ngr * gb * fused_col_bytes(g) + sf_wgemm_part_bytes(g) + sf_align((size_t)g.ncols * g.nalpha * sizeof(double)) +
          sf_exact_det_scratch_bytes(g, sf_exact_det_window(g)) + 4096;
 }
-static size_t legacy_scratch_bytes(const SfGeom &g) {
-  return (size_t)sf_wide_batch(g) * wide_col_bytes(g) + wide_target_bytes(g) +
-         sf_align((size_t)g.ncols * wide_nll_splits(g) * 2 * g.nu * 16 * sizeof(double)) +
-         sf_align((size_t)g.ncols * g.nalpha * sizeof(double)) + sf_exact_det_scratch_bytes(g, sf_exact_det_window(g));
-}
-size_t sf_wide_scratch_bytes(const SfGeom &g) {
-  const size_t a = fused_scratch_bytes(g), b = legacy_scratch_bytes(g);   // (the round-3 route stays selectable: sf_debug_set(23, 1))
-  return a > b ? a : b;
-}
+size_t sf_wide_scratch_bytes(const SfGeom &g) { return fused_scratch_bytes(g); }   // (round 5: round 3's route and its ~3 GB larger scratch are gone)
 
 // Batched n x n float64 GEMM on COLUMN-major matrices through k_dgemm (whose operands are row-major: a column-major X is the
 // row-major X^T):  tb = 0: C = Bm Am;  tb = 1: C = Bm^T Am ... with Am / Bm the column-major matrices in A / B -- i.e. the
@@ -1295,43 +1050,24 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
     if (int rc = wide_chol(gv, p, p2, nb, cflag, st)) return rc;
   if (precond)
     if (int rc = sf_launch_wtri_apply(gv, p, p2, nb, pre->B2, pre->B3, pre->small, cflag, pre->pflag, st)) return rc;
-  if (sf_tune().wide_eigh_variant == 3 || sf_tune().wide_eigh_variant == 4) {
-    // round 4 experiment (cmf_wjac.hip): the rotations of a visit on its 32 x 32 Gram matrix, applied by MFMA.  Same results,
-    // 6 % SLOWER than the scalar kernels below (profiles/r04_wjac_phase_clocks.txt): not the default.
-    if (int rc = sf_launch_wide_blockjac_mfma(gv, p2, nb, cflag, done, rot, 16, st)) return rc;
-    hipLaunchKernelGGL(k_blockjac_leftover, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, cflag, done);
-    hipLaunchKernelGGL(k_blockjac_finish, dim3(nb), dim3(512), 0, st, gv, p, p2, c0, cflag, lam, evec);
-    SF_LAUNCH_CHECK("k_blockjac_finish");
-    hipLaunchKernelGGL(k_eigh_global, dim3(nb), dim3(512), 0, st, cov, nuse, p, p2, c0, d, lam, evec, status, gv, 2, cflag, unit);
-    SF_LAUNCH_CHECK("k_eigh_global(fallback)");
-    return 0;
-  }
   SF_HIP(hipMemsetAsync(done, 0, (size_t)nb * sizeof(int32_t), st));
   SF_HIP(hipMemsetAsync(rot, 0, (size_t)nb * sizeof(int32_t), st));
   const int nblk = sf_cdiv(p2, BJ_B), mblk = nblk + (nblk & 1);
   int LDr = p2;
   while ((LDr % 32) != 16) ++LDr;
   const size_t lds = ((size_t)2 * BJ_B * LDr + 2 * BJ_B) * sizeof(double);
-  const int nsteps = (mblk > 1) ? mblk - 1 : 1;
   const int nrmax = sf_cdiv(p2, 16);
 #define BJ_SWEEPS(RM)                                                                                                            \
   {                                                                                                                              \
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac<RM>), lds)) return rc;                                    \
-    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac_x<RM>), ldsx)) return rc;                                 \
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_blockjac_q<RM>), lds)) return rc;                                  \
     for (int sweep = 0; sweep < nsweeps; ++sweep) { /* converged matrices drop out by their flag; no host round trip */          \
       /* (10-12 sweeps on flightline-like spectra; a matrix still rotating after 16 is redone by k_eigh_global, mode 2) */        \
       hipLaunchKernelGGL(k_blockjac<RM>, dim3(mblk / 2 > 0 ? mblk / 2 : 1, nb), dim3(BJ_NT), lds, st, gv, p2, LDr, nblk,         \
                          mblk > 1 ? mblk : 2, 0, cflag, done, rot);                                                              \
-      if (quad) {                                                                                                                \
-        for (int s = 1; s < msbE; ++s)                                                                                           \
-          hipLaunchKernelGGL(k_blockjac_q<RM>, dim3(msbE / 2, nb), dim3(2 * BJ_NT), lds, st, gv, p2, LDr, nblk, mblk, s, cflag,  \
-                             done, rot);                                                                                         \
-      } else {                                                                                                                   \
-        for (int s = 1; s < nsteps; ++s)                                                                                         \
-          hipLaunchKernelGGL(k_blockjac_x<RM>, dim3(mblk / 2, nb), dim3(BJ_NT), ldsx, st, gv, p2, LDr, nblk, mblk, s, cflag,     \
-                             done, rot);                                                                                         \
-      }                                                                                                                          \
+      for (int s = 1; s < msbE; ++s)                                                                                             \
+        hipLaunchKernelGGL(k_blockjac_q<RM>, dim3(msbE / 2, nb), dim3(2 * BJ_NT), lds, st, gv, p2, LDr, nblk, mblk, s, cflag,    \
+                           done, rot);                                                                                           \
       hipLaunchKernelGGL(k_blockjac_flags, dim3(sf_cdiv(nb, 256)), dim3(256), 0, st, nb, done, rot);                             \
     }                                                                                                                            \
   }
@@ -1340,10 +1076,8 @@ static int wide_eigh(const double *cov, const int32_t *nuse, int p, int p2, int 
   // after the last sweep -- one whose preconditioner was refused (pflag) and whose Cholesky still succeeded -- is redone by
   // k_eigh_global (mode 2), as after 16 sweeps without the preconditioner.
   const int nsweeps = precond ? 5 : 16;
-  // quad visits (k_blockjac_q): the default whenever there are at least two super-blocks; sf_debug_set(10, 5): the pair visits
+  // quad visits (k_blockjac_q) for the cross steps of a sweep (round 3's pair visits, k_blockjac_x, were removed in round 5)
   const int msb = mblk / 2, msbE = msb + (msb & 1);
-  const bool quad = msb >= 2 && sf_tune().wide_eigh_variant != 5;
-  const size_t ldsx = ((size_t)BJ_B * LDr + BJ_B) * sizeof(double);
   if (nrmax <= 8) BJ_SWEEPS(8)
   else if (nrmax <= 16) BJ_SWEEPS(16)
   else if (nrmax <= 24) BJ_SWEEPS(24)
@@ -1448,82 +1182,5 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
     return -2;
   }
   if (!nloo) nloo = nuse;
-  if (sf_tune().wide_gemm_variant != 1)
-    return wide_stats_fused(xt, xt_f64, mask_t, nuse, nloo, mu, alphas, g, cov, d, lam, evec, status, nll, alphaidx, scratch, st,
-                            target);
-  const int L = g.lines, p = g.p, NA16 = g.nu * 16, p2 = g.p + (g.p & 1);
-  const int bc = sf_wide_batch(g);
-  const int nsplit = wide_nll_splits(g);
-  const int rows = sf_cdiv(L, nsplit);
-  const size_t per = wide_col_bytes(g);
-  char *base = reinterpret_cast<char *>(scratch);
-  double *part = reinterpret_cast<double *>(base + (size_t)bc * per + wide_target_bytes(g));
-  // batch-strided views (column c of the batch at base + c*per would break the GEMM batch stride, so each
-  // array is laid out contiguously over the batch instead)
-  double *xc = reinterpret_cast<double *>(base);
-  double *z = xc + (size_t)bc * L * p;
-  double *rm = z + (size_t)bc * L * p;
-  double *W = rm + (size_t)bc * L * NA16;
-  double *Cm = W + (size_t)bc * p * p;
-  double *gv = Cm + (size_t)bc * p * NA16;
-  int32_t *flags = reinterpret_cast<int32_t *>(gv + (size_t)bc * 2 * p2 * p2);   // cflag | done | rot, bc each
-  double *Lc = reinterpret_cast<double *>(base + (size_t)bc * per);              // full-target route only
-  double *Bw = Lc + (size_t)bc * p * p;
-  int32_t *tflag = reinterpret_cast<int32_t *>(Bw + (size_t)bc * p * p);
-  for (int c0 = 0; c0 < g.ncols; c0 += bc) {
-    const int nb = (g.ncols - c0 < bc) ? g.ncols - c0 : bc;
-    // nuse: the rows the covariance is made of (ddof 1); nloo: the n of beta and of 1/(2n) (robust_mf.py:109, :116) --
-    // the same number in the column loop, separate in the function-level looshrinkage(I_zm, alphas, nll, n)
-    if (xt_f64)
-      hipLaunchKernelGGL(k_center<double>, dim3(256, nb), dim3(256), 0, st, reinterpret_cast<const double *>(xt), mask_t, mu,
-                         L, p, g.ps, c0, xc);
-    else
-      hipLaunchKernelGGL(k_center<float>, dim3(256, nb), dim3(256), 0, st, reinterpret_cast<const float *>(xt), mask_t, mu,
-                         L, p, g.ps, c0, xc);
-    SF_LAUNCH_CHECK("k_center");
-    // S = X~^T X~  (A = X~ stored [K = L][M = p] -> TA)
-    hipLaunchKernelGGL((k_dgemm<true, false, true>), dim3(sf_cdiv(p, WD_BM), sf_cdiv(p, WD_BN), nb), dim3(256), 0, st, xc, p,
-                       (size_t)L * p, xc, p, (size_t)L * p, cov + (size_t)c0 * p * p, p, (size_t)p * p, p, p, L, 1.0);
-    SF_LAUNCH_CHECK("k_dgemm(syrk)");
-    hipLaunchKernelGGL(k_scale_cov, dim3(64, nb), dim3(256), 0, st, cov, nuse, p, c0);
-    SF_LAUNCH_CHECK("k_scale_cov");
-    if (!target) {
-      if (int rc = wide_eigh(cov, nuse, p, p2, c0, nb, d, lam, evec, status, gv, flags, flags + bc, flags + 2 * bc, st)) return rc;
-    } else {
-      hipLaunchKernelGGL(k_wg_load, dim3(64, nb), dim3(256), 0, st, target, nuse, p, p2, c0, gv, flags);
-      SF_LAUNCH_CHECK("k_wg_load");
-      if (int rc = wide_chol(gv, p, p2, nb, flags, st)) return rc;
-      hipLaunchKernelGGL(k_wg_prep, dim3(64, nb), dim3(256), 0, st, gv, flags, cov, p, p2, c0, Lc, Bw, d, tflag);
-      hipLaunchKernelGGL(k_wg_solve<false>, dim3(sf_cdiv(p, 64), nb), dim3(64), 0, st, Lc, Bw, p);
-      hipLaunchKernelGGL(k_wg_transpose, dim3(64, nb), dim3(256), 0, st, Bw, p, 0);
-      hipLaunchKernelGGL(k_wg_solve<false>, dim3(sf_cdiv(p, 64), nb), dim3(64), 0, st, Lc, Bw, p);
-      hipLaunchKernelGGL(k_wg_transpose, dim3(64, nb), dim3(256), 0, st, Bw, p, 1);
-      SF_LAUNCH_CHECK("k_wg_whiten");
-      if (int rc = wide_eigh(Bw, nuse, p, p2, c0, nb, d, lam, evec, status, gv, flags, flags + bc, flags + 2 * bc, st, 1)) return rc;
-      hipLaunchKernelGGL(k_wg_back_in, dim3(64, nb), dim3(256), 0, st, evec, p, c0, Bw);
-      hipLaunchKernelGGL(k_wg_solve<true>, dim3(sf_cdiv(p, 64), nb), dim3(64), 0, st, Lc, Bw, p);
-      hipLaunchKernelGGL(k_wg_back_out, dim3(64, nb), dim3(256), 0, st, Bw, p, c0, d, evec, lam, status, tflag);
-      SF_LAUNCH_CHECK("k_wg_back");
-    }
-    hipLaunchKernelGGL(k_wmat, dim3(64, nb), dim3(256), 0, st, evec, d, p, c0, W);
-    SF_LAUNCH_CHECK("k_wmat");
-    hipLaunchKernelGGL(k_cmat, dim3(64, nb), dim3(256), 0, st, lam, nloo, status, alphas, g.nalpha, NA16, p, c0, Cm);
-    SF_LAUNCH_CHECK("k_cmat");
-    hipLaunchKernelGGL((k_dgemm<false, true>), dim3(sf_cdiv(L, WD_BM), sf_cdiv(p, WD_BN), nb), dim3(256), 0, st, xc, p,
-                       (size_t)L * p, W, p, (size_t)p * p, z, p, (size_t)L * p, L, p, p, 1.0);
-    SF_LAUNCH_CHECK("k_dgemm(Y^2)");
-    hipLaunchKernelGGL((k_dgemm<false, false>), dim3(sf_cdiv(L, WD_BM), sf_cdiv(NA16, WD_BN), nb), dim3(256), 0, st, z, p,
-                       (size_t)L * p, Cm, NA16, (size_t)p * NA16, rm, NA16, (size_t)L * NA16, L, NA16, p, 1.0);
-    SF_LAUNCH_CHECK("k_dgemm(r)");
-    hipLaunchKernelGGL(k_nllrows, dim3(nb, nsplit), dim3(256), 0, st, rm, nloo, status, alphas, g.nalpha, NA16, L, rows,
-                       c0, nsplit, part);
-    SF_LAUNCH_CHECK("k_nllrows");
-  }
-  double *rest = reinterpret_cast<double *>(reinterpret_cast<char *>(part) +
-                                            sf_align((size_t)g.ncols * nsplit * 2 * g.nu * 16 * sizeof(double)));
-  void *det_scratch = reinterpret_cast<char *>(rest) + sf_align((size_t)g.ncols * g.nalpha * sizeof(double));
-  if (int rc = sf_launch_nll_finish(part, nsplit, nloo, d, lam, status, alphas, g, nll, alphaidx, st, rest)) return rc;
-  // det() over/underflow exactly as scipy's running LU product has it (robust_mf.py:111-113), where the total
-  // log-determinant cannot decide
-  return sf_launch_exact_det(cov, nloo, status, alphas, g, sf_exact_det_window(g), rest, nll, alphaidx, det_scratch, st, target);
+  return wide_stats_fused(xt, xt_f64, mask_t, nuse, nloo, mu, alphas, g, cov, d, lam, evec, status, nll, alphaidx, scratch, st, target);
 }

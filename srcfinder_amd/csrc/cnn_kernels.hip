@@ -399,9 +399,7 @@ struct ConvDst {
 // POOL (buffer form, 1x1 convolutions only): the A tile is the 3x3 stride-1 pad-1 max pool of the input, taken while it is
 // fetched -- nine loads and eight maxima per element instead of a pooled copy in HBM (inception branch 4,
 // googlenet1.py:213-214).  Activations are >= 0 after ReLU, so the zero an out-of-range load returns is the identity.
-// DB (round 4): TWO LDS buffers for the A / B chunk -- the next chunk is stored while the current one is multiplied and one
-// barrier per chunk remains (the single-buffer form needs two around its store: 32-48 MFMAs per wave between barriers).
-template <int BK, int BN, int EXP = 0, bool BUF = false, bool POOL = false, bool DB = false>
+template <int BK, int BN, int EXP = 0, bool BUF = false, bool POOL = false>
 __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in, int M, int H, int W, int Cin, int ld_in,
                                                      const float *__restrict__ wt, const float *__restrict__ bias, int Cout,
                                                      int ks, ConvDst dst) {
@@ -411,8 +409,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in
   constexpr int NPA = BM / PPP;      // passes for the A tile
   constexpr int NPB = (BN + PPP - 1) / PPP;
   constexpr int NT = BN / 32;
-  __shared__ float As[(DB ? 2 : 1) * BK * LDA];
-  __shared__ float Bs[(DB ? 2 : 1) * BK * LDB];
+  __shared__ float As[BK * LDA];
+  __shared__ float Bs[BK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = tid % TPP, ri = tid / TPP;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -533,30 +531,29 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in
     for (int b = 0; b < NPB; ++b)
       rb[b] = wok[b] ? *reinterpret_cast<const float4 *>(wb[b] + (size_t)tap * Cin + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&]() {
 #pragma unroll
     for (int a = 0; a < NPA; ++a) {
-      float *d = As + buf * (BK * LDA) + (4 * q) * LDA + ri + PPP * a;
+      float *d = As + (4 * q) * LDA + ri + PPP * a;
       d[0] = ra[a].x; d[LDA] = ra[a].y; d[2 * LDA] = ra[a].z; d[3 * LDA] = ra[a].w;
     }
 #pragma unroll
     for (int b = 0; b < NPB; ++b) {
       if (ri + PPP * b < BN) {
-        float *d = Bs + buf * (BK * LDB) + (4 * q) * LDB + ri + PPP * b;
+        float *d = Bs + (4 * q) * LDB + ri + PPP * b;
         d[0] = rb[b].x; d[LDB] = rb[b].y; d[2 * LDB] = rb[b].z; d[3 * LDB] = rb[b].w;
       }
     }
   };
 
   gload(0);
-  lstore(0);
+  lstore();
   __syncthreads();
   const float *ap = As + (lane >> 5) * LDA + 32 * wave + (lane & 31);
   const float *bp = Bs + (lane >> 5) * LDB + (lane & 31);
   for (int it = 0; it < nit; ++it) {
     if (it + 1 < nit && !(EXP & 1)) gload(it + 1);
-    const int cur = DB ? (it & 1) : 0;
-    const float *apc = ap + cur * (BK * LDA), *bpc = bp + cur * (BK * LDB);
+    const float *apc = ap, *bpc = bp;
 #pragma unroll
     for (int kk = 0; kk < ((EXP & 4) ? 1 : BK / 2); ++kk) {
       const float a = apc[2 * kk * LDA];
@@ -566,16 +563,10 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const float *__restrict__ in
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
       }
     }
-    if (DB) {
-      // the other buffer was read by chunk it - 1: every wave is past it (the barrier that ended that iteration)
-      if (it + 1 < nit && !(EXP & 2)) lstore(cur ^ 1);
+    __syncthreads();
+    if (it + 1 < nit) {
+      if (!(EXP & 2)) lstore();
       __syncthreads();
-    } else {
-      __syncthreads();
-      if (it + 1 < nit) {
-        if (!(EXP & 2)) lstore(0);
-        __syncthreads();
-      }
     }
   }
   // epilogue: acc[t][r] = D[row = (r&3) + 8(r>>2) + 4(lane>>5)][col = lane&31]
@@ -813,12 +804,9 @@ int launch_conv(const float *in, int M, int H, int W, int Cin, int ld_in, const 
   const size_t bbytes = (size_t)Cout * ks * ks * Cin * 4;
   const size_t lim = (size_t)0x7ff00000 - ((size_t)fk * W + fk) * ld_in * 4;      // offsets + the tap offset stay below 2^31
   const bool buf = abytes < lim && bbytes < lim && sf_tune().cnn_conv_variant != 1;
-  const bool db = sf_tune().cnn_conv_variant == 2;   // two LDS buffers, one barrier per chunk
   if (POOL) {
     if (!buf) return 1;
     hipLaunchKernelGGL((k_conv_igemm<BK, BN, 0, true, POOL>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
-  } else if (buf && db) {
-    hipLaunchKernelGGL((k_conv_igemm<BK, BN, 0, true, false, true>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
   } else if (buf) {
     hipLaunchKernelGGL((k_conv_igemm<BK, BN, 0, true>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, wt, bias, Cout, ks, dst);
   } else {

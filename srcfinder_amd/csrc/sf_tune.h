@@ -5,7 +5,7 @@
 // holds no process-wide mutable state: a thread that flips a knob (tools/tune_*.py, the kernel-variant tests) changes
 // only the launches it issues itself.
 struct SfTune {
-  int score_variant = 0;      // key 1: score kernel form (cmf_score.hip): 100 = round 1, 10 / 11 = k_score_blk2 plain / nt
+  int score_variant = 0;      // key 1: score kernel form (cmf_score.hip): 100 = round 1 (16-byte pieces stored by the lanes), 200 = the launch's traffic only (timing), 1..9 = batch shapes
   int score_lpw = 0;          // key 2: lines per workgroup of the column-block score kernel
   int score_xcd = 1;          // key 3: XCD-aware block map of the column-block score kernel
   int sweep_variant = 0;      // key 4: 1 = force the 16x16x4 sweep, 2 = full-rank 4x4x4 sweep only
@@ -16,19 +16,15 @@ struct SfTune {
   int eigh_lpp = 0;           // key 7: lanes per column pair of the Jacobi eigensolver
   int sweep4r_waves = 8;      // key 8: waves per workgroup of the rank-factored sweep (k_sweep4r, form 1)
   int sweep4_form = 0;        // key 20: rank-28 sweep kernel: 0 = k_sweep4s (round 3: one streamed ring), 1 = k_sweep4r (round 2, both ranks), 3 = k_sweep4r for the rank-36 columns only, 4 = k_sweep4s renormalising after every tile; 100 + bits = timing experiments (-DSF_SWEEP_EXPERIMENTS)
-  int wide_eigh_variant = 0;  // key 10: 0 = blocked Jacobi behind the tridiagonal preconditioner (cmf_wtri.hip) for calls of 32 columns or more; 7 = the preconditioner for any number of columns; 6 = the sweeps from the Cholesky factor (round 4's first form: 11-12 sweeps); 1 = the single-workgroup eigensolver for every wide matrix, 5 = pair visits (k_blockjac_x, round 3) instead of the quad visits of round 4 (k_blockjac_q), 3 / 4 = the Gram-space / MFMA form of the blocked Jacobi with four / eight waves (cmf_wjac.hip; measured slower)
-  int wjac_stamps = 0;        // key 22: 1 = the wide Jacobi kernels accumulate their phase clocks (sf_debug_wjac_stamps)
-  int wide_gemm_variant = 0;  // key 23: 1 = round 3's wide-window route (k_center + three k_dgemm + k_nllrows, 36-column batches) instead of the fused 4x4x4 kernels of cmf_wgemm.hip
+  int wide_eigh_variant = 0;  // key 10: 0 = blocked Jacobi behind the tridiagonal preconditioner (cmf_wtri.hip) for calls of 32 columns or more; 7 = the preconditioner for any number of columns; 6 = the sweeps from the Cholesky factor (round 4's first form: 11-12 sweeps); 1 = the single-workgroup eigensolver for every wide matrix, 8 = as 7 with every preconditioner refused afterwards (the fallback's test)
+  int wjac_stamps = 0;        // key 22: 1 = the fused wide sweep accumulates its phase clocks (sf_debug_wsweep_stamps)
   int wsweep_variant = 0;     // key 24: the fused wide sweep: 0 = k_wsweep8 (eight waves, wave-private operand slices) where it applies; 1 = 32-row tiles, two workgroups per CU; 2 = eight waves on shared chunks; 4 = four waves on shared chunks (round 4's first form)
-  int wsyrk_variant = 0;      // key 25: (unused since the 128-band tile variant of the fused wide covariance was removed)
-  int score_wgs = 0;          // key 12: workgroups per CU k_score_blk2 is sized for (0 = occupancy query)
-  int cnn_pool_variant = 0;   // key 18: 1 = branch-4 pool taken inside the 1x1 convolution's tile fetch (sf_cnn_pool_conv; slower)
-  int cnn_conv_variant = 0;   // key 17: 1 = pointer-form tile loads in k_conv_igemm (cnn_kernels.hip), 2 = two LDS buffers / one barrier per chunk
+  int cnn_pool_variant = 0;   // key 18: inception branch 4: 0 = pool taken from the tile staged in LDS (k_poolconv), 3 = pool kernel then convolution, 2 = the same with the general pool kernel, 1 = pool inside the 1x1 convolution's tile fetch (nine reads; slower)
+  int cnn_conv_variant = 0;   // key 17: 1 = pointer-form tile loads in k_conv_igemm (cnn_kernels.hip; the form operands of 2 GB or more take)
   int cnn_variant = 0;        // key 16: 1 = the 8 x 8 conv1+pool kernel (cnn_kernels.hip)
   int det_variant = 0;        // key 15: 1 = the plain window rule of the exact-determinant pass in one round, 2 = no pass in sf_cmf_run's narrow branch
   int det_slots = 0;          // key 26: workgroups (work matrices) of a launch of the exact-determinant pass; 0 = as many as fit (512)
   int lu_variant = 0;         // key 14: 1 = the unblocked LU in the determinant passes (linalg.hip)
-  int score_exp = 0;          // key 13: timing experiments of k_score_blk2 (only with -DSF_SCORE_EXPERIMENTS)
 };
 SfTune &sf_tune();   // c_api.hip (thread_local)
 

@@ -182,7 +182,8 @@ int sf_cmf_column_profile(const double *img, int lines, int samples, int nbands,
 
 /* Robust variant (triage/cmf_profile.py:124-127, use_robust_stats): profile[5][samples] = npix, median, MAD
  * (median of |x - median|), and the (1-p) / p percentiles with numpy's 'nearest' rule (srcfinder_util.py:647-653,
- * called with p = 0.95), all on the float32 cast of the valid positive pixels.  lines <= 32768. */
+ * called with p = 0.95), all on the float32 cast of the valid positive pixels.  Any number of lines (up to 32768 the column is
+ * sorted in LDS, beyond that the order statistics are selected by radix passes over the product: the same numbers). */
 int sf_cmf_column_profile_robust(const double *img, int lines, int samples, int nbands, int band, double nodata,
                                  double p, double *profile, void *stream);
 
@@ -275,8 +276,8 @@ int sf_masks_compose(const uint8_t *cloud, const uint8_t *spec, const uint8_t *s
  * & ~nodata for the saliency and pmsk & (cmf > cmfthr) for the CMF: max, min, median, MAD (median of |x - median|),
  * truncated centre of mass of the pixels holding the maximum (:81-103).  bbox: scratch (nregions + 1) * 4 int32.
  * rec[nregions + 1][20] float64, row id: [0..3] bounding slices (row start, row stop, col start, col stop),
- * [4..10] saliency max, min, median, MAD, max row, max col, n; [11..17] the same for the CMF; [18] status (1 = the
- * region has more pixels than the LDS-resident sort holds: 32768 saliency / 16384 CMF values). */
+ * [4..10] saliency max, min, median, MAD, max row, max col, n; [11..17] the same for the CMF; [18] status, always 0 (a region
+ * of any size: up to 32768 saliency / 16384 CMF values are sorted in LDS, larger sets are selected by radix passes). */
 int sf_detect_region_stats(const int32_t *labels, int H, int W, int nregions, const float *sal, const double *cmf,
                            int cmf_nb, int cmf_band, const uint8_t *nodata, double cmfthr, int32_t *bbox, double *rec,
                            void *stream);

@@ -433,7 +433,10 @@ int sf_launch_colstats(const void *stat_scratch, int lines, int samples, int s0,
 // ---- robust column profile (triage/cmf_profile.py:124-127, use_robust_stats): median, MAD, 5th / 95th percentile
 // ('nearest') of a column's valid positive pixels.  One 1024-thread workgroup per column: the values (float32,
 // as the reference casts them) are gathered into LDS, bitonic-sorted, and the order statistics read off; the
-// MAD is a second sort of |x - median|.  Holds up to 32768 lines.
+// MAD is a second sort of |x - median|.  The LDS sort holds up to 32768 lines; longer columns (the reference has no cap:
+// triage/cmf_profile.py:124-127) take k_profile_robust_big: the same order statistics by radix selection on the float32 bit
+// patterns straight from the product in global memory (positive floats order like their bits) -- exact, so both kernels
+// give the same numbers.
 namespace {
 constexpr int PR_NT = 1024, PR_CAP = 32768;
 
@@ -502,6 +505,81 @@ __global__ __launch_bounds__(PR_NT) void k_profile_robust(const double *__restri
   lds_bitonic_sort(vals, npow2, tid);
   if (tid == 0) prof[2 * S + c] = (double)((n & 1) ? vals[n / 2] : (vals[n / 2 - 1] + vals[n / 2]) * 0.5f);
 }
+// ---- any number of lines: the k-th smallest of a column's valid values, mode 0 = the float32 values themselves, mode 1 =
+// |x - med|, by four 8-bit passes from the most significant byte down (a 256-bin histogram of the values that match the
+// prefix found so far, in LDS; thread 0 walks the bins).  Nothing is stored: every pass re-reads the column from the product.
+__device__ __forceinline__ bool pr_key(const double *__restrict__ img, size_t idx, double nodata, int mode, float med, unsigned &bits) {
+  const double v = img[idx];
+  const float vf = (float)v;
+  const bool ok = (v == v) && v != nodata && vf > 0.f;
+  bits = __float_as_uint(mode ? fabsf(vf - med) : vf);
+  return ok;
+}
+__device__ float pr_select(const double *__restrict__ img, int L, int S, int nb, int band, int c, double nodata, int mode, float med,
+                           unsigned k, unsigned *hist, unsigned *sh) {
+  const int tid = threadIdx.x;
+  unsigned prefix = 0, mask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256; i += PR_NT) hist[i] = 0;
+    __syncthreads();
+    for (int l = tid; l < L; l += PR_NT) {
+      unsigned b;
+      if (pr_key(img, ((size_t)l * S + c) * nb + band, nodata, mode, med, b) && (b & mask) == prefix) atomicAdd(&hist[(b >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned cum = 0, bsel = 255;
+      for (unsigned b = 0; b < 256; ++b) {
+        if (k < cum + hist[b]) { bsel = b; break; }
+        cum += hist[b];
+      }
+      sh[0] = prefix | (bsel << shift);
+      sh[1] = k - cum;
+    }
+    __syncthreads();
+    prefix = sh[0];
+    k = sh[1];
+    mask |= 255u << shift;
+    __syncthreads();
+  }
+  return __uint_as_float(prefix);
+}
+
+__global__ __launch_bounds__(PR_NT) void k_profile_robust_big(const double *__restrict__ img, int L, int S, int nb, int band,
+                                                               double nodata, float plo, float phi, double *__restrict__ prof) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sh[2];
+  __shared__ int cnt;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) cnt = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int l = tid; l < L; l += PR_NT) {
+    unsigned b;
+    mine += pr_key(img, ((size_t)l * S + c) * nb + band, nodata, 0, 0.f, b) ? 1 : 0;
+  }
+  atomicAdd(&cnt, mine);
+  __syncthreads();
+  const int n = cnt;
+  const double nanv = __builtin_nan("");
+  if (n == 0) {
+    if (tid == 0) { prof[c] = 0; prof[S + c] = nanv; prof[2 * S + c] = nanv; prof[3 * S + c] = nanv; prof[4 * S + c] = nanv; }
+    return;
+  }
+  auto sel = [&](int mode, float med, int k) { return pr_select(img, L, S, nb, band, c, nodata, mode, med, (unsigned)k, hist, sh); };
+  const float hi = sel(0, 0.f, n / 2);
+  const float med = (n & 1) ? hi : (sel(0, 0.f, n / 2 - 1) + hi) * 0.5f;   // float32 mean of the two middle values
+  const float vlo = sel(0, 0.f, nearest_index(n, plo)), vhi = sel(0, 0.f, nearest_index(n, phi));
+  const float mhi = sel(1, med, n / 2);
+  const float mad = (n & 1) ? mhi : (sel(1, med, n / 2 - 1) + mhi) * 0.5f;
+  if (tid == 0) {
+    prof[c] = (double)n;
+    prof[S + c] = (double)med;
+    prof[2 * S + c] = (double)mad;
+    prof[3 * S + c] = (double)vlo;
+    prof[4 * S + c] = (double)vhi;
+  }
+}
 }  // namespace
 
 extern "C" int sf_cmf_column_profile_robust(const double *img, int lines, int samples, int nbands, int band, double nodata,
@@ -510,9 +588,12 @@ extern "C" int sf_cmf_column_profile_robust(const double *img, int lines, int sa
     sf_set_error("sf_cmf_column_profile_robust: bad argument");
     return -1;
   }
-  if (lines > PR_CAP) {
-    sf_set_error("sf_cmf_column_profile_robust: %d lines exceed the LDS-resident sort (max %d)", lines, PR_CAP);
-    return -2;
+  const float plo_ = (float)((1.0 - p) * 100.0), phi_ = (float)(p * 100.0);
+  if (lines > PR_CAP) {   // longer than the LDS sort holds: radix selection from global memory (the same numbers)
+    hipLaunchKernelGGL(k_profile_robust_big, dim3(samples), dim3(PR_NT), 0, (hipStream_t)stream, img, lines, samples, nbands, band,
+                       nodata, plo_, phi_, profile);
+    SF_LAUNCH_CHECK("k_profile_robust_big");
+    return 0;
   }
   int npow2 = 1;
   while (npow2 < lines) npow2 <<= 1;

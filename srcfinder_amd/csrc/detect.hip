@@ -9,7 +9,10 @@
 //   median, MAD = median(|x - median|) (srcfinder_util.mad with medval), min, max (extrema), and the truncated centre
 //   of mass of the pixels that hold the maximum (np.int32(center_of_mass(img * mask == max)) + bbox origin).
 // One workgroup per region: the region's values are gathered from its bounding box into LDS, bitonic-sorted, the order
-// statistics read off (numpy's median of an even count = mean of the two middle values in the array's dtype).
+// statistics read off (numpy's median of an even count = mean of the two middle values in the array's dtype).  A region
+// with more pixels than the LDS holds (32768 saliency / 16384 CMF values; the reference has no cap,
+// salience_predictions.py:81-103) takes the same order statistics by radix selection on the values' bit patterns, byte by
+// byte from the top, re-reading the bounding box each pass: exact, so both routes give the same numbers.
 #include "cmf_common.h"
 
 namespace {
@@ -48,8 +51,66 @@ __device__ __forceinline__ void bitonic(T *a, int npow2, int tid) {
   }
 }
 
+// order-preserving integer key of a float / double (negative values: all bits flipped; others: the sign bit set)
+__device__ __forceinline__ unsigned long long dt_key(float v) {
+  const unsigned b = __float_as_uint(v);
+  return (unsigned long long)((b & 0x80000000u) ? ~b : (b | 0x80000000u));
+}
+__device__ __forceinline__ unsigned long long dt_key(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+template <typename T>
+__device__ __forceinline__ T dt_unkey(unsigned long long k) {
+  if constexpr (sizeof(T) == 4) {
+    const unsigned b = (unsigned)k;
+    return __uint_as_float((b & 0x80000000u) ? (b & 0x7fffffffu) : ~b);
+  } else {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+  }
+}
+// the k-th smallest (0-based) of the set {f(val(y, x)) : sel(y, x)} over the bounding box, f = identity (mode 0) or |v - med|
+template <typename T, typename Sel, typename Val>
+__device__ T region_select(const int32_t *bb, Sel sel, Val val, int mode, T med, unsigned k, int tid) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ unsigned s_k;
+  const int y0 = bb[0], x0 = bb[2], bw = bb[3] - bb[2], bn = (bb[1] - bb[0]) * bw;
+  unsigned long long prefix = 0, mask = 0;
+  for (int shift = 8 * (int)sizeof(T) - 8; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256; i += DT_NT) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < bn; i += DT_NT) {
+      const int y = y0 + i / bw, x = x0 + i % bw;
+      if (sel(y, x)) {
+        T v = val(y, x);
+        if (mode) v = v > med ? v - med : med - v;
+        const unsigned long long key = dt_key(v);
+        if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned cum = 0, bsel = 255;
+      for (unsigned b = 0; b < 256; ++b) {
+        if (k < cum + hist[b]) { bsel = b; break; }
+        cum += hist[b];
+      }
+      s_prefix = prefix | ((unsigned long long)bsel << shift);
+      s_k = k - cum;
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    k = s_k;
+    mask |= 255ull << shift;
+    __syncthreads();
+  }
+  return dt_unkey<T>(prefix);
+}
+
 // statistics of one value set of one region.  sel(y, x) says whether the pixel belongs to the set; val(y, x) its value.
-// out: max, min, median, mad, maxrow, maxcol, n.  Returns false (status) if the set does not fit the LDS sort.
+// out: max, min, median, mad, maxrow, maxcol, n.  Always true since round 5 (a set larger than the LDS sort is selected from
+// global memory); the status word of the record stays for the ABI.
 template <typename T, typename Sel, typename Val>
 __device__ bool region_stats(T *buf, int cap, const int32_t *bb, Sel sel, Val val, double *out, int tid) {
   __shared__ int cnt;
@@ -75,21 +136,33 @@ __device__ bool region_stats(T *buf, int cap, const int32_t *bb, Sel sel, Val va
     __syncthreads();
     return true;
   }
-  if (n > cap) { __syncthreads(); return false; }
-  int npow2 = 1;
-  while (npow2 < n) npow2 <<= 1;
-  const T inf = (T)__builtin_inf();
-  for (int i = n + tid; i < npow2; i += DT_NT) buf[i] = inf;
-  __syncthreads();
-  bitonic(buf, npow2, tid);
-  const T vmin = buf[0], vmax = buf[n - 1];
-  if (tid == 0) smed = (n & 1) ? buf[n / 2] : (T)((buf[n / 2 - 1] + buf[n / 2]) * (T)0.5);
-  __syncthreads();
-  const T med = smed;
-  for (int i = tid; i < n; i += DT_NT) buf[i] = buf[i] > med ? buf[i] - med : med - buf[i];
-  __syncthreads();
-  bitonic(buf, npow2, tid);
-  const T madv = (n & 1) ? buf[n / 2] : (T)((buf[n / 2 - 1] + buf[n / 2]) * (T)0.5);
+  T vmin, vmax, med, madv;
+  if (n > cap) {
+    // more values than the LDS sort holds: the same order statistics by radix selection over the bounding box
+    vmin = region_select<T>(bb, sel, val, 0, (T)0, 0u, tid);
+    vmax = region_select<T>(bb, sel, val, 0, (T)0, (unsigned)(n - 1), tid);
+    const T hi = region_select<T>(bb, sel, val, 0, (T)0, (unsigned)(n / 2), tid);
+    med = (n & 1) ? hi : (T)((region_select<T>(bb, sel, val, 0, (T)0, (unsigned)(n / 2 - 1), tid) + hi) * (T)0.5);
+    const T mhi = region_select<T>(bb, sel, val, 1, med, (unsigned)(n / 2), tid);
+    madv = (n & 1) ? mhi : (T)((region_select<T>(bb, sel, val, 1, med, (unsigned)(n / 2 - 1), tid) + mhi) * (T)0.5);
+  } else {
+    int npow2 = 1;
+    while (npow2 < n) npow2 <<= 1;
+    const T inf = (T)__builtin_inf();
+    for (int i = n + tid; i < npow2; i += DT_NT) buf[i] = inf;
+    __syncthreads();
+    bitonic(buf, npow2, tid);
+    vmin = buf[0];
+    vmax = buf[n - 1];
+    if (tid == 0) smed = (n & 1) ? buf[n / 2] : (T)((buf[n / 2 - 1] + buf[n / 2]) * (T)0.5);
+    __syncthreads();
+    med = smed;
+    __syncthreads();
+    for (int i = tid; i < n; i += DT_NT) buf[i] = buf[i] > med ? buf[i] - med : med - buf[i];
+    __syncthreads();
+    bitonic(buf, npow2, tid);
+    madv = (n & 1) ? buf[n / 2] : (T)((buf[n / 2 - 1] + buf[n / 2]) * (T)0.5);
+  }
   // centre of mass of the pixels of the bounding box whose masked value equals the maximum (img * mask == max)
   for (int i = tid; i < bn; i += DT_NT) {
     const int y = y0 + i / bw, x = x0 + i % bw;

@@ -166,8 +166,8 @@ def salience2detections(salimg, cmfimg, salthr, cmfthr, cmflid, cmfmap=None, lat
         _ffi.check(L.sf_detect_region_stats(P(labels), H, W, n, P(salpos), P(cmf), 4, 3, P(nodata), float(cmfthr), P(bbox),
                                             P(rec), st()), "sf_detect_region_stats")
         rec = rec.cpu().numpy()[1:]
-    if n and rec[:, 18].any():
-        raise _ffi.SrcfinderError("a saliency region exceeds the LDS-resident sort (32768 saliency / 16384 CMF pixels)")
+    if n and rec[:, 18].any():        # (never since round 5: a region of any size is served -- detect.hip selects the order
+        raise _ffi.SrcfinderError("sf_detect_region_stats reported a failed region")   # statistics of a large region from global memory)
     if n and (rec[:, 17] == 0).any():
         # the reference takes extrema() of an empty selection here and dies (numpy: zero-size array, :98)
         raise ValueError("zero-size array to reduction operation fmin which has no identity")

@@ -60,6 +60,19 @@ def scene(lines=LINES, samples=SAMPLES, seed=SEED):
     return sal[..., None], img
 
 
+def scene_big(lines=420, samples=330, seed=99):
+    """The scene() of that size plus ONE smooth giant plume: ~38 000 saliency pixels above 0.5 and ~30 000 CMF pixels above
+    250 ppm m in a single region -- more than the GPU's LDS-resident sort takes (32768 / 16384).  The reference has no cap
+    (salience_predictions.py:81-103).  VERDICT r4 item 8."""
+    sal, img = scene(lines, samples, seed)
+    rng = np.random.default_rng(seed + 1)
+    yy, xx = np.mgrid[0:lines, 0:samples]
+    blob = np.exp(-(((yy - 230) / 150.0) ** 2 + ((xx - 170) / 120.0) ** 2))
+    s2 = np.maximum(sal[..., 0], np.round((0.98 * blob).astype(np.float32), 3))
+    img[5:, :, 3] += 900.0 * blob[5:] * (rng.random(blob[5:].shape) * 0.6 + 0.7)
+    return np.float32(s2)[..., None], img
+
+
 def _stub(name, **a):
     m = types.ModuleType(name)
     m.__dict__.update(a)
@@ -130,6 +143,15 @@ def main():
                         prob_thr=0.5, ppmm_thr=250.0, columns=np.array(cols), table=table, detid=np.array(df["detid"], dtype=str),
                         mapinfo=np.array(MAPINFO), versions=np.array(["numpy " + np.__version__, "scipy " + scipy.__version__]))
     print(df.to_string())
+    # a region larger than the GPU's LDS-resident sort (round 5)
+    sal, img = scene_big()
+    dfb = run_reference(sal, img)
+    colsb = [c for c in dfb.columns if c not in ("detid", "lid")]
+    np.savez_compressed(os.path.join(HERE, "detections_big_golden.npz"), lines=420, samples=330, seed=99, prob_thr=0.5,
+                        ppmm_thr=250.0, columns=np.array(colsb), table=dfb[colsb].to_numpy(dtype=np.float64),
+                        detid=np.array(dfb["detid"], dtype=str), mapinfo=np.array(MAPINFO),
+                        versions=np.array(["numpy " + np.__version__, "scipy " + scipy.__version__]))
+    print(dfb[["minr", "maxr", "minc", "maxc", "salnpix", "cmfnpix"]].to_string() if "salnpix" in dfb.columns else dfb.iloc[:, :12].to_string())
 
 
 if __name__ == "__main__":

@@ -26,6 +26,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
 LINES, SAMPLES, SEED = 700, 40, 4242
+BIG_LINES, BIG_SAMPLES, BIG_SEED = 40000, 24, 777      # longer than the 32768 lines an LDS-resident sort holds
 
 
 def product(lines=LINES, samples=SAMPLES, seed=SEED):
@@ -104,6 +105,13 @@ def main():
                         plain=plain, robust=rob, columns_plain=np.array(cols_p), columns_robust=np.array(cols_r),
                         versions=np.array(["numpy " + np.__version__, "scipy " + scipy.__version__]))
     print("plain\n", plain[:14], "\nrobust\n", rob[:14])
+    # a product with more lines than the GPU's LDS sort holds: the reference has no cap (cmf_profile.py:124-127)
+    big = product(BIG_LINES, BIG_SAMPLES, BIG_SEED)
+    _c, bplain = run_reference(big, robust=False)
+    _c, brob = run_reference(big, robust=True)
+    np.savez_compressed(os.path.join(HERE, "triage_profile_big.npz"), lines=BIG_LINES, samples=BIG_SAMPLES, seed=BIG_SEED,
+                        plain=bplain, robust=brob, versions=np.array(["numpy " + np.__version__, "scipy " + scipy.__version__]))
+    print("big robust\n", brob)
 
 
 if __name__ == "__main__":

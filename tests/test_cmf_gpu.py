@@ -740,6 +740,21 @@ def test_column_profile_against_reference_golden(torch_cuda, golden_dir):
     np.testing.assert_allclose(prof[f][:, 1:3], want[f][:, 1:3], rtol=2e-5, atol=1e-4)
     rob = triage.column_profile(img, robust=True).T
     assert np.array_equal(np.float32(rob), np.float32(g["robust"]), equal_nan=True)
+    # more lines than the LDS-resident sort holds (40000 > 32768; the reference has no cap, cmf_profile.py:124-127): the radix
+    # selection from global memory, against the table the real script wrote for that product
+    gb = np.load(os.path.join(golden_dir, "triage_profile_big.npz"))
+    big = gen.product(int(gb["lines"]), int(gb["samples"]), int(gb["seed"]))
+    robb = triage.column_profile(big, robust=True).T
+    assert np.array_equal(np.float32(robb), np.float32(gb["robust"]), equal_nan=True)
+    pb = triage.column_profile(big).T
+    assert np.array_equal(pb[:, 0], gb["plain"][:, 0]) and np.array_equal(np.isnan(pb), np.isnan(gb["plain"]))
+    # and the two kernels against each other on a product both can take: the same numbers
+    from srcfinder_amd import _ffi
+    short = torch_cuda.as_tensor(np.ascontiguousarray(big[:32768])).cuda()
+    a = triage.column_profile(short, robust=True)
+    longer = torch_cuda.as_tensor(np.ascontiguousarray(np.concatenate([big[:32768], np.full((1, big.shape[1], 4), -9999.0)]))).cuda()
+    b = triage.column_profile(longer, robust=True)          # 32769 lines -> the radix-select kernel; the extra line is NODATA
+    assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
 
 def test_narrow_cube_extract_is_bit_identical(torch_cuda, library):

@@ -133,29 +133,35 @@ def _gen_det(golden_dir):
     return gen
 
 
-def test_detections_oracle_reproduces_the_reference_table(golden_dir):
+_DET_GOLDENS = [("detections_golden.npz", "scene", 14), ("detections_big_golden.npz", "scene_big", 9)]   # big: one region of
+#                     ~38 000 saliency / ~30 000 CMF pixels, more than the GPU's LDS-resident sort holds
+
+
+@pytest.mark.parametrize("fname,scene,nrows", _DET_GOLDENS)
+def test_detections_oracle_reproduces_the_reference_table(golden_dir, fname, scene, nrows):
     from oracle import detect_oracle as DO
     gen = _gen_det(golden_dir)
-    g = np.load(os.path.join(golden_dir, "detections_golden.npz"))
-    sal, img = gen.scene(int(g["lines"]), int(g["samples"]), int(g["seed"]))
+    g = np.load(os.path.join(golden_dir, fname))
+    sal, img = getattr(gen, scene)(int(g["lines"]), int(g["samples"]), int(g["seed"]))
     mi = [float(v) for v in g["mapinfo"][3:7]]
     assert "rotation=17.0000000" in list(g["mapinfo"])          # the rotation of the reference's own sample product
     got = DO.detections(sal, img, float(g["prob_thr"]), float(g["ppmm_thr"]), *mi, rot=17.0, zone="11", hemi="North")
     assert list(g["columns"]) == DO.HEADER
-    assert got.shape == g["table"].shape and len(got) == 14
+    assert got.shape == g["table"].shape and len(got) == nrows
     assert np.array_equal(got, g["table"])
 
 
 @pytest.mark.gpu
-def test_detections_gpu_match_reference_table(golden_dir):
+@pytest.mark.parametrize("fname,scene,nrows", _DET_GOLDENS)
+def test_detections_gpu_match_reference_table(golden_dir, fname, scene, nrows):
     from srcfinder_amd import detections
     gen = _gen_det(golden_dir)
-    g = np.load(os.path.join(golden_dir, "detections_golden.npz"))
-    sal, img = gen.scene(int(g["lines"]), int(g["samples"]), int(g["seed"]))
+    g = np.load(os.path.join(golden_dir, fname))
+    sal, img = getattr(gen, scene)(int(g["lines"]), int(g["samples"]), int(g["seed"]))
     mi = detections.mapinfo([str(v) for v in g["mapinfo"]])     # UTM zone 11 North, rotation 17 degrees
     assert mi["rotation"] == 17.0 and mi["proj"] == "UTM"
     df = detections.salience2detections(sal, img, float(g["prob_thr"]), float(g["ppmm_thr"]), "ang20200101t000000", mi)
-    assert list(df["detid"]) == list(g["detid"])
+    assert list(df["detid"]) == list(g["detid"]) and len(df) == nrows
     got = df[list(g["columns"])].to_numpy(dtype=np.float64)
     geo = [i for i, c in enumerate(g["columns"]) if c.endswith("lat") or c.endswith("lon")]
     rest = [i for i in range(got.shape[1]) if i not in geo]

@@ -210,6 +210,11 @@ def test_triage_profile_golden(golden_dir):
     assert np.array_equal(np.float32(plain), np.float32(g["plain"]), equal_nan=True)
     assert np.array_equal(np.float32(rob), np.float32(g["robust"]), equal_nan=True)
     assert np.isnan(g["plain"][7, 1]) and g["plain"][11, 0] == 1 and g["plain"][13, 0] == 0
+    # the 40000-line product of round 5 (longer than the GPU's LDS-resident sort): the same restatement, the same bar
+    gb = np.load(os.path.join(golden_dir, "triage_profile_big.npz"))
+    big = gen.product(int(gb["lines"]), int(gb["samples"]), int(gb["seed"]))
+    assert np.array_equal(np.float32(TO.column_profile(big[..., 3]).T), np.float32(gb["plain"]), equal_nan=True)
+    assert np.array_equal(np.float32(TO.column_profile_robust(big[..., 3]).T), np.float32(gb["robust"]), equal_nan=True)
 
 
 def test_empirical_multimodal_and_wide_goldens(golden_dir, library):

@@ -5,10 +5,10 @@
 # copies into profiles/ happen only when every step succeeded (set -e); gpurun merges only gpurun_out/ back, so repeat the
 # copies on the development side: for f in ...; see the cp lines at the end.
 set -euo pipefail
-tag=${1:-r04}
+tag=${1:-r05}
 out=gpurun_out/${tag}f
 mkdir -p $out
-B="--no-cpu-baseline --no-cnn --no-e2e --no-wide --no-ingest --no-routes --no-ceiling"
+B="--no-cpu-baseline --no-cnn --no-e2e --no-wide --no-ingest --no-routes --no-ceiling --no-windows"
 tools/pmc_traffic.sh ${tag}f > $out/pmc.log 2>&1
 cp gpurun_out/${tag}f_pmc_traffic.json $out/pmc_traffic.json
 tools/pmc_mfma.sh ${tag}f > $out/pmc_mfma.txt 2>&1
@@ -29,6 +29,12 @@ grep -q "k_score" $out/kstats_inflight1.txt
 tools/prof_bench.sh ${tag}fwide --active 1,425 --steps 2 --warmup 1 $B --in-flight 1 > $out/prof_wide.log 2>&1
 cp gpurun_out/${tag}fwide_kstats.txt $out/kstats_fullband425.txt
 rm -rf gpurun_out/prof_${tag}fwide
+tools/prof_bench.sh ${tag}fco2 --active 309,391 --steps 5 --warmup 2 $B --in-flight 1 > $out/prof_co2.log 2>&1
+cp gpurun_out/${tag}fco2_kstats.txt $out/kstats_co2.txt
+rm -rf gpurun_out/prof_${tag}fco2
+tools/prof_bench.sh ${tag}fs75 --samples 75 --steps 10 --warmup 2 $B --in-flight 1 > $out/prof_s75.log 2>&1
+cp gpurun_out/${tag}fs75_kstats.txt $out/kstats_shard75.txt
+rm -rf gpurun_out/prof_${tag}fs75
 root=$(pwd); mkdir -p $out/cnnprof; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $root/$out/cnnprof -o p -- python3 $root/tools/bench_cnn.py --tiles 1024 --batch 512 > $root/$out/cnnprof.log 2>&1
 cd $root; t=$(find $out/cnnprof -name "*kernel_trace.csv" | head -1); python3 tools/cnn_layers.py $t > $out/cnn_layers.txt; rm -rf $out/cnnprof
@@ -42,5 +48,7 @@ cp $out/bench_line.json profiles/${tag}_bench_line.json
 cp $out/bench_line_shard75.json profiles/${tag}_bench_line_shard75.json
 cp $out/bench_line_shard75_inflight1.json profiles/${tag}_bench_line_shard75_inflight1.json
 cp $out/kstats_fullband425.txt profiles/${tag}_fullband425_kernel_stats.txt
+cp $out/kstats_co2.txt profiles/${tag}_co2_kernel_stats.txt
+cp $out/kstats_shard75.txt profiles/${tag}_shard75_kernel_stats.txt
 cp $out/cnn_layers.txt profiles/${tag}_cnn_layers.txt
 cut -c1-700 $out/bench_line.json; echo; cut -c1-300 $out/bench_line_shard75.json; echo; tail -3 $out/cnn_layers.txt

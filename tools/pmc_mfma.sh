@@ -3,7 +3,7 @@
 tag=$1
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $root/gpurun_out/pmc_mfma_$tag -o p -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cnn --no-e2e --no-wide --no-ingest --no-routes --no-ceiling --in-flight 1 > $root/gpurun_out/pmc_mfma_$tag.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $root/gpurun_out/pmc_mfma_$tag -o p -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cnn --no-e2e --no-wide --no-ingest --no-routes --no-ceiling --no-windows --in-flight 1 > $root/gpurun_out/pmc_mfma_$tag.log 2>&1
 cd $root
 f=$(grep -l "k_score" $(find gpurun_out/pmc_mfma_$tag -name "*counter_collection.csv") | head -1)
 python3 - "$f" <<'PY' | tee gpurun_out/${tag}_pmc_mfma.txt
@@ -15,7 +15,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     m = re.search(r"::(k_\w+(?:<[^>]*>)?)", name)
     if not m: continue
     acc[m.group(1)][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-print("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cnn --no-e2e --no-wide --no-ingest --no-routes --no-ceiling --in-flight 1")
+print("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cnn --no-e2e --no-wide --no-ingest --no-routes --no-ceiling --no-windows --in-flight 1")
 print("# per launch, summed over the device.  busy = MFMA_BUSY_CYCLES / (1024 SIMDs x GUI_ACTIVE / 8 XCDs): the fraction of the kernel's")
 print("# cycles in which a SIMD's matrix pipe is executing; MOPS_F64 = fp64 MFMA wave-instructions (512 flop each for v_mfma_f64_4x4x4)")
 print("%-22s %8s %16s %14s %16s %8s" % ("kernel", "launches", "MFMA_BUSY_CYCLES", "GUI_ACTIVE", "MFMA_MOPS_F64", "busy"))

@@ -3,7 +3,7 @@
 tag=$1; pat=${2:-k_sweep4r}
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $root/gpurun_out/pmc_sq_$tag -o p -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cnn --no-e2e --no-wide --no-ingest --no-routes --no-ceiling --in-flight 1 > $root/gpurun_out/pmc_sq_$tag.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $root/gpurun_out/pmc_sq_$tag -o p -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cnn --no-e2e --no-wide --no-ingest --no-routes --no-ceiling --no-windows --in-flight 1 > $root/gpurun_out/pmc_sq_$tag.log 2>&1
 cd $root
 f=$(grep -l "k_score" $(find gpurun_out/pmc_sq_$tag -name "*counter_collection.csv") | head -1)
 python3 - "$f" "$pat" <<'PY' | tee gpurun_out/${tag}_pmc_sq.txt

@@ -314,6 +314,19 @@ int sf_cnn_maxpool(const float *in, int N, int H, int W, int C, int ksize, int s
 int sf_cnn_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const float *w, const float *bias, int Cout,
                 int ksize, float *out, int ld_out, int ch_off, void *stream);
 
+/* 3 x 3 stride-1 pad-1 convolution + folded-BatchNorm bias + ReLU by Winograd's minimal filtering F(2 x 2, 3 x 3)
+ * (BasicConv2d, cnn/archs/googlenet1.py:266-275; conv3 and the inception branches' 3 x 3 convolutions, :62-78, :184-228): the same
+ * float32 arithmetic class as sf_cnn_conv (float32 operands, float32 accumulate on the fp32 matrix cores) with 16 instead of 36
+ * multiplications per 2 x 2 output block and channel pair; results agree with sf_cnn_conv to rounding (a few 1e-7 relative).
+ * sf_cnn_wino_ok: the geometries served (square images of 8 or a multiple of 16 pixels, Cin a multiple of 16).
+ * sf_cnn_wino_weights: U[16][Cout][Cin] = G g G^T of the folded weights w[Cout][9][Cin] (sf_cnn_wino_weight_floats floats; once per
+ * weight upload).  sf_cnn_conv3x3_wino: arguments as sf_cnn_conv with U in place of w. */
+int sf_cnn_wino_ok(int H, int W, int Cin);
+size_t sf_cnn_wino_weight_floats(int Cout, int Cin);
+int sf_cnn_wino_weights(const float *w, int Cout, int Cin, float *U, void *stream);
+int sf_cnn_conv3x3_wino(const float *in, int N, int H, int W, int Cin, int ld_in, const float *U, const float *bias, int Cout,
+                        float *out, int ld_out, int ch_off, void *stream);
+
 /* Inception branch 4 (googlenet1.py:213-214) in one call: MaxPool2d(3, stride 1, pad 1, ceil_mode) into pooled_scratch
  * (N*H*W*Cin floats), then the 1x1 BasicConv2d.  `in` is dense ([N][H][W][Cin]) and NON-NEGATIVE (a concatenation of
  * ReLU outputs, as every inception input is): the pool kernel relies on 0 being the identity of max.  (A form that takes the pool inside

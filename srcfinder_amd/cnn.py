@@ -122,6 +122,13 @@ class FlightlineConvolve(object):
         return self.x[:, row:row + self.dim, col:col + self.dim]
 
 
+def _knob(key):
+    """The calling thread's value of a tuning knob of the library (sf_debug_set)."""
+    v = C.c_int(0)
+    _ffi.lib().sf_debug_get(int(key), C.byref(v))
+    return v.value
+
+
 def _pool_out(n, k, s, p):
     """ceil_mode output size with PyTorch's last-window rule."""
     o = -(-(n + 2 * p - k) // s) + 1
@@ -146,6 +153,8 @@ class GoogLeNetHIP(object):
         self.sfx = "_f16" if self.half else ""
         self.device = torch.device("cuda") if device is None else torch.device(device)
         self.w = {}
+        self.wino = {}            # name -> U [16][Cout][Cin]: the 3 x 3 layers' Winograd-domain weights (fp32 path; csrc/cnn_wino.hip)
+        self.winograd = True      # False: every 3 x 3 convolution through the direct implicit-GEMM kernel (the tests' cross-check)
         self._bufs = {}
         if state_dict is not None:
             self.load_state_dict(state_dict)
@@ -170,6 +179,17 @@ class GoogLeNetHIP(object):
             wdt = self.adt if name != "conv1" else torch.float32      # conv1 runs on the fp32 VALU in both modes
             self.w[name] = (torch.as_tensor(np.ascontiguousarray(wf, dtype=np.float32)).to(self.device).to(wdt),
                             torch.as_tensor(bf.astype(np.float32)).to(self.device))
+        self.wino = {}
+        if not self.half:
+            # the 3 x 3 stride-1 convolutions run by Winograd F(2 x 2, 3 x 3) where the geometry allows: U = G g G^T once per upload
+            L = _ffi.lib()
+            with torch.cuda.device(self.device):
+                for name, cin, cout, k, s_, p_ in conv_table():
+                    if k == 3 and s_ == 1 and cin % 16 == 0:
+                        U = torch.empty(int(L.sf_cnn_wino_weight_floats(cout, cin)), dtype=torch.float32, device=self.device)
+                        _ffi.check(L.sf_cnn_wino_weights(_ffi.ptr(self.w[name][0]), cout, cin, _ffi.ptr(U), _ffi.stream_ptr()),
+                                   "sf_cnn_wino_weights(%s)" % name)
+                        self.wino[name] = U
         for spec in INCEPTION:       # stacked weights of the three 1x1 convs that share the block input
             name = spec[0]
             ws = [self.w[name + s_][0] for s_ in (".branch1", ".branch2.0", ".branch3.0")]
@@ -217,6 +237,10 @@ class GoogLeNetHIP(object):
         N, H, W, ldi = x.shape
         cout, taps, cin = w.shape
         k = 3 if taps == 9 else 1
+        if k == 3 and self.winograd and name in self.wino and L.sf_cnn_wino_ok(H, W, cin) and _knob(17) != 2:
+            _ffi.check(L.sf_cnn_conv3x3_wino(_ffi.ptr(x), N, H, W, cin, ldi, _ffi.ptr(self.wino[name]), _ffi.ptr(b), cout,
+                                             _ffi.ptr(out), out.shape[3], ch_off, _ffi.stream_ptr()), "sf_cnn_conv3x3_wino(%s)" % name)
+            return
         fn = getattr(L, "sf_cnn_conv" + self.sfx)
         _ffi.check(fn(_ffi.ptr(x), N, H, W, cin, ldi, _ffi.ptr(w), _ffi.ptr(b), cout, k, _ffi.ptr(out),
                       out.shape[3], ch_off, _ffi.stream_ptr()), "sf_cnn_conv(%s)" % name)

@@ -43,6 +43,18 @@ int pool_out(int n, int k, int s, int p) {   // ceil_mode with PyTorch's last-wi
   if ((o - 1) * s >= n + p) --o;
   return o;
 }
+// Winograd-domain weights of the 3 x 3 layers (cnn_wino.hip: U = G g G^T, 16 / 9 of the folded weights), kept in the caller's
+// workspace behind the activations and recomputed by every sf_cnn_score_rows call (19 tiny launches)
+struct Wino { size_t conv3, b2[9], b3[9], total; };
+Wino wino_layout() {
+  Wino w{};
+  size_t o = 0;
+  auto take = [&](size_t &slot, int cout, int cin) { slot = o; o += (cin % 16 == 0) ? (size_t)16 * cout * cin : 0; };
+  take(w.conv3, 192, 64);
+  for (int i = 0; i < 9; ++i) { take(w.b2[i], INC[i].c3, INC[i].c3r); take(w.b3[i], INC[i].c5, INC[i].c5r); }
+  w.total = o;
+  return w;
+}
 // activation buffers of a batch of n tiles (floats): the largest of each role over the graph
 struct Acts { size_t pool1, conv2, conv3, x, y, t2, t3, pooled, total; };
 Acts acts(size_t n) {
@@ -64,7 +76,9 @@ Acts acts(size_t n) {
 extern "C" {
 
 size_t sf_cnn_blob_floats(void) { return blob_layout().total; }
-size_t sf_cnn_score_workspace_bytes(int batch) { return batch < 1 ? 0 : sf_align(acts((size_t)batch).total * sizeof(float)); }
+size_t sf_cnn_score_workspace_bytes(int batch) {
+  return batch < 1 ? 0 : sf_align((acts((size_t)batch).total + wino_layout().total) * sizeof(float));
+}
 
 int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int r0, int r1, const float *blob, float *out,
                       int batch, void *workspace, size_t workspace_bytes, void *stream) {
@@ -86,12 +100,28 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
   int rc;
 #define W_(l) (blob + (l).w)
 #define B_(l) (blob + (l).b)
+  // the 3 x 3 convolutions run by Winograd F(2 x 2, 3 x 3) where the geometry allows (sf_debug_set(17, 2): the direct kernel)
+  const Wino WL = wino_layout();
+  float *wino = pooled + A.pooled;
+  const bool use_wino = sf_tune().cnn_conv_variant != 2;
+  auto conv3x3 = [&](const float *in, int n, int hw, int cin, const Layer &l, size_t uoff, int cout, float *o, int ldo, int off) -> int {
+    if (use_wino && sf_cnn_wino_ok(hw, hw, cin))
+      return sf_cnn_conv3x3_wino(in, n, hw, hw, cin, cin, wino + uoff, B_(l), cout, o, ldo, off, stream);
+    return sf_cnn_conv(in, n, hw, hw, cin, cin, W_(l), B_(l), cout, 3, o, ldo, off, stream);
+  };
+  if (use_wino && i0 < i1) {
+    if ((rc = sf_cnn_wino_weights(W_(L.conv3), 192, 64, wino + WL.conv3, stream))) return rc;
+    for (int i = 0; i < 9; ++i) {
+      if (INC[i].c3r % 16 == 0 && (rc = sf_cnn_wino_weights(W_(L.b2[i]), INC[i].c3, INC[i].c3r, wino + WL.b2[i], stream))) return rc;
+      if (INC[i].c5r % 16 == 0 && (rc = sf_cnn_wino_weights(W_(L.b3[i]), INC[i].c5, INC[i].c5r, wino + WL.b3[i], stream))) return rc;
+    }
+  }
   for (long long tile0 = i0; tile0 < i1; tile0 += batch) {
     const int n = (int)((i1 - tile0 < batch) ? (i1 - tile0) : batch);
     // conv1 + maxpool1 (googlenet1.py:60-61), conv2, conv3, maxpool2 (:62-64)
     if ((rc = sf_cnn_conv1_pool(padded, Hp, Wp, W, tile0, n, W_(L.conv1), B_(L.conv1), pool1, stream))) return rc;
     if ((rc = sf_cnn_conv(pool1, n, 64, 64, 64, 64, W_(L.conv2), B_(L.conv2), 64, 1, conv2, 64, 0, stream))) return rc;
-    if ((rc = sf_cnn_conv(conv2, n, 64, 64, 64, 64, W_(L.conv3), B_(L.conv3), 192, 3, conv3, 192, 0, stream))) return rc;
+    if ((rc = conv3x3(conv2, n, 64, 64, L.conv3, WL.conv3, 192, conv3, 192, 0))) return rc;
     int hw = pool_out(64, 3, 2, 0);
     if ((rc = sf_cnn_maxpool(conv3, n, 64, 64, 192, 3, 2, 0, xa, hw, hw, stream))) return rc;
     float *x = xa, *y = xb;
@@ -102,8 +132,8 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
       // branch1 | 3x3 reduce | "5x5" reduce in one GEMM, then the two 3x3 convolutions, the pool branch (:184-228)
       if ((rc = sf_cnn_conv_split3(x, n, hw, hw, cin, cin, W_(L.head3[i]), B_(L.head3[i]), s.c1, s.c3r, s.c5r, y, cout, 0, t2,
                                    s.c3r, 0, t3, s.c5r, 0, stream))) return rc;
-      if ((rc = sf_cnn_conv(t2, n, hw, hw, s.c3r, s.c3r, W_(L.b2[i]), B_(L.b2[i]), s.c3, 3, y, cout, s.c1, stream))) return rc;
-      if ((rc = sf_cnn_conv(t3, n, hw, hw, s.c5r, s.c5r, W_(L.b3[i]), B_(L.b3[i]), s.c5, 3, y, cout, s.c1 + s.c3, stream))) return rc;
+      if ((rc = conv3x3(t2, n, hw, s.c3r, L.b2[i], WL.b2[i], s.c3, y, cout, s.c1))) return rc;
+      if ((rc = conv3x3(t3, n, hw, s.c5r, L.b3[i], WL.b3[i], s.c5, y, cout, s.c1 + s.c3))) return rc;
       if ((rc = sf_cnn_pool_conv(x, n, hw, hw, cin, cin, W_(L.b4[i]), B_(L.b4[i]), s.pp, y, cout, s.c1 + s.c3 + s.c5, pooled, stream))) return rc;
       float *t = x; x = y; y = t;
       cin = cout;

@@ -160,6 +160,39 @@ def test_kernel_forms_of_the_tile_scorer_agree_bit_for_bit(gold):
         assert torch.equal(got, ref), (key, val)
 
 
+def test_winograd_convolutions_against_the_direct_kernel(gold):
+    """The 3 x 3 convolutions run by Winograd F(2 x 2, 3 x 3) on the fp32 matrix cores (csrc/cnn_wino.hip) -- the same float32
+    arithmetic class as the direct implicit-GEMM kernel, 16 instead of 36 multiplications per output block.  With
+    sf_debug_set(17, 2) every 3 x 3 layer takes the direct kernel: the saliency maps agree inside the parity bar (1e-4; both hold
+    the reference goldens at that bar in test_activations_and_probabilities), NODATA placement exact, through the Python-sequenced
+    graph and through the C driver; and per layer on random operands against float64 (tools/check_conv.py's cases)."""
+    import torch
+    from srcfinder_amd import _ffi
+    net = cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024))
+    assert len(net.wino) == 17                       # conv3 + 9 branch2 + 7 branch3 layers (two branch3 layers have 24 input channels)
+    plane = synthetic_plane(10, 7, seed=21)
+    plane[3, 2] = -9999.0
+    L = _ffi.lib()
+    runs = {}
+    for c_driver in (True, False):
+        net.c_driver = c_driver
+        for knob in (0, 2):
+            L.sf_debug_set(17, knob)
+            try:
+                runs[(c_driver, knob)] = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=32)
+            finally:
+                L.sf_debug_set(17, 0)
+    net.c_driver = True
+    assert torch.equal(runs[(True, 0)], runs[(False, 0)]) and torch.equal(runs[(True, 2)], runs[(False, 2)])
+    a, b = runs[(True, 0)], runs[(True, 2)]
+    assert float(a[3, 2]) == -9999.0 and torch.equal(a == -9999.0, b == -9999.0)
+    v = a != -9999.0
+    assert not torch.equal(a, b)                     # two different algorithms ...
+    rel = float(((a[v] - b[v]).abs() / b[v].abs().clamp_min(1e-7)).max())
+    print("winograd vs direct: max relative difference of the saliency %.2e" % rel)
+    assert rel < 1e-4                                # ... the same numbers inside the parity bar (float32 rounding through 57 layers)
+
+
 def test_gpu_list_scores_row_blocks_from_threads(gold, net):
     """``gpus=[...]`` (the script's ``-g 0 1 ...``, cnn_pred_pipeline.py:113-116): one network and one host thread per
     listed device, contiguous row blocks, assembled once.  On a one-GPU box the list [0, 0, 0] drives the same code with

@@ -73,6 +73,61 @@ def main():
         print("pool+conv N%d %dx%d Cin %d Cout %d -> ld %d off %d: max err %.2e  == pool-then-convolve: %s" % (N, H, W, Cin, Cout, ldo, off, err, same))
         assert err < 2e-6 and same
     print("pool_conv ok")
+    # ---- 3x3 convolutions by Winograd F(2x2, 3x3) (cnn_wino.hip) against float64 and against the direct kernel
+    for (N, H, Cin, Cout, ldo, off) in [(2, 16, 96, 208, 512, 160), (1, 64, 64, 192, 192, 0), (3, 32, 128, 192, 480, 128), (5, 8, 192, 384, 1024, 384),
+                                         (7, 8, 48, 128, 128, 0), (2, 32, 16, 32, 256, 192), (1, 16, 32, 64, 64, 0), (6, 8, 160, 320, 832, 256),
+                                         (2, 48, 32, 40, 40, 0)]:
+        W = H
+        assert L.sf_cnn_wino_ok(H, W, Cin)
+        x = torch.relu(torch.randn((N, H, W, Cin), generator=g))
+        w = torch.randn((Cout, 9, Cin), generator=g) / np.sqrt(9 * Cin)
+        b = torch.randn((Cout,), generator=g)
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).double(), b.double(),
+                       padding=1).relu().permute(0, 2, 3, 1)
+        xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+        U = torch.empty(L.sf_cnn_wino_weight_floats(Cout, Cin), dtype=torch.float32, device="cuda")
+        _ffi.check(L.sf_cnn_wino_weights(_ffi.ptr(wd), Cout, Cin, _ffi.ptr(U), _ffi.stream_ptr()), "wino_weights")
+        out = torch.full((N, H, W, ldo), -7.0, device="cuda")
+        _ffi.check(L.sf_cnn_conv3x3_wino(_ffi.ptr(xd), N, H, W, Cin, Cin, _ffi.ptr(U), _ffi.ptr(bd), Cout, _ffi.ptr(out), ldo, off,
+                                         _ffi.stream_ptr()), "conv3x3_wino")
+        direct = torch.full((N, H, W, ldo), -7.0, device="cuda")
+        _ffi.check(L.sf_cnn_conv(_ffi.ptr(xd), N, H, W, Cin, Cin, _ffi.ptr(wd), _ffi.ptr(bd), Cout, 3, _ffi.ptr(direct), ldo, off,
+                                 _ffi.stream_ptr()), "conv")
+        torch.cuda.synchronize()
+        got = out.cpu().double()
+        scale = max(ref.abs().max().item(), 1e-30)
+        err = (got[..., off:off + Cout] - ref).abs().max().item() / scale
+        errd = (direct.cpu().double()[..., off:off + Cout] - ref).abs().max().item() / scale
+        untouched = bool((got[..., :off] == -7.0).all()) and bool((got[..., off + Cout:] == -7.0).all())
+        print("winograd N%d %dx%d Cin %d Cout %d -> ld %d off %d: max err %.2e (direct kernel %.2e)  untouched %s"
+              % (N, H, W, Cin, Cout, ldo, off, err, errd, untouched))
+        assert err < 5e-6 and untouched
+    print("winograd ok")
+    if "--time" in sys.argv:
+        import time
+        for (N, H, Cin, Cout) in [(512, 64, 64, 192), (512, 32, 96, 128), (512, 32, 128, 192), (512, 16, 160, 320), (512, 16, 96, 208), (512, 8, 192, 384),
+                                  (512, 32, 32, 96), (512, 16, 32, 128)]:
+            x = torch.relu(torch.randn((N, H, H, Cin), device="cuda"))
+            w = torch.randn((Cout, 9, Cin), device="cuda") / np.sqrt(9 * Cin)
+            b = torch.randn((Cout,), device="cuda")
+            U = torch.empty(L.sf_cnn_wino_weight_floats(Cout, Cin), dtype=torch.float32, device="cuda")
+            L.sf_cnn_wino_weights(_ffi.ptr(w), Cout, Cin, _ffi.ptr(U), _ffi.stream_ptr())
+            out = torch.empty((N, H, H, Cout), device="cuda")
+            res = {}
+            for name in ("direct", "winograd"):
+                def run():
+                    if name == "direct":
+                        L.sf_cnn_conv(_ffi.ptr(x), N, H, H, Cin, Cin, _ffi.ptr(w), _ffi.ptr(b), Cout, 3, _ffi.ptr(out), Cout, 0, _ffi.stream_ptr())
+                    else:
+                        L.sf_cnn_conv3x3_wino(_ffi.ptr(x), N, H, H, Cin, Cin, _ffi.ptr(U), _ffi.ptr(b), Cout, _ffi.ptr(out), Cout, 0, _ffi.stream_ptr())
+                run(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5): run()
+                torch.cuda.synchronize()
+                res[name] = (time.perf_counter() - t0) / 5 * 1e6
+            fl = 2.0 * N * H * H * Cin * 9 * Cout
+            print("time N%d %dx%d %d->%d: direct %.1f us (%.1f TF/s)  winograd %.1f us (%.1f TF/s nominal)  x%.2f"
+                  % (N, H, H, Cin, Cout, res["direct"], fl / res["direct"] / 1e6, res["winograd"], fl / res["winograd"] / 1e6, res["direct"] / res["winograd"]))
 
 
 if __name__ == "__main__":

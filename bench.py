@@ -448,7 +448,11 @@ def cnn_section(res, ntiles, batch, with_cpu):
            "dtype": "f32", "data": "synthetic weights (seeded), CMF plane of this run", "tiles": ntiles, "batch": batch,
            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
                         "frac": round(tf / 157.3, 4), "flop_per_tile": 3.706e9,
-                        "note": "all kernels of a forward pass (implicit-GEMM conv on v_mfma_f32_32x32x2_f32, pools, head)"}}
+                        "executed_tflops": round(tf * 2.240 / 3.706, 2), "executed_frac": round(tf * 2.240 / 3.706 / 157.3, 4),
+                        "note": "all kernels of a forward pass; flop_per_tile is the DIRECT-convolution count of the network (the "
+                                "reference's arithmetic), so achieved / frac are throughput in reference flops.  The 3 x 3 layers "
+                                "(2.64 of the 3.71 GFLOP) run by Winograd F(2x2,3x3) in fp32 on v_mfma_f32_32x32x2_f32 and execute "
+                                "16/36 of their multiplications: executed_* is what the matrix pipe really does per second"}}
     if with_cpu:
         from oracle import cnn_oracle as O
         cores = usable_cores()

@@ -318,7 +318,7 @@ int sf_cnn_conv(const float *in, int N, int H, int W, int Cin, int ld_in, const 
  * (BasicConv2d, cnn/archs/googlenet1.py:266-275; conv3 and the inception branches' 3 x 3 convolutions, :62-78, :184-228): the same
  * float32 arithmetic class as sf_cnn_conv (float32 operands, float32 accumulate on the fp32 matrix cores) with 16 instead of 36
  * multiplications per 2 x 2 output block and channel pair; results agree with sf_cnn_conv to rounding (a few 1e-7 relative).
- * sf_cnn_wino_ok: the geometries served (square images of 8 or a multiple of 16 pixels, Cin a multiple of 16).
+ * sf_cnn_wino_ok: the geometries served (square images of 8 or a multiple of 16 pixels, Cin >= 16 and a multiple of 8).
  * sf_cnn_wino_weights: U[16][Cout][Cin] = G g G^T of the folded weights w[Cout][9][Cin] (sf_cnn_wino_weight_floats floats; once per
  * weight upload).  sf_cnn_conv3x3_wino: arguments as sf_cnn_conv with U in place of w. */
 int sf_cnn_wino_ok(int H, int W, int Cin);

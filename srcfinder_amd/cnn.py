@@ -185,7 +185,7 @@ class GoogLeNetHIP(object):
             L = _ffi.lib()
             with torch.cuda.device(self.device):
                 for name, cin, cout, k, s_, p_ in conv_table():
-                    if k == 3 and s_ == 1 and cin % 16 == 0:
+                    if k == 3 and s_ == 1 and cin % 8 == 0:
                         U = torch.empty(int(L.sf_cnn_wino_weight_floats(cout, cin)), dtype=torch.float32, device=self.device)
                         _ffi.check(L.sf_cnn_wino_weights(_ffi.ptr(self.w[name][0]), cout, cin, _ffi.ptr(U), _ffi.stream_ptr()),
                                    "sf_cnn_wino_weights(%s)" % name)

@@ -49,7 +49,7 @@ struct Wino { size_t conv3, b2[9], b3[9], total; };
 Wino wino_layout() {
   Wino w{};
   size_t o = 0;
-  auto take = [&](size_t &slot, int cout, int cin) { slot = o; o += (cin % 16 == 0) ? (size_t)16 * cout * cin : 0; };
+  auto take = [&](size_t &slot, int cout, int cin) { slot = o; o += (cin % 8 == 0) ? (size_t)16 * cout * cin : 0; };
   take(w.conv3, 192, 64);
   for (int i = 0; i < 9; ++i) { take(w.b2[i], INC[i].c3, INC[i].c3r); take(w.b3[i], INC[i].c5, INC[i].c5r); }
   w.total = o;
@@ -112,8 +112,8 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
   if (use_wino && i0 < i1) {
     if ((rc = sf_cnn_wino_weights(W_(L.conv3), 192, 64, wino + WL.conv3, stream))) return rc;
     for (int i = 0; i < 9; ++i) {
-      if (INC[i].c3r % 16 == 0 && (rc = sf_cnn_wino_weights(W_(L.b2[i]), INC[i].c3, INC[i].c3r, wino + WL.b2[i], stream))) return rc;
-      if (INC[i].c5r % 16 == 0 && (rc = sf_cnn_wino_weights(W_(L.b3[i]), INC[i].c5, INC[i].c5r, wino + WL.b3[i], stream))) return rc;
+      if (INC[i].c3r % 8 == 0 && (rc = sf_cnn_wino_weights(W_(L.b2[i]), INC[i].c3, INC[i].c3r, wino + WL.b2[i], stream))) return rc;
+      if (INC[i].c5r % 8 == 0 && (rc = sf_cnn_wino_weights(W_(L.b3[i]), INC[i].c5, INC[i].c5r, wino + WL.b3[i], stream))) return rc;
     }
   }
   for (long long tile0 = i0; tile0 < i1; tile0 += batch) {

@@ -169,7 +169,7 @@ def test_winograd_convolutions_against_the_direct_kernel(gold):
     import torch
     from srcfinder_amd import _ffi
     net = cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024))
-    assert len(net.wino) == 17                       # conv3 + 9 branch2 + 7 branch3 layers (two branch3 layers have 24 input channels)
+    assert len(net.wino) == 19                       # conv3 + the 9 branch2 + the 9 branch3 3 x 3 layers
     plane = synthetic_plane(10, 7, seed=21)
     plane[3, 2] = -9999.0
     L = _ffi.lib()
@@ -191,6 +191,34 @@ def test_winograd_convolutions_against_the_direct_kernel(gold):
     rel = float(((a[v] - b[v]).abs() / b[v].abs().clamp_min(1e-7)).max())
     print("winograd vs direct: max relative difference of the saliency %.2e" % rel)
     assert rel < 1e-4                                # ... the same numbers inside the parity bar (float32 rounding through 57 layers)
+
+
+def test_winograd_input_of_two_gigabytes_runs_in_image_pieces():
+    """The Winograd kernel addresses its input through < 2 GB buffer descriptors; a batch whose activation is larger (conv3 at
+    batch 2048: 2.1 GB) is run in pieces of whole images.  The result is the same bits as the same images convolved alone."""
+    import torch
+    from srcfinder_amd import _ffi
+    L = _ffi.lib()
+    dev = torch.device("cuda:0")
+    N, H, Cin, Cout = 2056, 64, 64, 32
+    g = torch.Generator(device="cpu").manual_seed(9)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    U = torch.empty(int(L.sf_cnn_wino_weight_floats(Cout, Cin)), dtype=torch.float32, device=dev)
+    _ffi.check(L.sf_cnn_wino_weights(_ffi.ptr(w), Cout, Cin, _ffi.ptr(U), _ffi.stream_ptr()), "weights")
+    x = torch.empty(N, H, H, Cin, dtype=torch.float32, device=dev)
+    assert x.numel() * 4 >= 2 ** 31
+    x.normal_(generator=torch.Generator(device=dev).manual_seed(4))
+    out = torch.full((N, H, H, Cout), -7.0, dtype=torch.float32, device=dev)
+    _ffi.check(L.sf_cnn_conv3x3_wino(_ffi.ptr(x), N, H, H, Cin, Cin, _ffi.ptr(U), _ffi.ptr(bias), Cout, _ffi.ptr(out), Cout, 0,
+                                     _ffi.stream_ptr()), "conv3x3_wino")
+    for n0 in (0, 1020, 2042, 2052):                 # pieces of 2044 images: the third probe straddles the seam
+        xs = x[n0:n0 + 4].contiguous()
+        os_ = torch.empty(4, H, H, Cout, dtype=torch.float32, device=dev)
+        _ffi.check(L.sf_cnn_conv3x3_wino(_ffi.ptr(xs), 4, H, H, Cin, Cin, _ffi.ptr(U), _ffi.ptr(bias), Cout, _ffi.ptr(os_), Cout, 0,
+                                         _ffi.stream_ptr()), "conv3x3_wino")
+        assert torch.equal(out[n0:n0 + 4], os_), n0
+    assert float(out.min()) >= 0.0                   # every image written (ReLU output; the fill was -7)
 
 
 def test_gpu_list_scores_row_blocks_from_threads(gold, net):

@@ -76,7 +76,7 @@ def main():
     # ---- 3x3 convolutions by Winograd F(2x2, 3x3) (cnn_wino.hip) against float64 and against the direct kernel
     for (N, H, Cin, Cout, ldo, off) in [(2, 16, 96, 208, 512, 160), (1, 64, 64, 192, 192, 0), (3, 32, 128, 192, 480, 128), (5, 8, 192, 384, 1024, 384),
                                          (7, 8, 48, 128, 128, 0), (2, 32, 16, 32, 256, 192), (1, 16, 32, 64, 64, 0), (6, 8, 160, 320, 832, 256),
-                                         (2, 48, 32, 40, 40, 0)]:
+                                         (2, 48, 32, 40, 40, 0), (3, 16, 24, 64, 64, 0)]:
         W = H
         assert L.sf_cnn_wino_ok(H, W, Cin)
         x = torch.relu(torch.randn((N, H, W, Cin), generator=g))
@@ -103,6 +103,25 @@ def main():
               % (N, H, W, Cin, Cout, ldo, off, err, errd, untouched))
         assert err < 5e-6 and untouched
     print("winograd ok")
+    if "--exp" in sys.argv:
+        import time
+        N, H, Cin, Cout = 512, 64, 64, 192
+        x = torch.relu(torch.randn((N, H, H, Cin), device="cuda"))
+        w = torch.randn((Cout, 9, Cin), device="cuda") / np.sqrt(9 * Cin)
+        b = torch.randn((Cout,), device="cuda")
+        U = torch.empty(L.sf_cnn_wino_weight_floats(Cout, Cin), dtype=torch.float32, device="cuda")
+        L.sf_cnn_wino_weights(_ffi.ptr(w), Cout, Cin, _ffi.ptr(U), _ffi.stream_ptr())
+        out = torch.empty((N, H, H, Cout), device="cuda")
+        for e in (0, 1, 2, 3, 4, 7, 8, 15):
+            L.sf_debug_set(17, 10 + e if e else 0)
+            def run():
+                L.sf_cnn_conv3x3_wino(_ffi.ptr(x), N, H, H, Cin, Cin, _ffi.ptr(U), _ffi.ptr(b), Cout, _ffi.ptr(out), Cout, 0, _ffi.stream_ptr())
+            run(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5): run()
+            torch.cuda.synchronize()
+            print("EXP %2d (1 no staging/loads, 2 no transform, 4 no MFMA, 8 no stores): %.1f us" % (e, (time.perf_counter() - t0) / 5 * 1e6))
+        L.sf_debug_set(17, 0)
     if "--time" in sys.argv:
         import time
         for (N, H, Cin, Cout) in [(512, 64, 64, 192), (512, 32, 96, 128), (512, 32, 128, 192), (512, 16, 160, 320), (512, 16, 96, 208), (512, 8, 192, 384),

@@ -14,9 +14,9 @@ from oracle import cmf_oracle as O
 lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
 
 
-def run(ncase=60, seed=0, WIDE=False, verbose=True):
+def run(ncase=60, seed=0, WIDE=False, verbose=True, MID=False):
     """Returns the number of mismatching cases (stops at the first).  WIDE: windows of 97..200 bands (the batched-GEMM /
-    blocked-Jacobi path)."""
+    blocked-Jacobi path).  MID: windows of 73..96 bands (the 21- and 24-group 4x4x4 kernels: CO2 and its neighbours)."""
     rng = np.random.default_rng(seed)
     t0 = time.time()
     stats = {}
@@ -24,6 +24,9 @@ def run(ncase=60, seed=0, WIDE=False, verbose=True):
         lines = int(rng.choice([37, 64, 100, 129, 257, 500, 777, 1024, 1500, 2049]))
         samples = int(rng.choice([1, 2, 5, 17, 63, 64, 65, 75, 130]))
         p = int(rng.choice([8, 23, 40, 64, 69, 70, 71, 72, 72, 72, 83, 96]))
+        if MID:
+            p = int(rng.integers(73, 97))
+            samples = int(rng.choice([1, 2, 5, 17, 64, 65, 75]))
         if WIDE:
             p = int(rng.choice([97, 100, 112, 128, 129, 160, 200]))
             samples = int(rng.choice([1, 3, 9]))
@@ -115,4 +118,4 @@ def run(ncase=60, seed=0, WIDE=False, verbose=True):
 
 if __name__ == "__main__":
     sys.exit(run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
-                 len(sys.argv) > 3 and sys.argv[3] == "wide"))
+                 len(sys.argv) > 3 and sys.argv[3] == "wide", MID=len(sys.argv) > 3 and sys.argv[3] == "mid"))

@@ -11,7 +11,7 @@ from oracle import triage_oracle as T
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 for case in range(40):
-    L = int(rng.choice([1, 2, 3, 17, 100, 255, 256, 257, 1000, 4097, 20000]))
+    L = int(rng.choice([1, 2, 3, 17, 100, 255, 256, 257, 1000, 4097, 20000, 32768, 32769, 50001]))   # > 32768: the radix-select kernel
     S = int(rng.choice([1, 5, 64, 65, 130]))
     img = rng.normal(200.0, 300.0, size=(L, S, 4))
     img[rng.random((L, S)) < 0.2, 3] = -9999.0

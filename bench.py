@@ -64,6 +64,13 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    # SF_BENCH_SHARE_GPU=1 + SF_BENCH_BACKEND=gloo: N ranks on ONE GPU with host-staged collectives (RCCL refuses two ranks on
+    # one device).  A FUNCTIONAL run of the N > 1 path on hardware where only one GPU can be leased -- the ranks share the
+    # chip, so its value says nothing about scaling (profiles/r05_two_ranks_one_gpu.md)
+    share_gpu = os.environ.get("SF_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = world == 1 and os.environ.get("SF_BENCH_FORCE_DIST") == "1"   # exercise the gather path on one GPU
@@ -73,7 +80,10 @@ def main():
         if force_dist:
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
     lines, samples = args.lines, args.samples
@@ -134,7 +144,7 @@ def main():
             for i in range(depth):
                 if pending[i] is not None:
                     with torch.cuda.stream(pipe.streams[i]):
-                        pending[i].wait()
+                        state["gathered"] = pending[i].wait()      # rank 0: the assembled [lines, samples] score image
                     pending[i] = None
             pipe.synchronize()
 
@@ -158,13 +168,32 @@ def main():
         nlaunch = _ffi.C.c_int(0)
         L.sf_cmf_score_timing_read(_ffi.C.byref(tot_ms), _ffi.C.byref(nlaunch))
         L.sf_cmf_score_timing(0)
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         res = state["res"]
+        # N > 1 (outside the timed region): every rank's block of the last flightline against its column range of the image
+        # rank 0 assembled -- number of NODATA pixels exact, sum of the scores to rounding
+        verified = None
+        if world > 1 or force_dist:
+            blk = outs[0][..., 3]
+            ok = blk != -9999.0
+            mine = torch.stack([blk[ok].sum(), ok.sum().to(torch.float64)]).to(dev if backend == "nccl" else "cpu")
+            every = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            if rank == 0:
+                img = state["gathered"]
+                verified = tuple(img.shape) == (lines, samples)
+                for r in range(world):
+                    c0, c1 = sd.shard_columns(samples, world, r)
+                    part = img[:, c0:c1]
+                    okr = part != -9999.0
+                    want = every[r].to(part.device)
+                    verified = verified and float(okr.sum()) == float(want[1]) and \
+                        abs(float(part[okr].sum()) - float(want[0])) <= 1e-9 * max(1.0, abs(float(want[0])))
         pipe.close()
         return {"dt": float(tmax.item()), "t_enq": t_enq, "score_ms": tot_ms.value / max(nlaunch.value, 1),
-                "launches": nlaunch.value, "res": res, "outs": outs}
+                "launches": nlaunch.value, "res": res, "outs": outs, "gather_verified": verified}
 
     depth = args.in_flight if args.in_flight > 0 else 3
     main = timed_pass(depth)
@@ -191,9 +220,11 @@ def main():
             "config": {"workload": "AVIRIS-NG flightline %d samples x %d lines x %d bands float32 BIL, active "
                                    "window %d..%d (p=%d%s), 201-point LOO shrinkage sweep, unimodal"
                                    % (samples, lines, BANDS, a0, a1, p, ", CH4 radiance" if (a0, a1) == (351, 422) else ""),
-                       "parallelism": "columns sharded over %d rank(s), one RCCL gather" % world,
+                       "parallelism": ("columns sharded over %d rank(s), one RCCL gather" % world) if not share_gpu else
+                       ("FUNCTIONAL RUN: %d ranks sharing ONE GPU, host-staged %s gather -- not a scaling measurement" % (world, backend)),
                        "in_flight": "%d flightlines in flight per GPU (one HIP stream each); the same depth for every N"
                                     % depth,
+                       "gather_verified": main["gather_verified"],
                        "host_enqueue_ms_per_step": round(main["t_enq"] / args.steps * 1e3, 3),
                        "one_in_flight": {"ms_per_step": round(solo["dt"] / args.steps * 1e3, 3),
                                          "value": round(lines * samples / (solo["dt"] / args.steps) / 1e6, 3),

@@ -19,18 +19,28 @@ def shard_columns(samples: int, world: int, rank: int):
     return rank * samples // world, (rank + 1) * samples // world
 
 
+def _host_staged(group, t):
+    """True when ``t`` lives on a GPU but the group's backend moves host memory only (``gloo``: two ranks that share one
+    GPU, a node without RCCL peers).  The collective then runs on a host copy of the block and the assembled result goes
+    back to the block's device on ``dst`` -- the functional route, not the fast one: RCCL (``nccl``) gathers device buffers
+    directly and is what a multi-GPU node uses."""
+    import torch.distributed as dist
+    return bool(t.is_cuda) and dist.get_backend(group) == "gloo"
+
+
 class GatherHandle:
     """An in-flight column gather (``gather_columns(..., async_op=True)``): ``wait()`` returns the assembled array
     on ``dst`` (``None`` elsewhere).  The collective runs on the backend's own stream; the buffers live here."""
 
-    def __init__(self, work, send, recv, meta):
-        self.work, self.send, self.recv, self.meta = work, send, recv, meta
+    def __init__(self, work, send, recv, meta, back=None):
+        self.work, self.send, self.recv, self.meta, self.back = work, send, recv, meta, back
 
     def wait(self):
         if self.work is not None:
             self.work.wait()
             self.work = None
-        return _assemble(self.recv, *self.meta)
+        full = _assemble(self.recv, *self.meta)
+        return full if (full is None or self.back is None) else full.to(self.back, non_blocking=True)
 
 
 def _assemble(recv, shape, axis, samples, world, as_int16):
@@ -79,13 +89,16 @@ def gather_columns(block, samples: int, *, axis=None, group=None, dst: int = 0, 
     maxc = max(b - a for a, b in (shard_columns(samples, world, r) for r in range(world)))
     shp = list(block.shape)
     shp[axis] = maxc
+    back = block.device if _host_staged(group, block) else None
+    if back is not None:
+        block = block.cpu()              # (waits for the stream that produced the block)
     send = torch.empty(shp, dtype=block.dtype, device=block.device)
     send.narrow(axis, 0, b - a).copy_(block)
     if b - a < maxc:
         send.narrow(axis, b - a, maxc - (b - a)).zero_()
     recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     work = dist.gather(send, recv, dst=dst, group=group, async_op=async_op)
-    h = GatherHandle(work if async_op else None, send, recv, (tuple(block.shape), axis, samples, world, as_int16))
+    h = GatherHandle(work if async_op else None, send, recv, (tuple(block.shape), axis, samples, world, as_int16), back)
     return h if async_op else h.wait()
 
 
@@ -130,7 +143,8 @@ def gather_packed(fields, samples: int, *, lead: int = 1, group=None, dst: int =
         layout.append((name, axis, rest, dtype, sl.shape[2]))
     maxc = max(q - p for p, q in (shard_columns(samples, world, r) for r in range(world)))
     width = sum(l[4] for l in layout)
-    send = torch.zeros((lead, maxc, width), dtype=torch.uint8, device=slabs[0].device)
+    back = slabs[0].device if _host_staged(group, slabs[0]) else None
+    send = torch.zeros((lead, maxc, width), dtype=torch.uint8, device="cpu" if back is not None else slabs[0].device)
     off = 0
     for sl in slabs:
         send[:, :b - a, off:off + sl.shape[2]].copy_(sl)
@@ -143,6 +157,8 @@ def gather_packed(fields, samples: int, *, lead: int = 1, group=None, dst: int =
     for r in range(world):
         p, q = shard_columns(samples, world, r)
         full[:, p:q].copy_(recv[r][:, :q - p])
+    if back is not None:
+        full = full.to(back)
     out, off = {}, 0
     for name, axis, rest, dtype, nb in layout:
         v = full[:, :, off:off + nb].contiguous().view(dtype)
@@ -221,7 +237,8 @@ def gather_rows(block, rows: int, *, group=None, dst: int = 0):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     maxr = max(b - a for a, b in (shard_rows(rows, world, r) for r in range(world)))
-    send = torch.zeros((maxr,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    back = block.device if _host_staged(group, block) else None
+    send = torch.zeros((maxr,) + tuple(block.shape[1:]), dtype=block.dtype, device="cpu" if back is not None else block.device)
     send[:block.shape[0]].copy_(block)
     recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     dist.gather(send, recv, dst=dst, group=group)
@@ -231,7 +248,8 @@ def gather_rows(block, rows: int, *, group=None, dst: int = 0):
     for r in range(world):
         a, b = shard_rows(rows, world, r)
         parts.append(recv[r][:b - a])
-    return torch.cat(parts, 0)
+    full = torch.cat(parts, 0)
+    return full if back is None else full.to(back)
 
 
 def predict_flightline_sharded(cmf2d, *, group=None, dst: int = 0, compute=None, **kw):
@@ -260,5 +278,9 @@ def fcn_predict_flightline_sharded(cmf2d, *, scale: int = 32, group=None, dst: i
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     s0, s1 = shard_rows(scale * scale, world, rank)
     part = compute(cmf2d, shifts=(s0, s1), scale=scale, **kw).contiguous()
+    if _host_staged(group, part):
+        host = part.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        return host.to(part.device) if rank == dst else None
     dist.reduce(part, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return part if rank == dst else None

@@ -467,7 +467,7 @@ def sweep_routes(cube_bil, library=None, *, gas="ch4", reflectance=False, active
     factorisation of its coefficient matrix when the column's eigenvalue spectrum allows it (cmf_lowrank.hip) and by the full
     matrix otherwise (at 72 bands: 814 / 954 / 1260 MFMAs per 16-row tile; "full" columns of the wider windows take the
     16x16x4 kernel) -- the reference pays one cost for any data (robust_mf.py:105-117).  Runs stages 1-4 through the C ABI and
-    the factorisation's test hook; returns counts {"rank28", "rank36", "full", "skipped"} (skipped: status != 0)."""
+    the factorisation's test hook; returns counts {"rank24", "rank28", "rank36", "full", "skipped"} (skipped: status != 0)."""
     torch = _torch()
     if not (torch.is_tensor(cube_bil) and cube_bil.is_cuda):
         raise TypeError("sweep_routes needs the resident cube")
@@ -507,7 +507,7 @@ def sweep_routes(cube_bil, library=None, *, gas="ch4", reflectance=False, active
         check(L.sf_debug_lowrank(P(lam), P(nuse), P(status), P(al), nalpha, p, ncols, P(ufrag), P(wfrag), P(lrok), st),
               "sf_debug_lowrank")
         ok = status == 0
-        counts = {"rank28": int(((lrok == 1) & ok).sum()), "rank36": int(((lrok == 2) & ok).sum()),
+        counts = {"rank24": int(((lrok == 3) & ok).sum()), "rank28": int(((lrok == 1) & ok).sum()), "rank36": int(((lrok == 2) & ok).sum()),
                   "full": int(((lrok == 0) & ok).sum()), "skipped": int((~ok).sum())}
     return counts
 

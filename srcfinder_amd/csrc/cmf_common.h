@@ -198,10 +198,12 @@ static inline int sf_sw4_groups(int p) {
   const int s4 = (p + 3) / 4;
   return (s4 == 18 || s4 == 21 || s4 == 24) ? s4 : 0;
 }
-constexpr int SF_LR_K = 28, SF_LR_K2 = 36;   // ranks of the factored sweep coefficients (cmf_lowrank.hip); fragments use the K2 layout
+constexpr int SF_LR_K0 = 24, SF_LR_K = 28, SF_LR_K2 = 36;   // ranks of the factored sweep coefficients (cmf_lowrank.hip); fragments use the K2 layout
+// verdict per column (lrok): 0 = not factored (full-rank sweep), 1 = rank 28, 2 = rank 36, 3 = rank 24
+constexpr int sf_lr_code(int nk) { return nk == SF_LR_K0 / 4 ? 3 : (nk == SF_LR_K / 4 ? 1 : 2); }
 size_t sf_lowrank_bytes(const SfGeom &g);
 int sf_launch_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas, const SfGeom &g,
-                      double *ufrag, double *wfrag, int32_t *lrok, hipStream_t st);
+                      double *ufrag, double *wfrag, int32_t *lrok, hipStream_t st, int allow_k0 = 1);
 // cmf_cov4.hip: the production-window covariance on the 4x4x4 fp64 MFMA
 size_t sf_cov4_scratch_bytes(const SfGeom &g);
 int sf_launch_cov4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,

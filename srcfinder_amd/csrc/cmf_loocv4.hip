@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_sweep4r(const float *__restrict_
   const int g = lane >> 4, li = lane & 15;
   const int c = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
   double *po = part + ((size_t)c * nsplit + split) * 2 * NA16;
-  if (status[c] != 0 || lrok[c] != (NK == SF_LR_K / 4 ? 1 : 2)) return;   // another instantiation / k_sweep4 takes these columns
+  if (status[c] != 0 || lrok[c] != sf_lr_code(NK)) return;   // another instantiation / k_sweep4 takes these columns
   // ---- prologue: three table copies
   {
     auto copy = [&](double *dst, const double *src, int nel) {
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(512, 1) void k_sweep4s(const float *__restrict__ xt
   const int c = split_fastest ? blockIdx.y : blockIdx.x, split = split_fastest ? blockIdx.x : blockIdx.y;
   const int nsplit = split_fastest ? gridDim.x : gridDim.y;
   double *po = part + ((size_t)c * nsplit + split) * 2 * NA16;
-  if (status[c] != 0 || lrok[c] != (NK == SF_LR_K / 4 ? 1 : 2)) return;   // another instantiation / k_sweep4 takes these columns
+  if (status[c] != 0 || lrok[c] != sf_lr_code(NK)) return;   // another instantiation / k_sweep4 takes these columns
   // ---- prologue: the tables, permuted into the pair layouts.  Every global load of the workgroup is issued first (16-byte
   // loads, compile-time trip counts: ~17 per thread in flight at once), then the LDS stores: with one workgroup per CU
   // nothing else runs on the CU meanwhile, and a load-store loop paid one L2 round trip per iteration
@@ -1160,7 +1160,12 @@ int launch_sweep4r(const float *xt, const uint8_t *mask_t, const int32_t *nuse, 
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK1>), SwS<NK1>::lds_bytes())) return rc;
     const int sfast = sf_tune().sweep_grid != 1;
     const dim3 grid = sfast ? dim3(nsplit, g.ncols) : dim3(g.ncols, nsplit);
-    if (form == 0 || form == 3) hipLaunchKernelGGL((k_sweep4s<NK1>), grid, dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS, sfast);
+    if (form == 0 || form == 3 || form == 5) hipLaunchKernelGGL((k_sweep4s<NK1>), grid, dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS, sfast);
+    if (form == 0) {   // rank 24 (lrok == 3; the factorisation offers it only to this form: sf_launch_sweep4)
+      constexpr int NK0 = SF_LR_K0 / 4;
+      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK0>), SwS<NK0>::lds_bytes())) return rc;
+      hipLaunchKernelGGL((k_sweep4s<NK0>), grid, dim3(512), SwS<NK0>::lds_bytes(), st, SW4R_ARGS, sfast);
+    }
     if (form == 4) {   // renormalisation after every tile (the form of the round's first half): A/B and the bit-identity test
       if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK1, 0, 1>), SwS<NK1>::lds_bytes())) return rc;
       hipLaunchKernelGGL((k_sweep4s<NK1, 0, 1>), grid, dim3(512), SwS<NK1>::lds_bytes(), st, SW4R_ARGS, sfast);
@@ -1213,6 +1218,14 @@ int launch_sweep4s_nj(const float *xt, const uint8_t *mask_t, const int32_t *nus
   hipLaunchKernelGGL((k_sweep4s<NK1, 0, 4, NJ>), grid, dim3(512), S1::lds_bytes(), st, xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam,
                      wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part, 1);
   SF_LAUNCH_CHECK("k_sweep4s");
+  {
+    constexpr int NK0 = SF_LR_K0 / 4;
+    using S0 = SwS<NK0, NJ>;
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK0, 0, 4, NJ>), S0::lds_bytes())) return rc;
+    hipLaunchKernelGGL((k_sweep4s<NK0, 0, 4, NJ>), grid, dim3(512), S0::lds_bytes(), st, xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam,
+                       wfrag, wstride, status, alphas, g.nalpha, g.lines, g.p, g.ps, rows, part, 1);
+    SF_LAUNCH_CHECK("k_sweep4s(rank 24)");
+  }
   if constexpr (SwS<NK2, NJ>::lds_bytes() <= 160 * 1024) {
     using S2 = SwS<NK2, NJ>;
     if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_sweep4s<NK2, 0, 4, NJ>), S2::lds_bytes())) return rc;
@@ -1247,7 +1260,9 @@ int sf_launch_sweep4(const float *xt, const uint8_t *mask_t, const int32_t *nuse
     int32_t *lrok = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(wfrag2) +
                                                 sf_align((size_t)g.ncols * S4M * (SF_LR_K2 / 4) * 64 * sizeof(double)));
     if (lrok_out) *lrok_out = lrok;
-    if (int rc = sf_launch_lowrank(lam, nuse, status, alphas, g, ufrag, wfrag2, lrok, st)) return rc;
+    // (the rank-24 tier exists in the streamed kernel only: the debug forms of sf_debug_set(20, .) sweep ranks 28 / 36; form 5 is
+    //  the default with that tier switched off -- what the bit-for-bit comparisons against forms 1 and 4 run)
+    if (int rc = sf_launch_lowrank(lam, nuse, status, alphas, g, ufrag, wfrag2, lrok, st, nj > S4J || sf_tune().sweep4_form == 0)) return rc;
     if (nj == 21)
       return launch_sweep4s_nj<21>(xt, mask_t, nuse, mu, ufrag, wfrag2, lrok, lam, wfrag, wstride, status, alphas, g, nsplit, part, st);
     if (nj == 24)

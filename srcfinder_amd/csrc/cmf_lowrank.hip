@@ -20,6 +20,7 @@
 namespace {
 
 constexpr int LR_NA = 16 * SF_SW4_NM;      // 208
+constexpr int LR_K0 = SF_LR_K0;            // 24: enough for a noise-floor cluster + a few signal directions (round 5)
 constexpr int LR_K = SF_LR_K;              // 28: the fast rank
 constexpr int LR_K2 = SF_LR_K2;            // 36: second chance for spectra with a wider eigenvalue range
 constexpr int LR_NK2 = LR_K2 / 4;          // fragment layout stride (both ranks share the 36-wide layout)
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(32 * NJ)
 void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
                const int32_t *__restrict__ status, const double *__restrict__ alphas,
                int nalpha, int p, double *__restrict__ ufrag, double *__restrict__ wfrag,
-               int32_t *__restrict__ lrok) {
+               int32_t *__restrict__ lrok, int allow_k0) {
   constexpr int LR_P = 4 * NJ, LR_NT = 8 * LR_P, NJE = NJ + (NJ & 1);   // NJE: eigen groups of the sweep's pair layout (even)
   static_assert(LR_NT >= 576 && LR_NT <= 1024, "the Q_K phase needs 36 x 16 threads");
   __shared__ double V[LR_K2][LR_NA];            // reflector s: 0 above row s, 1 at row s, x_i * scale below
@@ -132,11 +133,11 @@ void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
   int mypos = -1;                               // step at which this group's column was pivoted
   int kuse = 0;                                 // accepted rank: LR_K, LR_K2 or 0 (full-rank sweep)
   for (int s = 0; s < LR_K2; ++s) {
-    if (s == LR_K) {   // rank 28 reached: is the trailing block already at the rounding floor?  (same answer in every thread)
+    if ((s == LR_K0 && allow_k0) || s == LR_K) {   // rank 24 / 28 reached: is the trailing block already at the rounding floor?  (same answer in every thread)
       double bn = 0.0;
       for (int j = 0; j < LR_P; ++j) bn = fmax(bn, cnorm[j]);
       const double r00 = s_r00;
-      if (sqrt(bn) <= 1e-14 * r00 && r00 > 0.0) { kuse = LR_K; break; }
+      if (sqrt(bn) <= 1e-14 * r00 && r00 > 0.0) { kuse = s; break; }
     }
     // pivot = the remaining column of largest norm (lowest index on ties; pivoted columns carry -1).  Every 8-lane
     // group scans all 72 candidates (9 per lane) and finishes with three DPP exchanges: no cross-wave traffic, no
@@ -241,7 +242,7 @@ void k_lowrank(const double *__restrict__ lam, const int32_t *__restrict__ nuse,
   }
   if (!lam_ok) kuse = 0;   // (near-)singular or indefinite correlation matrix: the full-rank kernel
   if (NJ == 24 && kuse == LR_K2) kuse = 0;   // the rank-36 tables of 24 band groups do not fit the LDS (cmf_loocv4.hip)
-  if (tid == 0) lrok[c] = (kuse == LR_K) ? 1 : ((kuse == LR_K2) ? 2 : 0);
+  if (tid == 0) lrok[c] = (kuse == 0) ? 0 : sf_lr_code(kuse / 4);
   if (kuse == 0) return;
   // ---- U fragments: ufrag[(jg*NK + mg)*16 + 4q + n] = -U[4jg+q][4mg+n];  U[j][m] = R[m][column j]: rows m <= its step
   //      of a pivoted column (below them sat its reflector), all K rows of the others -- straight from the registers
@@ -305,13 +306,13 @@ size_t sf_lowrank_bytes(const SfGeom &g) {
 }
 
 int sf_launch_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas, const SfGeom &g,
-                      double *ufrag, double *wfrag, int32_t *lrok, hipStream_t st) {
+                      double *ufrag, double *wfrag, int32_t *lrok, hipStream_t st, int allow_k0) {
   if (g.s4 == 21)
-    hipLaunchKernelGGL(k_lowrank<21>, dim3(g.ncols), dim3(32 * 21), 0, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok);
+    hipLaunchKernelGGL(k_lowrank<21>, dim3(g.ncols), dim3(32 * 21), 0, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok, allow_k0);
   else if (g.s4 == 24)
-    hipLaunchKernelGGL(k_lowrank<24>, dim3(g.ncols), dim3(32 * 24), 0, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok);
+    hipLaunchKernelGGL(k_lowrank<24>, dim3(g.ncols), dim3(32 * 24), 0, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok, allow_k0);
   else
-    hipLaunchKernelGGL(k_lowrank<18>, dim3(g.ncols), dim3(32 * 18), 0, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok);
+    hipLaunchKernelGGL(k_lowrank<18>, dim3(g.ncols), dim3(32 * 18), 0, st, lam, nuse, status, alphas, g.nalpha, g.p, ufrag, wfrag, lrok, allow_k0);
   SF_LAUNCH_CHECK("k_lowrank");
   return 0;
 }

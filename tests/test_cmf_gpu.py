@@ -264,7 +264,7 @@ def test_sweep_routes_of_the_co2_and_96_band_windows(torch_cuda, library, active
             x = 10.0 + 0.5 * (rng.standard_normal((lines, p)) * sd) @ qmat.T
             cube[3:, a0 - 1:a1, c] = x[3:].astype(np.float32)
     routes = cmf.sweep_routes(torch.as_tensor(cube).cuda(), library, active=active)
-    assert routes["rank28"] >= 3 and routes["rank36"] + routes["full"] >= 1, routes
+    assert routes["rank24"] + routes["rank28"] >= 3 and routes["rank36"] + routes["full"] >= 1, routes
     res = cmf.robust_mf(cube, library, active=active, metadata=True, to_numpy=True)
     o = O.robust_mf_oracle(cube, library, active=active)
     _compare_run(res, o, lines, samples)
@@ -987,10 +987,10 @@ def test_lowrank_factorisation_of_sweep_coefficients(torch_cuda):
                                   _ffi.ptr(uf), _ffi.ptr(wf), _ffi.ptr(ok), _ffi.stream_ptr()), "sf_debug_lowrank")
     torch.cuda.synchronize()
     uf, wf, ok = uf.cpu().numpy(), wf.cpu().numpy(), ok.cpu().numpy()
-    # rank 28 / n ~ p (condition 1e6): still factored / n < p (singular): full-rank sweep / 5.5 decades: rank 36
-    assert list(ok[:4]) == [1, 1, 1, 1] and ok[4] in (1, 2) and ok[5] == 0 and ok[6] == 2, ok
+    # rank 24 (code 3) or 28 (code 1) / n ~ p (condition 1e6): still factored / n < p (singular): full-rank sweep / 5.5 decades: rank 36
+    assert all(v in (1, 3) for v in ok[:4]) and ok[4] in (1, 2, 3) and ok[5] == 0 and ok[6] == 2, ok
     for c in (0, 1, 2, 3, 4, 6):
-        K = 28 if ok[c] == 1 else 36
+        K = {3: 24, 1: 28, 2: 36}[int(ok[c])]
         n = float(nuse[c])
         beta = (1.0 - al) / (n - 1.0)
         B = lam[c][:, None] * beta[None, :] / (n * beta[None, :] * lam[c][:, None] + al[None, :])   # row-scaled B' [72, 201]
@@ -1439,7 +1439,8 @@ def test_sweep_kernels_agree_bit_for_bit(torch_cuda, library):
     bit for bit -- on windows of 72 and 70 bands (out-of-window bands switched off), with a ragged line count (a second,
     short row split; tiles that end inside a 16-row group), NaN / negative rows and an all-NODATA column.  Form 4 is the
     streamed kernel renormalising its running products after every tile instead of every fourth (scaling by powers of two:
-    the same bits)."""
+    the same bits); form 5 the default without its rank-24 tier.  The default itself (rank 24 where the factorisation
+    allows) gives the same alpha indices and product, its NLL curves agree to 1e-12."""
     from srcfinder_amd import _ffi
     L = _ffi.lib()
     cube = make_cube_numpy(2500, 21, seed=31, abscf_full=library[:, 2], nodata_column=4, nodata_lines=5)
@@ -1449,18 +1450,26 @@ def test_sweep_kernels_agree_bit_for_bit(torch_cuda, library):
     dev = torch_cuda.as_tensor(cube).cuda()
     for active in ((351, 422), (352, 421)):
         runs = []
-        for form in (1, 4, 0):
+        for form in (1, 4, 5, 0):
             L.sf_debug_set(20, form)
             try:
                 runs.append(cmf.robust_mf(dev, library, active=active, metadata=True, to_numpy=True, return_nll=True))
             finally:
                 L.sf_debug_set(20, 0)
-        new = runs[-1]
-        for old in runs[:-1]:
+        new = runs[-2]                                            # form 5: the streamed kernel at ranks 28 / 36
+        for old in runs[:-2]:
             assert np.array_equal(old.status, new.status) and np.array_equal(old.alphaidx, new.alphaidx)
             assert np.array_equal(old.nll, new.nll, equal_nan=True), active
             assert np.array_equal(old.out, new.out, equal_nan=True) and np.array_equal(old.bgmeta, new.bgmeta)
         assert (new.status == 0).sum() == 20 and np.isfinite(new.nll[new.status == 0]).any()
+        # the default adds the rank-24 tier (round 5): the same factorisation stopped four steps earlier where the trailing
+        # block is already at the rounding floor -- same alpha, same product, NLL to rounding
+        dflt = runs[-1]
+        assert cmf.sweep_routes(dev, library, active=active)["rank24"] >= 10
+        assert np.array_equal(dflt.status, new.status) and np.array_equal(dflt.alphaidx, new.alphaidx)
+        assert np.array_equal(dflt.out, new.out, equal_nan=True) and np.array_equal(dflt.bgmeta, new.bgmeta)
+        fin = np.isfinite(new.nll)
+        assert np.array_equal(np.isfinite(dflt.nll), fin) and np.allclose(dflt.nll[fin], new.nll[fin], rtol=1e-12, atol=0)
 
 
 def test_zero_target_scores_nan_like_the_reference(torch_cuda, library):

@@ -36,6 +36,6 @@ a.record()
 for _ in range(20): run()
 b.record(); torch.cuda.synchronize()
 okh = ok.cpu().numpy()
-print("k_lowrank on %d columns: %.3f ms per launch; verdicts rank28/rank36/full = %d/%d/%d" % (nc, a.elapsed_time(b) / 20, (okh == 1).sum(), (okh == 2).sum(), (okh == 0).sum()))
+print("k_lowrank on %d columns: %.3f ms per launch; verdicts rank24/rank28/rank36/full = %d/%d/%d/%d" % (nc, a.elapsed_time(b) / 20, (okh == 3).sum(), (okh == 1).sum(), (okh == 2).sum(), (okh == 0).sum()))
 use = okh > 0
 np.savez(sys.argv[1], ufrag=uf.cpu().numpy()[use], wfrag=wf.cpu().numpy()[use], lrok=okh)

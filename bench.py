@@ -48,6 +48,7 @@ def main():
                     help="skip the CO2 (p = 83) and reflectance (-R, p = 416) window sections (cmf/robust_mf.py:186-191)")
     ap.add_argument("--cpu-columns", type=int, default=12)    # ~7 s of one host core (+ the all-cores sample)
     ap.add_argument("--active", type=str, default="", help="a0,a1 (1-based inclusive) override of the active window, e.g. 1,425")
+    ap.add_argument("--knob", action="append", default=[], help="key=value for sf_debug_set (tuning / A-B runs; repeatable)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="flightlines in flight per GPU (srcfinder_amd.inflight); 0 = the default, 3 for every N")
     args = ap.parse_args()
@@ -110,6 +111,9 @@ def main():
     # its HIP-event time includes kernels of the other streams).
     from srcfinder_amd.inflight import FlightlinePipeline
     L = _ffi.lib()
+    for kv in args.knob:
+        k, v = kv.split("=")
+        L.sf_debug_set(int(k), int(v))
 
     def barrier():
         if world > 1 or force_dist:

@@ -187,11 +187,18 @@ int sf_cmf_column_profile(const double *img, int lines, int samples, int nbands,
 int sf_cmf_column_profile_robust(const double *img, int lines, int samples, int nbands, int band, double nodata,
                                  double p, double *profile, void *stream);
 
-/* Test hook: the rank-28 / rank-36 factorisation B = U W of the sweep's coefficient matrix (cmf_lowrank.hip), in
+/* Test hook: the rank-24 / 28 / 36 factorisation B = U W of the sweep's coefficient matrix (cmf_lowrank.hip), in
  * the fragment order the sweep reads: ufrag[ncols][18*9*16], wfrag[ncols][13*9*64], lrok[ncols] (0 full rank,
- * 1 rank 28, 2 rank 36). */
+ * 1 rank 28, 2 rank 36, 3 rank 24). */
 int sf_debug_lowrank(const double *lam, const int32_t *nuse, const int32_t *status, const double *alphas,
                      int nalpha, int p, int ncols, double *ufrag, double *wfrag, int32_t *lrok, void *stream);
+
+/* Test hook of the wide windows' rank factorisation (csrc/cmf_wlr.hip; 257..432 bands): wlr_out[c] = 0 when column c's sweep
+ * runs unfactored, else the rank (24..31) of the factorisation of its coefficient matrix (cmf/robust_mf.py:105-117 restated).
+ * scratch: sf_debug_wlr_bytes(ncols) bytes of device memory. */
+size_t sf_debug_wlr_bytes(int ncols);
+int sf_debug_wlr(const double *lam, const int32_t *nloo, const int32_t *status, const double *alphas, int nalpha, int p,
+                 int ncols, void *scratch, int32_t *wlr_out, void *stream);
 
 /* Test / tuning hook: phase clocks of the tiles of the fused wide-window sweep (cmf_wgemm.hip), accumulated while
  * sf_debug_set(22, 1) is on: out8 = tiles, Y = X~ W, r = Z C + rows, then (k_wsweep8) the r

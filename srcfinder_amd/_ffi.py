@@ -66,6 +66,8 @@ SIGNATURES = {
     "sf_cmf_score_cluster": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, vp]),
     "sf_cmf_colstats_rows": (i32, [vp, i32, i32, i32, vp, i32, i32, f64, vp, vp]),
     "sf_debug_lowrank": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "sf_debug_wlr_bytes": (C.c_size_t, [i32]),
+    "sf_debug_wlr": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "sf_debug_wsweep_stamps": (i32, [vp, i32]),
     "sf_debug_wtri_scratch_bytes": (sz, [i32, i32]),
     "sf_debug_wtri": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp]),

@@ -467,7 +467,9 @@ def sweep_routes(cube_bil, library=None, *, gas="ch4", reflectance=False, active
     factorisation of its coefficient matrix when the column's eigenvalue spectrum allows it (cmf_lowrank.hip) and by the full
     matrix otherwise (at 72 bands: 814 / 954 / 1260 MFMAs per 16-row tile; "full" columns of the wider windows take the
     16x16x4 kernel) -- the reference pays one cost for any data (robust_mf.py:105-117).  Runs stages 1-4 through the C ABI and
-    the factorisation's test hook; returns counts {"rank24", "rank28", "rank36", "full", "skipped"} (skipped: status != 0)."""
+    the factorisation's test hook; returns counts {"rank24", "rank28", "rank36", "full", "skipped"} (skipped: status != 0).
+    Windows of 257..432 bands (full-band, -R): {"factored", "unfactored", "skipped", "ranks": {rank: columns}} -- the wide sweep's second
+    product through the rank factorisation of cmf_wlr.hip, or unfactored (a spectrum spread densely over decades)."""
     torch = _torch()
     if not (torch.is_tensor(cube_bil) and cube_bil.is_cuda):
         raise TypeError("sweep_routes needs the resident cube")
@@ -476,8 +478,9 @@ def sweep_routes(cube_bil, library=None, *, gas="ch4", reflectance=False, active
     a0, a1 = active if active is not None else active_window(gas, reflectance)
     p = a1 - a0 + 1
     nj = (p + 3) // 4
-    if nj not in (18, 21, 24):
-        return {"note": "windows other than 69..72, 81..84 and 93..96 bands take one route (p = %d)" % p}
+    wide = 256 < p <= 432             # k_wsweep8's windows: the r phase through the rank factorisation of cmf_wlr.hip, or plain
+    if nj not in (18, 21, 24) and not wide:
+        return {"note": "windows other than 69..72, 81..84, 93..96 and 257..432 bands take one route (p = %d)" % p}
     nje = nj + (nj & 1)
     s0, s1 = (0, samples) if columns is None else (int(columns[0]), int(columns[1]))
     ncols = s1 - s0
@@ -499,8 +502,22 @@ def sweep_routes(cube_bil, library=None, *, gas="ch4", reflectance=False, active
         check(L.sf_cmf_extract_columns(P(cube_bil.contiguous()), lines, bands, samples, s0, s1, a0 - 1, p, P(xt), P(mask), st),
               "sf_cmf_extract_columns")
         check(L.sf_cmf_column_mean(P(xt), 0, P(mask), lines, p, ncols, P(nuse), P(mu), P(ws), st), "sf_cmf_column_mean")
-        check(L.sf_cmf_covariance(P(xt), 0, P(mask), P(nuse), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
-        check(L.sf_cmf_eigh(P(S), P(nuse), p, ncols, P(d), P(lam), P(evec), P(status), P(ws), st), "sf_cmf_eigh")
+        if wide:        # stages 3-5 of the wide windows are one call; the eigenvalues it leaves are what the factorisation sees
+            nll = torch.empty((ncols, nalpha), **f64)
+            aidx = torch.empty(ncols, dtype=torch.int32, device=dev)
+            check(L.sf_cmf_wide_stats(P(xt), 0, P(mask), P(nuse), P(nuse), P(mu), P(al), nalpha, lines, p, ncols, P(S), P(d), P(lam),
+                                      P(evec), P(status), P(nll), P(aidx), P(ws), st), "sf_cmf_wide_stats")
+        else:
+            check(L.sf_cmf_covariance(P(xt), 0, P(mask), P(nuse), P(mu), lines, p, ncols, P(S), P(ws), st), "sf_cmf_covariance")
+            check(L.sf_cmf_eigh(P(S), P(nuse), p, ncols, P(d), P(lam), P(evec), P(status), P(ws), st), "sf_cmf_eigh")
+        if wide:
+            scratch = torch.empty(int(L.sf_debug_wlr_bytes(ncols)), dtype=torch.uint8, device=dev)
+            wlr = torch.empty(ncols, dtype=torch.int32, device=dev)
+            check(L.sf_debug_wlr(P(lam), P(nuse), P(status), P(al), nalpha, p, ncols, P(scratch), P(wlr), st), "sf_debug_wlr")
+            ok = status == 0
+            ranks = {int(k): int(((wlr == k) & ok).sum()) for k in torch.unique(wlr[ok]).tolist() if k > 0}
+            return {"factored": int(((wlr > 0) & ok).sum()), "unfactored": int(((wlr == 0) & ok).sum()),
+                    "skipped": int((~ok).sum()), "ranks": ranks}
         ufrag = torch.empty((ncols, nje * 9 * 16), **f64)
         wfrag = torch.empty((ncols, 13 * 9 * 64), **f64)
         lrok = torch.empty(ncols, dtype=torch.int32, device=dev)

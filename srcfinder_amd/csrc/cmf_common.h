@@ -158,6 +158,12 @@ int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, cons
 int sf_wgemm_splits(const SfGeom &g);
 size_t sf_wgemm_operand_bytes(const SfGeom &g);   // W and C of g.ncols columns
 size_t sf_wgemm_part_bytes(const SfGeom &g);      // the sweep partials of the whole flightline
+// rank factorisation of the wide sweep's coefficient matrix (cmf_wlr.hip): operand images U8 / T8 and the verdict per column
+size_t sf_wlr_scratch_bytes(int nb);
+size_t sf_wlr_image_bytes(int nb);
+int sf_launch_wlr(const double *lam, const int32_t *nloo, const int32_t *status, const double *alphas, int nalpha, int p, int nb,
+                  int njw, int njl, void *scratch, void *images, const double **U8, const double **T8, const int32_t **wlr,
+                  hipStream_t st);
 // cmf_wtri.hip: the tridiagonal preconditioner of the wide eigensolver; cmf_wide.hip: the batched float64 GEMM it uses
 // (column-major n x n matrices: C = Y X for tb = 0, C = Y^T X ... see the definition), matrices with skip1 / skip2 != 0 untouched
 size_t sf_wtri_small_bytes(int p, int nb);

@@ -618,14 +618,25 @@ int ws_launch(const void *xt, const uint8_t *mask_t, const int32_t *nloo, const 
 // keeps one exchange per 8-alpha chunk (the eight K-slices' partial r meet in `red`), with the row reductions of chunk
 // ch - 1 placed beside the MFMAs of chunk ch.
 // --------------------------------------------------------------------------------------------------------------------
+// FACT (round 5): the r phase through the rank factorisation of its coefficient matrix (cmf_wlr.hip): beta_a r(a) = Z C diag(beta)
+// = (Z Uc) T with Uc [p x 32] and T [32 x 208] -- four chunks of eight factor columns take the place of the 26 chunks of eight
+// alphas (G = Z Uc: 448 instead of 2912 MFMAs per wave and tile, 8 exchanges instead of 26), then every wave multiplies the
+// complete G [64 rows x 32] by ITS 28 alphas of T (224 MFMAs, no exchange) and reduces the rows of its alphas in registers.
+// Factor column 31 is the all-ones column: G[., 31] = sum_j Z_j = r(alpha = 1), the grid point whose beta = 0 scales everything
+// else of its column to nothing (T[31][a] = 1 there, 0 elsewhere).  Columns the factorisation refused (wlr == 0) are swept by the
+// plain instantiation; each returns at once on the other's columns.
 constexpr int W8_NW = 8;
-template <int NJW, int NJL>
+constexpr int W8_NCF = 4;      // chunks of eight factor columns
+constexpr int W8_GST = 36;     // row stride of G in LDS (doubles): the A-operand reads of 16 rows x 4 factors spread over the banks
+constexpr int W8_NAG = 7;      // groups of four alphas per wave in the second product (8 x 28 = 224 >= 208 slots)
+template <int NJW, int NJL, bool FACT = false>
 __global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restrict__ xt, const uint8_t *__restrict__ mask_t,
                                                        const int32_t *__restrict__ nloo, const double *__restrict__ mu,
                                                        const double *__restrict__ W8, const double *__restrict__ C8,
                                                        const int32_t *__restrict__ status, const double *__restrict__ alphas,
                                                        int nalpha, int NA, int L, int p, int ps, int P16, int rows_per_wg,
-                                                       int nsplit, int ncols, double *__restrict__ part, int stamp) {
+                                                       int nsplit, int ncols, double *__restrict__ part, int stamp,
+                                                       const double *__restrict__ T8, const int32_t *__restrict__ wlr) {
   constexpr int NI = 4, RT = 64, NW = W8_NW, NT = 64 * NW;
   constexpr int SW = 4 * NJW;            // columns per wave slot
   constexpr int WSL = 16 * SW;           // doubles per W slice [16 band rows][SW]
@@ -647,9 +658,11 @@ __global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restri
   const int q = lane >> 4, m = (lane >> 2) & 3, n = lane & 3;
   double *po = part + ((size_t)c * nsplit + split) * 2 * NA;
   if (status[c] != 0) {
-    for (int i = tid; i < 2 * NA; i += NT) po[i] = 0.0;
+    if (!FACT)
+      for (int i = tid; i < 2 * NA; i += NT) po[i] = 0.0;
     return;
   }
+  if (wlr != nullptr && (wlr[c] != 0) != FACT) return;   // the other instantiation's column
   const double nn = (double)nloo[c];
   for (int i = tid; i < NA; i += NT) betas[i] = (i < nalpha) ? (1.0 - alphas[i]) / (nn - 1.0) : 0.0;
   for (int i = tid; i < P16; i += NT) mus[i] = (i < p) ? mu[(size_t)c * p + i] : 0.0;
@@ -657,7 +670,7 @@ __global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restri
   const int rbeg = split * rows_per_wg, rend = min(L, rbeg + rows_per_wg);
   const float *xc = xt + (size_t)c * L * ps;
   const uint8_t *mp = mask_t + (size_t)c * L;
-  const int NKC = P16 / 16, NCC = NA / WS_CA;
+  const int NKC = P16 / 16, NCC = FACT ? W8_NCF : NA / WS_CA;
   // the split's running (mantissa, exponent, sum, flag) of alpha 8 ch + wave live in lane ch of this wave's registers
   double Pv = 1.0, Sv = 0.0;
   int Ev = 0, Nv = 0;
@@ -673,6 +686,17 @@ __global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restri
     // (the instruction's immediate offset moves the global AND the LDS address: one address pair per 4 KB)
     if (s < NKC) {
       const char *src = Wc + (size_t)s * NW * WSL * 8;
+#pragma unroll
+      for (int pb = 0; pb < NPW; pb += 4) {
+        ws_glb_void *gp = (ws_glb_void *)(src + pb * 1024 + loff);
+        ws_lds_void *lp = (ws_lds_void *)(dst + pb * 1024);
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+        if (pb + 1 < NPW) __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+        if (pb + 2 < NPW) __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+        if (pb + 3 < NPW) __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+      }
+    } else if (FACT && s == NKC + W8_NCF) {   // this wave's 28 alphas of T: [8 factor groups][7 alpha groups][16], 7 KB like a W slice
+      const char *src = reinterpret_cast<const char *>(T8 + ((size_t)c * NW + wave) * WSL);
 #pragma unroll
       for (int pb = 0; pb < NPW; pb += 4) {
         ws_glb_void *gp = (ws_glb_void *)(src + pb * 1024 + loff);
@@ -805,6 +829,106 @@ __global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restri
     //  [3] wait for the chunk's copy, [5] MFMAs + row reductions, [6] exchange + barrier, [7] the wave's whole tile)
     const bool probe = stamp >= 16 && wave == stamp - 16;
     unsigned long long pd0 = 0, pd1 = 0, pd2 = 0, pd3 = 0;
+    if constexpr (FACT) {
+      static_assert(W8_GST * 64 <= 2 * NW * RW && WSL == 8 * W8_NAG * 16, "G fits red; a T slice is a W slice");
+      const unsigned long long vrows = __ballot(rowok);   // bit r: row r of the tile counts
+      double gch[W8_NCF];
+      // ---- G = Z Uc, eight factor columns a chunk: the waves' K-slice partials meet in red, wave w sums factor 8 ch + w (lane = row)
+#pragma unroll
+      for (int ch = 0; ch < W8_NCF; ++ch, ++gs) {
+        __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);
+        asm volatile("" ::: "memory");
+        glds(NKC + ch + 1, gs + 1);        // the next chunk; behind the last one the T slice
+        const double *bcol = bw0 + (gs & 1) * (NW * WSL) + q * WS_CA + n;
+        double ra[NI], rb[NI];
+#pragma unroll
+        for (int I = 0; I < NI; ++I) { ra[I] = 0.0; rb[I] = 0.0; }
+#pragma unroll
+        for (int J = 0; J < NJW; ++J) {
+          const double ca = bcol[(size_t)4 * WS_CA * J], cb = bcol[(size_t)4 * WS_CA * J + 4];
+#pragma unroll
+          for (int I = 0; I < NI; ++I) {
+            ra[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[I][J], ca, ra[I], 0, 0, 0);
+            rb[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[I][J], cb, rb[I], 0, 0, 0);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // red is free: the last chunk's partials (the last tile's G) are read
+        double *wa = red + (size_t)wave * RW, *wb = red + (size_t)(NW + wave) * RW;
+#pragma unroll
+        for (int I = 0; I < NI; ++I) {
+          wa[I * RS + lane] = ra[I];
+          wb[I * RS + lane] = rb[I];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const double *rp = red + (size_t)(wave >> 2) * NW * RW + (lane >> 4) * RS + 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (wave & 3);
+        gch[ch] = ((rp[0 * RW] + rp[1 * RW]) + (rp[2 * RW] + rp[3 * RW])) + ((rp[4 * RW] + rp[5 * RW]) + (rp[6 * RW] + rp[7 * RW]));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave has its factors: red becomes G [64][GST]
+#pragma unroll
+      for (int ch = 0; ch < W8_NCF; ++ch) red[lane * W8_GST + 8 * ch + wave] = gch[ch];
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      double ga[NI][2 * W8_NCF];           // A operands: G[row 16 I + 4 m + n][factor 4 kk + q]
+#pragma unroll
+      for (int I = 0; I < NI; ++I)
+#pragma unroll
+        for (int kk = 0; kk < 2 * W8_NCF; ++kk) ga[I][kk] = red[(16 * I + 4 * m + n) * W8_GST + 4 * kk + q];
+      __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);   // the T slice has landed
+      asm volatile("" ::: "memory");
+      const double *tb = bw0 + (gs & 1) * (NW * WSL) + 4 * q + n;
+      ++gs;
+      if (more) {   // the next tile's first chunk goes to the other buffer (its last reader was factor chunk 3)
+        glds(0, gs);
+        xload(xa, 0, r0 + RT);
+      }
+      // ---- beta r = G T for this wave's 28 alphas; lane (q, m, n) gets rows 16 I + 4 m + q of alpha 28 w + 4 ag + n
+#pragma unroll
+      for (int ag = 0; ag < W8_NAG; ++ag) {
+        double o[NI];
+#pragma unroll
+        for (int I = 0; I < NI; ++I) o[I] = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 2 * W8_NCF; ++kk) {
+          const double tv = tb[(kk * W8_NAG + ag) * 16];
+#pragma unroll
+          for (int I = 0; I < NI; ++I) o[I] = __builtin_amdgcn_mfma_f64_4x4x4f64(ga[I][kk], tv, o[I], 0, 0, 0);
+        }
+        const int ai = 28 * wave + 4 * ag + n;
+        const double beta0 = betas[ai < NA ? ai : NA - 1];
+        const bool bz = !(beta0 > 0.0);                    // alpha = 1 (and the padding slots): o is r itself, q = 1
+        double prod0 = 1.0, ssum0 = 0.0;
+        int neg = 0;
+#pragma unroll
+        for (int I = 0; I < NI; ++I) {
+          const bool ok = (vrows >> (16 * I + 4 * m + q)) & 1ull;
+          const double q0 = bz ? 1.0 : 1.0 - o[I];
+          double y0 = __builtin_amdgcn_rcp(q0);
+          y0 = __builtin_fma(y0, __builtin_fma(-q0, y0, 1.0), y0);
+          y0 = __builtin_fma(y0, __builtin_fma(-q0, y0, 1.0), y0);
+          prod0 *= ok ? q0 : 1.0;
+          ssum0 += ok ? o[I] * y0 : 0.0;
+          neg |= (ok && q0 < 0.0) ? 1 : 0;
+        }
+        // the 16 lanes (q, m) of an alpha: two rotations inside the 16-lane rows (m), two exchanges across them (q)
+        prod0 *= ws_dpp<0x124>(prod0);  ssum0 += ws_dpp<0x124>(ssum0);   // row_ror:4
+        prod0 *= ws_dpp<0x128>(prod0);  ssum0 += ws_dpp<0x128>(ssum0);   // row_ror:8
+        neg |= __builtin_amdgcn_update_dpp(0, neg, 0x124, 0xF, 0xF, false);
+        neg |= __builtin_amdgcn_update_dpp(0, neg, 0x128, 0xF, 0xF, false);
+#pragma unroll
+        for (int msk = 16; msk <= 32; msk <<= 1) {
+          const double po2 = __hiloint2double(__shfl_xor(__double2hiint(prod0), msk, 64), __shfl_xor(__double2loint(prod0), msk, 64));
+          const double so2 = __hiloint2double(__shfl_xor(__double2hiint(ssum0), msk, 64), __shfl_xor(__double2loint(ssum0), msk, 64));
+          prod0 *= po2;
+          ssum0 += so2;
+          neg |= __shfl_xor(neg, msk, 64);
+        }
+        const bool mine = (lane >> 2) == ag && lane < 4 * W8_NAG;   // lane l keeps alpha 28 w + l (its n is l & 3)
+        const double pm0 = Pv * prod0;
+        Ev += mine ? __builtin_amdgcn_frexp_exp(pm0) : 0;
+        Pv = mine ? __builtin_amdgcn_frexp_mant(pm0) : Pv;
+        Sv += mine ? ssum0 : 0.0;
+        Nv |= mine ? neg : 0;
+      }
+    } else {
     for (int ch = 0; ch < NCC; ++ch, ++gs) {
       unsigned long long pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0;
       if (probe) pk0 = __builtin_readcyclecounter();
@@ -926,6 +1050,7 @@ __global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restri
       glds(0, gs);
       xload(xa, 0, r0 + RT);
     }
+    }
     if (stamp && tid == 0) {
       const unsigned long long tk2 = __builtin_readcyclecounter();
       atomicAdd(&g_ws_stamps[0], 1ull);
@@ -933,7 +1058,17 @@ __global__ __launch_bounds__(64 * W8_NW, 1) void k_wsweep8(const float *__restri
       atomicAdd(&g_ws_stamps[2], tk2 - tk1);
     }
   }
-  if (lane < NCC) {
+  if constexpr (FACT) {
+    if (lane < 4 * W8_NAG) {
+      const int ai = 28 * wave + lane;
+      if (ai < NA) {
+        const bool in = ai < nalpha;
+        const double beta0 = betas[ai];
+        po[ai] = in ? log(Pv) + (double)Ev * 0.6931471805599453094 : 0.0;
+        po[NA + ai] = in ? (Nv ? __builtin_nan("") : (beta0 > 0.0 ? Sv / beta0 : Sv)) : 0.0;   // the sums were of beta r / q
+      }
+    }
+  } else if (lane < NCC) {
     const int ai = WS_CA * lane + wave;
     const bool in = ai < nalpha;
     po[ai] = in ? log(Pv) + (double)Ev * 0.6931471805599453094 : 0.0;
@@ -999,9 +1134,14 @@ static int wg_ldw(const SfGeom &g) { return g.p <= 256 ? 256 : (g.p <= 432 ? 432
 static int wg_na(const SfGeom &g) { return g.nu * 16; }   // (a multiple of the 8 alphas of a C chunk)   // alpha slots = the stride k_nll reads the partials with
 // scratch of the fused route: W [ncols][P16][LDW], Ct [ncols][NA / 16][LDW][16], the sweep partials [ncols][nsplit][2][NA]
 static size_t wg_ldw_alloc(const SfGeom &g) { const size_t l = wg_ldw(g); return l == 432 ? 448 : l; }   // (k_wsweep8's 8 x 56 slots)
+static bool wg_factored(const SfGeom &g, int xt_f64) {   // the rank-factored r phase: k_wsweep8's windows, 201-point grid
+  return !xt_f64 && wg_ldw(g) == 432 && wg_na(g) == 208 && sf_tune().wsweep_variant == 0;
+}
 size_t sf_wgemm_operand_bytes(const SfGeom &g) {
   const size_t P16 = wg_p16(g), LDW = wg_ldw_alloc(g), NA = wg_na(g);
-  return sf_align((size_t)g.ncols * P16 * LDW * sizeof(double)) + sf_align((size_t)g.ncols * NA * LDW * sizeof(double) + 1024);
+  size_t b = sf_align((size_t)g.ncols * P16 * LDW * sizeof(double)) + sf_align((size_t)g.ncols * NA * LDW * sizeof(double) + 1024);
+  if (wg_ldw(g) == 432 && wg_na(g) == 208) b += sf_wlr_image_bytes(g.ncols) + sf_wlr_scratch_bytes(g.ncols);   // (whatever the knob says)
+  return b;
 }
 size_t sf_wgemm_part_bytes(const SfGeom &g) {
   return sf_align((size_t)g.ncols * sf_wgemm_splits(g) * 2 * wg_na(g) * sizeof(double));
@@ -1047,7 +1187,7 @@ int sf_launch_wsweep(const void *xt, int xt_f64, const uint8_t *mask_t, const in
   // sf_debug_set(24, v): 0 = k_wsweep8 where it applies (float32 rows, 256 < p <= 432); 1: 32-row tiles, 8-band chunks, two
   // workgroups per CU; 2: eight waves on shared chunks; 4: round 4's first form (four waves, shared chunks)
   const int lite = sf_tune().wsweep_variant;
-  if (!xt_f64 && LDW == 432 && lite == 0) {
+  if (!xt_f64 && LDW == 432 && (lite == 0 || lite == 5)) {   // (5: k_wsweep8 with the r phase unfactored for every column)
     // eight waves, wave-private operand slices, no barrier in the Y phase (k_wsweep8)
     constexpr int NJW = 14, NJL = 13;
     const size_t lds = ws8_lds_bytes<NJW>(P16, NA);
@@ -1059,9 +1199,24 @@ int sf_launch_wsweep(const void *xt, int xt_f64, const uint8_t *mask_t, const in
                        g.nalpha, NA / 8, g.p, Ct);
     SF_LAUNCH_CHECK("k_cmat_t8");
     const int grid = 8 * sf_cdiv(nb, 8) * nsplit;
+    // sf_debug_set(24, 5): every column through the unfactored r phase (the A/B of the round-5 factorisation)
+    const double *U8 = nullptr, *T8 = nullptr;
+    const int32_t *wlr = nullptr;
+    if (wg_factored(g, xt_f64)) {
+      char *img = reinterpret_cast<char *>(Ct) + sf_align((size_t)nb * NA * wg_ldw_alloc(g) * sizeof(double) + 1024);
+      char *scr = img + sf_wlr_image_bytes(nb);
+      if (int rc = sf_launch_wlr(lam + (size_t)c0 * g.p, nloo + c0, status + c0, alphas, g.nalpha, g.p, nb, NJW, NJL, scr, img, &U8, &T8,
+                                 &wlr, st))
+        return rc;
+      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_wsweep8<NJW, NJL, true>), lds)) return rc;
+      hipLaunchKernelGGL((k_wsweep8<NJW, NJL, true>), dim3(grid), dim3(64 * W8_NW), lds, st, reinterpret_cast<const float *>(xb),
+                         mask_t + (size_t)c0 * g.lines, nloo + c0, mu + (size_t)c0 * g.p, Wp, U8, status + c0, alphas, g.nalpha, NA,
+                         g.lines, g.p, g.ps, P16, rows, nsplit, nb, part + (size_t)c0 * nsplit * 2 * NA, 0, T8, wlr);
+      SF_LAUNCH_CHECK("k_wsweep8(factored)");
+    }
     hipLaunchKernelGGL((k_wsweep8<NJW, NJL>), dim3(grid), dim3(64 * W8_NW), lds, st, reinterpret_cast<const float *>(xb),
                        mask_t + (size_t)c0 * g.lines, nloo + c0, mu + (size_t)c0 * g.p, Wp, Ct, status + c0, alphas, g.nalpha, NA,
-                       g.lines, g.p, g.ps, P16, rows, nsplit, nb, part + (size_t)c0 * nsplit * 2 * NA, sf_tune().wjac_stamps);
+                       g.lines, g.p, g.ps, P16, rows, nsplit, nb, part + (size_t)c0 * nsplit * 2 * NA, sf_tune().wjac_stamps, nullptr, wlr);
     SF_LAUNCH_CHECK("k_wsweep8");
     return 0;
   }

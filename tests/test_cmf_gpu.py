@@ -1508,6 +1508,47 @@ def test_multimodal_and_wide_column_shards(torch_cuda, golden_dir, library):
     assert np.array_equal(part.alphaidx, full.alphaidx[2:6])
 
 
+def test_wide_sweep_rank_factored_against_the_unfactored_kernel(torch_cuda, library):
+    """Round 5: on k_wsweep8's windows (257..432 bands) the sweep's second product runs through the rank factorisation of its
+    coefficient matrix (cmf_wlr.hip: proxy eigenvalues -> k_lowrank -> checked and completed against the real spectrum) where
+    the column's spectrum allows it -- a noise-floor cluster plus a few signal directions, as a flightline column has -- and
+    unfactored otherwise (sf_debug_set(24, 5): every column unfactored).  One cube holds both kinds: same status, same alpha
+    indices, the same product bit for bit (the scores depend on alpha only), NLL curves to 1e-11; and both routes against the
+    faithful oracle."""
+    from srcfinder_amd import _ffi
+    torch = torch_cuda
+    L = _ffi.lib()
+    lines, samples, active = 5000, 6, (5, 420)
+    p = active[1] - active[0] + 1
+    cube = make_cube_numpy(lines, samples, seed=58, abscf_full=library[:, 2], active=active, nodata_column=2, nodata_lines=3)
+    rng = np.random.default_rng(8)
+    for c in (4, 5):                                             # spectra spread densely over 4.5 decades: not factored
+        qmat, _ = np.linalg.qr(rng.standard_normal((p, p)))
+        sd = np.sqrt(np.exp(np.linspace(0.0, -4.5 * np.log(10.0), p)))
+        x = 10.0 + 0.5 * (rng.standard_normal((lines, p)) * sd) @ qmat.T
+        cube[3:, active[0] - 1:active[1], c] = x[3:].astype(np.float32)
+    dev = torch.as_tensor(cube).cuda()
+    routes = cmf.sweep_routes(dev, library, active=active)
+    assert routes["factored"] >= 3 and routes["unfactored"] >= 1 and routes["skipped"] == 1, routes
+    assert all(24 <= k <= 31 for k in routes["ranks"]), routes
+    runs = []
+    for knob in (0, 5):
+        L.sf_debug_set(24, knob)
+        try:
+            runs.append(cmf.robust_mf(dev, library, active=active, metadata=True, to_numpy=True, return_nll=True))
+        finally:
+            L.sf_debug_set(24, 0)
+    a, b = runs
+    assert np.array_equal(a.status, b.status) and np.array_equal(a.alphaidx, b.alphaidx) and np.array_equal(a.bgmeta, b.bgmeta)
+    assert np.array_equal(a.out, b.out, equal_nan=True)
+    fin = np.isfinite(b.nll)
+    assert np.array_equal(np.isfinite(a.nll), fin) and not np.array_equal(a.nll, b.nll)     # two different evaluations ...
+    assert np.allclose(a.nll[fin], b.nll[fin], rtol=1e-11, atol=0)                         # ... of the same curves
+    with np.errstate(all="ignore"):
+        o = O.robust_mf_oracle(cube, library, active=active)
+    _compare_run(a, o, lines, samples)
+
+
 def test_multimodal_on_a_wide_window(torch_cuda, library):
     """-R -k 2 (reflectance window 5..420, p = 416) with injected labels and with -r: the per-cluster statistics go through
     sf_cmf_wide_stats (separate row count and n), the cluster score kernel reads its filter from global memory."""

@@ -99,6 +99,11 @@ def main():
     cube = make_cube_torch(lines, ncols, seed=1234 + rank, abscf_full=lib[:, 2], device=dev,
                            nodata_column=(ncols // 3))
     torch.cuda.synchronize()
+    # The generator's temporaries (GB-sized blocks) stay in torch's caching allocator, and product buffers carved out of those
+    # segments make the HBM-bound kernels up to 8 % slower than buffers in fresh segments (score kernel 0.807 against 0.735-0.75 ms
+    # for the same launch, persistent per buffer: tools/score_placement_probe.py, profiles/r05_score_placement.md).  Data
+    # generation is not part of the path: its leftovers go back to the driver before the pipeline allocates anything.
+    torch.cuda.empty_cache()
 
     # A production run works through a queue of flightlines: `depth` of them are in flight on this GPU, each on its own
     # HIP stream with its own scratch and product buffer (srcfinder_amd/inflight.py), so one flightline's latency-bound
@@ -121,6 +126,7 @@ def main():
         torch.cuda.synchronize()
 
     def timed_pass(depth):
+        torch.cuda.empty_cache()                 # (placement, see above: no product buffer out of an earlier pass's freed blocks)
         pipe = FlightlinePipeline(depth, dev)
         outs = [torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev) for _ in range(depth)]
         pending = [None] * depth                 # per slot: the gather handle of the flightline that used it last

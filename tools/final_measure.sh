@@ -11,6 +11,7 @@ mkdir -p $out
 B="--no-cpu-baseline --no-cnn --no-e2e --no-wide --no-ingest --no-routes --no-ceiling --no-windows"
 tools/pmc_traffic.sh ${tag}f > $out/pmc.log 2>&1
 cp gpurun_out/${tag}f_pmc_traffic.json $out/pmc_traffic.json
+cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json   # (on the box: the bench runs below quote it when the kernel source sha matches)
 tools/pmc_mfma.sh ${tag}f > $out/pmc_mfma.txt 2>&1
 tools/pmc_sq.sh ${tag}f k_sweep4s > $out/pmc_sq.txt 2>&1
 tools/prof_bench.sh ${tag}fif1 --in-flight 1 --steps 5 --warmup 2 $B > $out/prof_if1.log 2>&1

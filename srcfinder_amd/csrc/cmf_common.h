@@ -215,6 +215,13 @@ size_t sf_cov4_scratch_bytes(const SfGeom &g);
 int sf_launch_cov4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const SfGeom &g,
                    double *cov, void *scratch, hipStream_t st);
 int sf_launch_wfrag4(const double *evec, const double *d, const SfGeom &g, size_t wstride, double *wfrag, hipStream_t st);
+// k_sweep4s for the windows of 21 / 24 band groups: their own translation units (cmf_loocv4_21.hip, cmf_loocv4_24.hip)
+int sf_launch_sweep4s_21(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *ufrag,
+                         const double *wfrag2, const int32_t *lrok, const double *lam, const double *wfrag, size_t wstride,
+                         const int32_t *status, const double *alphas, const SfGeom &g, int nsplit, double *part, hipStream_t st);
+int sf_launch_sweep4s_24(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *ufrag,
+                         const double *wfrag2, const int32_t *lrok, const double *lam, const double *wfrag, size_t wstride,
+                         const int32_t *status, const double *alphas, const SfGeom &g, int nsplit, double *part, hipStream_t st);
 int sf_launch_sweep4(const float *xt, const uint8_t *mask_t, const int32_t *nuse, const double *mu, const double *lam,
                      const double *wfrag, size_t wstride, const int32_t *status, const double *alphas, const SfGeom &g,
                      int nsplit, double *part, int variant, void *lr_scratch, hipStream_t st,

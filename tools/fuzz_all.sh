@@ -15,6 +15,7 @@ run tools/fuzz_looshrinkage.py 80 703
 run tools/fuzz_wide_full.py 8 704
 run tools/fuzz_multimodal.py 40 705
 run tools/fuzz_parity.py 50 706 mid
+run tools/fuzz_parity.py 12 708 fact
 run tools/fuzz_triage.py 707
 run tools/fuzz_cnn.py
 cat $out

@@ -14,9 +14,10 @@ from oracle import cmf_oracle as O
 lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
 
 
-def run(ncase=60, seed=0, WIDE=False, verbose=True, MID=False):
+def run(ncase=60, seed=0, WIDE=False, verbose=True, MID=False, FACT=False):
     """Returns the number of mismatching cases (stops at the first).  WIDE: windows of 97..200 bands (the batched-GEMM /
-    blocked-Jacobi path).  MID: windows of 73..96 bands (the 21- and 24-group 4x4x4 kernels: CO2 and its neighbours)."""
+    blocked-Jacobi path).  MID: windows of 73..96 bands (the 21- and 24-group 4x4x4 kernels: CO2 and its neighbours).
+    FACT: windows of 257..432 bands (k_wsweep8 with the rank-factored second product, or unfactored where the spectrum refuses)."""
     rng = np.random.default_rng(seed)
     t0 = time.time()
     stats = {}
@@ -27,11 +28,15 @@ def run(ncase=60, seed=0, WIDE=False, verbose=True, MID=False):
         if MID:
             p = int(rng.integers(73, 97))
             samples = int(rng.choice([1, 2, 5, 17, 64, 65, 75]))
+        if FACT:
+            p = int(rng.choice([257, 300, 350, 416, 420, 425]))
+            samples = int(rng.choice([1, 2, 3]))
+            lines = int(rng.choice([p + 40, 1200, 2500]))
         if WIDE:
             p = int(rng.choice([97, 100, 112, 128, 129, 160, 200]))
             samples = int(rng.choice([1, 3, 9]))
             lines = int(rng.choice([100, 257, 500, 900]))
-        a0 = int(rng.integers(1, 425 - p + 1))
+        a0 = int(rng.integers(1, 425 - p + 2))
         a0 = min(a0, 350) if p == 72 and rng.random() < 0.5 else a0
         active = (a0, a0 + p - 1)
         refl = bool(rng.random() < 0.2)
@@ -118,4 +123,5 @@ def run(ncase=60, seed=0, WIDE=False, verbose=True, MID=False):
 
 if __name__ == "__main__":
     sys.exit(run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
-                 len(sys.argv) > 3 and sys.argv[3] == "wide", MID=len(sys.argv) > 3 and sys.argv[3] == "mid"))
+                 len(sys.argv) > 3 and sys.argv[3] == "wide", MID=len(sys.argv) > 3 and sys.argv[3] == "mid",
+                 FACT=len(sys.argv) > 3 and sys.argv[3] == "fact"))

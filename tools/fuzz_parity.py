@@ -31,7 +31,7 @@ def run(ncase=60, seed=0, WIDE=False, verbose=True, MID=False, FACT=False):
         if FACT:
             p = int(rng.choice([257, 300, 350, 416, 420, 425]))
             samples = int(rng.choice([1, 2, 3]))
-            lines = int(rng.choice([p + 40, 1200, 2500]))
+            lines = int(rng.choice([p + 40, 1200, 2500, 6000]))      # (6000 lines: the noise cluster is narrow enough to be factored)
         if WIDE:
             p = int(rng.choice([97, 100, 112, 128, 129, 160, 200]))
             samples = int(rng.choice([1, 3, 9]))

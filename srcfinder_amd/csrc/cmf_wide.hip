@@ -1124,6 +1124,10 @@ static int wide_stats_fused(const void *xt, int xt_f64, const uint8_t *mask_t, c
       return rc;
     if (int rc = wide_chol(gv0, p, p2, ngr * gb, fl0, st, gb, (size_t)gb * per)) return rc;
   }
+  // (phased route: ONE covariance launch over all columns instead of one per group -- fewer partly filled last rounds of the
+  //  chip's 512 workgroup slots: 70.0 -> 68.4 ms a flightline, same bits)
+  if (phase == 1)
+    if (int rc = sf_launch_wsyrk(xt, xt_f64, mask_t, nuse, mu, g, 0, g.ncols, cov, st)) return rc;
   for (int gi = 0; gi < ngr; ++gi) {
     const int c0 = gi * gb, nb = (g.ncols - c0 < gb) ? g.ncols - c0 : gb;
     char *gbase = base + (size_t)gi * gb * per;
@@ -1141,7 +1145,7 @@ static int wide_stats_fused(const void *xt, int xt_f64, const uint8_t *mask_t, c
     const WidePre pre{Lc, Bw, small, flags + 4 * gb};
     // gv of matrix i must sit at gv + i * 2 p2^2 (the eigensolver kernels index it that way): gv_b may be padded, so the
     // group's gv block is addressed densely and simply has to fit
-    if (phase != 2)
+    if (phase == 0)
       if (int rc = sf_launch_wsyrk(xt, xt_f64, mask_t, nuse, mu, g, c0, nb, cov, st)) return rc;
     if (!target) {
       if (phase == 1 && nb < gb) {   // (the all-groups launches walk gb slots per group: the unused ones of a short group are flagged)

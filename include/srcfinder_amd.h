@@ -334,6 +334,25 @@ int sf_cnn_wino_weights(const float *w, int Cout, int Cin, float *U, void *strea
 int sf_cnn_conv3x3_wino(const float *in, int N, int H, int W, int Cin, int ld_in, const float *U, const float *bias, int Cout,
                         float *out, int ld_out, int ch_off, void *stream);
 
+/* The same float32 convolutions by OPERAND SPLITTING on the float16 matrix cores (csrc/cnn_split.hip): a = a_hi + a_lo (two fp16
+ * halves = 22 mantissa bits), a w = a_hi w_hi + a_hi w_lo + a_lo w_hi as three fp16 MFMAs with float32 accumulation.  Same
+ * tolerance class as sf_cnn_conv (errors against float64 of a few 1e-7 relative, as the fp32 kernel's; the reference goldens at
+ * 1e-4) at 1.5-2.6 x its speed -- NOT the fp16-storage option (sf_cnn_*_f16).  sf_cnn_split_weights: folded weights
+ * w[Cout][K = k*k*Cin] -> hi[Cout*K], lo[Cout*K] (float16) of w 2^e(co) and wscale[Cout] = 2^-e(co) (a power of two per output
+ * channel that keeps the low halves normal; once per weight upload).  sf_cnn_conv_split / sf_cnn_conv_split3_split: arguments
+ * as sf_cnn_conv / sf_cnn_conv_split3 with (hi, lo, wscale) in place of w and ascale, a power of two the activations are
+ * multiplied by on their way in (1).  An activation with |a ascale| >= 65504 has no float16: the launch raises a device flag,
+ * sf_cnn_split_overflow(&flag, reset, stream) reads (and clears) it after synchronising the stream -- the caller then repeats the
+ * work with sf_cnn_conv.  BasicConv2d / Inception -- googlenet1.py:184-228, :266-275. */
+int sf_cnn_split_weights(const float *w, int Cout, int K, void *hi, void *lo, float *wscale, void *stream);
+int sf_cnn_conv_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
+                      const float *wscale, const float *bias, int Cout, int ksize, float ascale, float *out, int ld_out, int ch_off,
+                      void *stream);
+int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
+                             const float *wscale, const float *bias, int c0, int c1, int c2, float ascale, float *out0, int ld0,
+                             int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, void *stream);
+int sf_cnn_split_overflow(int *flag, int reset, void *stream);
+
 /* Inception branch 4 (googlenet1.py:213-214) in one call: MaxPool2d(3, stride 1, pad 1, ceil_mode) into pooled_scratch
  * (N*H*W*Cin floats), then the 1x1 BasicConv2d.  `in` is dense ([N][H][W][Cin]) and NON-NEGATIVE (a concatenation of
  * ReLU outputs, as every inception input is): the pool kernel relies on 0 being the identity of max.  (A form that takes the pool inside

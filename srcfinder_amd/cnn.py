@@ -155,6 +155,7 @@ class GoogLeNetHIP(object):
         self.w = {}
         self.wino = {}            # name -> U [16][Cout][Cin]: the 3 x 3 layers' Winograd-domain weights (fp32 path; csrc/cnn_wino.hip)
         self.winograd = True      # False: every 3 x 3 convolution through the direct implicit-GEMM kernel (the tests' cross-check)
+        self.split = {}           # name -> (hi, lo, scale): fp16 halves of the folded weights for the split-operand kernels (csrc/cnn_split.hip)
         self._bufs = {}
         if state_dict is not None:
             self.load_state_dict(state_dict)
@@ -195,6 +196,23 @@ class GoogLeNetHIP(object):
             ws = [self.w[name + s_][0] for s_ in (".branch1", ".branch2.0", ".branch3.0")]
             bs = [self.w[name + s_][1] for s_ in (".branch1", ".branch2.0", ".branch3.0")]
             self.w[name + ".head3"] = (torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous())
+        self.split = {}
+        if not self.half:
+            # every convolution but conv1 and the pool-projections runs by operand splitting on the fp16 matrix cores (the default;
+            # sf_debug_set(17, 4): Winograd / fp32 matrix cores, 2: the direct fp32 kernel): hi | lo halves + per-channel scales
+            L = _ffi.lib()
+            with torch.cuda.device(self.device):
+                for name in self.w:
+                    if name == "conv1" or name.endswith(".branch4.1") or name.endswith(".branch1") or name.endswith(".0"):
+                        continue
+                    w, _b = self.w[name]
+                    cout, K = w.shape[0], w.shape[1] * w.shape[2]
+                    hi = torch.empty(cout * K, dtype=torch.float16, device=self.device)
+                    lo = torch.empty_like(hi)
+                    sc = torch.empty(cout, dtype=torch.float32, device=self.device)
+                    _ffi.check(L.sf_cnn_split_weights(_ffi.ptr(w), cout, K, _ffi.ptr(hi), _ffi.ptr(lo), _ffi.ptr(sc), _ffi.stream_ptr()),
+                               "sf_cnn_split_weights(%s)" % name)
+                    self.split[name] = (hi, lo, sc)
         self.fcw = torch.as_tensor(np.ascontiguousarray(npy(sd["fc.weight"]), dtype=np.float32)).to(self.device)
         self.fcb = torch.as_tensor(np.ascontiguousarray(npy(sd["fc.bias"]), dtype=np.float32)).to(self.device)
         if self.fcw.shape != (2, 1024):
@@ -237,7 +255,14 @@ class GoogLeNetHIP(object):
         N, H, W, ldi = x.shape
         cout, taps, cin = w.shape
         k = 3 if taps == 9 else 1
-        if k == 3 and self.winograd and name in self.wino and L.sf_cnn_wino_ok(H, W, cin) and _knob(17) != 2:
+        mode = _knob(17)
+        if mode == 0 and name in self.split:
+            hi, lo, sc = self.split[name]
+            _ffi.check(L.sf_cnn_conv_split(_ffi.ptr(x), N, H, W, cin, ldi, _ffi.ptr(hi), _ffi.ptr(lo), _ffi.ptr(sc), _ffi.ptr(b), cout, k,
+                                           C.c_float(1.0), _ffi.ptr(out), out.shape[3], ch_off, _ffi.stream_ptr()),
+                       "sf_cnn_conv_split(%s)" % name)
+            return
+        if k == 3 and self.winograd and name in self.wino and L.sf_cnn_wino_ok(H, W, cin) and mode == 4:
             _ffi.check(L.sf_cnn_conv3x3_wino(_ffi.ptr(x), N, H, W, cin, ldi, _ffi.ptr(self.wino[name]), _ffi.ptr(b), cout,
                                              _ffi.ptr(out), out.shape[3], ch_off, _ffi.stream_ptr()), "sf_cnn_conv3x3_wino(%s)" % name)
             return
@@ -261,10 +286,17 @@ class GoogLeNetHIP(object):
         t2 = self._buf("t2", (N, H, W, c3r))
         t3 = self._buf("t3", (N, H, W, c5r))
         w3, b3 = self.w[name + ".head3"]            # branch1 | branch2[0] | branch3[0] in one GEMM
-        fn = getattr(_ffi.lib(), "sf_cnn_conv_split3" + self.sfx)
-        _ffi.check(fn(_ffi.ptr(x), N, H, W, cin, x.shape[3], _ffi.ptr(w3), _ffi.ptr(b3), c1, c3r, c5r, _ffi.ptr(y),
-                      y.shape[3], 0, _ffi.ptr(t2), c3r, 0, _ffi.ptr(t3), c5r, 0, _ffi.stream_ptr()),
-                   "sf_cnn_conv_split3(%s)" % name)
+        if not self.half and _knob(17) == 0 and (name + ".head3") in self.split:
+            hi, lo, sc = self.split[name + ".head3"]
+            _ffi.check(_ffi.lib().sf_cnn_conv_split3_split(_ffi.ptr(x), N, H, W, cin, x.shape[3], _ffi.ptr(hi), _ffi.ptr(lo), _ffi.ptr(sc),
+                                                           _ffi.ptr(b3), c1, c3r, c5r, C.c_float(1.0), _ffi.ptr(y), y.shape[3], 0,
+                                                           _ffi.ptr(t2), c3r, 0, _ffi.ptr(t3), c5r, 0, _ffi.stream_ptr()),
+                       "sf_cnn_conv_split3_split(%s)" % name)
+        else:
+            fn = getattr(_ffi.lib(), "sf_cnn_conv_split3" + self.sfx)
+            _ffi.check(fn(_ffi.ptr(x), N, H, W, cin, x.shape[3], _ffi.ptr(w3), _ffi.ptr(b3), c1, c3r, c5r, _ffi.ptr(y),
+                          y.shape[3], 0, _ffi.ptr(t2), c3r, 0, _ffi.ptr(t3), c5r, 0, _ffi.stream_ptr()),
+                       "sf_cnn_conv_split3(%s)" % name)
         self._conv(t2, name + ".branch2.1", y, c1)
         self._conv(t3, name + ".branch3.1", y, c1 + c3)
         if self.sfx or x.shape[3] != cin:           # fp16 path / strided input: pool, then convolve
@@ -400,6 +432,23 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
             n = min(batch, i1 - t0)
             net.forward_tiles(ds.x, W, t0, n, plane=ds.plane, out=out)
     out = out.view(H, W)
+    if not net.half and _knob(17) == 0:
+        # the split-operand kernels carry the activations in float16 halves: one at or beyond 65504 raises a flag and the rows are
+        # scored again on the fp32 matrix cores (Winograd / implicit GEMM) -- never a silently wrong map
+        L = _ffi.lib()
+        flag = C.c_int(0)
+        with torch.cuda.device(net.device):
+            _ffi.check(L.sf_cnn_split_overflow(C.byref(flag), 1, _ffi.stream_ptr()), "sf_cnn_split_overflow")
+        if flag.value:
+            import warnings
+            warnings.warn("srcfinder_amd.cnn: an activation exceeded the float16 range of the split-operand kernels; "
+                          "rows %d..%d are scored again on the fp32 matrix cores" % (r0, r1))
+            L.sf_debug_set(17, 4)
+            try:
+                return predict_flightline(cmf2d, model, weights=weights, batch=batch, rows=rows, net=net, to_numpy=to_numpy,
+                                          precision=precision)
+            finally:
+                L.sf_debug_set(17, 0)
     return out.cpu().numpy() if to_numpy else out
 
 
@@ -481,4 +530,17 @@ def fcn_predict_flightline(cmf2d, model="COVID_QC", weights=None, scale=32, batc
             pred = net.forward_fcn(canvas[:n])
             _ffi.check(L.sf_cnn_fcn_stitch(_ffi.ptr(pred), n, a, scale, pred.shape[1], pred.shape[2], _ffi.ptr(plane), H, W,
                                            NODATA, _ffi.ptr(out), st), "sf_cnn_fcn_stitch")
+        if not net.half and _knob(17) == 0:          # the split-operand kernels' float16 range (see predict_flightline)
+            flag = C.c_int(0)
+            _ffi.check(L.sf_cnn_split_overflow(C.byref(flag), 1, st), "sf_cnn_split_overflow")
+            if flag.value:
+                import warnings
+                warnings.warn("srcfinder_amd.cnn: an activation exceeded the float16 range of the split-operand kernels; "
+                              "the map is computed again on the fp32 matrix cores")
+                L.sf_debug_set(17, 4)
+                try:
+                    return fcn_predict_flightline(cmf2d, model, weights=weights, scale=scale, batch=batch, net=net, to_numpy=to_numpy,
+                                                  precision=precision, shifts=shifts)
+                finally:
+                    L.sf_debug_set(17, 0)
     return out.cpu().numpy() if to_numpy else out

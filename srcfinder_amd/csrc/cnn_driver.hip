@@ -55,6 +55,26 @@ Wino wino_layout() {
   w.total = o;
   return w;
 }
+// Split-operand weights (cnn_split.hip: fp16 hi | lo halves of the folded weights scaled per output channel, + the scales) of every
+// convolution but conv1 and the pool-projections, kept behind the Winograd weights and recomputed by every call (29 tiny launches)
+struct SplitL { size_t h, s; };          // offsets: halves (hi; lo follows at + cout * taps * cin), scale floats
+struct Splits { SplitL conv2, conv3, head3[9], b2[9], b3[9]; size_t halves, scales; };
+Splits split_layout() {
+  Splits S{};
+  size_t oh = 0, os = 0;
+  auto take = [&](SplitL &l, int cout, int taps, int cin) { l.h = oh; oh += 2 * conv_floats(cout, taps, cin); l.s = os; os += cout; };
+  take(S.conv2, 64, 1, 64);
+  take(S.conv3, 192, 9, 64);
+  for (int i = 0; i < 9; ++i) {
+    const Incep &s = INC[i];
+    take(S.head3[i], s.c1 + s.c3r + s.c5r, 1, s.cin);
+    take(S.b2[i], s.c3, 9, s.c3r);
+    take(S.b3[i], s.c5, 9, s.c5r);
+  }
+  S.halves = (oh + 7) / 8 * 8;
+  S.scales = (os + 3) / 4 * 4;      // (the halves behind the scales start on a 16-byte boundary)
+  return S;
+}
 // activation buffers of a batch of n tiles (floats): the largest of each role over the graph
 struct Acts { size_t pool1, conv2, conv3, x, y, t2, t3, pooled, total; };
 Acts acts(size_t n) {
@@ -77,7 +97,8 @@ extern "C" {
 
 size_t sf_cnn_blob_floats(void) { return blob_layout().total; }
 size_t sf_cnn_score_workspace_bytes(int batch) {
-  return batch < 1 ? 0 : sf_align((acts((size_t)batch).total + wino_layout().total) * sizeof(float));
+  const Splits S = split_layout();
+  return batch < 1 ? 0 : sf_align((acts((size_t)batch).total + wino_layout().total + S.scales) * sizeof(float) + S.halves * 2);
 }
 
 int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int r0, int r1, const float *blob, float *out,
@@ -97,18 +118,42 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
         *t2 = xb + A.y, *t3 = t2 + A.t2, *pooled = t3 + A.t3;
   const int Hp = H + 255, Wp = W + 255;
   const long long i0 = (long long)r0 * W, i1 = (long long)r1 * W;
-  int rc;
+  int rc = 0;
 #define W_(l) (blob + (l).w)
 #define B_(l) (blob + (l).b)
-  // the 3 x 3 convolutions run by Winograd F(2 x 2, 3 x 3) where the geometry allows (sf_debug_set(17, 2): the direct kernel)
+  // sf_debug_set(17, .): 0 every convolution but conv1 and the pool-projections by operand splitting on the fp16 matrix cores
+  // (cnn_split.hip; the default), 4 round 5's first form -- the 3 x 3 convolutions by Winograd F(2 x 2, 3 x 3) where the geometry
+  // allows, the rest on the fp32 matrix cores --, 2 the direct fp32 kernel for everything
   const Wino WL = wino_layout();
+  const Splits SL = split_layout();
   float *wino = pooled + A.pooled;
-  const bool use_wino = sf_tune().cnn_conv_variant != 2;
-  auto conv3x3 = [&](const float *in, int n, int hw, int cin, const Layer &l, size_t uoff, int cout, float *o, int ldo, int off) -> int {
+  float *sscale = wino + WL.total;
+  _Float16 *shalf = reinterpret_cast<_Float16 *>(sscale + SL.scales);
+  const int mode = sf_tune().cnn_conv_variant;
+  const bool use_split = mode == 0, use_wino = mode == 4;
+  auto half_lo = [&](const SplitL &sl, int cout, int taps, int cin) { return shalf + sl.h + conv_floats(cout, taps, cin); };
+  auto conv3x3 = [&](const float *in, int n, int hw, int cin, const Layer &l, size_t uoff, const SplitL &sl, int cout, float *o,
+                     int ldo, int off) -> int {
+    if (use_split)
+      return sf_cnn_conv_split(in, n, hw, hw, cin, cin, shalf + sl.h, half_lo(sl, cout, 9, cin), sscale + sl.s, B_(l), cout, 3, 1.0f, o,
+                               ldo, off, stream);
     if (use_wino && sf_cnn_wino_ok(hw, hw, cin))
       return sf_cnn_conv3x3_wino(in, n, hw, hw, cin, cin, wino + uoff, B_(l), cout, o, ldo, off, stream);
     return sf_cnn_conv(in, n, hw, hw, cin, cin, W_(l), B_(l), cout, 3, o, ldo, off, stream);
   };
+  if (use_split && i0 < i1) {
+    auto prep = [&](const Layer &l, const SplitL &sl, int cout, int taps, int cin) {
+      return sf_cnn_split_weights(W_(l), cout, taps * cin, shalf + sl.h, half_lo(sl, cout, taps, cin), sscale + sl.s, stream);
+    };
+    if ((rc = prep(L.conv2, SL.conv2, 64, 1, 64))) return rc;
+    if ((rc = prep(L.conv3, SL.conv3, 192, 9, 64))) return rc;
+    for (int i = 0; i < 9; ++i) {
+      const Incep &s = INC[i];
+      if ((rc = prep(L.head3[i], SL.head3[i], s.c1 + s.c3r + s.c5r, 1, s.cin))) return rc;
+      if ((rc = prep(L.b2[i], SL.b2[i], s.c3, 9, s.c3r))) return rc;
+      if ((rc = prep(L.b3[i], SL.b3[i], s.c5, 9, s.c5r))) return rc;
+    }
+  }
   if (use_wino && i0 < i1) {
     if ((rc = sf_cnn_wino_weights(W_(L.conv3), 192, 64, wino + WL.conv3, stream))) return rc;
     for (int i = 0; i < 9; ++i) {
@@ -120,8 +165,13 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
     const int n = (int)((i1 - tile0 < batch) ? (i1 - tile0) : batch);
     // conv1 + maxpool1 (googlenet1.py:60-61), conv2, conv3, maxpool2 (:62-64)
     if ((rc = sf_cnn_conv1_pool(padded, Hp, Wp, W, tile0, n, W_(L.conv1), B_(L.conv1), pool1, stream))) return rc;
-    if ((rc = sf_cnn_conv(pool1, n, 64, 64, 64, 64, W_(L.conv2), B_(L.conv2), 64, 1, conv2, 64, 0, stream))) return rc;
-    if ((rc = conv3x3(conv2, n, 64, 64, L.conv3, WL.conv3, 192, conv3, 192, 0))) return rc;
+    if (use_split)
+      rc = sf_cnn_conv_split(pool1, n, 64, 64, 64, 64, shalf + SL.conv2.h, half_lo(SL.conv2, 64, 1, 64), sscale + SL.conv2.s,
+                             B_(L.conv2), 64, 1, 1.0f, conv2, 64, 0, stream);
+    else
+      rc = sf_cnn_conv(pool1, n, 64, 64, 64, 64, W_(L.conv2), B_(L.conv2), 64, 1, conv2, 64, 0, stream);
+    if (rc) return rc;
+    if ((rc = conv3x3(conv2, n, 64, 64, L.conv3, WL.conv3, SL.conv3, 192, conv3, 192, 0))) return rc;
     int hw = pool_out(64, 3, 2, 0);
     if ((rc = sf_cnn_maxpool(conv3, n, 64, 64, 192, 3, 2, 0, xa, hw, hw, stream))) return rc;
     float *x = xa, *y = xb;
@@ -130,10 +180,16 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
       const Incep &s = INC[i];
       const int cout = s.c1 + s.c3 + s.c5 + s.pp;
       // branch1 | 3x3 reduce | "5x5" reduce in one GEMM, then the two 3x3 convolutions, the pool branch (:184-228)
-      if ((rc = sf_cnn_conv_split3(x, n, hw, hw, cin, cin, W_(L.head3[i]), B_(L.head3[i]), s.c1, s.c3r, s.c5r, y, cout, 0, t2,
-                                   s.c3r, 0, t3, s.c5r, 0, stream))) return rc;
-      if ((rc = conv3x3(t2, n, hw, s.c3r, L.b2[i], WL.b2[i], s.c3, y, cout, s.c1))) return rc;
-      if ((rc = conv3x3(t3, n, hw, s.c5r, L.b3[i], WL.b3[i], s.c5, y, cout, s.c1 + s.c3))) return rc;
+      if (use_split)
+        rc = sf_cnn_conv_split3_split(x, n, hw, hw, cin, cin, shalf + SL.head3[i].h, half_lo(SL.head3[i], s.c1 + s.c3r + s.c5r, 1, cin),
+                                      sscale + SL.head3[i].s, B_(L.head3[i]), s.c1, s.c3r, s.c5r, 1.0f, y, cout, 0, t2, s.c3r, 0, t3,
+                                      s.c5r, 0, stream);
+      else
+        rc = sf_cnn_conv_split3(x, n, hw, hw, cin, cin, W_(L.head3[i]), B_(L.head3[i]), s.c1, s.c3r, s.c5r, y, cout, 0, t2, s.c3r, 0,
+                                t3, s.c5r, 0, stream);
+      if (rc) return rc;
+      if ((rc = conv3x3(t2, n, hw, s.c3r, L.b2[i], WL.b2[i], SL.b2[i], s.c3, y, cout, s.c1))) return rc;
+      if ((rc = conv3x3(t3, n, hw, s.c5r, L.b3[i], WL.b3[i], SL.b3[i], s.c5, y, cout, s.c1 + s.c3))) return rc;
       if ((rc = sf_cnn_pool_conv(x, n, hw, hw, cin, cin, W_(L.b4[i]), B_(L.b4[i]), s.pp, y, cout, s.c1 + s.c3 + s.c5, pooled, stream))) return rc;
       float *t = x; x = y; y = t;
       cin = cout;

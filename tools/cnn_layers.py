@@ -3,6 +3,7 @@
 k_conv1_pool / k_conv1 and the following k_head, in order, with grid and duration.
    python tools/cnn_layers.py <kernel_trace.csv>"""
 import csv
+import re
 import sys
 
 
@@ -10,6 +11,9 @@ def main(path):
     rows = []
     for r in csv.DictReader(open(path)):
         n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
+        if n.startswith("_Z"):                     # a name the profiler's demangler gave up on (_Float16 parameters): k_name<first int argument>
+            m = re.search(r"\d+(k_[a-z0-9_]+)(?:ILi(\d+))?", n)
+            n = (m.group(1) + ("<%s>" % m.group(2) if m.group(2) else "")) if m else n
         if n.startswith("k_"):
             rows.append((int(r["Start_Timestamp"]), n, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
                          r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Grid_Size_Y", ""), r.get("Workgroup_Size_X", "")))

@@ -343,14 +343,19 @@ int sf_cnn_conv3x3_wino(const float *in, int N, int H, int W, int Cin, int ld_in
  * as sf_cnn_conv / sf_cnn_conv_split3 with (hi, lo, wscale) in place of w and ascale, a power of two the activations are
  * multiplied by on their way in (1).  An activation with |a ascale| >= 65504 has no float16: the launch raises a device flag,
  * sf_cnn_split_overflow(&flag, reset, stream) reads (and clears) it after synchronising the stream -- the caller then repeats the
- * work with sf_cnn_conv.  BasicConv2d / Inception -- googlenet1.py:184-228, :266-275. */
+ * work with sf_cnn_conv.  in_split / out_split / out12_split: the tensor is in the SPLIT FORMAT instead of float32 -- per pixel and
+ * 8-channel group sixteen float16, the eight high halves then the eight low halves, in the bytes of the dense float32 tensor
+ * ([M][C/8][2][8]; C a multiple of 8, ld == C, no channel offset, ascale 1).  A tensor only split-operand convolutions read (conv2's
+ * output, the 3 x 3 reducers' outputs of an Inception block) is written that way by its producer's epilogue and fetched without
+ * conversion by its consumers: the split is done once per value, not once per (value, tap, channel tile).
+ * BasicConv2d / Inception -- googlenet1.py:184-228, :266-275. */
 int sf_cnn_split_weights(const float *w, int Cout, int K, void *hi, void *lo, float *wscale, void *stream);
-int sf_cnn_conv_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
-                      const float *wscale, const float *bias, int Cout, int ksize, float ascale, float *out, int ld_out, int ch_off,
-                      void *stream);
+int sf_cnn_conv_split(const float *in, int in_split, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
+                      const float *wscale, const float *bias, int Cout, int ksize, float ascale, float *out, int out_split, int ld_out,
+                      int ch_off, void *stream);
 int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
                              const float *wscale, const float *bias, int c0, int c1, int c2, float ascale, float *out0, int ld0,
-                             int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, void *stream);
+                             int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, int out12_split, void *stream);
 int sf_cnn_split_overflow(int *flag, int reset, void *stream);
 
 /* Inception branch 4 (googlenet1.py:213-214) in one call: MaxPool2d(3, stride 1, pad 1, ceil_mode) into pooled_scratch

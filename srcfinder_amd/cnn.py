@@ -257,9 +257,13 @@ class GoogLeNetHIP(object):
         k = 3 if taps == 9 else 1
         mode = _knob(17)
         if mode == 0 and name in self.split:
+            # tensors only split-operand convolutions read travel in the split format (csrc/cnn_split.hip): conv2's output, and the
+            # 3 x 3 reducers' outputs that _inception's split3 call leaves in t2 / t3
             hi, lo, sc = self.split[name]
-            _ffi.check(L.sf_cnn_conv_split(_ffi.ptr(x), N, H, W, cin, ldi, _ffi.ptr(hi), _ffi.ptr(lo), _ffi.ptr(sc), _ffi.ptr(b), cout, k,
-                                           C.c_float(1.0), _ffi.ptr(out), out.shape[3], ch_off, _ffi.stream_ptr()),
+            in_split = 1 if (k == 3) else 0
+            out_split = 1 if name == "conv2" else 0
+            _ffi.check(L.sf_cnn_conv_split(_ffi.ptr(x), in_split, N, H, W, cin, ldi, _ffi.ptr(hi), _ffi.ptr(lo), _ffi.ptr(sc), _ffi.ptr(b),
+                                           cout, k, C.c_float(1.0), _ffi.ptr(out), out_split, out.shape[3], ch_off, _ffi.stream_ptr()),
                        "sf_cnn_conv_split(%s)" % name)
             return
         if k == 3 and self.winograd and name in self.wino and L.sf_cnn_wino_ok(H, W, cin) and mode == 4:
@@ -290,7 +294,7 @@ class GoogLeNetHIP(object):
             hi, lo, sc = self.split[name + ".head3"]
             _ffi.check(_ffi.lib().sf_cnn_conv_split3_split(_ffi.ptr(x), N, H, W, cin, x.shape[3], _ffi.ptr(hi), _ffi.ptr(lo), _ffi.ptr(sc),
                                                            _ffi.ptr(b3), c1, c3r, c5r, C.c_float(1.0), _ffi.ptr(y), y.shape[3], 0,
-                                                           _ffi.ptr(t2), c3r, 0, _ffi.ptr(t3), c5r, 0, _ffi.stream_ptr()),
+                                                           _ffi.ptr(t2), c3r, 0, _ffi.ptr(t3), c5r, 0, 1, _ffi.stream_ptr()),
                        "sf_cnn_conv_split3_split(%s)" % name)
         else:
             fn = getattr(_ffi.lib(), "sf_cnn_conv_split3" + self.sfx)

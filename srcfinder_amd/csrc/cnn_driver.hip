@@ -134,9 +134,9 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
   auto half_lo = [&](const SplitL &sl, int cout, int taps, int cin) { return shalf + sl.h + conv_floats(cout, taps, cin); };
   auto conv3x3 = [&](const float *in, int n, int hw, int cin, const Layer &l, size_t uoff, const SplitL &sl, int cout, float *o,
                      int ldo, int off) -> int {
-    if (use_split)
-      return sf_cnn_conv_split(in, n, hw, hw, cin, cin, shalf + sl.h, half_lo(sl, cout, 9, cin), sscale + sl.s, B_(l), cout, 3, 1.0f, o,
-                               ldo, off, stream);
+    if (use_split)      // (its input -- conv2's output, a 3 x 3 reducer's -- arrives in the split format)
+      return sf_cnn_conv_split(in, 1, n, hw, hw, cin, cin, shalf + sl.h, half_lo(sl, cout, 9, cin), sscale + sl.s, B_(l), cout, 3, 1.0f,
+                               o, 0, ldo, off, stream);
     if (use_wino && sf_cnn_wino_ok(hw, hw, cin))
       return sf_cnn_conv3x3_wino(in, n, hw, hw, cin, cin, wino + uoff, B_(l), cout, o, ldo, off, stream);
     return sf_cnn_conv(in, n, hw, hw, cin, cin, W_(l), B_(l), cout, 3, o, ldo, off, stream);
@@ -166,8 +166,8 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
     // conv1 + maxpool1 (googlenet1.py:60-61), conv2, conv3, maxpool2 (:62-64)
     if ((rc = sf_cnn_conv1_pool(padded, Hp, Wp, W, tile0, n, W_(L.conv1), B_(L.conv1), pool1, stream))) return rc;
     if (use_split)
-      rc = sf_cnn_conv_split(pool1, n, 64, 64, 64, 64, shalf + SL.conv2.h, half_lo(SL.conv2, 64, 1, 64), sscale + SL.conv2.s,
-                             B_(L.conv2), 64, 1, 1.0f, conv2, 64, 0, stream);
+      rc = sf_cnn_conv_split(pool1, 0, n, 64, 64, 64, 64, shalf + SL.conv2.h, half_lo(SL.conv2, 64, 1, 64), sscale + SL.conv2.s,
+                             B_(L.conv2), 64, 1, 1.0f, conv2, 1, 64, 0, stream);
     else
       rc = sf_cnn_conv(pool1, n, 64, 64, 64, 64, W_(L.conv2), B_(L.conv2), 64, 1, conv2, 64, 0, stream);
     if (rc) return rc;
@@ -183,7 +183,7 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
       if (use_split)
         rc = sf_cnn_conv_split3_split(x, n, hw, hw, cin, cin, shalf + SL.head3[i].h, half_lo(SL.head3[i], s.c1 + s.c3r + s.c5r, 1, cin),
                                       sscale + SL.head3[i].s, B_(L.head3[i]), s.c1, s.c3r, s.c5r, 1.0f, y, cout, 0, t2, s.c3r, 0, t3,
-                                      s.c5r, 0, stream);
+                                      s.c5r, 0, 1, stream);
       else
         rc = sf_cnn_conv_split3(x, n, hw, hw, cin, cin, W_(L.head3[i]), B_(L.head3[i]), s.c1, s.c3r, s.c5r, y, cout, 0, t2, s.c3r, 0,
                                 t3, s.c5r, 0, stream);

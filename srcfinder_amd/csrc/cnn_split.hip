@@ -32,7 +32,14 @@ constexpr int SP_LD = 40;   // halves per LDS row (32 + 8 pad = 80 bytes)
 struct ConvDstS {
   float *p[3];
   int ld[3], off[3], end[3];
+  int fmt[3];      // 0: float32 [pixel][channel]; 1: the split format below (dense tensors: ld == the segment's channels, off == 0)
 };
+// The SPLIT FORMAT of an activation tensor [M][C], C a multiple of 8: per pixel and 8-channel group 16 halves -- the eight high halves,
+// then the eight low halves -- i.e. [M][C / 8][2][8] float16 in the bytes of the [M][C] float32 tensor, the group of channel c at the
+// byte offset of float32 channel 8 (c / 8).  A convolution whose only consumers are split-operand convolutions (the 3 x 3 reducers'
+// outputs, conv2) writes it from its epilogue, and the consumer's tile fetch -- the same addresses as for float32 -- lands the two
+// halves ready for LDS: the split, a third of a chunk's time in the kernel below, is done once per value instead of once per
+// (value, tap, channel tile).
 
 // hi / lo halves of eight floats (scaled by s); big: the largest magnitude seen (float16 ends at 65504)
 __device__ __forceinline__ void sp_split8(const sp_f4 &x0, const sp_f4 &x1, float s, sp_h8 &hi, sp_h8 &lo, float &big) {
@@ -49,7 +56,7 @@ __device__ __forceinline__ void sp_split8(const sp_f4 &x0, const sp_f4 &x1, floa
 // (A form with two LDS sets and two register sets -- loads two chunks ahead, one barrier per chunk -- needed 306 registers, ran one
 //  workgroup per CU and was 1.7 x SLOWER: what hides the trips to L2 here is three workgroups per CU, not a deeper pipeline.)
 __device__ int g_sp_overflow;
-template <int BN>
+template <int BN, bool ASPLIT = false>      // ASPLIT: the input is in the split format
 __global__ __launch_bounds__(256) void k_conv_split(const float *__restrict__ in, int M, int H, int W, int Cin, int ld_in,
                                                     const _Float16 *__restrict__ whi, const _Float16 *__restrict__ wlo,
                                                     const float *__restrict__ wscale, const float *__restrict__ bias, int Cout,
@@ -66,7 +73,15 @@ __global__ __launch_bounds__(256) void k_conv_split(const float *__restrict__ in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int q = tid & 3, ri = tid >> 2;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware order: workgroup id -> (XCD = id & 7, slot = id >> 3); an XCD walks ITS contiguous eighth of the pixel tiles with the
+  // channel tiles of a pixel tile in consecutive slots, so the activations a pixel tile fetches -- once per channel tile and tap,
+  // and the rows above / below are its neighbours' -- come from that XCD's L2 after the first touch (the kernel is bound by
+  // exactly this traffic: 128 -> 192 channels at 32 x 32 re-reads its 268 MB input 27 times)
+  const int MT = (M + BM - 1) / BM, NT = (Cout + BN - 1) / BN, per = (MT + 7) / 8;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int mt = xcd * per + slot / NT, nt_ = slot - (slot / NT) * NT;
+  if (mt >= MT || slot / NT >= per) return;
+  const int m0 = mt * BM, n0 = nt_ * BN;
   const int pad = ks >> 1, taps = ks * ks, nchunk = (Cin + BK - 1) / BK, nit = taps * nchunk;
 
   constexpr unsigned OOB = 0x80000000u;
@@ -137,10 +152,15 @@ __global__ __launch_bounds__(256) void k_conv_split(const float *__restrict__ in
     _Float16 *Ah = sm + S * SETH, *Al = Ah + BM * SP_LD, *Bh = Al + BM * SP_LD, *Bl = Bh + BN * SP_LD;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      sp_h8 hi, lo;
-      sp_split8(ra[S][a][0], ra[S][a][1], ascale, hi, lo, big);
-      *reinterpret_cast<sp_h8 *>(Ah + (ri + 64 * a) * SP_LD + 8 * q) = hi;
-      *reinterpret_cast<sp_h8 *>(Al + (ri + 64 * a) * SP_LD + 8 * q) = lo;
+      if constexpr (ASPLIT) {
+        *reinterpret_cast<sp_f4 *>(Ah + (ri + 64 * a) * SP_LD + 8 * q) = ra[S][a][0];
+        *reinterpret_cast<sp_f4 *>(Al + (ri + 64 * a) * SP_LD + 8 * q) = ra[S][a][1];
+      } else {
+        sp_h8 hi, lo;
+        sp_split8(ra[S][a][0], ra[S][a][1], ascale, hi, lo, big);
+        *reinterpret_cast<sp_h8 *>(Ah + (ri + 64 * a) * SP_LD + 8 * q) = hi;
+        *reinterpret_cast<sp_h8 *>(Al + (ri + 64 * a) * SP_LD + 8 * q) = lo;
+      }
     }
 #pragma unroll
     for (int b = 0; b < NPB; ++b) {
@@ -189,7 +209,6 @@ __global__ __launch_bounds__(256) void k_conv_split(const float *__restrict__ in
       __syncthreads();
     }
   }
-  if (!(big < 65504.f)) g_sp_overflow = 1;      // (every writer stores 1)
   // epilogue: acc[r] = D[row = (r&3) + 8(r>>2) + 4(lane>>5)][col = lane&31]; unscale (powers of two), bias, ReLU
   const float ia = 1.0f / ascale;
 #pragma unroll
@@ -201,15 +220,34 @@ __global__ __launch_bounds__(256) void k_conv_split(const float *__restrict__ in
       const int cbase = (sg == 0) ? 0 : dst.end[sg - 1];
       float *op = dst.p[sg] + dst.off[sg] + (co - cbase);
       const int ld = dst.ld[sg];
+      if (dst.fmt[sg]) {      // split format: halves (m 2 ld + 16 (c / 8) + c % 8) and + 8
+        const int cl = co - cbase;
+        _Float16 *hp = reinterpret_cast<_Float16 *>(dst.p[sg]) + 16 * (cl >> 3) + (cl & 7);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < M) op[(size_t)m * ld] = fmaxf(__builtin_fmaf(acc[i][j][r], sc, bb), 0.f);
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float v = fmaxf(__builtin_fmaf(acc[i][j][r], sc, bb), 0.f);
+            const _Float16 h = (_Float16)v;
+            big = fmaxf(big, v);
+            if (m < M) {
+              hp[(size_t)m * 2 * ld] = h;
+              hp[(size_t)m * 2 * ld + 8] = (_Float16)(v - (float)h);
+            }
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < M) op[(size_t)m * ld] = fmaxf(__builtin_fmaf(acc[i][j][r], sc, bb), 0.f);
+          }
+      }
     }
   }
+  if (!(big < 65504.f)) g_sp_overflow = 1;      // (every writer stores 1; NaN counts)
 }
 
 // per output channel: e = the power of two that puts max |w| into [2^12, 2^13); hi / lo halves of w 2^e; wscale = 2^-e
@@ -245,10 +283,13 @@ __global__ void k_split_weights(const float *__restrict__ w, int Cout, int K, _F
 }
 
 template <int BN>
-int launch_split(const float *in, int M, int H, int W, int Cin, int ld_in, const _Float16 *whi, const _Float16 *wlo,
+int launch_split(const float *in, int in_split, int M, int H, int W, int Cin, int ld_in, const _Float16 *whi, const _Float16 *wlo,
                  const float *wscale, const float *bias, int Cout, int ks, float ascale, const ConvDstS &dst, hipStream_t st) {
-  dim3 grid(sf_cdiv(M, 128), sf_cdiv(Cout, BN));
-  hipLaunchKernelGGL((k_conv_split<BN>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst);
+  dim3 grid(8 * sf_cdiv(sf_cdiv(M, 128), 8) * sf_cdiv(Cout, BN));
+  if (in_split)
+    hipLaunchKernelGGL((k_conv_split<BN, true>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst);
+  else
+    hipLaunchKernelGGL((k_conv_split<BN, false>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst);
   SF_LAUNCH_CHECK("k_conv_split");
   return 0;
 }
@@ -265,7 +306,7 @@ int sf_cnn_split_weights(const float *w, int Cout, int K, void *hi, void *lo, fl
   return 0;
 }
 
-static int split_go(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo, const float *wscale,
+static int split_go(const float *in, int in_split, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo, const float *wscale,
                     const float *bias, int Cout, int ksize, float ascale, const ConvDstS &d, hipStream_t st) {
   const long long Ml = (long long)N * H * W;
   const size_t halo = 2 * ((size_t)(ksize >> 1) * W + (ksize >> 1)) * ld_in * 4 + 64, img = (size_t)H * W * ld_in * 4;
@@ -279,7 +320,7 @@ static int split_go(const float *in, int N, int H, int W, int Cin, int ld_in, co
       const int nn = (N - n0 < per) ? N - n0 : per;
       ConvDstS dd = d;
       for (int k = 0; k < 3; ++k) dd.p[k] = d.p[k] + (size_t)n0 * H * W * d.ld[k];
-      if (int rc = split_go(in + (size_t)n0 * H * W * ld_in, nn, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, dd, st))
+      if (int rc = split_go(in + (size_t)n0 * H * W * ld_in, in_split, nn, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, dd, st))
         return rc;
     }
     return 0;
@@ -289,16 +330,17 @@ static int split_go(const float *in, int N, int H, int W, int Cin, int ld_in, co
   // windows/s against 43.2-43.7 k in alternating runs; 192 / 256-channel tiles need 228 / 270 registers, run two / one workgroup
   // per CU instead of three and were slower still: what hides this kernel's trips to L2 is occupancy.)
   if (Cout > 64 && sf_cdiv(Cout, 128) * 128 <= sf_cdiv(Cout, 64) * 64)
-    return launch_split<128>(in, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
-  return launch_split<64>(in, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
+    return launch_split<128>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
+  return launch_split<64>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
 }
 
-int sf_cnn_conv_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
-                      const float *wscale, const float *bias, int Cout, int ksize, float ascale, float *out, int ld_out, int ch_off,
-                      void *stream) {
+int sf_cnn_conv_split(const float *in, int in_split, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
+                      const float *wscale, const float *bias, int Cout, int ksize, float ascale, float *out, int out_split, int ld_out,
+                      int ch_off, void *stream) {
   if (!in || !whi || !wlo || !wscale || !bias || !out || N < 1 || (ksize != 1 && ksize != 3) || (Cin & 7) || (ld_in & 3) ||
-      Cin > ld_in || ch_off < 0 || ch_off + Cout > ld_out || !(ascale > 0.f)) {
-    sf_set_error("sf_cnn_conv_split: bad argument (ksize 1|3, Cin multiple of 8)");
+      Cin > ld_in || ch_off < 0 || ch_off + Cout > ld_out || !(ascale > 0.f) || (in_split && (ld_in != Cin || ascale != 1.0f)) ||
+      (out_split && (ld_out != Cout || ch_off != 0 || (Cout & 7)))) {
+    sf_set_error("sf_cnn_conv_split: bad argument (ksize 1|3, Cin multiple of 8; split-format tensors are dense, ascale 1)");
     return -1;
   }
   ConvDstS d{};
@@ -306,14 +348,16 @@ int sf_cnn_conv_split(const float *in, int N, int H, int W, int Cin, int ld_in, 
   d.ld[0] = d.ld[1] = d.ld[2] = ld_out;
   d.off[0] = d.off[1] = d.off[2] = ch_off;
   d.end[0] = d.end[1] = d.end[2] = Cout;
-  return split_go(in, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, d, (hipStream_t)stream);
+  d.fmt[0] = d.fmt[1] = d.fmt[2] = out_split ? 1 : 0;
+  return split_go(in, in_split, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, d, (hipStream_t)stream);
 }
 
 int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
                              const float *wscale, const float *bias, int c0, int c1, int c2, float ascale, float *out0, int ld0,
-                             int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, void *stream) {
+                             int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, int out12_split, void *stream) {
   if (!in || !whi || !wlo || !wscale || !bias || !out0 || !out1 || !out2 || N < 1 || (Cin & 7) || (ld_in & 3) || Cin > ld_in ||
-      c0 < 1 || c1 < 1 || c2 < 1 || off0 + c0 > ld0 || off1 + c1 > ld1 || off2 + c2 > ld2 || !(ascale > 0.f)) {
+      c0 < 1 || c1 < 1 || c2 < 1 || off0 + c0 > ld0 || off1 + c1 > ld1 || off2 + c2 > ld2 || !(ascale > 0.f) ||
+      (out12_split && (ld1 != c1 || off1 != 0 || (c1 & 7) || ld2 != c2 || off2 != 0 || (c2 & 7)))) {
     sf_set_error("sf_cnn_conv_split3_split: bad argument");
     return -1;
   }
@@ -322,7 +366,8 @@ int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int 
   d.ld[0] = ld0; d.ld[1] = ld1; d.ld[2] = ld2;
   d.off[0] = off0; d.off[1] = off1; d.off[2] = off2;
   d.end[0] = c0; d.end[1] = c0 + c1; d.end[2] = c0 + c1 + c2;
-  return split_go(in, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, c0 + c1 + c2, 1, ascale, d, (hipStream_t)stream);
+  d.fmt[0] = 0; d.fmt[1] = d.fmt[2] = out12_split ? 1 : 0;
+  return split_go(in, 0, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, c0 + c1 + c2, 1, ascale, d, (hipStream_t)stream);
 }
 
 // 1 when a launch since the last reset met an activation float16 cannot hold (the caller repeats the work on the fp32 kernels)

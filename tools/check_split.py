@@ -10,7 +10,7 @@ L = _ffi.lib()
 raw = C.CDLL(os.path.join(ROOT, "srcfinder_amd", "libsrcfinder_amd.so"))
 vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
 raw.sf_cnn_split_weights.argtypes = [vp, i32, i32, vp, vp, vp, vp]
-raw.sf_cnn_conv_split.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, f32, vp, i32, i32, vp]
+raw.sf_cnn_conv_split.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, f32, vp, i32, i32, i32, vp]
 P, st = _ffi.ptr, _ffi.stream_ptr
 for kv in sys.argv[1:]:
     k, v = kv.split("="); L.sf_debug_set(int(k), int(v))
@@ -26,7 +26,7 @@ def layer(N, H, Cin, Cout, ks, timeit=True):
     sc = torch.empty(Cout, dtype=torch.float32, device=dev)
     assert raw.sf_cnn_split_weights(P(w), Cout, K, P(hi), P(lo), P(sc), st()) == 0
     o_sp = torch.empty(N, H, H, Cout, dtype=torch.float32, device=dev); o_d = torch.empty_like(o_sp)
-    run_sp = lambda: raw.sf_cnn_conv_split(P(x), N, H, H, Cin, Cin, P(hi), P(lo), P(sc), P(b), Cout, ks, 1.0, P(o_sp), Cout, 0, st())
+    run_sp = lambda: raw.sf_cnn_conv_split(P(x), 0, N, H, H, Cin, Cin, P(hi), P(lo), P(sc), P(b), Cout, ks, 1.0, P(o_sp), 0, Cout, 0, st())
     run_d = lambda: L.sf_cnn_conv(P(x), N, H, H, Cin, Cin, P(w), P(b), Cout, ks, P(o_d), Cout, 0, st())
     assert run_sp() == 0 and run_d() == 0
     torch.cuda.synchronize()

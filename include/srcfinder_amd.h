@@ -356,6 +356,11 @@ int sf_cnn_conv_split(const float *in, int in_split, int N, int H, int W, int Ci
 int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
                              const float *wscale, const float *bias, int c0, int c1, int c2, float ascale, float *out0, int ld0,
                              int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, int out12_split, void *stream);
+/* branch4 of an Inception (MaxPool2d(3, 1, 1, ceil_mode) + 1x1 BasicConv2d, googlenet1.py:213-214) by operand splitting: arguments as
+ * sf_cnn_pool_conv with (hi, lo, wscale); dense input, image width dividing 128 (sf_cnn_pool_conv_split_ok; else sf_cnn_pool_conv). */
+int sf_cnn_pool_conv_split_ok(int N, int H, int W, int Cin, int Cout);
+int sf_cnn_pool_conv_split(const float *in, int N, int H, int W, int Cin, const void *whi, const void *wlo, const float *wscale,
+                           const float *bias, int Cout, float *out, int ld_out, int ch_off, void *stream);
 int sf_cnn_split_overflow(int *flag, int reset, void *stream);
 
 /* Inception branch 4 (googlenet1.py:213-214) in one call: MaxPool2d(3, stride 1, pad 1, ceil_mode) into pooled_scratch

@@ -48,6 +48,8 @@ SIGNATURES = {
     "sf_cnn_conv_split": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, C.c_float, vp, i32, i32, i32, vp]),
     "sf_cnn_conv_split3_split": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, C.c_float, vp, i32, i32, vp, i32, i32,
                                        vp, i32, i32, i32, vp]),
+    "sf_cnn_pool_conv_split_ok": (i32, [i32, i32, i32, i32, i32]),
+    "sf_cnn_pool_conv_split": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
     "sf_cnn_split_overflow": (i32, [vp, i32, vp]),
     "sf_cnn_wino_weights": (i32, [vp, i32, i32, vp, vp]),
     "sf_cnn_conv3x3_wino": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp]),

@@ -203,7 +203,7 @@ class GoogLeNetHIP(object):
             L = _ffi.lib()
             with torch.cuda.device(self.device):
                 for name in self.w:
-                    if name == "conv1" or name.endswith(".branch4.1") or name.endswith(".branch1") or name.endswith(".0"):
+                    if name == "conv1" or name.endswith(".branch1") or name.endswith(".0"):
                         continue
                     w, _b = self.w[name]
                     cout, K = w.shape[0], w.shape[1] * w.shape[2]
@@ -306,6 +306,13 @@ class GoogLeNetHIP(object):
         if self.sfx or x.shape[3] != cin:           # fp16 path / strided input: pool, then convolve
             pooled = self._pool(x, "pool_s1", 3, 1, 1)
             self._conv(pooled, name + ".branch4.1", y, c1 + c3 + c5)
+        elif _knob(17) == 0 and (name + ".branch4.1") in self.split and \
+                _ffi.lib().sf_cnn_pool_conv_split_ok(N, H, W, cin, self.w[name + ".branch4.1"][0].shape[0]):
+            hi, lo, sc = self.split[name + ".branch4.1"]
+            w4, b4 = self.w[name + ".branch4.1"]
+            _ffi.check(_ffi.lib().sf_cnn_pool_conv_split(_ffi.ptr(x), N, H, W, cin, _ffi.ptr(hi), _ffi.ptr(lo), _ffi.ptr(sc), _ffi.ptr(b4),
+                                                         w4.shape[0], _ffi.ptr(y), y.shape[3], c1 + c3 + c5, _ffi.stream_ptr()),
+                       "sf_cnn_pool_conv_split(%s)" % name)
         else:                                       # pool + 1x1 convolution in one C call
             w4, b4 = self.w[name + ".branch4.1"]
             scratch = self._buf("pool_s1", (N, H, W, cin))

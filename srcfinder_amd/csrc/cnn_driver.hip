@@ -56,9 +56,9 @@ Wino wino_layout() {
   return w;
 }
 // Split-operand weights (cnn_split.hip: fp16 hi | lo halves of the folded weights scaled per output channel, + the scales) of every
-// convolution but conv1 and the pool-projections, kept behind the Winograd weights and recomputed by every call (29 tiny launches)
+// convolution but conv1, kept behind the Winograd weights and recomputed by every call (38 tiny launches)
 struct SplitL { size_t h, s; };          // offsets: halves (hi; lo follows at + cout * taps * cin), scale floats
-struct Splits { SplitL conv2, conv3, head3[9], b2[9], b3[9]; size_t halves, scales; };
+struct Splits { SplitL conv2, conv3, head3[9], b2[9], b3[9], b4[9]; size_t halves, scales; };
 Splits split_layout() {
   Splits S{};
   size_t oh = 0, os = 0;
@@ -70,6 +70,7 @@ Splits split_layout() {
     take(S.head3[i], s.c1 + s.c3r + s.c5r, 1, s.cin);
     take(S.b2[i], s.c3, 9, s.c3r);
     take(S.b3[i], s.c5, 9, s.c5r);
+    take(S.b4[i], s.pp, 1, s.cin);
   }
   S.halves = (oh + 7) / 8 * 8;
   S.scales = (os + 3) / 4 * 4;      // (the halves behind the scales start on a 16-byte boundary)
@@ -152,6 +153,7 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
       if ((rc = prep(L.head3[i], SL.head3[i], s.c1 + s.c3r + s.c5r, 1, s.cin))) return rc;
       if ((rc = prep(L.b2[i], SL.b2[i], s.c3, 9, s.c3r))) return rc;
       if ((rc = prep(L.b3[i], SL.b3[i], s.c5, 9, s.c5r))) return rc;
+      if ((rc = prep(L.b4[i], SL.b4[i], s.pp, 1, s.cin))) return rc;
     }
   }
   if (use_wino && i0 < i1) {
@@ -190,7 +192,12 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
       if (rc) return rc;
       if ((rc = conv3x3(t2, n, hw, s.c3r, L.b2[i], WL.b2[i], SL.b2[i], s.c3, y, cout, s.c1))) return rc;
       if ((rc = conv3x3(t3, n, hw, s.c5r, L.b3[i], WL.b3[i], SL.b3[i], s.c5, y, cout, s.c1 + s.c3))) return rc;
-      if ((rc = sf_cnn_pool_conv(x, n, hw, hw, cin, cin, W_(L.b4[i]), B_(L.b4[i]), s.pp, y, cout, s.c1 + s.c3 + s.c5, pooled, stream))) return rc;
+      if (use_split && sf_cnn_pool_conv_split_ok(n, hw, hw, cin, s.pp))
+        rc = sf_cnn_pool_conv_split(x, n, hw, hw, cin, shalf + SL.b4[i].h, half_lo(SL.b4[i], s.pp, 1, cin), sscale + SL.b4[i].s, B_(L.b4[i]),
+                                    s.pp, y, cout, s.c1 + s.c3 + s.c5, stream);
+      else
+        rc = sf_cnn_pool_conv(x, n, hw, hw, cin, cin, W_(L.b4[i]), B_(L.b4[i]), s.pp, y, cout, s.c1 + s.c3 + s.c5, pooled, stream);
+      if (rc) return rc;
       float *t = x; x = y; y = t;
       cin = cout;
       if (i == 1 || i == 6) {      // maxpool3 after 3b (3x3 s2), maxpool4 after 4e (2x2 s2), both ceil_mode (:68, :75)

@@ -282,6 +282,181 @@ __global__ void k_split_weights(const float *__restrict__ w, int Cout, int K, _F
   }
 }
 
+// ---- inception branch 4 by operand splitting: 3 x 3 stride-1 pad-1 max pool + 1 x 1 convolution in one launch (googlenet1.py:213-214).
+// The staging of cnn_kernels.hip's k_poolconv -- the tile's 128 pixels (whole image rows: W divides 128) plus one image row above and
+// below, raw float32, linear in LDS; every thread pools its (pixel, channel quad) items from there -- feeding the split operand tiles
+// of k_conv_split: the pooled values are split on their way into the A tiles.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restrict__ in, int M, int H, int W, int Cin,
+                                                           const _Float16 *__restrict__ whi, const _Float16 *__restrict__ wlo,
+                                                           const float *__restrict__ wscale, const float *__restrict__ bias, int Cout,
+                                                           float *__restrict__ out, int ld_out, int ch_off) {
+  constexpr int BM = 128, BK = 32, KQ = BK / 4;
+  constexpr int WN = (BN >= 128) ? 2 : 1, WM = 4 / WN, TM = BM / (32 * WM), TN = BN / (32 * WN), NPB = BN / 64;
+  constexpr int RMAX = BM + 2 * 32;                         // raw pixels at W = 32
+  constexpr int NRAW = (RMAX * KQ + 255) / 256, NPOOL = BM * KQ / 256;
+  __shared__ __attribute__((aligned(16))) float raw[RMAX * BK];
+  __shared__ __attribute__((aligned(16))) _Float16 sm[(2 * BM + 2 * BN) * SP_LD];
+  _Float16 *Ah = sm, *Al = Ah + BM * SP_LD, *Bh = Al + BM * SP_LD, *Bl = Bh + BN * SP_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int q = tid & 3, ri = tid >> 2;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int R = BM + 2 * W, nchunk = (Cin + BK - 1) / BK;
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (unsigned)((size_t)M * Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(whi), 0, (unsigned)((size_t)Cout * Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(wlo), 0, (unsigned)((size_t)Cout * Cin * 2), 0x00020000);
+  unsigned rawoff[NRAW];
+  int rawq[NRAW];
+#pragma unroll
+  for (int r = 0; r < NRAW; ++r) {
+    const int idx = tid + 256 * r, rpx = idx / KQ, quad = idx - rpx * KQ;
+    const long long m = (long long)m0 - W + rpx;
+    rawq[r] = 4 * quad;
+    rawoff[r] = (rpx < R && m >= 0 && m < M) ? (unsigned)(((size_t)m * Cin + 4 * quad) * 4) : OOB;
+  }
+  unsigned woff[NPB];
+#pragma unroll
+  for (int b = 0; b < NPB; ++b) {
+    const int co = n0 + ri + 64 * b;
+    woff[b] = (co < Cout) ? (unsigned)(((size_t)co * Cin + 8 * q) * 2) : OOB;
+  }
+  const int pq = tid % KQ, pblk = tid / KQ;                 // pooled items: quad pq of pixel 32 a + permuted block (k_poolconv's bank order)
+  int ppx[NPOOL];
+  unsigned pmask[NPOOL];
+#pragma unroll
+  for (int a = 0; a < NPOOL; ++a) {
+    const int b8 = pblk & 7;
+    const int perm = (b8 & 4) | ((b8 & 1) << 1) | ((b8 >> 1) & 1);             // 0 2 1 3 4 6 5 7
+    const int px = (256 / KQ) * a + (pblk & ~7) + perm;
+    ppx[a] = px;
+    const int m = m0 + px;
+    const bool ok = m < M;
+    const int mm = ok ? m : 0;
+    const int x = mm % W, y = (mm / W) % H;
+    unsigned vm = 0;
+    for (int tp = 0; tp < 9; ++tp) {
+      const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+      if (ok && yy >= 0 && yy < H && xx >= 0 && xx < W) vm |= 1u << tp;
+    }
+    pmask[a] = vm;
+  }
+  sp_f16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float big = 0.f;
+  sp_u4 rr[NRAW], rbh[NPB], rbl[NPB];
+  auto gload = [&](int it) {
+    const int c0 = it * BK;
+    const unsigned sa = (unsigned)(c0 * 4), sb = (unsigned)(c0 * 2);
+#pragma unroll
+    for (int r = 0; r < NRAW; ++r) rr[r] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (c0 + rawq[r] < Cin) ? rawoff[r] : OOB, sa, 0);
+    const bool kin = c0 + 8 * q < Cin;
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+      rbh[b] = __builtin_amdgcn_raw_buffer_load_b128(rsH, kin ? woff[b] : OOB, sb, 0);
+      rbl[b] = __builtin_amdgcn_raw_buffer_load_b128(rsL, kin ? woff[b] : OOB, sb, 0);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int r = 0; r < NRAW; ++r)
+      if (tid + 256 * r < RMAX * KQ) *reinterpret_cast<sp_u4 *>(raw + 4 * (tid + 256 * r)) = rr[r];
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+      *reinterpret_cast<sp_u4 *>(Bh + (ri + 64 * b) * SP_LD + 8 * q) = rbh[b];
+      *reinterpret_cast<sp_u4 *>(Bl + (ri + 64 * b) * SP_LD + 8 * q) = rbl[b];
+    }
+  };
+  auto pool = [&]() {             // A tiles = hi / lo halves of the max over the 3 x 3 neighbourhood
+#pragma unroll
+    for (int a = 0; a < NPOOL; ++a) {
+      const float *c = raw + ((ppx[a] + W) * KQ + pq) * 4;
+      sp_f4 mx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int d = ((tp / 3 - 1) * W + (tp % 3 - 1)) * KQ * 4;
+        if ((pmask[a] >> tp) & 1u) {     // (a masked tap is never read; 0 is the identity: the activations are ReLU outputs)
+          const sp_f4 v = *reinterpret_cast<const sp_f4 *>(c + d);
+          mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+        }
+      }
+      const float v4[4] = {mx.x, mx.y, mx.z, mx.w};
+      _Float16 h4[4], l4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        h4[k] = (_Float16)v4[k];
+        l4[k] = (_Float16)(v4[k] - (float)h4[k]);
+        big = fmaxf(big, v4[k]);
+      }
+      typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<h4_t *>(Ah + ppx[a] * SP_LD + 4 * pq) = h4_t{h4[0], h4[1], h4[2], h4[3]};
+      *reinterpret_cast<h4_t *>(Al + ppx[a] * SP_LD + 4 * pq) = h4_t{l4[0], l4[1], l4[2], l4[3]};
+    }
+  };
+  const int aoff = (32 * TM * wm + (lane & 31)) * SP_LD + 8 * (lane >> 5);
+  const int boff = (32 * TN * wn + (lane & 31)) * SP_LD + 8 * (lane >> 5);
+  gload(0);
+  stage();
+  __syncthreads();
+  pool();
+  __syncthreads();
+  for (int it = 0; it < nchunk; ++it) {
+    if (it + 1 < nchunk) gload(it + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      sp_h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const sp_h8 *>(Ah + aoff + i * 32 * SP_LD + 16 * kk);
+        al[i] = *reinterpret_cast<const sp_h8 *>(Al + aoff + i * 32 * SP_LD + 16 * kk);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const sp_h8 *>(Bh + boff + j * 32 * SP_LD + 16 * kk);
+        bl[j] = *reinterpret_cast<const sp_h8 *>(Bl + boff + j * 32 * SP_LD + 16 * kk);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (it + 1 < nchunk) {
+      stage();
+      __syncthreads();
+      pool();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + 32 * (TN * wn + j) + (lane & 31);
+    if (co < Cout) {
+      const float bb = bias[co], sc = wscale[co];
+      float *op = out + ch_off + co;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < M) op[(size_t)m * ld_out] = fmaxf(__builtin_fmaf(acc[i][j][r], sc, bb), 0.f);
+        }
+    }
+  }
+  if (!(big < 65504.f)) g_sp_overflow = 1;
+}
+
+
 template <int BN, int BM = 128>
 int launch_split(const float *in, int in_split, int M, int H, int W, int Cin, int ld_in, const _Float16 *whi, const _Float16 *wlo,
                  const float *wscale, const float *bias, int Cout, int ks, float ascale, const ConvDstS &dst, hipStream_t st) {
@@ -370,6 +545,30 @@ int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int 
   d.end[0] = c0; d.end[1] = c0 + c1; d.end[2] = c0 + c1 + c2;
   d.fmt[0] = 0; d.fmt[1] = d.fmt[2] = out12_split ? 1 : 0;
   return split_go(in, 0, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, c0 + c1 + c2, 1, ascale, d, (hipStream_t)stream);
+}
+
+// 1 when sf_cnn_pool_conv_split takes this geometry (whole image rows per 128-pixel tile, operands below 2 GB); else sf_cnn_pool_conv
+int sf_cnn_pool_conv_split_ok(int N, int H, int W, int Cin, int Cout) {
+  return (W >= 1 && W <= 32 && 128 % W == 0 && (Cin & 7) == 0 && (size_t)N * H * W * Cin * 4 < 0x7ff00000u &&
+          (size_t)Cout * Cin * 2 < 0x7ff00000u) ? 1 : 0;
+}
+int sf_cnn_pool_conv_split(const float *in, int N, int H, int W, int Cin, const void *whi, const void *wlo, const float *wscale,
+                           const float *bias, int Cout, float *out, int ld_out, int ch_off, void *stream) {
+  if (!in || !whi || !wlo || !wscale || !bias || !out || N < 1 || ch_off < 0 || ch_off + Cout > ld_out ||
+      !sf_cnn_pool_conv_split_ok(N, H, W, Cin, Cout)) {
+    sf_set_error("sf_cnn_pool_conv_split: bad argument (dense input, W dividing 128, Cin multiple of 8, operands < 2 GB)");
+    return -1;
+  }
+  const int M = N * H * W;
+  const _Float16 *h = reinterpret_cast<const _Float16 *>(whi), *l = reinterpret_cast<const _Float16 *>(wlo);
+  if (Cout > 64)
+    hipLaunchKernelGGL((k_poolconv_split<128>), dim3(sf_cdiv(M, 128), sf_cdiv(Cout, 128)), dim3(256), 0, (hipStream_t)stream, in, M, H, W,
+                       Cin, h, l, wscale, bias, Cout, out, ld_out, ch_off);
+  else
+    hipLaunchKernelGGL((k_poolconv_split<64>), dim3(sf_cdiv(M, 128), sf_cdiv(Cout, 64)), dim3(256), 0, (hipStream_t)stream, in, M, H, W,
+                       Cin, h, l, wscale, bias, Cout, out, ld_out, ch_off);
+  SF_LAUNCH_CHECK("k_poolconv_split");
+  return 0;
 }
 
 // 1 when a launch since the last reset met an activation float16 cannot hold (the caller repeats the work on the fp32 kernels)

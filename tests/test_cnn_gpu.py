@@ -179,7 +179,7 @@ def test_split_operand_and_winograd_convolutions_against_the_direct_kernel(gold)
     from srcfinder_amd import _ffi
     net = cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024))
     assert len(net.wino) == 19                       # conv3 + the 9 branch2 + the 9 branch3 3 x 3 layers
-    assert len(net.split) == 29                      # conv2, conv3, 9 x (head3, branch2.1, branch3.1)
+    assert len(net.split) == 38                      # conv2, conv3, 9 x (head3, branch2.1, branch3.1, branch4.1)
     plane = synthetic_plane(10, 7, seed=21)
     plane[3, 2] = -9999.0
     L = _ffi.lib()

@@ -492,12 +492,12 @@ def cnn_section(res, ntiles, batch, with_cpu):
                         "note": "all kernels of a forward pass; flop_per_tile is the direct-convolution count of the network (the "
                                 "reference's arithmetic) and peak the fp32 matrix-core peak, so frac is throughput in reference "
                                 "fp32 flops against what the fp32 instruction could deliver.  Every convolution of the trunk but "
-                                "conv1 and the pool-projections (3.43 of the 3.71 GFLOP) runs by OPERAND SPLITTING on the fp16 matrix "
+                                "conv1 (3.60 of the 3.71 GFLOP) runs by OPERAND SPLITTING on the fp16 matrix "
                                 "cores -- fp32 operands as fp16 hi + lo halves, three v_mfma_f32_32x32x16_f16 per product, fp32 "
                                 "accumulate: the fp32 tolerance class (errors against float64 equal to the fp32 kernel's; the "
                                 "reference goldens at 1e-4), not reduced precision -- so frac may exceed what the fp32 pipe allows; "
                                 "frac_of_fp16_peak_executed counts the three fp16 products per multiply against 2500 TFLOP/s",
-                        "frac_of_fp16_peak_executed": round(tf * (3.0 * 3.43 + 0.277) / 3.706 / 2500.0, 4)}}
+                        "frac_of_fp16_peak_executed": round(tf * (3.0 * 3.603 + 0.103) / 3.706 / 2500.0, 4)}}
     if with_cpu:
         from oracle import cnn_oracle as O
         cores = usable_cores()

@@ -57,7 +57,7 @@ __device__ __forceinline__ void sp_split8(const sp_f4 &x0, const sp_f4 &x1, floa
 //  workgroup per CU and was 1.7 x SLOWER: what hides the trips to L2 here is three workgroups per CU, not a deeper pipeline.)
 __device__ int g_sp_overflow;
 template <int BN, bool ASPLIT = false, int BMT = 128>      // ASPLIT: the input is in the split format; BMT: pixels per tile
-__global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : ((BN == 128 && BMT == 128) ? 3 : 2)) void k_conv_split(const float *__restrict__ in, int M, int H, int W, int Cin, int ld_in,
+__global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 && BMT == 128) || (BN == 64 && BMT == 256)) ? 3 : 2)) void k_conv_split(const float *__restrict__ in, int M, int H, int W, int Cin, int ld_in,
                                                     const _Float16 *__restrict__ whi, const _Float16 *__restrict__ wlo,
                                                     const float *__restrict__ wscale, const float *__restrict__ bias, int Cout,
                                                     int ks, float ascale, ConvDstS dst) {
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : ((BN == 128 && 
   constexpr int WN = (BN >= 128) ? 2 : 1;          // waves along N: 2 x 2 waves of 64 x BN/2, or 4 x 1 waves of 32 x 64
   constexpr int WM = 4 / WN;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
-  constexpr int NPB = BN / 64;
-  static_assert(BN == 64 || BN == 128 || BN == 192 || BN == 256, "channel tile");
+  constexpr int NPB = (BN + 63) / 64;            // weight-tile passes of 64 rows (the last one partly used at BN = 96)
+  static_assert(BN == 64 || BN == 96 || BN == 128 || BN == 192 || BN == 256, "channel tile");
   constexpr int NSET = 1;
   constexpr int SETH = (2 * BM + 2 * BN) * SP_LD;     // halves per set: A hi | A lo | B hi | B lo
   __shared__ __attribute__((aligned(16))) _Float16 sm[NSET * SETH];
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : ((BN == 128 && 
 #pragma unroll
   for (int b = 0; b < NPB; ++b) {
     const int co = n0 + ri + 64 * b;
-    woff[b] = (co < Cout) ? (unsigned)(((size_t)co * taps * Cin + 8 * q) * 2) : OOB;
+    woff[b] = (co < Cout && ri + 64 * b < BN) ? (unsigned)(((size_t)co * taps * Cin + 8 * q) * 2) : OOB;
   }
   sp_f16 acc[TM][TN];
 #pragma unroll
@@ -164,8 +164,10 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : ((BN == 128 && 
     }
 #pragma unroll
     for (int b = 0; b < NPB; ++b) {
-      *reinterpret_cast<sp_u4 *>(Bh + (ri + 64 * b) * SP_LD + 8 * q) = rbh[S][b];
-      *reinterpret_cast<sp_u4 *>(Bl + (ri + 64 * b) * SP_LD + 8 * q) = rbl[S][b];
+      if (BN % 64 == 0 || ri + 64 * b < BN) {
+        *reinterpret_cast<sp_u4 *>(Bh + (ri + 64 * b) * SP_LD + 8 * q) = rbh[S][b];
+        *reinterpret_cast<sp_u4 *>(Bl + (ri + 64 * b) * SP_LD + 8 * q) = rbl[S][b];
+      }
     }
   };
   const int aoff = (32 * TM * wm + (lane & 31)) * SP_LD + 8 * (lane >> 5);
@@ -503,7 +505,10 @@ static int split_go(const float *in, int in_split, int N, int H, int W, int Cin,
   const _Float16 *h = reinterpret_cast<const _Float16 *>(whi), *l = reinterpret_cast<const _Float16 *>(wlo);
   // The channel tile: 128 where it pads the output channels no more than 64-channel tiles do.  (128 throughout: 41-42.3 k
   // windows/s against 43.2-43.7 k in alternating runs; 192 / 256-channel tiles need 228 / 270 registers, run two / one workgroup
-  // per CU instead of three and were slower still: what hides this kernel's trips to L2 is occupancy.)
+  // per CU instead of three and were slower still: what hides this kernel's trips to L2 is occupancy; 96-channel tiles of 256
+  // pixels for 96 / 192 / 288 channels -- 236 registers, two workgroups per CU -- were the same within the noise.)
+  if (sf_tune().cnn_variant == 7 && Cout % 96 == 0 && Cout % 128 != 0)      // A/B (sf_debug_set(16, 7)): 96-channel tiles for 96 / 192 / 288
+    return launch_split<96, 256>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
   if (Cout > 64 && sf_cdiv(Cout, 128) * 128 <= sf_cdiv(Cout, 64) * 64)
     return launch_split<128>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
   // 64-channel tiles take 256 pixels: wave tiles of 64 x 64 as in the 128 x 128 form -- 8 fragment reads per 12 matrix instructions

@@ -507,8 +507,6 @@ static int split_go(const float *in, int in_split, int N, int H, int W, int Cin,
   // windows/s against 43.2-43.7 k in alternating runs; 192 / 256-channel tiles need 228 / 270 registers, run two / one workgroup
   // per CU instead of three and were slower still: what hides this kernel's trips to L2 is occupancy; 96-channel tiles of 256
   // pixels for 96 / 192 / 288 channels -- 236 registers, two workgroups per CU -- were the same within the noise.)
-  if (sf_tune().cnn_variant == 7 && Cout % 96 == 0 && Cout % 128 != 0)      // A/B (sf_debug_set(16, 7)): 96-channel tiles for 96 / 192 / 288
-    return launch_split<96, 256>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
   if (Cout > 64 && sf_cdiv(Cout, 128) * 128 <= sf_cdiv(Cout, 64) * 64)
     return launch_split<128>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
   // 64-channel tiles take 256 pixels: wave tiles of 64 x 64 as in the 128 x 128 form -- 8 fragment reads per 12 matrix instructions

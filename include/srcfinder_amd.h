@@ -389,7 +389,10 @@ int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, co
  * NODATA, plane may be NULL).  blob: the BatchNorm-folded float32 weights in ONE array of sf_cnn_blob_floats() values:
  * for conv1, conv2, conv3, then per inception block {branch1|branch2.0|branch3.0 stacked, branch2.1, branch3.1,
  * branch4.1}, then fc: weights [Cout][k*k][Cin] followed by the bias [Cout].  workspace >=
- * sf_cnn_score_workspace_bytes(batch) (activations of one batch).  All launches are enqueued on `stream`. */
+ * sf_cnn_score_workspace_bytes(batch) (activations of one batch + the Winograd / split-operand forms of the weights).  All launches
+ * are enqueued on `stream`.  By default the convolutions run by operand splitting on the fp16 matrix cores (sf_cnn_conv_split: the
+ * float32 tolerance class); a caller that cannot rule out activations of 65504 or more checks sf_cnn_split_overflow() after the call
+ * and, if the flag is up, repeats it with sf_debug_set(17, 4) (fp32 matrix cores) -- srcfinder_amd.cnn.predict_flightline does. */
 size_t sf_cnn_blob_floats(void);
 size_t sf_cnn_score_workspace_bytes(int batch);
 int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int r0, int r1, const float *blob, float *out,

@@ -48,6 +48,7 @@ def main():
                     help="skip the CO2 (p = 83) and reflectance (-R, p = 416) window sections (cmf/robust_mf.py:186-191)")
     ap.add_argument("--cpu-columns", type=int, default=12)    # ~7 s of one host core (+ the all-cores sample)
     ap.add_argument("--active", type=str, default="", help="a0,a1 (1-based inclusive) override of the active window, e.g. 1,425")
+    ap.add_argument("--no-placement", action="store_true", help="skip the product-buffer placement pick of the setup phase")
     ap.add_argument("--knob", action="append", default=[], help="key=value for sf_debug_set (tuning / A-B runs; repeatable)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="flightlines in flight per GPU (srcfinder_amd.inflight); 0 = the default, 3 for every N")
@@ -129,6 +130,27 @@ def main():
         torch.cuda.empty_cache()                 # (placement, see above: no product buffer out of an earlier pass's freed blocks)
         pipe = FlightlinePipeline(depth, dev)
         outs = [torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev) for _ in range(depth)]
+        if not args.no_placement:
+            # Placement of the product buffers (setup, untimed; profiles/r05_score_placement.md): the record-writing kernel takes
+            # 0.735 .. 0.81 ms depending on where the allocator put its 383 MB product buffer, persistently per buffer.  A few
+            # more candidates are allocated, one flightline is run into each with the score kernel's HIP events on, and the
+            # fastest `depth` are kept -- what a long-running host would do once for its buffer pool.
+            cands = outs + [torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev) for _ in range(3)]
+            tms = []
+            for c in cands:
+                L.sf_cmf_score_timing(1)
+                pipe.submit(cube, lib, out=c, out_column0=0, active=(a0, a1))
+                pipe.synchronize()
+                tot, nl = _ffi.C.c_double(0.0), _ffi.C.c_int(0)
+                L.sf_cmf_score_timing_read(_ffi.C.byref(tot), _ffi.C.byref(nl))
+                L.sf_cmf_score_timing(0)
+                tms.append(tot.value / max(nl.value, 1))
+            order = sorted(range(len(cands)), key=lambda i: tms[i])
+            outs = [cands[i] for i in order[:depth]]
+            placement = {"candidate_score_ms": [round(t, 4) for t in tms], "kept": sorted(round(tms[i], 4) for i in order[:depth])}
+            del cands
+        else:
+            placement = None
         pending = [None] * depth                 # per slot: the gather handle of the flightline that used it last
         state = {}
 
@@ -203,7 +225,7 @@ def main():
                         abs(float(part[okr].sum()) - float(want[0])) <= 1e-9 * max(1.0, abs(float(want[0])))
         pipe.close()
         return {"dt": float(tmax.item()), "t_enq": t_enq, "score_ms": tot_ms.value / max(nlaunch.value, 1),
-                "launches": nlaunch.value, "res": res, "outs": outs, "gather_verified": verified}
+                "launches": nlaunch.value, "res": res, "outs": outs, "gather_verified": verified, "placement": placement}
 
     depth = args.in_flight if args.in_flight > 0 else 3
     main = timed_pass(depth)
@@ -235,6 +257,9 @@ def main():
                        "in_flight": "%d flightlines in flight per GPU (one HIP stream each); the same depth for every N"
                                     % depth,
                        "gather_verified": main["gather_verified"],
+                       "product_buffer_placement": {"three_in_flight": main["placement"], "one_in_flight": solo["placement"],
+                                                    "note": "setup, untimed: score-kernel ms of one flightline into each candidate product "
+                                                            "buffer; the fastest are kept (profiles/r05_score_placement.md)"},
                        "host_enqueue_ms_per_step": round(main["t_enq"] / args.steps * 1e3, 3),
                        "one_in_flight": {"ms_per_step": round(solo["dt"] / args.steps * 1e3, 3),
                                          "value": round(lines * samples / (solo["dt"] / args.steps) / 1e6, 3),

@@ -14,11 +14,12 @@ raw.sf_cnn_conv_split.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, 
 P, st = _ffi.ptr, _ffi.stream_ptr
 for kv in sys.argv[1:]:
     k, v = kv.split("="); L.sf_debug_set(int(k), int(v))
+XS = float(os.environ.get("SF_CHECK_XSCALE", "1"))     # activation scale (float16's low halves go subnormal below ~0.25)
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(5)
 
 def layer(N, H, Cin, Cout, ks, timeit=True):
-    x = torch.relu(torch.randn(N, H, H, Cin, generator=g)).to(dev)
+    x = (torch.relu(torch.randn(N, H, H, Cin, generator=g)) * XS).to(dev)
     w = (torch.randn(Cout, ks, ks, Cin, generator=g) * (0.7 / np.sqrt(ks * ks * Cin))).to(dev)
     b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
     K = ks * ks * Cin

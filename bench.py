@@ -54,6 +54,11 @@ def main():
                     help="flightlines in flight per GPU (srcfinder_amd.inflight); 0 = the default, 3 for every N")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD torch.distributed.run, before
+        # this process has imported torch or touched the GPU (never an exec of a process that initialised HIP)
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     from srcfinder_amd import _ffi, cmf
@@ -64,8 +69,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (torch.distributed.run --nproc-per-node %d), "
+                         "or run `python bench.py --gpus %d` with no WORLD_SIZE in the environment and it starts them itself"
+                         % (args.gpus, world, args.gpus, args.gpus))
     # SF_BENCH_SHARE_GPU=1 + SF_BENCH_BACKEND=gloo: N ranks on ONE GPU with host-staged collectives (RCCL refuses two ranks on
     # one device).  A FUNCTIONAL run of the N > 1 path on hardware where only one GPU can be leased -- the ranks share the
     # chip, so its value says nothing about scaling (profiles/r05_two_ranks_one_gpu.md)
@@ -119,7 +125,9 @@ def main():
     L = _ffi.lib()
     for kv in args.knob:
         k, v = kv.split("=")
-        L.sf_debug_set(int(k), int(v))
+        if L.sf_debug_set(int(k), int(v)) != 0:
+            raise SystemExit("--knob %s: sf_debug_set refused the key (a retired or unknown knob: the A/B run would measure "
+                             "the same code twice)" % kv)
 
     def barrier():
         if world > 1 or force_dist:
@@ -129,27 +137,12 @@ def main():
     def timed_pass(depth):
         torch.cuda.empty_cache()                 # (placement, see above: no product buffer out of an earlier pass's freed blocks)
         pipe = FlightlinePipeline(depth, dev)
-        outs = [torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev) for _ in range(depth)]
         if not args.no_placement:
-            # Placement of the product buffers (setup, untimed; profiles/r05_score_placement.md): the record-writing kernel takes
-            # 0.735 .. 0.81 ms depending on where the allocator put its 383 MB product buffer, persistently per buffer.  A few
-            # more candidates are allocated, one flightline is run into each with the score kernel's HIP events on, and the
-            # fastest `depth` are kept -- what a long-running host would do once for its buffer pool.
-            cands = outs + [torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev) for _ in range(3)]
-            tms = []
-            for c in cands:
-                L.sf_cmf_score_timing(1)
-                pipe.submit(cube, lib, out=c, out_column0=0, active=(a0, a1))
-                pipe.synchronize()
-                tot, nl = _ffi.C.c_double(0.0), _ffi.C.c_int(0)
-                L.sf_cmf_score_timing_read(_ffi.C.byref(tot), _ffi.C.byref(nl))
-                L.sf_cmf_score_timing(0)
-                tms.append(tot.value / max(nl.value, 1))
-            order = sorted(range(len(cands)), key=lambda i: tms[i])
-            outs = [cands[i] for i in order[:depth]]
-            placement = {"candidate_score_ms": [round(t, 4) for t in tms], "kept": sorted(round(tms[i], 4) for i in order[:depth])}
-            del cands
+            # the library's own opt-in buffer pool (FlightlinePipeline.pick_product_buffers): what a long-running
+            # host does once for its product buffers -- set-up, untimed; --no-placement = plain torch.empty buffers
+            outs, placement = pipe.pick_product_buffers(cube, lib, spares=3, shape=(lines, ncols, 4), active=(a0, a1))
         else:
+            outs = [torch.empty((lines, ncols, 4), dtype=torch.float64, device=dev) for _ in range(depth)]
             placement = None
         pending = [None] * depth                 # per slot: the gather handle of the flightline that used it last
         state = {}
@@ -258,8 +251,9 @@ def main():
                                     % depth,
                        "gather_verified": main["gather_verified"],
                        "product_buffer_placement": {"three_in_flight": main["placement"], "one_in_flight": solo["placement"],
-                                                    "note": "setup, untimed: score-kernel ms of one flightline into each candidate product "
-                                                            "buffer; the fastest are kept (profiles/r05_score_placement.md)"},
+                                                    "note": "FlightlinePipeline.pick_product_buffers (library API, set-up, untimed): score-kernel "
+                                                            "ms of one flightline into each candidate product buffer; the fastest are "
+                                                            "kept (profiles/r05_score_placement.md)"},
                        "host_enqueue_ms_per_step": round(main["t_enq"] / args.steps * 1e3, 3),
                        "one_in_flight": {"ms_per_step": round(solo["dt"] / args.steps * 1e3, 3),
                                          "value": round(lines * samples / (solo["dt"] / args.steps) / 1e6, 3),
@@ -310,6 +304,41 @@ def main():
     flush_c_stdio()
     if rank == 0:
         print(json.dumps(line), flush=True)      # the last line of the job's output
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` as a child process and relay
+    its output.  Called before torch is imported, so this parent never initialises the GPU; the child is a child, not an exec.
+    Rank 0's JSON line is printed again as the LAST line of this process's stdout (the ranks' stderr / banners may trail it in
+    the child's stream); the return value is the child's exit code."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this host driver (RCCL peers)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+    result = None
+    for ln in proc.stdout:
+        s = ln.strip()
+        if s.startswith('{"metric"') and s.endswith("}"):
+            result = s                                       # held back: printed last
+        else:
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if result is not None:
+        print(result, flush=True)
+    elif rc == 0:
+        print("bench.py: the %d ranks exited 0 but printed no result line" % n, file=sys.stderr)
+        rc = 1
+    return rc
 
 
 def window_section(cube, lib, active, reflectance, depth, steps, ch4_ms):
@@ -439,15 +468,16 @@ def e2e_section(cube, lib, cmf_seconds, cnn, strip_lines=2500):
     sal = torch.zeros(lines * ncols, dtype=torch.float32, device=net.device)
     t_first, n_strip = r0 * ncols, strip_lines * ncols
 
-    def run_strip():
-        for t0 in range(t_first, t_first + n_strip, batch):
-            net.forward_tiles(ds.x, ncols, t0, min(batch, t_first + n_strip - t0), plane=ds.plane, out=sal)
+    net.calibrate(ds, batch)                                                    # the split route's per-layer activation scales
 
-    for t0 in range(t_first, t_first + 4 * batch, batch):                       # buffers, code objects (not the strip: ~50 s)
-        net.forward_tiles(ds.x, ncols, t0, batch, plane=ds.plane, out=sal)
+    def run_strip():
+        # one overflow slot per batch, read once at the end; raised batches are scored again on the fp32 matrix cores
+        return C.score_tiles(net, ds, t_first, t_first + n_strip, batch, sal, route="split")
+
+    C.score_tiles(net, ds, t_first, t_first + 4 * batch, batch, sal, route="split")   # buffers, code objects (not the strip: ~50 s)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_strip()
+    rescued = run_strip()
     torch.cuda.synchronize()
     t_strip = time.perf_counter() - t0
     tiles_per_s = n_strip / t_strip
@@ -473,6 +503,7 @@ def e2e_section(cube, lib, cmf_seconds, cnn, strip_lines=2500):
                         "scaled to the flightline's %d windows" % (n_strip, strip_lines, r0, t_strip, tiles_per_s,
                                                                    lines * ncols),
             "strip": {"lines": strip_lines, "windows": n_strip, "seconds": round(t_strip, 3), "windows_per_s": round(tiles_per_s, 1),
+                      "batches_rescored_on_fp32": int(rescued),
                       "note": "measured, not extrapolated: the row shard one of 8 ranks scores (cnn/cnn_pred_pipeline.py:159-189)"},
             "data": "synthetic weights (seeded), the CMF plane of this flightline",
             "approximate_mode": {"mode": "fcn shift-and-stitch (the reference's fast mode; not result-equivalent), fp32, whole plane",
@@ -499,19 +530,30 @@ def cnn_section(res, ntiles, batch, with_cpu):
     out = torch.zeros(rows * W, dtype=torch.float32, device=net.device)
     ntiles = min(ntiles, rows * W)
 
-    def run():
-        for t0 in range(0, ntiles, batch):
-            net.forward_tiles(ds.x, W, t0, min(batch, ntiles - t0), plane=ds.plane, out=out)
+    scales = net.calibrate(ds, batch)                # the split route's per-layer activation scales, from this plane
 
-    run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def run(route="split"):
+        return cnn.score_tiles(net, ds, 0, ntiles, batch, out, route=route)
+
+    def timed(route):
+        run(route)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = run(route)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, n
+
+    dt_w, _ = timed("winograd")                      # the other float32-tolerance route, kept on record beside the default
+    dt, rescued = timed("split")
     tf = ntiles * 3.706e9 / dt / 1e12
     sec = {"metric": "CNN tiles/s (GoogLeNet, one 256x256 window per pixel)", "value": round(ntiles / dt, 1), "unit": "tiles/s",
            "dtype": "f32 (split-operand: fp16 hi + lo halves, fp32 accumulate)", "data": "synthetic weights (seeded), CMF plane of this run", "tiles": ntiles, "batch": batch,
+           "route": "split (an argument of the call; per-layer activation scales calibrated on this plane: 2^%d .. 2^%d; one overflow "
+                    "slot per batch, %d of %d batches re-scored on the fp32 matrix cores)"
+                    % (int(np.log2(min(scales))), int(np.log2(max(scales))), rescued, (ntiles + batch - 1) // batch),
+           "fp32_mfma_route": {"value": round(ntiles / dt_w, 1), "unit": "tiles/s",
+                               "note": "route=\"winograd\": Winograd F(2x2, 3x3) + implicit GEMM on the fp32 matrix cores (the split "
+                                       "route's rescue path), same windows"},
            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
                         "frac": round(tf / 157.3, 4), "flop_per_tile": 3.706e9,
                         "note": "all kernels of a forward pass; flop_per_tile is the direct-convolution count of the network (the "

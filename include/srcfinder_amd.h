@@ -105,6 +105,13 @@ int sf_cmf_exact_det(const double *cov, const double *target, const int32_t *nlo
 int sf_cmf_eigh_general(const double *cov, const double *target, const int32_t *nuse, int p, int ncols, double *r_tmp,
                         double *l_tmp, double *d, double *lam, double *evec, int32_t *status, void *scratch, void *stream);
 
+/* Eigenpairs of ncols symmetric positive definite matrices A[ncols][p][p] of 97 .. 512 rows, as they are (no correlation scaling):
+ * lam[ncols][p], evec[ncols][p][p] (row j = eigenvector j), status[ncols] (2: a non-positive or non-finite diagonal).  The wide
+ * eigensolver of sf_cmf_wide_stats on a caller's matrices: scipy.linalg.eig of a covariance matrix as the reference's PCA calls it
+ * with -R -k 2 (p = 416; cmf/robust_mf.py:78-84, :310-312).  scratch >= sf_cmf_eigh_wide_scratch_bytes(p, ncols). */
+size_t sf_cmf_eigh_wide_scratch_bytes(int p, int ncols);
+int sf_cmf_eigh_wide(const double *A, int p, int ncols, double *lam, double *evec, int32_t *status, void *scratch, void *stream);
+
 /* Stage 5 -- leave-one-out NLL for every alpha (robust_mf.py:105-117) and its argmin (:121-127):
  * nll[ncols][nalpha] (inf where the reference's det over/underflows), alphaidx[ncols] (-1 if none). */
 int sf_cmf_loocv(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const double *mu,
@@ -340,28 +347,35 @@ int sf_cnn_conv3x3_wino(const float *in, int N, int H, int W, int Cin, int ld_in
  * 1e-4) at 1.5-2.6 x its speed -- NOT the fp16-storage option (sf_cnn_*_f16).  sf_cnn_split_weights: folded weights
  * w[Cout][K = k*k*Cin] -> hi[Cout*K], lo[Cout*K] (float16) of w 2^e(co) and wscale[Cout] = 2^-e(co) (a power of two per output
  * channel that keeps the low halves normal; once per weight upload).  sf_cnn_conv_split / sf_cnn_conv_split3_split: arguments
- * as sf_cnn_conv / sf_cnn_conv_split3 with (hi, lo, wscale) in place of w and ascale, a power of two the activations are
- * multiplied by on their way in (1).  An activation with |a ascale| >= 65504 has no float16: the launch raises a device flag,
- * sf_cnn_split_overflow(&flag, reset, stream) reads (and clears) it after synchronising the stream -- the caller then repeats the
- * work with sf_cnn_conv.  in_split / out_split / out12_split: the tensor is in the SPLIT FORMAT instead of float32 -- per pixel and
+ * as sf_cnn_conv / sf_cnn_conv_split3 with (hi, lo, wscale) in place of w and ascale, a power of two the layer's input
+ * activations are (fp32 input) or were (split-format input: by their producer's oscale) multiplied by; the epilogue divides it out
+ * exactly.  The two ends of float16's range are part of the contract.  UNDERFLOW: below |a ascale| = 0.125 an activation's low half
+ * is subnormal (absolute error 2^-25) -- sf_cnn_calibrate measures every split layer's largest input on a sample of the plane's
+ * windows and returns the powers of two that put it at 2^9..2^10.  OVERFLOW: an activation with |a ascale| >= 65504 has no
+ * float16 -- the launch stores 1 into `overflow`, a device int OF THE CALLER (one per call, batch or stream; the library keeps no
+ * flag of its own, so concurrent streams and threads cannot see each other's), and the caller repeats that work with sf_cnn_conv /
+ * sf_cnn_conv3x3_wino (sf_cnn_score_rows and srcfinder_amd.cnn do it themselves).
+ * in_split / out_split / out12_split: the tensor is in the SPLIT FORMAT instead of float32 -- per pixel and
  * 8-channel group sixteen float16, the eight high halves then the eight low halves, in the bytes of the dense float32 tensor
- * ([M][C/8][2][8]; C a multiple of 8, ld == C, no channel offset, ascale 1).  A tensor only split-operand convolutions read (conv2's
- * output, the 3 x 3 reducers' outputs of an Inception block) is written that way by its producer's epilogue and fetched without
- * conversion by its consumers: the split is done once per value, not once per (value, tap, channel tile).
+ * ([M][C/8][2][8]; C a multiple of 8, ld == C, no channel offset), scaled by oscale (= the consumer's ascale).  A tensor only
+ * split-operand convolutions read (conv2's output, the 3 x 3 reducers' outputs of an Inception block) is written that way by its
+ * producer's epilogue and fetched without conversion by its consumers: the split is done once per value, not once per (value,
+ * tap, channel tile).  sf_cnn_absmax: max |x| of n floats folded into *amax (a device float the caller zeroed; order-independent).
  * BasicConv2d / Inception -- googlenet1.py:184-228, :266-275. */
 int sf_cnn_split_weights(const float *w, int Cout, int K, void *hi, void *lo, float *wscale, void *stream);
 int sf_cnn_conv_split(const float *in, int in_split, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
-                      const float *wscale, const float *bias, int Cout, int ksize, float ascale, float *out, int out_split, int ld_out,
-                      int ch_off, void *stream);
+                      const float *wscale, const float *bias, int Cout, int ksize, float ascale, float *out, int out_split, float oscale,
+                      int ld_out, int ch_off, int *overflow, void *stream);
 int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
                              const float *wscale, const float *bias, int c0, int c1, int c2, float ascale, float *out0, int ld0,
-                             int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, int out12_split, void *stream);
+                             int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, int out12_split, float oscale1,
+                             float oscale2, int *overflow, void *stream);
+int sf_cnn_absmax(const float *x, size_t n, float *amax, void *stream);
 /* branch4 of an Inception (MaxPool2d(3, 1, 1, ceil_mode) + 1x1 BasicConv2d, googlenet1.py:213-214) by operand splitting: arguments as
  * sf_cnn_pool_conv with (hi, lo, wscale); dense input, image width dividing 128 (sf_cnn_pool_conv_split_ok; else sf_cnn_pool_conv). */
 int sf_cnn_pool_conv_split_ok(int N, int H, int W, int Cin, int Cout);
 int sf_cnn_pool_conv_split(const float *in, int N, int H, int W, int Cin, const void *whi, const void *wlo, const float *wscale,
-                           const float *bias, int Cout, float *out, int ld_out, int ch_off, void *stream);
-int sf_cnn_split_overflow(int *flag, int reset, void *stream);
+                           const float *bias, int Cout, float ascale, float *out, int ld_out, int ch_off, int *overflow, void *stream);
 
 /* Inception branch 4 (googlenet1.py:213-214) in one call: MaxPool2d(3, stride 1, pad 1, ceil_mode) into pooled_scratch
  * (N*H*W*Cin floats), then the 1x1 BasicConv2d.  `in` is dense ([N][H][W][Cin]) and NON-NEGATIVE (a concatenation of
@@ -389,14 +403,26 @@ int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, co
  * NODATA, plane may be NULL).  blob: the BatchNorm-folded float32 weights in ONE array of sf_cnn_blob_floats() values:
  * for conv1, conv2, conv3, then per inception block {branch1|branch2.0|branch3.0 stacked, branch2.1, branch3.1,
  * branch4.1}, then fc: weights [Cout][k*k][Cin] followed by the bias [Cout].  workspace >=
- * sf_cnn_score_workspace_bytes(batch) (activations of one batch + the Winograd / split-operand forms of the weights).  All launches
- * are enqueued on `stream`.  By default the convolutions run by operand splitting on the fp16 matrix cores (sf_cnn_conv_split: the
- * float32 tolerance class); a caller that cannot rule out activations of 65504 or more checks sf_cnn_split_overflow() after the call
- * and, if the flag is up, repeats it with sf_debug_set(17, 4) (fp32 matrix cores) -- srcfinder_amd.cnn.predict_flightline does. */
+ * sf_cnn_score_workspace_bytes(batch) (activations of one batch + the Winograd / split-operand forms of the weights + the overflow
+ * slots).  All launches are enqueued on `stream`.
+ * route (an ARGUMENT of the call -- nothing process- or thread-wide selects the arithmetic):
+ *   0  operand splitting on the fp16 matrix cores (sf_cnn_conv_split: the float32 tolerance class; the product's default).  Both
+ *      ends of float16's range are handled inside the call: `scales` = the sf_cnn_num_scales() per-layer activation scales (HOST
+ *      floats, powers of two, e.g. from sf_cnn_calibrate) or NULL -- the call then calibrates itself on a fixed sample of the
+ *      plane's windows (a function of the plane alone: every row range and batch size of a flightline gets the same scales, hence
+ *      the same bits); every batch owns an overflow slot in the workspace, the slots are read back every 1024 batches and a batch
+ *      that raised its slot is scored AGAIN on route 4 before the call returns (*rescued, if given, counts them).  The call
+ *      therefore synchronises `stream` before returning on this route;
+ *   4  Winograd F(2 x 2, 3 x 3) + fp32 implicit GEMM on the fp32 matrix cores;   2 (1)  the direct fp32 kernel for everything.
+ * sf_cnn_calibrate: the scales alone (host array of sf_cnn_num_scales() floats: [0] maxpool1's output, [1] conv2's output,
+ * [2 + 3 i ...] inception block i's input, its 3 x 3 reducer's output, its "5 x 5" reducer's output); synchronises `stream`. */
 size_t sf_cnn_blob_floats(void);
 size_t sf_cnn_score_workspace_bytes(int batch);
+int sf_cnn_num_scales(void);
+int sf_cnn_calibrate(const float *padded, int H, int W, const float *blob, int batch, void *workspace, size_t workspace_bytes,
+                     float *scales, void *stream);
 int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int r0, int r1, const float *blob, float *out,
-                      int batch, void *workspace, size_t workspace_bytes, void *stream);
+                      int batch, int route, const float *scales, int *rescued, void *workspace, size_t workspace_bytes, void *stream);
 
 /* FCN shift-and-stitch, the reference's approximate fast mode (cnn/fcn_pred_pipeline.py).
  * sf_cnn_fcn_prepare: ClampCH4 + Normalize of the plane, embedded at (top, left) = divmod(shift, scale) in a zero canvas

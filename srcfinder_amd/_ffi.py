@@ -31,6 +31,8 @@ SIGNATURES = {
     "sf_cmf_exact_det_scratch_bytes": (sz, [i32, i32, i32, i32]),
     "sf_cmf_exact_det": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "sf_cmf_eigh_general": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "sf_cmf_eigh_wide_scratch_bytes": (C.c_size_t, [i32, i32]),
+    "sf_cmf_eigh_wide": (i32, [vp, i32, i32, vp, vp, vp, vp, vp]),
     "sf_cmf_loocv": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
     "sf_cmf_filter": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "sf_cmf_score": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, f64,
@@ -45,12 +47,14 @@ SIGNATURES = {
     "sf_cnn_wino_ok": (i32, [i32, i32, i32]),
     "sf_cnn_wino_weight_floats": (C.c_size_t, [i32, i32]),
     "sf_cnn_split_weights": (i32, [vp, i32, i32, vp, vp, vp, vp]),
-    "sf_cnn_conv_split": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, C.c_float, vp, i32, i32, i32, vp]),
+    "sf_cnn_conv_split": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, C.c_float, vp, i32, C.c_float, i32, i32, vp, vp]),
+    "sf_cnn_absmax": (i32, [vp, sz, vp, vp]),
+    "sf_cnn_num_scales": (i32, []),
+    "sf_cnn_calibrate": (i32, [vp, i32, i32, vp, i32, vp, sz, vp, vp]),
     "sf_cnn_conv_split3_split": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, C.c_float, vp, i32, i32, vp, i32, i32,
-                                       vp, i32, i32, i32, vp]),
+                                       vp, i32, i32, i32, C.c_float, C.c_float, vp, vp]),
     "sf_cnn_pool_conv_split_ok": (i32, [i32, i32, i32, i32, i32]),
-    "sf_cnn_pool_conv_split": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
-    "sf_cnn_split_overflow": (i32, [vp, i32, vp]),
+    "sf_cnn_pool_conv_split": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, C.c_float, vp, i32, i32, vp, vp]),
     "sf_cnn_wino_weights": (i32, [vp, i32, i32, vp, vp]),
     "sf_cnn_conv3x3_wino": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp]),
     "sf_cnn_pool_conv": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp, vp]),
@@ -59,7 +63,7 @@ SIGNATURES = {
     "sf_cnn_head": (i32, [vp, i32, i32, i32, vp, vp, vp, i64, f32, vp, vp]),
     "sf_cnn_blob_floats": (sz, []),
     "sf_cnn_score_workspace_bytes": (sz, [i32]),
-    "sf_cnn_score_rows": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, sz, vp]),
+    "sf_cnn_score_rows": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, sz, vp]),
     "sf_cnn_fcn_prepare": (i32, [vp, i32, i32, f32, f32, f32, f32, i32, i32, i32, i32, i32, vp, vp]),
     "sf_cnn_conv1_image": (i32, [vp, i32, i32, i32, vp, vp, vp, i32, vp]),
     "sf_cnn_fcn_stitch": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, f32, vp, vp]),

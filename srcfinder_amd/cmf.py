@@ -667,16 +667,17 @@ def eig(A, **kwargs):
     """``scipy.linalg.eig(A, left=False, right=True)`` (robust_mf.py:78-84) for the one use the reference makes of it:
     the eigendecomposition of a covariance matrix (:312).  Returns ``(w, vr)`` with complex128 ``w`` (imaginary parts 0)
     and unit-norm eigenvectors in the columns of ``vr``; the ORDER of the pairs is the eigensolver's (LAPACK's geev does
-    not sort either -- the reference takes "the first six").  Symmetric matrices of up to 96 rows
-    (one-sided Jacobi on the GPU); anything else is refused."""
+    not sort either -- the reference takes "the first six").  Symmetric matrices of up to 512 rows
+    (one-sided Jacobi on the GPU: in LDS up to 96 rows, the blocked wide eigensolver above -- the -R -k 2 run calls
+    eig(cov(...)) at p = 416, :310); anything else is refused."""
     torch = _torch()
     _lapack_kwargs(kwargs, ("left", "right"))
     if kwargs.get("left", False) or not kwargs.get("right", True):
         raise NotImplementedError("eig(): only left=False, right=True")
     a = _square(A, "eig")
     n = a.shape[0]
-    if n > 96:
-        raise NotImplementedError("eig(): more than 96 rows")
+    if n > 512:
+        raise NotImplementedError("eig(): more than 512 rows")
     if not np.allclose(a, a.T, rtol=1e-12, atol=1e-12 * np.abs(a).max()):
         raise NotImplementedError("eig(): nonsymmetric matrix")
     a = (a + a.T) * 0.5
@@ -689,15 +690,21 @@ def eig(A, **kwargs):
     dev = torch.device("cuda", torch.cuda.current_device())
     f64 = dict(dtype=torch.float64, device=dev)
     S = torch.as_tensor((a + shift * np.eye(n))[None], device=dev)
-    T = torch.eye(n, **f64)[None].contiguous()
-    nrows = torch.tensor([n + 2], dtype=torch.int32, device=dev)
     d, lam = torch.empty((1, n), **f64), torch.empty((1, n), **f64)
-    evec, r_tmp, l_tmp = (torch.empty((1, n, n), **f64) for _ in range(3))
+    evec = torch.empty((1, n, n), **f64)
     status = torch.empty(1, dtype=torch.int32, device=dev)
-    ws = _Workspace.get(L.sf_cmf_workspace_bytes(n + 2, n, 1, 1), dev)
-    _ffi.check(L.sf_cmf_eigh_general(_ffi.ptr(S), _ffi.ptr(T), _ffi.ptr(nrows), n, 1, _ffi.ptr(r_tmp), _ffi.ptr(l_tmp),
-                                     _ffi.ptr(d), _ffi.ptr(lam), _ffi.ptr(evec), _ffi.ptr(status), _ffi.ptr(ws),
-                                     _ffi.stream_ptr()), "sf_cmf_eigh_general")
+    if n > 96:
+        ws = _Workspace.get(L.sf_cmf_eigh_wide_scratch_bytes(n, 1), dev)
+        _ffi.check(L.sf_cmf_eigh_wide(_ffi.ptr(S), n, 1, _ffi.ptr(lam), _ffi.ptr(evec), _ffi.ptr(status), _ffi.ptr(ws),
+                                      _ffi.stream_ptr()), "sf_cmf_eigh_wide")
+    else:
+        T = torch.eye(n, **f64)[None].contiguous()
+        nrows = torch.tensor([n + 2], dtype=torch.int32, device=dev)
+        r_tmp, l_tmp = torch.empty((1, n, n), **f64), torch.empty((1, n, n), **f64)
+        ws = _Workspace.get(L.sf_cmf_workspace_bytes(n + 2, n, 1, 1), dev)
+        _ffi.check(L.sf_cmf_eigh_general(_ffi.ptr(S), _ffi.ptr(T), _ffi.ptr(nrows), n, 1, _ffi.ptr(r_tmp), _ffi.ptr(l_tmp),
+                                         _ffi.ptr(d), _ffi.ptr(lam), _ffi.ptr(evec), _ffi.ptr(status), _ffi.ptr(ws),
+                                         _ffi.stream_ptr()), "sf_cmf_eigh_general")
     if int(status.item()) != 0:
         raise np.linalg.LinAlgError("eig(): the eigensolver did not converge (status %d)" % int(status.item()))
     w = lam[0].cpu().numpy() - shift

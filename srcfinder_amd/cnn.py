@@ -28,6 +28,8 @@ MODEL_NORM = {
 }
 BN_EPS = 0.001          # googlenet1.py:270
 NODATA = -9999.0
+# the convolutions' arithmetic routes (all float32 in / float32 accumulate; include/srcfinder_amd.h: sf_cnn_score_rows)
+ROUTES = {"split": 0, "winograd": 4, "direct": 2, "direct_pointer": 1}
 
 
 def _torch():
@@ -157,6 +159,11 @@ class GoogLeNetHIP(object):
         self.winograd = True      # False: every 3 x 3 convolution through the direct implicit-GEMM kernel (the tests' cross-check)
         self.split = {}           # name -> (hi, lo, scale): fp16 halves of the folded weights for the split-operand kernels (csrc/cnn_split.hip)
         self._bufs = {}
+        # the split-operand route's per-layer activation scales (powers of two; include/srcfinder_amd.h: sf_cnn_calibrate).  1 until
+        # calibrate() has seen a plane; predict_flightline calibrates on every plane it scores
+        self.ascale = [1.0] * int(_ffi.lib().sf_cnn_num_scales())
+        self.route = None         # None: the calling thread's sf_debug_set(17, .) (0 unless a tool set it); else ROUTES / a code
+        self._route, self._flag = 0, None      # (state of the forward pass in progress)
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
@@ -248,22 +255,73 @@ class GoogLeNetHIP(object):
             self._bufs[key] = b
         return b[:n].view(*shape)
 
+    # -- the convolutions' route and the split-operand route's range contracts --------------------------------
+    def _route_code(self, route=None):
+        """0 operand splitting (fp16 matrix cores, fp32 tolerance class; default), 4 Winograd + fp32 matrix cores, 2 / 1 the direct
+        fp32 kernel.  An explicit argument wins, then ``self.route``, then the calling thread's tuning knob 17 (tools)."""
+        r = self.route if route is None else route
+        if r is None:
+            return 0 if self.half else _knob(17)
+        r = ROUTES.get(r, r) if isinstance(r, str) else int(r)
+        if r not in (0, 1, 2, 4):
+            raise ValueError("route must be one of %r or 0 / 4 / 2 / 1" % (sorted(ROUTES),))
+        return r
+
+    def overflow_slots(self, n):
+        """``n`` zeroed device ints for ``forward_tiles(..., overflow=slots[i:i+1])``: one per batch, read once at the end."""
+        torch = _torch()
+        return torch.zeros(int(n), dtype=torch.int32, device=self.device)
+
+    def calibrate(self, ds, batch=64):
+        """Per-layer activation scales of the split-operand route from a fixed sample of the plane's windows
+        (``sf_cnn_calibrate``: a function of the plane and the weights alone).  ``ds``: a FlightlineConvolve."""
+        torch = _torch()
+        if self.half:
+            return self.ascale
+        L = _ffi.lib()
+        H, W = ds.inshape[1], ds.inshape[2]
+        with torch.cuda.device(self.device):
+            wsb = L.sf_cnn_score_workspace_bytes(int(batch))
+            ws = self._buf("c_driver_ws", ((wsb + 3) // 4,))
+            sc = (C.c_float * len(self.ascale))()
+            _ffi.check(L.sf_cnn_calibrate(_ffi.ptr(ds.x), H, W, _ffi.ptr(self.packed_blob()), int(batch), _ffi.ptr(ws),
+                                          C.c_size_t(ws.numel() * 4), sc, _ffi.stream_ptr()), "sf_cnn_calibrate")
+        self.ascale = [float(v) for v in sc]
+        return self.ascale
+
+    def _begin(self, route, overflow):
+        """Set the pass's route and overflow slot; returns True when this call owns the slot (and must check it itself)."""
+        torch = _torch()
+        self._route = self._route_code(route)
+        own = False
+        if self._route == 0 and not self.half:
+            if overflow is None:
+                if getattr(self, "_own_flag", None) is None:
+                    self._own_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+                self._own_flag.zero_()
+                overflow, own = self._own_flag, True
+            if overflow.dtype != torch.int32 or overflow.numel() < 1 or overflow.device != self.device:
+                raise ValueError("overflow must be an int32 tensor on the network's device")
+        self._flag = overflow
+        return own
+
     # -- operators -------------------------------------------------------------------------------------------
-    def _conv(self, x, name, out, ch_off):
+    def _conv(self, x, name, out, ch_off, a_in=1.0, a_out=1.0):
         L = _ffi.lib()
         w, b = self.w[name]
         N, H, W, ldi = x.shape
         cout, taps, cin = w.shape
         k = 3 if taps == 9 else 1
-        mode = _knob(17)
+        mode = self._route
         if mode == 0 and name in self.split:
             # tensors only split-operand convolutions read travel in the split format (csrc/cnn_split.hip): conv2's output, and the
-            # 3 x 3 reducers' outputs that _inception's split3 call leaves in t2 / t3
+            # 3 x 3 reducers' outputs that _inception's split3 call leaves in t2 / t3 -- scaled by their consumer's activation scale
             hi, lo, sc = self.split[name]
             in_split = 1 if (k == 3) else 0
             out_split = 1 if name == "conv2" else 0
             _ffi.check(L.sf_cnn_conv_split(_ffi.ptr(x), in_split, N, H, W, cin, ldi, _ffi.ptr(hi), _ffi.ptr(lo), _ffi.ptr(sc), _ffi.ptr(b),
-                                           cout, k, C.c_float(1.0), _ffi.ptr(out), out_split, out.shape[3], ch_off, _ffi.stream_ptr()),
+                                           cout, k, C.c_float(a_in), _ffi.ptr(out), out_split, C.c_float(a_out), out.shape[3], ch_off,
+                                           _ffi.ptr(self._flag), _ffi.stream_ptr()),
                        "sf_cnn_conv_split(%s)" % name)
             return
         if k == 3 and self.winograd and name in self.wino and L.sf_cnn_wino_ok(H, W, cin) and mode == 4:
@@ -283,35 +341,39 @@ class GoogLeNetHIP(object):
         _ffi.check(fn(_ffi.ptr(x), N, H, W, Cc, k, s, p, _ffi.ptr(out), Ho, Wo, _ffi.stream_ptr()), "sf_cnn_maxpool")
         return out
 
-    def _inception(self, x, spec):
+    def _inception(self, x, spec, blk=0):
         name, cin, c1, c3r, c3, c5r, c5, pp = spec
+        split = not self.half and self._route == 0
+        ax, a2, a3 = (self.ascale[2 + 3 * blk], self.ascale[3 + 3 * blk], self.ascale[4 + 3 * blk]) if split else (1.0, 1.0, 1.0)
         N, H, W, _ = x.shape
         y = self._buf(name + ".y", (N, H, W, c1 + c3 + c5 + pp))
         t2 = self._buf("t2", (N, H, W, c3r))
         t3 = self._buf("t3", (N, H, W, c5r))
         w3, b3 = self.w[name + ".head3"]            # branch1 | branch2[0] | branch3[0] in one GEMM
-        if not self.half and _knob(17) == 0 and (name + ".head3") in self.split:
+        if split and (name + ".head3") in self.split:
             hi, lo, sc = self.split[name + ".head3"]
             _ffi.check(_ffi.lib().sf_cnn_conv_split3_split(_ffi.ptr(x), N, H, W, cin, x.shape[3], _ffi.ptr(hi), _ffi.ptr(lo), _ffi.ptr(sc),
-                                                           _ffi.ptr(b3), c1, c3r, c5r, C.c_float(1.0), _ffi.ptr(y), y.shape[3], 0,
-                                                           _ffi.ptr(t2), c3r, 0, _ffi.ptr(t3), c5r, 0, 1, _ffi.stream_ptr()),
+                                                           _ffi.ptr(b3), c1, c3r, c5r, C.c_float(ax), _ffi.ptr(y), y.shape[3], 0,
+                                                           _ffi.ptr(t2), c3r, 0, _ffi.ptr(t3), c5r, 0, 1, C.c_float(a2), C.c_float(a3),
+                                                           _ffi.ptr(self._flag), _ffi.stream_ptr()),
                        "sf_cnn_conv_split3_split(%s)" % name)
         else:
             fn = getattr(_ffi.lib(), "sf_cnn_conv_split3" + self.sfx)
             _ffi.check(fn(_ffi.ptr(x), N, H, W, cin, x.shape[3], _ffi.ptr(w3), _ffi.ptr(b3), c1, c3r, c5r, _ffi.ptr(y),
                           y.shape[3], 0, _ffi.ptr(t2), c3r, 0, _ffi.ptr(t3), c5r, 0, _ffi.stream_ptr()),
                        "sf_cnn_conv_split3(%s)" % name)
-        self._conv(t2, name + ".branch2.1", y, c1)
-        self._conv(t3, name + ".branch3.1", y, c1 + c3)
+        self._conv(t2, name + ".branch2.1", y, c1, a_in=a2)
+        self._conv(t3, name + ".branch3.1", y, c1 + c3, a_in=a3)
         if self.sfx or x.shape[3] != cin:           # fp16 path / strided input: pool, then convolve
             pooled = self._pool(x, "pool_s1", 3, 1, 1)
-            self._conv(pooled, name + ".branch4.1", y, c1 + c3 + c5)
-        elif _knob(17) == 0 and (name + ".branch4.1") in self.split and \
+            self._conv(pooled, name + ".branch4.1", y, c1 + c3 + c5, a_in=ax)
+        elif split and (name + ".branch4.1") in self.split and \
                 _ffi.lib().sf_cnn_pool_conv_split_ok(N, H, W, cin, self.w[name + ".branch4.1"][0].shape[0]):
             hi, lo, sc = self.split[name + ".branch4.1"]
             w4, b4 = self.w[name + ".branch4.1"]
             _ffi.check(_ffi.lib().sf_cnn_pool_conv_split(_ffi.ptr(x), N, H, W, cin, _ffi.ptr(hi), _ffi.ptr(lo), _ffi.ptr(sc), _ffi.ptr(b4),
-                                                         w4.shape[0], _ffi.ptr(y), y.shape[3], c1 + c3 + c5, _ffi.stream_ptr()),
+                                                         w4.shape[0], C.c_float(ax), _ffi.ptr(y), y.shape[3], c1 + c3 + c5,
+                                                         _ffi.ptr(self._flag), _ffi.stream_ptr()),
                        "sf_cnn_pool_conv_split(%s)" % name)
         else:                                       # pool + 1x1 convolution in one C call
             w4, b4 = self.w[name + ".branch4.1"]
@@ -325,13 +387,15 @@ class GoogLeNetHIP(object):
         """maxpool1 .. inception5b on the conv1 activations a1 [N, H, W, 64] (googlenet1.py:61-86); with ``pooled`` a1 is
         already the output of maxpool1 (the fused conv1 + pool kernel of the tile scorer)."""
         x = a1 if pooled else self._pool(a1, "pool1", 3, 2, 0)
+        split = not self.half and self._route == 0
+        s0, s1 = (self.ascale[0], self.ascale[1]) if split else (1.0, 1.0)
         a3 = self._buf("conv2", x.shape)
-        self._conv(x, "conv2", a3, 0)
+        self._conv(x, "conv2", a3, 0, a_in=s0, a_out=s1)
         a4 = self._buf("conv3", tuple(x.shape[:3]) + (192,))
-        self._conv(a3, "conv3", a4, 0)
+        self._conv(a3, "conv3", a4, 0, a_in=s1)
         x = self._pool(a4, "pool2", 3, 2, 0)
-        for spec in INCEPTION:
-            x = self._inception(x, spec)
+        for blk, spec in enumerate(INCEPTION):
+            x = self._inception(x, spec, blk)
             if taps is not None:
                 taps[spec[0]] = x.clone()
             if spec[0] == "inception3b":
@@ -340,13 +404,15 @@ class GoogLeNetHIP(object):
                 x = self._pool(x, "pool4", 2, 2, 0)
         return x
 
-    def forward_fcn(self, canvas, out=None):
+    def forward_fcn(self, canvas, out=None, route=None, overflow=None):
         """Fully convolutional pass (fcn_pred_pipeline.py:157-160, :229-231): canvas [N, Hc, Wc] float32 (already
-        transformed) -> softmax(final_conv(trunk))[:, 1] as [N, Hc/32, Wc/32] float32."""
+        transformed) -> softmax(final_conv(trunk))[:, 1] as [N, Hc/32, Wc/32] float32.  ``route`` / ``overflow``: see
+        :meth:`forward_tiles`."""
         torch = _torch()
         L = _ffi.lib()
         N, Hc, Wc = canvas.shape
         with torch.cuda.device(self.device):
+            own = self._begin(route, overflow)
             st = _ffi.stream_ptr()
             Ho, Wo = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
             a1 = self._buf("conv1", (N, Ho, Wo, 64))
@@ -360,14 +426,26 @@ class GoogLeNetHIP(object):
             _ffi.check(getattr(L, "sf_cnn_head" + self.sfx)(_ffi.ptr(x), n * hq * wq, 1, cc, _ffi.ptr(self.fcw),
                                                             _ffi.ptr(self.fcb), None, C.c_longlong(0), NODATA,
                                                             _ffi.ptr(out), st), "sf_cnn_head")
+            if own and int(self._flag.item()):
+                _overflow_warning("a canvas batch")
+                return self.forward_fcn(canvas, out=out, route=4)
         return out
 
-    def forward_tiles(self, padded, width, tile0, ntiles, plane=None, out=None, taps=None):
-        """Score tiles tile0..tile0+ntiles-1 of the padded plane; writes ``out[tile0:tile0+ntiles]`` (float32)."""
+    def forward_tiles(self, padded, width, tile0, ntiles, plane=None, out=None, taps=None, route=None, overflow=None):
+        """Score tiles tile0..tile0+ntiles-1 of the padded plane; writes ``out[tile0:tile0+ntiles]`` (float32).
+
+        ``route``: ``"split"`` (operand splitting on the fp16 matrix cores -- the float32 tolerance class; default), ``"winograd"``,
+        ``"direct"`` -- an argument of THIS call (default: ``self.route``, else the calling thread's tuning knob 17).
+        ``overflow`` (split route): a device int32 slot the kernels raise when an activation leaves float16's range.  Without one
+        the call uses a slot of its own, reads it (one host synchronisation) and scores the batch AGAIN on the fp32 matrix cores
+        when it is up -- never a silently wrong result.  A caller that wants to stay asynchronous passes one slot per batch
+        (:meth:`overflow_slots`), reads them once at the end and repeats the raised batches with ``route="winograd"``
+        (:func:`score_tiles` does exactly that)."""
         torch = _torch()
         L = _ffi.lib()
         Hp, Wp = padded.shape[-2], padded.shape[-1]
         with torch.cuda.device(self.device):
+            own = self._begin(route, overflow)
             st = _ffi.stream_ptr()
             w, b = self.w["conv1"]
             if taps is None and not self.half and getattr(self, "fuse_conv1", True):
@@ -389,11 +467,40 @@ class GoogLeNetHIP(object):
             _ffi.check(getattr(L, "sf_cnn_head" + self.sfx)(_ffi.ptr(x), ntiles, H * W, Cc, _ffi.ptr(self.fcw),
                                                             _ffi.ptr(self.fcb), _ffi.ptr(plane), C.c_longlong(tile0),
                                                             NODATA, _ffi.ptr(out), st), "sf_cnn_head")
+            if own and int(self._flag.item()):
+                _overflow_warning("tiles %d..%d" % (tile0, tile0 + ntiles))
+                return self.forward_tiles(padded, width, tile0, ntiles, plane=plane, out=out, taps=taps, route=4)
         return out
 
 
+def _overflow_warning(what):
+    import warnings
+    warnings.warn("srcfinder_amd.cnn: an activation exceeded the float16 range of the split-operand kernels; %s scored again on "
+                  "the fp32 matrix cores" % what)
+
+
+def score_tiles(net, ds, t_first, t_last, batch, out, route=None):
+    """``net.forward_tiles`` over the windows [t_first, t_last) of the FlightlineConvolve ``ds`` in batches, asynchronously: on the
+    split-operand route every batch raises its own overflow slot, the slots are read ONCE after the last batch and only the raised
+    batches are scored again on the fp32 matrix cores (cnn_pred_pipeline.py:173-181).  Returns the number of batches re-scored."""
+    W = ds.inshape[2]
+    starts = list(range(int(t_first), int(t_last), int(batch)))
+    code = net._route_code(route)
+    slots = net.overflow_slots(len(starts)) if (code == 0 and not net.half) else None
+    for i, t0 in enumerate(starts):
+        net.forward_tiles(ds.x, W, t0, min(batch, t_last - t0), plane=ds.plane, out=out, route=code,
+                          overflow=None if slots is None else slots[i:i + 1])
+    redo = [] if slots is None else [i for i, v in enumerate(slots.cpu().tolist()) if v]
+    for i in redo:
+        t0 = starts[i]
+        net.forward_tiles(ds.x, W, t0, min(batch, t_last - t0), plane=ds.plane, out=out, route=4)
+    if redo:
+        _overflow_warning("%d of %d batches" % (len(redo), len(starts)))
+    return len(redo)
+
+
 def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=None, rows=None, net=None, to_numpy=False,
-                       precision="fp32"):
+                       precision="fp32", route=None, info=None, scales=None):
     """saliency[H, W] float32 = softmax(GoogLeNet(window))[:, 1] for the 256x256 window centred on every pixel,
     -9999 where ``cmf2d`` is -9999 (cnn_pred_pipeline.py:159-189).
 
@@ -404,6 +511,14 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
               every batch, cnn_pred_pipeline.py:113-116).  Here every listed GPU gets its own copy of the weights and
               of the 69 MB padded plane and scores a contiguous block of image rows from its own host thread; the
               blocks are copied to the first device once.  A negative index (the reference's CPU run) is refused.
+    route   : the convolutions' arithmetic -- ``"split"`` (default: fp32 operands as fp16 hi + lo halves on the fp16 matrix cores,
+              the float32 tolerance class), ``"winograd"`` (fp32 matrix cores), ``"direct"``.  On the split route the per-layer
+              activation scales are calibrated on this plane and a batch whose activations leave float16's range is scored again
+              on the fp32 matrix cores inside the call (with a warning): route and overflow handling are per call, so concurrent
+              threads / streams / GPUs cannot disturb each other.
+    scales  : split route only: the per-layer activation scales (``sf_cnn_num_scales()`` powers of two) instead of the
+              calibration on this plane (a campaign that wants ONE set of scales for all its flightlines; the tests)
+    info    : optional dict; receives ``rescued_batches``, ``route`` and the ``scales`` used
     """
     torch = _torch()
     if gpus is not None and len(gpus) > 0:
@@ -415,7 +530,7 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
         if len(gpus) > 1:
             if net is not None or rows is not None:
                 raise ValueError("gpus=[...] builds one network per device: do not pass net= or rows=")
-            return _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision)
+            return _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision, route, info, scales)
         if net is None:
             if weights is None:
                 raise ValueError("weights (a GoogLeNet state_dict) are required")
@@ -428,42 +543,40 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
     H, W = ds.inshape[1], ds.inshape[2]
     out = torch.zeros(H * W, dtype=torch.float32, device=net.device)
     r0, r1 = (0, H) if rows is None else rows
+    code = net._route_code(route)
+    rescued = 0
+    if code == 0 and not net.half:
+        # ONE set of scales for the call, whichever driver sequences the graph: the caller's, or sf_cnn_calibrate on this plane
+        if scales is not None:
+            if len(scales) != len(net.ascale):
+                raise ValueError("scales must hold %d values" % len(net.ascale))
+            net.ascale = [float(v) for v in scales]
+        else:
+            net.calibrate(ds, batch)
     if not net.half and getattr(net, "c_driver", True):
-        # the C-side driver sequences the whole graph for the row range: one library call
+        # the C-side driver sequences the whole graph for the row range: one library call (calibration, per-batch overflow slots
+        # and the fp32 re-scoring of raised batches included)
         L = _ffi.lib()
         with torch.cuda.device(net.device):
             wsb = L.sf_cnn_score_workspace_bytes(int(batch))
             ws = net._buf("c_driver_ws", ((wsb + 3) // 4,))
+            nres = C.c_int(0)
+            sc = (C.c_float * len(net.ascale))(*net.ascale)
             _ffi.check(L.sf_cnn_score_rows(_ffi.ptr(ds.x), _ffi.ptr(ds.plane), H, W, int(r0), int(r1), _ffi.ptr(net.packed_blob()),
-                                           _ffi.ptr(out), int(batch), _ffi.ptr(ws), C.c_size_t(ws.numel() * 4), _ffi.stream_ptr()),
-                       "sf_cnn_score_rows")
+                                           _ffi.ptr(out), int(batch), code, sc, C.byref(nres), _ffi.ptr(ws),
+                                           C.c_size_t(ws.numel() * 4), _ffi.stream_ptr()), "sf_cnn_score_rows")
+            rescued = nres.value
+        if rescued:
+            _overflow_warning("%d batch(es) of rows %d..%d" % (rescued, r0, r1))
     else:
-        i0, i1 = r0 * W, r1 * W
-        for t0 in range(i0, i1, batch):
-            n = min(batch, i1 - t0)
-            net.forward_tiles(ds.x, W, t0, n, plane=ds.plane, out=out)
+        rescued = score_tiles(net, ds, r0 * W, r1 * W, batch, out, route=code)
+    if info is not None:
+        info.update(rescued_batches=rescued, route=code, scales=list(net.ascale) if code == 0 else None)
     out = out.view(H, W)
-    if not net.half and _knob(17) == 0:
-        # the split-operand kernels carry the activations in float16 halves: one at or beyond 65504 raises a flag and the rows are
-        # scored again on the fp32 matrix cores (Winograd / implicit GEMM) -- never a silently wrong map
-        L = _ffi.lib()
-        flag = C.c_int(0)
-        with torch.cuda.device(net.device):
-            _ffi.check(L.sf_cnn_split_overflow(C.byref(flag), 1, _ffi.stream_ptr()), "sf_cnn_split_overflow")
-        if flag.value:
-            import warnings
-            warnings.warn("srcfinder_amd.cnn: an activation exceeded the float16 range of the split-operand kernels; "
-                          "rows %d..%d are scored again on the fp32 matrix cores" % (r0, r1))
-            L.sf_debug_set(17, 4)
-            try:
-                return predict_flightline(cmf2d, model, weights=weights, batch=batch, rows=rows, net=net, to_numpy=to_numpy,
-                                          precision=precision)
-            finally:
-                L.sf_debug_set(17, 0)
     return out.cpu().numpy() if to_numpy else out
 
 
-def _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision):
+def _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision, route=None, info=None, scales=None):
     """Row blocks of the saliency map on several GPUs of one process (one host thread per device)."""
     import threading
     torch = _torch()
@@ -472,8 +585,10 @@ def _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision):
     plane = cmf2d.detach().cpu().numpy() if torch.is_tensor(cmf2d) else np.asarray(cmf2d, dtype=np.float32)
     H = plane.shape[0]
     n = len(gpus)
-    parts, errs = [None] * n, [None] * n
-    # the library's tuning knobs are per calling thread: hand the caller's CNN knobs to the workers
+    parts, errs, infos = [None] * n, [None] * n, [dict() for _ in range(n)]
+    # the library's tuning knobs are per calling thread: hand the caller's CNN knobs to the workers (the convolutions' route is
+    # resolved HERE, once, and passed to every worker as an argument)
+    route = GoogLeNetHIP._route_code(_RouteOnly(precision), route)
     import ctypes
     L = _ffi.lib()
     knobs = {}
@@ -490,7 +605,7 @@ def _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision):
             with torch.cuda.device(dev):
                 net = GoogLeNetHIP(weights, device=dev, precision=precision)
                 r0, r1 = i * H // n, (i + 1) * H // n
-                sal = predict_flightline(plane, model, net=net, batch=batch, rows=(r0, r1))
+                sal = predict_flightline(plane, model, net=net, batch=batch, rows=(r0, r1), route=route, info=infos[i], scales=scales)
                 parts[i] = sal[r0:r1].to(torch.device("cuda", gpus[0]), non_blocking=False)
         except Exception as e:                                  # surfaced in the caller's thread
             errs[i] = e
@@ -503,12 +618,22 @@ def _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision):
     for e in errs:
         if e is not None:
             raise e
+    if info is not None:
+        info.update(rescued_batches=sum(d.get("rescued_batches", 0) for d in infos), route=route,
+                    per_block_rescued=[d.get("rescued_batches", 0) for d in infos], scales=infos[0].get("scales"))
     out = torch.cat(parts, 0)
     return out.cpu().numpy() if to_numpy else out
 
 
+class _RouteOnly(object):
+    """(just enough of a network for GoogLeNetHIP._route_code before the per-device networks exist)"""
+
+    def __init__(self, precision):
+        self.route, self.half = None, precision == "fp16"
+
+
 def fcn_predict_flightline(cmf2d, model="COVID_QC", weights=None, scale=32, batch=8, net=None, to_numpy=False,
-                           precision="fp32", shifts=None):
+                           precision="fp32", shifts=None, route=None):
     """The reference's FCN shift-and-stitch fast mode (cnn/fcn_pred_pipeline.py:32-95, :157-160, :225-249): the trunk
     runs fully convolutionally over the whole flightline once per (top, left) shift, the 1x1 head gives one
     probability per ``scale`` x ``scale`` cell and the ``scale**2`` maps are interlaced.  An approximation of
@@ -531,27 +656,31 @@ def fcn_predict_flightline(cmf2d, model="COVID_QC", weights=None, scale=32, batc
     out = torch.zeros((H, W), dtype=torch.float32, device=net.device)
     s0, s1 = (0, scale * scale) if shifts is None else shifts
     L = _ffi.lib()
+    code = net._route_code(route)
     with torch.cuda.device(net.device):
         st = _ffi.stream_ptr()
+        if code == 0 and not net.half:
+            # the split route's activation scales: calibrated on this plane's 256 x 256 windows (the same trunk, the same statistics)
+            net.calibrate(FlightlineConvolve(plane, (mean, std) if (vmin, vmax) == (0.0, 4000.0) else
+                                             Compose([ClampCH4(int(vmin), int(vmax)), Normalize([mean], [std])]), device=net.device))
         canvas = torch.empty((batch, Hc, Wc), dtype=torch.float32, device=net.device)
-        for a in range(s0, s1, batch):
+        starts = list(range(s0, s1, batch))
+        slots = net.overflow_slots(len(starts)) if (code == 0 and not net.half) else None
+
+        def run(i, rt):
+            a = starts[i]
             n = min(batch, s1 - a)
             _ffi.check(L.sf_cnn_fcn_prepare(_ffi.ptr(plane), H, W, float(vmin), float(vmax), float(mean), float(std), scale,
                                             a, n, Hc, Wc, _ffi.ptr(canvas), st), "sf_cnn_fcn_prepare")
-            pred = net.forward_fcn(canvas[:n])
+            pred = net.forward_fcn(canvas[:n], route=rt, overflow=None if (slots is None or rt != 0) else slots[i:i + 1])
             _ffi.check(L.sf_cnn_fcn_stitch(_ffi.ptr(pred), n, a, scale, pred.shape[1], pred.shape[2], _ffi.ptr(plane), H, W,
                                            NODATA, _ffi.ptr(out), st), "sf_cnn_fcn_stitch")
-        if not net.half and _knob(17) == 0:          # the split-operand kernels' float16 range (see predict_flightline)
-            flag = C.c_int(0)
-            _ffi.check(L.sf_cnn_split_overflow(C.byref(flag), 1, st), "sf_cnn_split_overflow")
-            if flag.value:
-                import warnings
-                warnings.warn("srcfinder_amd.cnn: an activation exceeded the float16 range of the split-operand kernels; "
-                              "the map is computed again on the fp32 matrix cores")
-                L.sf_debug_set(17, 4)
-                try:
-                    return fcn_predict_flightline(cmf2d, model, weights=weights, scale=scale, batch=batch, net=net, to_numpy=to_numpy,
-                                                  precision=precision, shifts=shifts)
-                finally:
-                    L.sf_debug_set(17, 0)
+
+        for i in range(len(starts)):
+            run(i, code)
+        redo = [] if slots is None else [i for i, v in enumerate(slots.cpu().tolist()) if v]
+        for i in redo:                               # the split-operand kernels' float16 range (see predict_flightline)
+            run(i, 4)
+        if redo:
+            _overflow_warning("%d of %d shift batches" % (len(redo), len(starts)))
     return out.cpu().numpy() if to_numpy else out

@@ -1177,6 +1177,29 @@ static int wide_stats_fused(const void *xt, int xt_f64, const uint8_t *mask_t, c
   return sf_launch_exact_det(cov, nloo, status, alphas, g, sf_exact_det_window(g), rest, nll, alphaidx, det_scratch, st, target);
 }
 
+// Eigenpairs of symmetric positive definite matrices of 97 .. 512 rows AS THEY ARE (no correlation scaling): the wide eigensolver
+// (blocked Cholesky, blocked one-sided Jacobi on the factor; the single-workgroup solver for a matrix whose Cholesky fails) on
+// caller-provided matrices -- the host-side eig() of the reference's PCA (cmf/robust_mf.py:78-84, :310-312 with -R -k 2: p = 416).
+extern "C" size_t sf_cmf_eigh_wide_scratch_bytes(int p, int ncols) {
+  if (p < 1 || ncols < 1) return 0;
+  const int p2 = p + (p & 1);
+  return sf_align((size_t)ncols * 2 * p2 * p2 * sizeof(double)) + sf_align((size_t)4 * ncols * sizeof(int32_t));
+}
+extern "C" int sf_cmf_eigh_wide(const double *A, int p, int ncols, double *lam, double *evec, int32_t *status, void *scratch,
+                                void *stream) {
+  if (!A || !lam || !evec || !status || !scratch || p <= SF_MAX_ACTIVE_FUSED || p > 512 || ncols < 1) {
+    sf_set_error("sf_cmf_eigh_wide: bad argument (97 .. 512 rows; sf_cmf_eigh_general with an identity target serves the smaller ones)");
+    return -1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int p2 = p + (p & 1);
+  double *gv = reinterpret_cast<double *>(scratch);
+  int32_t *flags = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(scratch) + sf_align((size_t)ncols * 2 * p2 * p2 * sizeof(double)));
+  int32_t *nrows = flags + 3 * ncols;      // (the kernels' "rows behind the matrix": any count above 1 says "a real matrix")
+  SF_HIP(hipMemsetAsync(nrows, 0x01, (size_t)ncols * sizeof(int32_t), st));      // 0x01010101 > 1
+  return wide_eigh(A, nrows, p, p2, 0, ncols, nullptr, lam, evec, status, gv, flags, flags + ncols, flags + 2 * ncols, st, 1);
+}
+
 int sf_launch_wide_stats(const void *xt, int xt_f64, const uint8_t *mask_t, const int32_t *nuse, const int32_t *nloo,
                          const double *mu, const double *alphas, const SfGeom &g, double *cov, double *d, double *lam,
                          double *evec, int32_t *status, double *nll, int32_t *alphaidx, void *scratch, hipStream_t st,

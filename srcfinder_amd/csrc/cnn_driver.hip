@@ -92,19 +92,212 @@ Acts acts(size_t n) {
   return a;
 }
 
+// per-layer activation scales of the split-operand route (cnn_split.hip): one power of two per tensor a split convolution reads
+//   [0] maxpool1's output (conv2's input)   [1] conv2's output (conv3's)   [2 + 3 i + {0, 1, 2}] inception block i: its input (the
+//   three stacked 1 x 1 and the pool-projection), the 3 x 3 reducer's output, the "5 x 5" reducer's output
+constexpr int NSCALE = 2 + 3 * 9;
+constexpr int NFLAG = 1024;              // overflow slots: one per batch, read back every NFLAG batches
+// behind the weights' split forms: the overflow slots of the batches in flight and the calibration maxima
+size_t tail_bytes() { return (size_t)NFLAG * sizeof(int) + 64 * sizeof(float); }
+
+struct Net {
+  const float *blob;
+  Blob L; Wino WL; Splits SL; Acts A;
+  float *pool1, *conv2, *conv3, *xa, *xb, *t2, *t3, *pooled, *wino, *sscale;
+  _Float16 *shalf;
+  int *flags;
+  float *amax;
+  bool wino_ready = false, split_ready = false;
+  hipStream_t st;
+};
+
+Net make_net(const float *blob, int batch, void *workspace, void *stream) {
+  Net N{};
+  N.blob = blob;
+  N.L = blob_layout(); N.WL = wino_layout(); N.SL = split_layout(); N.A = acts((size_t)batch);
+  float *ws = reinterpret_cast<float *>(workspace);
+  N.pool1 = ws; N.conv2 = N.pool1 + N.A.pool1; N.conv3 = N.conv2 + N.A.conv2; N.xa = N.conv3 + N.A.conv3; N.xb = N.xa + N.A.x;
+  N.t2 = N.xb + N.A.y; N.t3 = N.t2 + N.A.t2; N.pooled = N.t3 + N.A.t3;
+  N.wino = N.pooled + N.A.pooled;
+  N.sscale = N.wino + N.WL.total;
+  N.shalf = reinterpret_cast<_Float16 *>(N.sscale + N.SL.scales);
+  N.flags = reinterpret_cast<int *>(N.shalf + N.SL.halves);
+  N.amax = reinterpret_cast<float *>(N.flags + NFLAG);
+  N.st = (hipStream_t)stream;
+  return N;
+}
+#define W_(l) (N.blob + (l).w)
+#define B_(l) (N.blob + (l).b)
+_Float16 *half_lo(Net &N, const SplitL &sl, int cout, int taps, int cin) { return N.shalf + sl.h + conv_floats(cout, taps, cin); }
+
+int prepare_split(Net &N) {
+  if (N.split_ready) return 0;
+  int rc = 0;
+  auto prep = [&](const Layer &l, const SplitL &sl, int cout, int taps, int cin) {
+    return sf_cnn_split_weights(W_(l), cout, taps * cin, N.shalf + sl.h, half_lo(N, sl, cout, taps, cin), N.sscale + sl.s, N.st);
+  };
+  if ((rc = prep(N.L.conv2, N.SL.conv2, 64, 1, 64))) return rc;
+  if ((rc = prep(N.L.conv3, N.SL.conv3, 192, 9, 64))) return rc;
+  for (int i = 0; i < 9; ++i) {
+    const Incep &s = INC[i];
+    if ((rc = prep(N.L.head3[i], N.SL.head3[i], s.c1 + s.c3r + s.c5r, 1, s.cin))) return rc;
+    if ((rc = prep(N.L.b2[i], N.SL.b2[i], s.c3, 9, s.c3r))) return rc;
+    if ((rc = prep(N.L.b3[i], N.SL.b3[i], s.c5, 9, s.c5r))) return rc;
+    if ((rc = prep(N.L.b4[i], N.SL.b4[i], s.pp, 1, s.cin))) return rc;
+  }
+  N.split_ready = true;
+  return 0;
+}
+int prepare_wino(Net &N) {
+  if (N.wino_ready) return 0;
+  int rc = 0;
+  if ((rc = sf_cnn_wino_weights(W_(N.L.conv3), 192, 64, N.wino + N.WL.conv3, N.st))) return rc;
+  for (int i = 0; i < 9; ++i) {
+    if (INC[i].c3r % 8 == 0 && (rc = sf_cnn_wino_weights(W_(N.L.b2[i]), INC[i].c3, INC[i].c3r, N.wino + N.WL.b2[i], N.st))) return rc;
+    if (INC[i].c5r % 8 == 0 && (rc = sf_cnn_wino_weights(W_(N.L.b3[i]), INC[i].c5, INC[i].c5r, N.wino + N.WL.b3[i], N.st))) return rc;
+  }
+  N.wino_ready = true;
+  return 0;
+}
+
+// One batch of windows through the eval graph (googlenet1.py:110-163) on the given route:
+//   0 operand splitting on the fp16 matrix cores (cnn_split.hip; `as`: the NSCALE activation scales, `flag`: this batch's overflow slot)
+//   4 Winograd F(2 x 2, 3 x 3) for the 3 x 3 layers where the geometry allows + the fp32 implicit GEMM (cnn_wino.hip / cnn_kernels.hip)
+//   2 the direct fp32 implicit GEMM for everything (1: its pointer-form tile loads, chosen inside sf_cnn_conv by sf_debug_set(17, 1))
+// amax != nullptr (routes 4 / 2): the largest magnitude of every tensor a split convolution would read is folded into amax[NSCALE]
+int run_batch(Net &N, const float *padded, const float *plane, int H, int W, long long tile0, int n, int route, const float *as, int *flag,
+              float *amax, float *out) {
+  const int Hp = H + 255, Wp = W + 255;
+  const bool use_split = route == 0, use_wino = route == 4;
+  void *stream = (void *)N.st;
+  int rc = 0;
+  auto conv3x3 = [&](const float *in, int hw, int cin, const Layer &l, size_t uoff, const SplitL &sl, int cout, float a_in, float *o, int ldo,
+                     int off) -> int {
+    if (use_split)      // (its input -- conv2's output, a 3 x 3 reducer's -- arrives in the split format, scaled by a_in)
+      return sf_cnn_conv_split(in, 1, n, hw, hw, cin, cin, N.shalf + sl.h, half_lo(N, sl, cout, 9, cin), N.sscale + sl.s, B_(l), cout, 3, a_in,
+                               o, 0, 1.0f, ldo, off, flag, stream);
+    if (use_wino && sf_cnn_wino_ok(hw, hw, cin))
+      return sf_cnn_conv3x3_wino(in, n, hw, hw, cin, cin, N.wino + uoff, B_(l), cout, o, ldo, off, stream);
+    return sf_cnn_conv(in, n, hw, hw, cin, cin, W_(l), B_(l), cout, 3, o, ldo, off, stream);
+  };
+  auto peak = [&](const float *x, size_t count, int slot) -> int { return amax ? sf_cnn_absmax(x, count, amax + slot, stream) : 0; };
+  // conv1 + maxpool1 (googlenet1.py:60-61), conv2, conv3, maxpool2 (:62-64)
+  if ((rc = sf_cnn_conv1_pool(padded, Hp, Wp, W, tile0, n, W_(N.L.conv1), B_(N.L.conv1), N.pool1, stream))) return rc;
+  if ((rc = peak(N.pool1, (size_t)n * 64 * 64 * 64, 0))) return rc;
+  if (use_split)
+    rc = sf_cnn_conv_split(N.pool1, 0, n, 64, 64, 64, 64, N.shalf + N.SL.conv2.h, half_lo(N, N.SL.conv2, 64, 1, 64), N.sscale + N.SL.conv2.s,
+                           B_(N.L.conv2), 64, 1, as[0], N.conv2, 1, as[1], 64, 0, flag, stream);
+  else
+    rc = sf_cnn_conv(N.pool1, n, 64, 64, 64, 64, W_(N.L.conv2), B_(N.L.conv2), 64, 1, N.conv2, 64, 0, stream);
+  if (rc) return rc;
+  if ((rc = peak(N.conv2, (size_t)n * 64 * 64 * 64, 1))) return rc;
+  if ((rc = conv3x3(N.conv2, 64, 64, N.L.conv3, N.WL.conv3, N.SL.conv3, 192, use_split ? as[1] : 1.0f, N.conv3, 192, 0))) return rc;
+  int hw = pool_out(64, 3, 2, 0);
+  if ((rc = sf_cnn_maxpool(N.conv3, n, 64, 64, 192, 3, 2, 0, N.xa, hw, hw, stream))) return rc;
+  float *x = N.xa, *y = N.xb;
+  int cin = 192;
+  for (int i = 0; i < 9; ++i) {
+    const Incep &s = INC[i];
+    const int cout = s.c1 + s.c3 + s.c5 + s.pp;
+    const float ax = use_split ? as[2 + 3 * i] : 1.0f, a2 = use_split ? as[3 + 3 * i] : 1.0f, a3 = use_split ? as[4 + 3 * i] : 1.0f;
+    if ((rc = peak(x, (size_t)n * hw * hw * cin, 2 + 3 * i))) return rc;
+    // branch1 | 3x3 reduce | "5x5" reduce in one GEMM, then the two 3x3 convolutions, the pool branch (:184-228)
+    if (use_split)
+      rc = sf_cnn_conv_split3_split(x, n, hw, hw, cin, cin, N.shalf + N.SL.head3[i].h, half_lo(N, N.SL.head3[i], s.c1 + s.c3r + s.c5r, 1, cin),
+                                    N.sscale + N.SL.head3[i].s, B_(N.L.head3[i]), s.c1, s.c3r, s.c5r, ax, y, cout, 0, N.t2, s.c3r, 0, N.t3,
+                                    s.c5r, 0, 1, a2, a3, flag, stream);
+    else
+      rc = sf_cnn_conv_split3(x, n, hw, hw, cin, cin, W_(N.L.head3[i]), B_(N.L.head3[i]), s.c1, s.c3r, s.c5r, y, cout, 0, N.t2, s.c3r, 0,
+                              N.t3, s.c5r, 0, stream);
+    if (rc) return rc;
+    if ((rc = peak(N.t2, (size_t)n * hw * hw * s.c3r, 3 + 3 * i))) return rc;
+    if ((rc = peak(N.t3, (size_t)n * hw * hw * s.c5r, 4 + 3 * i))) return rc;
+    if ((rc = conv3x3(N.t2, hw, s.c3r, N.L.b2[i], N.WL.b2[i], N.SL.b2[i], s.c3, a2, y, cout, s.c1))) return rc;
+    if ((rc = conv3x3(N.t3, hw, s.c5r, N.L.b3[i], N.WL.b3[i], N.SL.b3[i], s.c5, a3, y, cout, s.c1 + s.c3))) return rc;
+    if (use_split && sf_cnn_pool_conv_split_ok(n, hw, hw, cin, s.pp))
+      rc = sf_cnn_pool_conv_split(x, n, hw, hw, cin, N.shalf + N.SL.b4[i].h, half_lo(N, N.SL.b4[i], s.pp, 1, cin), N.sscale + N.SL.b4[i].s,
+                                  B_(N.L.b4[i]), s.pp, ax, y, cout, s.c1 + s.c3 + s.c5, flag, stream);
+    else
+      rc = sf_cnn_pool_conv(x, n, hw, hw, cin, cin, W_(N.L.b4[i]), B_(N.L.b4[i]), s.pp, y, cout, s.c1 + s.c3 + s.c5, N.pooled, stream);
+    if (rc) return rc;
+    float *t = x; x = y; y = t;
+    cin = cout;
+    if (i == 1 || i == 6) {      // maxpool3 after 3b (3x3 s2), maxpool4 after 4e (2x2 s2), both ceil_mode (:68, :75)
+      const int k = (i == 1) ? 3 : 2, ho = pool_out(hw, k, 2, 0);
+      if ((rc = sf_cnn_maxpool(x, n, hw, hw, cin, k, 2, 0, y, ho, ho, stream))) return rc;
+      t = x; x = y; y = t;
+      hw = ho;
+    }
+  }
+  // global average pool, FC, softmax[:, 1], NODATA rule (:87-89; cnn_pred_pipeline.py:177-189)
+  if (out) return sf_cnn_head(x, n, hw * hw, cin, W_(N.L.fc), B_(N.L.fc), plane, tile0, -9999.0f, out, stream);
+  return 0;
+}
+
+// The activation scales from a FIXED sample of the plane's windows (eight groups of up to eight consecutive windows, evenly spaced
+// over all H W of them -- a function of the plane alone, not of `batch`, so every row shard and batch size of a flightline works with the same
+// scales and produces the same bits): one pass on the fp32 matrix cores, the largest magnitude of every tensor a split convolution
+// reads, then the power of two that puts it into [2^9, 2^10)
+int calibrate(Net &N, const float *padded, int H, int W, int batch, float *scales) {
+  int rc = 0;
+  if ((rc = prepare_wino(N))) return rc;
+  SF_HIP(hipMemsetAsync(N.amax, 0, NSCALE * sizeof(float), N.st));
+  const long long T = (long long)H * W;
+  const int per = (int)(T < 8 ? T : 8);               // windows per group: independent of `batch` (run in pieces of <= batch)
+  const int groups = (T <= per) ? 1 : 8;
+  long long last = -1;
+  for (int g = 0; g < groups; ++g) {
+    const long long t0 = (groups == 1) ? 0 : (T - per) * g / (groups - 1);
+    if (t0 <= last) continue;                         // (tiny planes: groups that coincide)
+    last = t0;
+    for (int k = 0; k < per; k += batch) {
+      const int n = (per - k < batch) ? per - k : batch;
+      if ((rc = run_batch(N, padded, nullptr, H, W, t0 + k, n, 4, nullptr, nullptr, N.amax, nullptr))) return rc;
+    }
+  }
+  float mx[NSCALE];
+  SF_HIP(hipMemcpyAsync(mx, N.amax, sizeof(mx), hipMemcpyDeviceToHost, N.st));
+  SF_HIP(hipStreamSynchronize(N.st));
+  for (int i = 0; i < NSCALE; ++i) {
+    float s = 1.0f;
+    if (mx[i] > 0.f && mx[i] < 3.0e38f) {
+      int ex;
+      frexpf(mx[i], &ex);                             // mx = f 2^ex, f in [0.5, 1)
+      int e = 10 - ex;
+      e = e > 40 ? 40 : (e < -40 ? -40 : e);
+      s = ldexpf(1.0f, e);
+    }
+    scales[i] = s;
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t sf_cnn_blob_floats(void) { return blob_layout().total; }
+int sf_cnn_num_scales(void) { return NSCALE; }
 size_t sf_cnn_score_workspace_bytes(int batch) {
   const Splits S = split_layout();
-  return batch < 1 ? 0 : sf_align((acts((size_t)batch).total + wino_layout().total + S.scales) * sizeof(float) + S.halves * 2);
+  return batch < 1 ? 0 : sf_align((acts((size_t)batch).total + wino_layout().total + S.scales) * sizeof(float) + S.halves * 2 + tail_bytes());
+}
+
+int sf_cnn_calibrate(const float *padded, int H, int W, const float *blob, int batch, void *workspace, size_t workspace_bytes,
+                     float *scales, void *stream) {
+  if (!padded || !blob || !workspace || !scales || H < 1 || W < 1 || batch < 1) { sf_set_error("sf_cnn_calibrate: bad argument"); return -1; }
+  if (workspace_bytes < sf_cnn_score_workspace_bytes(batch)) {
+    sf_set_error("sf_cnn_calibrate: workspace too small: need %zu bytes, got %zu", sf_cnn_score_workspace_bytes(batch), workspace_bytes);
+    return -4;
+  }
+  Net N = make_net(blob, batch, workspace, stream);
+  return calibrate(N, padded, H, W, batch, scales);
 }
 
 int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int r0, int r1, const float *blob, float *out,
-                      int batch, void *workspace, size_t workspace_bytes, void *stream) {
-  if (!padded || !blob || !out || !workspace || H < 1 || W < 1 || r0 < 0 || r1 > H || r0 > r1 || batch < 1) {
+                      int batch, int route, const float *scales, int *rescued, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!padded || !blob || !out || !workspace || H < 1 || W < 1 || r0 < 0 || r1 > H || r0 > r1 || batch < 1 ||
+      (route != 0 && route != 4 && route != 2 && route != 1)) {
     sf_set_error("sf_cnn_score_rows: bad argument");
     return -1;
   }
@@ -112,107 +305,61 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
     sf_set_error("sf_cnn_score_rows: workspace too small: need %zu bytes, got %zu", sf_cnn_score_workspace_bytes(batch), workspace_bytes);
     return -4;
   }
-  const Blob L = blob_layout();
-  const Acts A = acts((size_t)batch);
-  float *ws = reinterpret_cast<float *>(workspace);
-  float *pool1 = ws, *conv2 = pool1 + A.pool1, *conv3 = conv2 + A.conv2, *xa = conv3 + A.conv3, *xb = xa + A.x,
-        *t2 = xb + A.y, *t3 = t2 + A.t2, *pooled = t3 + A.t3;
-  const int Hp = H + 255, Wp = W + 255;
+  if (rescued) *rescued = 0;
+  Net N = make_net(blob, batch, workspace, stream);
   const long long i0 = (long long)r0 * W, i1 = (long long)r1 * W;
+  if (i0 >= i1) return 0;
   int rc = 0;
-#define W_(l) (blob + (l).w)
-#define B_(l) (blob + (l).b)
-  // sf_debug_set(17, .): 0 every convolution but conv1 and the pool-projections by operand splitting on the fp16 matrix cores
-  // (cnn_split.hip; the default), 4 round 5's first form -- the 3 x 3 convolutions by Winograd F(2 x 2, 3 x 3) where the geometry
-  // allows, the rest on the fp32 matrix cores --, 2 the direct fp32 kernel for everything
-  const Wino WL = wino_layout();
-  const Splits SL = split_layout();
-  float *wino = pooled + A.pooled;
-  float *sscale = wino + WL.total;
-  _Float16 *shalf = reinterpret_cast<_Float16 *>(sscale + SL.scales);
-  const int mode = sf_tune().cnn_conv_variant;
-  const bool use_split = mode == 0, use_wino = mode == 4;
-  auto half_lo = [&](const SplitL &sl, int cout, int taps, int cin) { return shalf + sl.h + conv_floats(cout, taps, cin); };
-  auto conv3x3 = [&](const float *in, int n, int hw, int cin, const Layer &l, size_t uoff, const SplitL &sl, int cout, float *o,
-                     int ldo, int off) -> int {
-    if (use_split)      // (its input -- conv2's output, a 3 x 3 reducer's -- arrives in the split format)
-      return sf_cnn_conv_split(in, 1, n, hw, hw, cin, cin, shalf + sl.h, half_lo(sl, cout, 9, cin), sscale + sl.s, B_(l), cout, 3, 1.0f,
-                               o, 0, ldo, off, stream);
-    if (use_wino && sf_cnn_wino_ok(hw, hw, cin))
-      return sf_cnn_conv3x3_wino(in, n, hw, hw, cin, cin, wino + uoff, B_(l), cout, o, ldo, off, stream);
-    return sf_cnn_conv(in, n, hw, hw, cin, cin, W_(l), B_(l), cout, 3, o, ldo, off, stream);
-  };
-  if (use_split && i0 < i1) {
-    auto prep = [&](const Layer &l, const SplitL &sl, int cout, int taps, int cin) {
-      return sf_cnn_split_weights(W_(l), cout, taps * cin, shalf + sl.h, half_lo(sl, cout, taps, cin), sscale + sl.s, stream);
-    };
-    if ((rc = prep(L.conv2, SL.conv2, 64, 1, 64))) return rc;
-    if ((rc = prep(L.conv3, SL.conv3, 192, 9, 64))) return rc;
-    for (int i = 0; i < 9; ++i) {
-      const Incep &s = INC[i];
-      if ((rc = prep(L.head3[i], SL.head3[i], s.c1 + s.c3r + s.c5r, 1, s.cin))) return rc;
-      if ((rc = prep(L.b2[i], SL.b2[i], s.c3, 9, s.c3r))) return rc;
-      if ((rc = prep(L.b3[i], SL.b3[i], s.c5, 9, s.c5r))) return rc;
-      if ((rc = prep(L.b4[i], SL.b4[i], s.pp, 1, s.cin))) return rc;
+  if (route != 0) {
+    if (route == 4 && (rc = prepare_wino(N))) return rc;
+    for (long long tile0 = i0; tile0 < i1; tile0 += batch) {
+      const int n = (int)((i1 - tile0 < batch) ? (i1 - tile0) : batch);
+      if ((rc = run_batch(N, padded, plane, H, W, tile0, n, route, nullptr, nullptr, nullptr, out))) return rc;
     }
+    return 0;
   }
-  if (use_wino && i0 < i1) {
-    if ((rc = sf_cnn_wino_weights(W_(L.conv3), 192, 64, wino + WL.conv3, stream))) return rc;
-    for (int i = 0; i < 9; ++i) {
-      if (INC[i].c3r % 8 == 0 && (rc = sf_cnn_wino_weights(W_(L.b2[i]), INC[i].c3, INC[i].c3r, wino + WL.b2[i], stream))) return rc;
-      if (INC[i].c5r % 8 == 0 && (rc = sf_cnn_wino_weights(W_(L.b3[i]), INC[i].c5, INC[i].c5r, wino + WL.b3[i], stream))) return rc;
-    }
-  }
-  for (long long tile0 = i0; tile0 < i1; tile0 += batch) {
-    const int n = (int)((i1 - tile0 < batch) ? (i1 - tile0) : batch);
-    // conv1 + maxpool1 (googlenet1.py:60-61), conv2, conv3, maxpool2 (:62-64)
-    if ((rc = sf_cnn_conv1_pool(padded, Hp, Wp, W, tile0, n, W_(L.conv1), B_(L.conv1), pool1, stream))) return rc;
-    if (use_split)
-      rc = sf_cnn_conv_split(pool1, 0, n, 64, 64, 64, 64, shalf + SL.conv2.h, half_lo(SL.conv2, 64, 1, 64), sscale + SL.conv2.s,
-                             B_(L.conv2), 64, 1, 1.0f, conv2, 1, 64, 0, stream);
-    else
-      rc = sf_cnn_conv(pool1, n, 64, 64, 64, 64, W_(L.conv2), B_(L.conv2), 64, 1, conv2, 64, 0, stream);
-    if (rc) return rc;
-    if ((rc = conv3x3(conv2, n, 64, 64, L.conv3, WL.conv3, SL.conv3, 192, conv3, 192, 0))) return rc;
-    int hw = pool_out(64, 3, 2, 0);
-    if ((rc = sf_cnn_maxpool(conv3, n, 64, 64, 192, 3, 2, 0, xa, hw, hw, stream))) return rc;
-    float *x = xa, *y = xb;
-    int cin = 192;
-    for (int i = 0; i < 9; ++i) {
-      const Incep &s = INC[i];
-      const int cout = s.c1 + s.c3 + s.c5 + s.pp;
-      // branch1 | 3x3 reduce | "5x5" reduce in one GEMM, then the two 3x3 convolutions, the pool branch (:184-228)
-      if (use_split)
-        rc = sf_cnn_conv_split3_split(x, n, hw, hw, cin, cin, shalf + SL.head3[i].h, half_lo(SL.head3[i], s.c1 + s.c3r + s.c5r, 1, cin),
-                                      sscale + SL.head3[i].s, B_(L.head3[i]), s.c1, s.c3r, s.c5r, 1.0f, y, cout, 0, t2, s.c3r, 0, t3,
-                                      s.c5r, 0, 1, stream);
-      else
-        rc = sf_cnn_conv_split3(x, n, hw, hw, cin, cin, W_(L.head3[i]), B_(L.head3[i]), s.c1, s.c3r, s.c5r, y, cout, 0, t2, s.c3r, 0,
-                                t3, s.c5r, 0, stream);
-      if (rc) return rc;
-      if ((rc = conv3x3(t2, n, hw, s.c3r, L.b2[i], WL.b2[i], SL.b2[i], s.c3, y, cout, s.c1))) return rc;
-      if ((rc = conv3x3(t3, n, hw, s.c5r, L.b3[i], WL.b3[i], SL.b3[i], s.c5, y, cout, s.c1 + s.c3))) return rc;
-      if (use_split && sf_cnn_pool_conv_split_ok(n, hw, hw, cin, s.pp))
-        rc = sf_cnn_pool_conv_split(x, n, hw, hw, cin, shalf + SL.b4[i].h, half_lo(SL.b4[i], s.pp, 1, cin), sscale + SL.b4[i].s, B_(L.b4[i]),
-                                    s.pp, y, cout, s.c1 + s.c3 + s.c5, stream);
-      else
-        rc = sf_cnn_pool_conv(x, n, hw, hw, cin, cin, W_(L.b4[i]), B_(L.b4[i]), s.pp, y, cout, s.c1 + s.c3 + s.c5, pooled, stream);
-      if (rc) return rc;
-      float *t = x; x = y; y = t;
-      cin = cout;
-      if (i == 1 || i == 6) {      // maxpool3 after 3b (3x3 s2), maxpool4 after 4e (2x2 s2), both ceil_mode (:68, :75)
-        const int k = (i == 1) ? 3 : 2, ho = pool_out(hw, k, 2, 0);
-        if ((rc = sf_cnn_maxpool(x, n, hw, hw, cin, k, 2, 0, y, ho, ho, stream))) return rc;
-        t = x; x = y; y = t;
-        hw = ho;
+  // route 0: operand splitting with its two range contracts.  Underflow: the per-layer activation scales (the caller's, or a
+  // calibration pass over the plane).  Overflow: every batch owns a device flag; the flags are read back every NFLAG batches and
+  // the batches that raised theirs are scored again on the fp32 matrix cores -- so this route synchronises the stream before it
+  // returns, and what it returns is never silently wrong
+  float as[NSCALE];
+  if (scales) {
+    for (int i = 0; i < NSCALE; ++i) {
+      int e;
+      if (!(scales[i] > 0.f && scales[i] < 3.0e38f && frexpf(scales[i], &e) == 0.5f)) {
+        sf_set_error("sf_cnn_score_rows: scales[%d] is not a power of two", i);
+        return -1;
       }
+      as[i] = scales[i];
     }
-    // global average pool, FC, softmax[:, 1], NODATA rule (:87-89; cnn_pred_pipeline.py:177-189)
-    if ((rc = sf_cnn_head(x, n, hw * hw, cin, W_(L.fc), B_(L.fc), plane, tile0, -9999.0f, out, stream))) return rc;
+  } else if ((rc = calibrate(N, padded, H, W, batch, as))) return rc;
+  if ((rc = prepare_split(N))) return rc;
+  int host_flags[NFLAG];
+  long long group0 = i0;
+  while (group0 < i1) {
+    SF_HIP(hipMemsetAsync(N.flags, 0, NFLAG * sizeof(int), N.st));
+    int nb = 0;
+    long long tile0 = group0;
+    for (; tile0 < i1 && nb < NFLAG; tile0 += batch, ++nb) {
+      const int n = (int)((i1 - tile0 < batch) ? (i1 - tile0) : batch);
+      if ((rc = run_batch(N, padded, plane, H, W, tile0, n, 0, as, N.flags + nb, nullptr, out))) return rc;
+    }
+    SF_HIP(hipMemcpyAsync(host_flags, N.flags, nb * sizeof(int), hipMemcpyDeviceToHost, N.st));
+    SF_HIP(hipStreamSynchronize(N.st));
+    for (int b = 0; b < nb; ++b) {
+      if (!host_flags[b]) continue;
+      const long long t0 = group0 + (long long)b * batch;
+      const int n = (int)((i1 - t0 < batch) ? (i1 - t0) : batch);
+      if ((rc = prepare_wino(N))) return rc;
+      if ((rc = run_batch(N, padded, plane, H, W, t0, n, 4, nullptr, nullptr, nullptr, out))) return rc;
+      if (rescued) ++*rescued;
+    }
+    group0 = tile0;
   }
-#undef W_
-#undef B_
+  SF_HIP(hipStreamSynchronize(N.st));
   return 0;
 }
+#undef W_
+#undef B_
 
 }  // extern "C"

@@ -8,10 +8,12 @@
 //
 // float16's exponent range is the catch: a_lo ~ 2^-12 |a| is subnormal (absolute error 2^-25) once |a| < 0.25.  The weights
 // are therefore scaled per output channel by a power of two that puts the channel's largest weight at ~2^13 (sf_cnn_split_weights;
-// the epilogue multiplies by 2^-e: exact); the activations -- post-ReLU, O(1) -- take a caller's power of two (ascale, 1 by default:
-// below 0.25 an activation's low half is subnormal, an ABSOLUTE error of 2^-25, invisible beside the activations that matter).
-// An activation of 65504 or more has no float16: the kernel raises a flag (sf_cnn_split_overflow) and the caller repeats the
-// batch on the fp32 kernels -- the result is never silently wrong.
+// the epilogue multiplies by 2^-e: exact); the activations take a power of two PER LAYER (ascale; cnn_driver.hip's calibration
+// puts the layer's largest activation of a sample of windows at 2^9..2^10: an activation's low half is subnormal -- an ABSOLUTE
+// error of 2^-25 -- only below 2^-13 of that maximum, and 64 x headroom is left above it).
+// An activation with |a ascale| >= 65504 has no float16: the launch stores 1 into the CALLER's device int (`overflow`, one per
+// call / batch / stream -- the library keeps no flag of its own) and the caller repeats that batch on the fp32 kernels
+// (sf_cnn_score_rows and srcfinder_amd.cnn do) -- the result is never silently wrong.
 //
 // Implicit GEMM as in cnn_f16.hip: 128 pixels x BN channels per workgroup, 32 input channels of one tap per chunk, operand
 // tiles [row][k] with 80-byte rows -- here four of them (A hi / lo, B hi / lo); the activations are split on their way
@@ -33,6 +35,7 @@ struct ConvDstS {
   float *p[3];
   int ld[3], off[3], end[3];
   int fmt[3];      // 0: float32 [pixel][channel]; 1: the split format below (dense tensors: ld == the segment's channels, off == 0)
+  float oscale[3]; // split-format segments: the power of two their CONSUMER expects (its ascale), applied before the split
 };
 // The SPLIT FORMAT of an activation tensor [M][C], C a multiple of 8: per pixel and 8-channel group 16 halves -- the eight high halves,
 // then the eight low halves -- i.e. [M][C / 8][2][8] float16 in the bytes of the [M][C] float32 tensor, the group of channel c at the
@@ -55,12 +58,11 @@ __device__ __forceinline__ void sp_split8(const sp_f4 &x0, const sp_f4 &x1, floa
 
 // (A form with two LDS sets and two register sets -- loads two chunks ahead, one barrier per chunk -- needed 306 registers, ran one
 //  workgroup per CU and was 1.7 x SLOWER: what hides the trips to L2 here is three workgroups per CU, not a deeper pipeline.)
-__device__ int g_sp_overflow;
 template <int BN, bool ASPLIT = false, int BMT = 128>      // ASPLIT: the input is in the split format; BMT: pixels per tile
 __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 && BMT == 128) || (BN == 64 && BMT == 256)) ? 3 : 2)) void k_conv_split(const float *__restrict__ in, int M, int H, int W, int Cin, int ld_in,
                                                     const _Float16 *__restrict__ whi, const _Float16 *__restrict__ wlo,
                                                     const float *__restrict__ wscale, const float *__restrict__ bias, int Cout,
-                                                    int ks, float ascale, ConvDstS dst) {
+                                                    int ks, float ascale, ConvDstS dst, int *__restrict__ overflow) {
   constexpr int BM = BMT, BK = 32, NPA = BM / 64;
   constexpr int WN = (BN >= 128) ? 2 : 1;          // waves along N: 2 x 2 waves of 64 x BN/2, or 4 x 1 waves of 32 x 64
   constexpr int WM = 4 / WN;
@@ -225,12 +227,13 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
       if (dst.fmt[sg]) {      // split format: halves (m 2 ld + 16 (c / 8) + c % 8) and + 8
         const int cl = co - cbase;
         _Float16 *hp = reinterpret_cast<_Float16 *>(dst.p[sg]) + 16 * (cl >> 3) + (cl & 7);
+        const float os = dst.oscale[sg];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const float v = fmaxf(__builtin_fmaf(acc[i][j][r], sc, bb), 0.f);
+            const float v = fmaxf(__builtin_fmaf(acc[i][j][r], sc, bb), 0.f) * os;
             const _Float16 h = (_Float16)v;
             big = fmaxf(big, v);
             if (m < M) {
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
       }
     }
   }
-  if (!(big < 65504.f)) g_sp_overflow = 1;      // (every writer stores 1; NaN counts)
+  if (!(big < 65504.f)) *overflow = 1;      // (every writer stores 1; NaN counts)
 }
 
 // per output channel: e = the power of two that puts max |w| into [2^12, 2^13); hi / lo halves of w 2^e; wscale = 2^-e
@@ -292,7 +295,8 @@ template <int BN>
 __global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restrict__ in, int M, int H, int W, int Cin,
                                                            const _Float16 *__restrict__ whi, const _Float16 *__restrict__ wlo,
                                                            const float *__restrict__ wscale, const float *__restrict__ bias, int Cout,
-                                                           float *__restrict__ out, int ld_out, int ch_off) {
+                                                           float ascale, float *__restrict__ out, int ld_out, int ch_off,
+                                                           int *__restrict__ overflow) {
   constexpr int BM = 128, BK = 32, KQ = BK / 4;
   constexpr int WN = (BN >= 128) ? 2 : 1, WM = 4 / WN, TM = BM / (32 * WM), TN = BN / (32 * WN), NPB = BN / 64;
   constexpr int RMAX = BM + 2 * 32;                         // raw pixels at W = 32
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restri
           mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
         }
       }
-      const float v4[4] = {mx.x, mx.y, mx.z, mx.w};
+      const float v4[4] = {mx.x * ascale, mx.y * ascale, mx.z * ascale, mx.w * ascale};
       _Float16 h4[4], l4[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restri
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + 32 * (TN * wn + j) + (lane & 31);
     if (co < Cout) {
-      const float bb = bias[co], sc = wscale[co];
+      const float bb = bias[co], sc = wscale[co] * (1.0f / ascale);
       float *op = out + ch_off + co;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -455,20 +459,36 @@ __global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restri
         }
     }
   }
-  if (!(big < 65504.f)) g_sp_overflow = 1;
+  if (!(big < 65504.f)) *overflow = 1;
 }
 
 
 template <int BN, int BM = 128>
 int launch_split(const float *in, int in_split, int M, int H, int W, int Cin, int ld_in, const _Float16 *whi, const _Float16 *wlo,
-                 const float *wscale, const float *bias, int Cout, int ks, float ascale, const ConvDstS &dst, hipStream_t st) {
+                 const float *wscale, const float *bias, int Cout, int ks, float ascale, const ConvDstS &dst, int *overflow,
+                 hipStream_t st) {
   dim3 grid(8 * sf_cdiv(sf_cdiv(M, BM), 8) * sf_cdiv(Cout, BN));
   if (in_split)
-    hipLaunchKernelGGL((k_conv_split<BN, true, BM>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst);
+    hipLaunchKernelGGL((k_conv_split<BN, true, BM>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst, overflow);
   else
-    hipLaunchKernelGGL((k_conv_split<BN, false, BM>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst);
+    hipLaunchKernelGGL((k_conv_split<BN, false, BM>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst, overflow);
   SF_LAUNCH_CHECK("k_conv_split");
   return 0;
+}
+
+// max |x| over n floats, OR-ed into *amax (a device float the caller zeroed; values are compared as their bit patterns, so the
+// result does not depend on the order): the calibration of the split-operand layers' activation scales (cnn_driver.hip)
+__global__ void k_absmax(const float *__restrict__ x, size_t n, float *__restrict__ amax) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = fabsf(x[i]);
+    m = (v > m || v != v) ? v : m;                    // (a NaN wins: its pattern is above every finite one)
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(m, o);
+    m = (__float_as_uint(t) > __float_as_uint(m)) ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m != 0.f) atomicMax(reinterpret_cast<unsigned *>(amax), __float_as_uint(m));
 }
 
 }  // namespace
@@ -484,7 +504,7 @@ int sf_cnn_split_weights(const float *w, int Cout, int K, void *hi, void *lo, fl
 }
 
 static int split_go(const float *in, int in_split, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo, const float *wscale,
-                    const float *bias, int Cout, int ksize, float ascale, const ConvDstS &d, hipStream_t st) {
+                    const float *bias, int Cout, int ksize, float ascale, const ConvDstS &d, int *overflow, hipStream_t st) {
   const long long Ml = (long long)N * H * W;
   const size_t halo = 2 * ((size_t)(ksize >> 1) * W + (ksize >> 1)) * ld_in * 4 + 64, img = (size_t)H * W * ld_in * 4;
   if ((size_t)Cout * ksize * ksize * Cin * 2 >= 0x7ff00000u || img + halo >= 0x7ff00000u) {
@@ -497,7 +517,7 @@ static int split_go(const float *in, int in_split, int N, int H, int W, int Cin,
       const int nn = (N - n0 < per) ? N - n0 : per;
       ConvDstS dd = d;
       for (int k = 0; k < 3; ++k) dd.p[k] = d.p[k] + (size_t)n0 * H * W * d.ld[k];
-      if (int rc = split_go(in + (size_t)n0 * H * W * ld_in, in_split, nn, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, dd, st))
+      if (int rc = split_go(in + (size_t)n0 * H * W * ld_in, in_split, nn, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, dd, overflow, st))
         return rc;
     }
     return 0;
@@ -508,19 +528,22 @@ static int split_go(const float *in, int in_split, int N, int H, int W, int Cin,
   // per CU instead of three and were slower still: what hides this kernel's trips to L2 is occupancy; 96-channel tiles of 256
   // pixels for 96 / 192 / 288 channels -- 236 registers, two workgroups per CU -- were the same within the noise.)
   if (Cout > 64 && sf_cdiv(Cout, 128) * 128 <= sf_cdiv(Cout, 64) * 64)
-    return launch_split<128>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
+    return launch_split<128>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, overflow, st);
   // 64-channel tiles take 256 pixels: wave tiles of 64 x 64 as in the 128 x 128 form -- 8 fragment reads per 12 matrix instructions
   // instead of 6 per 6 (the kernel sits at the LDS's bandwidth): 48.9 k -> 49.9 k windows/s
-  return launch_split<64, 256>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, st);
+  return launch_split<64, 256>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, overflow, st);
 }
 
+static bool sp_pow2(float v) { int e; return v > 0.f && v < 3.0e38f && frexpf(v, &e) == 0.5f; }
+
 int sf_cnn_conv_split(const float *in, int in_split, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
-                      const float *wscale, const float *bias, int Cout, int ksize, float ascale, float *out, int out_split, int ld_out,
-                      int ch_off, void *stream) {
-  if (!in || !whi || !wlo || !wscale || !bias || !out || N < 1 || (ksize != 1 && ksize != 3) || (Cin & 7) || (ld_in & 3) ||
-      Cin > ld_in || ch_off < 0 || ch_off + Cout > ld_out || !(ascale > 0.f) || (in_split && (ld_in != Cin || ascale != 1.0f)) ||
-      (out_split && (ld_out != Cout || ch_off != 0 || (Cout & 7)))) {
-    sf_set_error("sf_cnn_conv_split: bad argument (ksize 1|3, Cin multiple of 8; split-format tensors are dense, ascale 1)");
+                      const float *wscale, const float *bias, int Cout, int ksize, float ascale, float *out, int out_split, float oscale,
+                      int ld_out, int ch_off, int *overflow, void *stream) {
+  if (!in || !whi || !wlo || !wscale || !bias || !out || !overflow || N < 1 || (ksize != 1 && ksize != 3) || (Cin & 7) || (ld_in & 3) ||
+      Cin > ld_in || ch_off < 0 || ch_off + Cout > ld_out || !sp_pow2(ascale) || (in_split && ld_in != Cin) ||
+      (out_split && (ld_out != Cout || ch_off != 0 || (Cout & 7) || !sp_pow2(oscale)))) {
+    sf_set_error("sf_cnn_conv_split: bad argument (ksize 1|3, Cin multiple of 8; split-format tensors are dense; ascale / oscale powers "
+                 "of two; overflow: a device int of the caller)");
     return -1;
   }
   ConvDstS d{};
@@ -529,15 +552,17 @@ int sf_cnn_conv_split(const float *in, int in_split, int N, int H, int W, int Ci
   d.off[0] = d.off[1] = d.off[2] = ch_off;
   d.end[0] = d.end[1] = d.end[2] = Cout;
   d.fmt[0] = d.fmt[1] = d.fmt[2] = out_split ? 1 : 0;
-  return split_go(in, in_split, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, d, (hipStream_t)stream);
+  d.oscale[0] = d.oscale[1] = d.oscale[2] = out_split ? oscale : 1.0f;
+  return split_go(in, in_split, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, d, overflow, (hipStream_t)stream);
 }
 
 int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
                              const float *wscale, const float *bias, int c0, int c1, int c2, float ascale, float *out0, int ld0,
-                             int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, int out12_split, void *stream) {
-  if (!in || !whi || !wlo || !wscale || !bias || !out0 || !out1 || !out2 || N < 1 || (Cin & 7) || (ld_in & 3) || Cin > ld_in ||
-      c0 < 1 || c1 < 1 || c2 < 1 || off0 + c0 > ld0 || off1 + c1 > ld1 || off2 + c2 > ld2 || !(ascale > 0.f) ||
-      (out12_split && (ld1 != c1 || off1 != 0 || (c1 & 7) || ld2 != c2 || off2 != 0 || (c2 & 7)))) {
+                             int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, int out12_split, float oscale1,
+                             float oscale2, int *overflow, void *stream) {
+  if (!in || !whi || !wlo || !wscale || !bias || !out0 || !out1 || !out2 || !overflow || N < 1 || (Cin & 7) || (ld_in & 3) || Cin > ld_in ||
+      c0 < 1 || c1 < 1 || c2 < 1 || off0 + c0 > ld0 || off1 + c1 > ld1 || off2 + c2 > ld2 || !sp_pow2(ascale) ||
+      (out12_split && (ld1 != c1 || off1 != 0 || (c1 & 7) || ld2 != c2 || off2 != 0 || (c2 & 7) || !sp_pow2(oscale1) || !sp_pow2(oscale2)))) {
     sf_set_error("sf_cnn_conv_split3_split: bad argument");
     return -1;
   }
@@ -547,7 +572,8 @@ int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int 
   d.off[0] = off0; d.off[1] = off1; d.off[2] = off2;
   d.end[0] = c0; d.end[1] = c0 + c1; d.end[2] = c0 + c1 + c2;
   d.fmt[0] = 0; d.fmt[1] = d.fmt[2] = out12_split ? 1 : 0;
-  return split_go(in, 0, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, c0 + c1 + c2, 1, ascale, d, (hipStream_t)stream);
+  d.oscale[0] = 1.0f; d.oscale[1] = out12_split ? oscale1 : 1.0f; d.oscale[2] = out12_split ? oscale2 : 1.0f;
+  return split_go(in, 0, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, c0 + c1 + c2, 1, ascale, d, overflow, (hipStream_t)stream);
 }
 
 // 1 when sf_cnn_pool_conv_split takes this geometry (whole image rows per 128-pixel tile, operands below 2 GB); else sf_cnn_pool_conv
@@ -556,35 +582,29 @@ int sf_cnn_pool_conv_split_ok(int N, int H, int W, int Cin, int Cout) {
           (size_t)Cout * Cin * 2 < 0x7ff00000u) ? 1 : 0;
 }
 int sf_cnn_pool_conv_split(const float *in, int N, int H, int W, int Cin, const void *whi, const void *wlo, const float *wscale,
-                           const float *bias, int Cout, float *out, int ld_out, int ch_off, void *stream) {
-  if (!in || !whi || !wlo || !wscale || !bias || !out || N < 1 || ch_off < 0 || ch_off + Cout > ld_out ||
+                           const float *bias, int Cout, float ascale, float *out, int ld_out, int ch_off, int *overflow, void *stream) {
+  if (!in || !whi || !wlo || !wscale || !bias || !out || !overflow || N < 1 || ch_off < 0 || ch_off + Cout > ld_out || !sp_pow2(ascale) ||
       !sf_cnn_pool_conv_split_ok(N, H, W, Cin, Cout)) {
-    sf_set_error("sf_cnn_pool_conv_split: bad argument (dense input, W dividing 128, Cin multiple of 8, operands < 2 GB)");
+    sf_set_error("sf_cnn_pool_conv_split: bad argument (dense input, W dividing 128, Cin multiple of 8, operands < 2 GB, ascale a power of two)");
     return -1;
   }
   const int M = N * H * W;
   const _Float16 *h = reinterpret_cast<const _Float16 *>(whi), *l = reinterpret_cast<const _Float16 *>(wlo);
   if (Cout > 64)
     hipLaunchKernelGGL((k_poolconv_split<128>), dim3(sf_cdiv(M, 128), sf_cdiv(Cout, 128)), dim3(256), 0, (hipStream_t)stream, in, M, H, W,
-                       Cin, h, l, wscale, bias, Cout, out, ld_out, ch_off);
+                       Cin, h, l, wscale, bias, Cout, ascale, out, ld_out, ch_off, overflow);
   else
     hipLaunchKernelGGL((k_poolconv_split<64>), dim3(sf_cdiv(M, 128), sf_cdiv(Cout, 64)), dim3(256), 0, (hipStream_t)stream, in, M, H, W,
-                       Cin, h, l, wscale, bias, Cout, out, ld_out, ch_off);
+                       Cin, h, l, wscale, bias, Cout, ascale, out, ld_out, ch_off, overflow);
   SF_LAUNCH_CHECK("k_poolconv_split");
   return 0;
 }
 
-// 1 when a launch since the last reset met an activation float16 cannot hold (the caller repeats the work on the fp32 kernels)
-int sf_cnn_split_overflow(int *flag, int reset, void *stream) {
-  if (flag) {
-    SF_HIP(hipMemcpyFromSymbolAsync(flag, HIP_SYMBOL(g_sp_overflow), sizeof(int), 0, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    SF_HIP(hipStreamSynchronize((hipStream_t)stream));
-  }
-  if (reset) {
-    const int z = 0;
-    SF_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sp_overflow), &z, sizeof(int), 0, hipMemcpyHostToDevice, (hipStream_t)stream));
-    SF_HIP(hipStreamSynchronize((hipStream_t)stream));
-  }
+int sf_cnn_absmax(const float *x, size_t n, float *amax, void *stream) {
+  if (!x || !amax || n < 1) { sf_set_error("sf_cnn_absmax: bad argument"); return -1; }
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_absmax, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, amax);
+  SF_LAUNCH_CHECK("k_absmax");
   return 0;
 }
 

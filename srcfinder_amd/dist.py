@@ -177,14 +177,17 @@ def robust_mf_sharded(cube_shard, library, samples: int, *, group=None, dst: int
     ``gather="score"`` (default; the north star's "single gather of the final score image"): the image
     collective carries the float64 CMF band only -- 8 B/pixel, 12 MB per rank of a 598 x 20000 flightline (plus the 4 B/pixel
     of the int16 metadata image and 8 B/pixel of a label image when the run produced them, in the SAME collective).  ``dst``
-    gets ``score`` [lines, samples] float64; the RGB quick-look bands of the 4-band product are a copy of three cube bands
-    and stay with the rank that read those columns (``out`` of this rank's own block is returned as ``out_local`` on every
-    rank).  ``gather="product"``: the whole [lines, samples, nb] float64 product (32 B/pixel, 48 MB per rank) as ``out`` too.
+    gets ``score`` [lines, samples] float64.  The RGB quick-look bands of the reference's 4-band product
+    (cmf/robust_mf.py:212-228, :395-397) are a copy of three cube bands and stay with the rank that read those columns:
+    EVERY rank -- ``dst`` or not -- gets its own block [lines, ncols_r, nb] as ``out_local``, so each rank can write its
+    columns of the BIP product itself (or the caller asks for ``gather="product"``).
+    ``gather="product"``: the whole [lines, samples, nb] float64 product (32 B/pixel, 48 MB per rank) as ``out`` on ``dst``,
+    ``score`` a view of its last band.
 
     Either way TWO collectives: the image slab above, and ONE small record slab (``alphaidx``, ``nuse``, ``status`` [samples]
     -- [samples, k] for a multimodal run --, ``colstats`` [3, samples], ``nll`` when asked for: <= 5 KB per rank for the
-    unimodal product).  Returns the dict on ``dst`` and ``None`` elsewhere (``{"out_local": ...}`` is attached to the dict
-    on ``dst`` only).  ``compute`` defaults to :func:`srcfinder_amd.cmf.robust_mf`; tests inject a CPU stand-in to exercise
+    unimodal product).  Returns a dict on every rank: the gathered fields + ``out_local`` on ``dst``, ``{"out_local": ...}``
+    alone elsewhere.  ``compute`` defaults to :func:`srcfinder_amd.cmf.robust_mf`; tests inject a CPU stand-in to exercise
     the sharding and the collectives without a GPU."""
     import torch.distributed as dist
     if gather not in ("score", "product"):
@@ -210,12 +213,11 @@ def robust_mf_sharded(cube_shard, library, samples: int, *, group=None, dst: int
     full = gather_packed(images, samples, lead=lines, group=group, dst=dst)
     rec = gather_packed(records, samples, lead=1, group=group, dst=dst)
     if dist.get_rank(group) != dst:
-        return None
+        return {"out_local": out}
     full.update(rec)
     if gather == "product":
         full["score"] = full["out"][..., full["out"].shape[2] - 1]
-    else:
-        full["out_local"] = out
+    full["out_local"] = out
     return full
 
 

@@ -85,6 +85,38 @@ class FlightlinePipeline:
     def slot_of_next(self):
         return self._n % self.depth
 
+    def pick_product_buffers(self, cube_bil, library, *, spares=3, shape=None, **kw):
+        """A pool of ``depth`` product buffers ``[lines, ncols, 4]`` float64 for ``submit(..., out=...)``, chosen by measurement.
+
+        The record-writing score kernel is HBM-bound and its time depends, persistently per buffer, on where the caching
+        allocator put the 383 MB product buffer (0.735 .. 0.81 ms for the same launch, up to 8 %;
+        profiles/r05_score_placement.md).  A long-running host pays for that once: ``depth + spares`` candidates are allocated,
+        one flightline is run into each with the score kernel's HIP events on (``sf_cmf_score_timing``), and the fastest
+        ``depth`` are kept; the rest go back to the allocator.  Opt-in set-up work of ~``depth + spares`` flightline steps --
+        ``submit`` works with any buffer (or none).  ``kw`` is passed to ``robust_mf`` (``active=``, ``reflectance=`` ...).
+        Returns ``(buffers, report)``; ``report`` holds the candidates' score-kernel ms and the kept ones."""
+        import torch
+        from . import _ffi
+        L = _ffi.lib()
+        if shape is None:
+            shape = (cube_bil.shape[0], cube_bil.shape[2], 4)
+        cands = [torch.empty(shape, dtype=torch.float64, device=self.device) for _ in range(self.depth + int(spares))]
+        tms = []
+        for c in cands:
+            L.sf_cmf_score_timing(1)
+            try:
+                self.submit(cube_bil, library, out=c, out_column0=0, **kw)
+                self.synchronize()
+                tot, nl = _ffi.C.c_double(0.0), _ffi.C.c_int(0)
+                L.sf_cmf_score_timing_read(_ffi.C.byref(tot), _ffi.C.byref(nl))
+            finally:
+                L.sf_cmf_score_timing(0)
+            tms.append(tot.value / max(nl.value, 1))
+        order = sorted(range(len(cands)), key=lambda i: tms[i])
+        keep = [cands[i] for i in order[:self.depth]]
+        report = {"candidate_score_ms": [round(t, 4) for t in tms], "kept": sorted(round(tms[i], 4) for i in order[:self.depth])}
+        return keep, report
+
     def synchronize(self):
         for st in self.streams:
             st.synchronize()

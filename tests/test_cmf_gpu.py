@@ -1106,6 +1106,20 @@ def test_linalg_wrappers_follow_scipy(torch_cuda):
     wo = np.sort(np.linalg.eigvalsh(spd))
     assert np.iscomplexobj(w) and np.allclose(np.sort(w.real), wo, rtol=1e-11) and np.all(w.imag == 0)
     np.testing.assert_allclose(spd @ v, v * w.real, rtol=0, atol=1e-11 * wo[-1])
+    # above 96 rows the wide eigensolver (sf_cmf_eigh_wide): the reference's PCA calls eig(cov(...)) at p = 416 with -R -k 2
+    # (cmf/robust_mf.py:310); a flightline-like spectrum (a cluster at the noise floor + a few signal directions) and a plain one
+    for n, spec in ((130, None), (416, "cluster")):
+        x = rng.normal(size=(3 * n, n))
+        if spec == "cluster":
+            x = 0.01 * x + rng.normal(size=(3 * n, 5)) @ rng.normal(size=(5, n))
+        big = np.cov(x.T)
+        w, v = cmf.eig(big)
+        wo = np.sort(np.linalg.eigvalsh(big))
+        assert np.allclose(np.sort(w.real), wo, rtol=1e-10, atol=1e-13 * wo[-1]) and np.all(w.imag == 0)
+        np.testing.assert_allclose(big @ v, v * w.real, rtol=0, atol=1e-10 * wo[-1])
+        np.testing.assert_allclose(v.T @ v, np.eye(n), rtol=0, atol=1e-10)
+    with pytest.raises(NotImplementedError):
+        cmf.eig(np.eye(513))
     # prefix overflow: diag(1e200, 1e200, 1e-300): the total determinant is 1e100, the running product reaches inf first
     d = np.diag([1e200, 1e200, 1e-300])
     assert O.det(d) == np.inf and cmf.det(d) == np.inf

@@ -44,7 +44,7 @@ def _worker(rank, world, port, q):
             else:
                 ok = ok and torch.equal(got["out_local"], ref.out[:, s0:s1])
         else:
-            ok = ok and got is None
+            ok = ok and set(got) == {"out_local"} and tuple(got["out_local"].shape[:2]) == (lines, s1 - s0)
     # the tile scorer: row shards, one gather of the float32 blocks
     net = cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024))
     plane = synthetic_plane(9, 6, seed=3)
@@ -76,3 +76,21 @@ def test_two_ranks_share_one_gpu_and_reproduce_the_single_run():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res == {0: True, 1: True}
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
+    """`python bench.py --gpus 2` with no WORLD_SIZE (the shape of the driver's command): the script starts its two ranks as a
+    child torch.distributed.run, relays rank 0's JSON line as the last line and returns the child's exit code.  One GPU here,
+    so the two ranks share it over host-staged gloo collectives (a functional run, not a scaling number)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SF_BENCH_SHARE_GPU="1", SF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--lines", "1200",
+           "--samples", "40", "--no-placement"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    line = json.loads(last)
+    assert line["n_gpus"] == 2 and line["config"]["gather_verified"] is True
+    assert line["value"] > 0 and line["scaling"] == "strong"

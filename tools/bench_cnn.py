@@ -30,7 +30,8 @@ def main():
     from srcfinder_amd import _ffi
     for kv in args.knob:
         k, v = kv.split("=")
-        _ffi.lib().sf_debug_set(int(k), int(v))
+        if _ffi.lib().sf_debug_set(int(k), int(v)) != 0:
+            raise SystemExit("--knob %s: sf_debug_set refused the key" % kv)
     sd = synthetic_state_dict(2024)
     net = cnn.GoogLeNetHIP(sd, precision=args.precision)
     net.fuse_conv1 = not args.no_fuse

@@ -10,11 +10,13 @@ L = _ffi.lib()
 raw = C.CDLL(os.path.join(ROOT, "srcfinder_amd", "libsrcfinder_amd.so"))
 vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
 raw.sf_cnn_split_weights.argtypes = [vp, i32, i32, vp, vp, vp, vp]
-raw.sf_cnn_conv_split.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, f32, vp, i32, i32, i32, vp]
+raw.sf_cnn_conv_split.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, f32, vp, i32, f32, i32, i32, vp, vp]
 P, st = _ffi.ptr, _ffi.stream_ptr
 for kv in sys.argv[1:]:
     k, v = kv.split("="); L.sf_debug_set(int(k), int(v))
 XS = float(os.environ.get("SF_CHECK_XSCALE", "1"))     # activation scale (float16's low halves go subnormal below ~0.25)
+AS = float(os.environ.get("SF_CHECK_ASCALE", "1"))     # the layer's ascale (a power of two): SF_CHECK_XSCALE=2e-4 SF_CHECK_ASCALE=4096 ...
+flag = torch.zeros(1, dtype=torch.int32, device="cuda:0")
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(5)
 
@@ -27,7 +29,7 @@ def layer(N, H, Cin, Cout, ks, timeit=True):
     sc = torch.empty(Cout, dtype=torch.float32, device=dev)
     assert raw.sf_cnn_split_weights(P(w), Cout, K, P(hi), P(lo), P(sc), st()) == 0
     o_sp = torch.empty(N, H, H, Cout, dtype=torch.float32, device=dev); o_d = torch.empty_like(o_sp)
-    run_sp = lambda: raw.sf_cnn_conv_split(P(x), 0, N, H, H, Cin, Cin, P(hi), P(lo), P(sc), P(b), Cout, ks, 1.0, P(o_sp), 0, Cout, 0, st())
+    run_sp = lambda: raw.sf_cnn_conv_split(P(x), 0, N, H, H, Cin, Cin, P(hi), P(lo), P(sc), P(b), Cout, ks, AS, P(o_sp), 0, 1.0, Cout, 0, P(flag), st())
     run_d = lambda: L.sf_cnn_conv(P(x), N, H, H, Cin, Cin, P(w), P(b), Cout, ks, P(o_d), Cout, 0, st())
     assert run_sp() == 0 and run_d() == 0
     torch.cuda.synchronize()

@@ -406,7 +406,9 @@ int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, co
  * sf_cnn_score_workspace_bytes(batch) (activations of one batch + the Winograd / split-operand forms of the weights + the overflow
  * slots).  All launches are enqueued on `stream`.
  * route (an ARGUMENT of the call -- nothing process- or thread-wide selects the arithmetic):
- *   0  operand splitting on the fp16 matrix cores (sf_cnn_conv_split: the float32 tolerance class; the product's default).  Both
+ *   0  operand splitting on the fp16 matrix cores (sf_cnn_conv_split: the float32 tolerance class; the product's default) with the
+ *      trunk up to conv3 SHARED between the overlapping windows (below: sf_cnn_ring_pool1 ...); 3 = the same with every window
+ *      evaluated on its own (round 5's form; bit-identical to the kernels sequenced one batch at a time).  Both
  *      ends of float16's range are handled inside the call: `scales` = the sf_cnn_num_scales() per-layer activation scales (HOST
  *      floats, powers of two, e.g. from sf_cnn_calibrate) or NULL -- the call then calibrates itself on a fixed sample of the
  *      plane's windows (a function of the plane alone: every row range and batch size of a flightline gets the same scales, hence
@@ -417,12 +419,35 @@ int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, co
  * sf_cnn_calibrate: the scales alone (host array of sf_cnn_num_scales() floats: [0] maxpool1's output, [1] conv2's output,
  * [2 + 3 i ...] inception block i's input, its 3 x 3 reducer's output, its "5 x 5" reducer's output); synchronises `stream`. */
 size_t sf_cnn_blob_floats(void);
-size_t sf_cnn_score_workspace_bytes(int batch);
+size_t sf_cnn_score_workspace_bytes(int batch, int H, int W);   /* H = W = 0: without the trunk-sharing buffers (routes 3, 4, 2, 1; sf_cnn_calibrate) */
 int sf_cnn_num_scales(void);
 int sf_cnn_calibrate(const float *padded, int H, int W, const float *blob, int batch, void *workspace, size_t workspace_bytes,
                      float *scales, void *stream);
 int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int r0, int r1, const float *blob, float *out,
                       int batch, int route, const float *scales, int *rescued, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Trunk sharing (csrc/cnn_share.hip): cnn_pred_pipeline.py:53-58 scores one 256 x 256 window per pixel, so neighbouring windows
+ * overlap by 255/256.  Through conv3 (googlenet1.py:110-120) a window's activation at (y, x) of the 64 x 64 grid depends on the
+ * window only through its zero padding: conv3 at y, x in 2..61 equals the same stack evaluated fully convolutionally on the whole
+ * padded plane at the window's phase (r & 3, c & 3) -- 16 phase maps, built once per strip of image rows with the FCN kernels --
+ * and only the ring is per window:
+ *   sf_cnn_phase_canvas  canvas[Hc][Wc] = padded[y0 + u][x0 + v] (zero outside): the plane shifted by a phase
+ *   sf_cnn_ring_pool1    maxpool1(conv1(window)) at the 252 border positions of the 64 x 64 grid (border index: row 0 -> x, row 63 ->
+ *                        64 + x, column 0 -> 127 + y, column 63 -> 189 + y): out[ntiles][252][64]
+ *   sf_cnn_conv3_ring    conv3 at the 496 ring positions (rows 0, 1, 62, 63: y' 64 + x with y' = 0..3, then 256 + 4 (y - 2) + {0, 1, 2, 3}
+ *                        for x = 0, 1, 62, 63), taps from the window's own conv2 border [N][252][64] or the conv2 phase maps
+ *                        [16][Hq][Wq][64] in front of it (one allocation, split format): out[N][496][Cout]
+ *   sf_cnn_pool2_shared  maxpool2 (googlenet1.py:64) from that ring tensor + the conv3 phase maps [16][Hq][Wq][C]: out[N][32][32][C]
+ * Window t of the batch = image pixel ((tile0 + t) / W, (tile0 + t) % W); its origin in phase map (r & 3) * 4 + (c & 3) is
+ * ((r >> 2) - Rb, c >> 2).  sf_cnn_score_rows (route 0) sequences all of it. */
+int sf_cnn_phase_canvas(const float *padded, int Hp, int Wp, int y0, int x0, int Hc, int Wc, float *canvas, void *stream);
+int sf_cnn_ring_pool1(const float *padded, int Hp, int Wp, int W, long long tile0, int ntiles, const float *w, const float *bias,
+                      float *out, void *stream);
+int sf_cnn_conv3_ring(const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, const void *whi,
+                      const void *wlo, const float *wscale, const float *bias, int Cout, float ascale, float *out, int *overflow,
+                      void *stream);
+int sf_cnn_pool2_shared(const float *ring, const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, int C, float *out,
+                        void *stream);
 
 /* FCN shift-and-stitch, the reference's approximate fast mode (cnn/fcn_pred_pipeline.py).
  * sf_cnn_fcn_prepare: ClampCH4 + Normalize of the plane, embedded at (top, left) = divmod(shift, scale) in a zero canvas

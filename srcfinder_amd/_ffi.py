@@ -50,6 +50,10 @@ SIGNATURES = {
     "sf_cnn_conv_split": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, C.c_float, vp, i32, C.c_float, i32, i32, vp, vp]),
     "sf_cnn_absmax": (i32, [vp, sz, vp, vp]),
     "sf_cnn_num_scales": (i32, []),
+    "sf_cnn_phase_canvas": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "sf_cnn_ring_pool1": (i32, [vp, i32, i32, i32, C.c_longlong, i32, vp, vp, vp, vp]),
+    "sf_cnn_conv3_ring": (i32, [vp, C.c_longlong, i32, i32, i32, i32, i32, sz, vp, vp, vp, vp, i32, C.c_float, vp, vp, vp]),
+    "sf_cnn_pool2_shared": (i32, [vp, vp, C.c_longlong, i32, i32, i32, i32, i32, i32, vp, vp]),
     "sf_cnn_calibrate": (i32, [vp, i32, i32, vp, i32, vp, sz, vp, vp]),
     "sf_cnn_conv_split3_split": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, C.c_float, vp, i32, i32, vp, i32, i32,
                                        vp, i32, i32, i32, C.c_float, C.c_float, vp, vp]),
@@ -62,7 +66,7 @@ SIGNATURES = {
                                  vp, i32, i32, vp]),
     "sf_cnn_head": (i32, [vp, i32, i32, i32, vp, vp, vp, i64, f32, vp, vp]),
     "sf_cnn_blob_floats": (sz, []),
-    "sf_cnn_score_workspace_bytes": (sz, [i32]),
+    "sf_cnn_score_workspace_bytes": (C.c_size_t, [i32, i32, i32]),
     "sf_cnn_score_rows": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, sz, vp]),
     "sf_cnn_fcn_prepare": (i32, [vp, i32, i32, f32, f32, f32, f32, i32, i32, i32, i32, i32, vp, vp]),
     "sf_cnn_conv1_image": (i32, [vp, i32, i32, i32, vp, vp, vp, i32, vp]),

@@ -29,7 +29,10 @@ MODEL_NORM = {
 BN_EPS = 0.001          # googlenet1.py:270
 NODATA = -9999.0
 # the convolutions' arithmetic routes (all float32 in / float32 accumulate; include/srcfinder_amd.h: sf_cnn_score_rows)
-ROUTES = {"split": 0, "winograd": 4, "direct": 2, "direct_pointer": 1}
+# "split": operand splitting on the fp16 matrix cores; through the C driver (sf_cnn_score_rows) with the trunk up to conv3 SHARED
+# between the overlapping windows (csrc/cnn_share.hip), sequenced from Python one batch at a time (forward_tiles) every window on
+# its own -- "split_unshared" names that form on both drivers (bit-identical between them)
+ROUTES = {"split": 0, "split_unshared": 3, "winograd": 4, "direct": 2, "direct_pointer": 1}
 
 
 def _torch():
@@ -263,8 +266,8 @@ class GoogLeNetHIP(object):
         if r is None:
             return 0 if self.half else _knob(17)
         r = ROUTES.get(r, r) if isinstance(r, str) else int(r)
-        if r not in (0, 1, 2, 4):
-            raise ValueError("route must be one of %r or 0 / 4 / 2 / 1" % (sorted(ROUTES),))
+        if r not in (0, 1, 2, 3, 4):
+            raise ValueError("route must be one of %r or 0 / 3 / 4 / 2 / 1" % (sorted(ROUTES),))
         return r
 
     def overflow_slots(self, n):
@@ -281,7 +284,7 @@ class GoogLeNetHIP(object):
         L = _ffi.lib()
         H, W = ds.inshape[1], ds.inshape[2]
         with torch.cuda.device(self.device):
-            wsb = L.sf_cnn_score_workspace_bytes(int(batch))
+            wsb = L.sf_cnn_score_workspace_bytes(int(batch), 0, 0)
             ws = self._buf("c_driver_ws", ((wsb + 3) // 4,))
             sc = (C.c_float * len(self.ascale))()
             _ffi.check(L.sf_cnn_calibrate(_ffi.ptr(ds.x), H, W, _ffi.ptr(self.packed_blob()), int(batch), _ffi.ptr(ws),
@@ -293,6 +296,8 @@ class GoogLeNetHIP(object):
         """Set the pass's route and overflow slot; returns True when this call owns the slot (and must check it itself)."""
         torch = _torch()
         self._route = self._route_code(route)
+        if self._route == 3:
+            self._route = 0        # (the Python-sequenced graph always evaluates every window on its own)
         own = False
         if self._route == 0 and not self.half:
             if overflow is None:
@@ -300,7 +305,8 @@ class GoogLeNetHIP(object):
                     self._own_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
                 self._own_flag.zero_()
                 overflow, own = self._own_flag, True
-            if overflow.dtype != torch.int32 or overflow.numel() < 1 or overflow.device != self.device:
+            same = overflow.is_cuda and (self.device.index is None or overflow.device.index == self.device.index)
+            if overflow.dtype != torch.int32 or overflow.numel() < 1 or not same:
                 raise ValueError("overflow must be an int32 tensor on the network's device")
         self._flag = overflow
         return own
@@ -479,14 +485,34 @@ def _overflow_warning(what):
                   "the fp32 matrix cores" % what)
 
 
+def _score_rows_c(net, ds, r0, r1, batch, out, code):
+    """sf_cnn_score_rows on image rows [r0, r1) with the network's current activation scales; returns the batches re-scored."""
+    torch = _torch()
+    L = _ffi.lib()
+    H, W = ds.inshape[1], ds.inshape[2]
+    with torch.cuda.device(net.device):
+        wsb = L.sf_cnn_score_workspace_bytes(int(batch), H if code == 0 else 0, W if code == 0 else 0)
+        ws = net._buf("c_driver_ws", ((wsb + 3) // 4,))
+        nres = C.c_int(0)
+        sc = (C.c_float * len(net.ascale))(*net.ascale)
+        _ffi.check(L.sf_cnn_score_rows(_ffi.ptr(ds.x), _ffi.ptr(ds.plane), H, W, int(r0), int(r1), _ffi.ptr(net.packed_blob()),
+                                       _ffi.ptr(out), int(batch), code, sc, C.byref(nres), _ffi.ptr(ws),
+                                       C.c_size_t(ws.numel() * 4), _ffi.stream_ptr()), "sf_cnn_score_rows")
+    if nres.value:
+        _overflow_warning("%d batch(es) of rows %d..%d" % (nres.value, r0, r1))
+    return nres.value
+
+
 def score_tiles(net, ds, t_first, t_last, batch, out, route=None):
     """``net.forward_tiles`` over the windows [t_first, t_last) of the FlightlineConvolve ``ds`` in batches, asynchronously: on the
     split-operand route every batch raises its own overflow slot, the slots are read ONCE after the last batch and only the raised
     batches are scored again on the fp32 matrix cores (cnn_pred_pipeline.py:173-181).  Returns the number of batches re-scored."""
     W = ds.inshape[2]
-    starts = list(range(int(t_first), int(t_last), int(batch)))
     code = net._route_code(route)
-    slots = net.overflow_slots(len(starts)) if (code == 0 and not net.half) else None
+    if not net.half and getattr(net, "c_driver", True) and t_first % W == 0 and t_last % W == 0 and t_last > t_first:
+        return _score_rows_c(net, ds, t_first // W, t_last // W, batch, out, code)       # whole image rows: the C-side driver
+    starts = list(range(int(t_first), int(t_last), int(batch)))
+    slots = net.overflow_slots(len(starts)) if (code in (0, 3) and not net.half) else None
     for i, t0 in enumerate(starts):
         net.forward_tiles(ds.x, W, t0, min(batch, t_last - t0), plane=ds.plane, out=out, route=code,
                           overflow=None if slots is None else slots[i:i + 1])
@@ -545,7 +571,7 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
     r0, r1 = (0, H) if rows is None else rows
     code = net._route_code(route)
     rescued = 0
-    if code == 0 and not net.half:
+    if code in (0, 3) and not net.half:
         # ONE set of scales for the call, whichever driver sequences the graph: the caller's, or sf_cnn_calibrate on this plane
         if scales is not None:
             if len(scales) != len(net.ascale):
@@ -554,24 +580,13 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
         else:
             net.calibrate(ds, batch)
     if not net.half and getattr(net, "c_driver", True):
-        # the C-side driver sequences the whole graph for the row range: one library call (calibration, per-batch overflow slots
+        # the C-side driver sequences the whole graph for the row range: one library call (shared trunk, per-batch overflow slots
         # and the fp32 re-scoring of raised batches included)
-        L = _ffi.lib()
-        with torch.cuda.device(net.device):
-            wsb = L.sf_cnn_score_workspace_bytes(int(batch))
-            ws = net._buf("c_driver_ws", ((wsb + 3) // 4,))
-            nres = C.c_int(0)
-            sc = (C.c_float * len(net.ascale))(*net.ascale)
-            _ffi.check(L.sf_cnn_score_rows(_ffi.ptr(ds.x), _ffi.ptr(ds.plane), H, W, int(r0), int(r1), _ffi.ptr(net.packed_blob()),
-                                           _ffi.ptr(out), int(batch), code, sc, C.byref(nres), _ffi.ptr(ws),
-                                           C.c_size_t(ws.numel() * 4), _ffi.stream_ptr()), "sf_cnn_score_rows")
-            rescued = nres.value
-        if rescued:
-            _overflow_warning("%d batch(es) of rows %d..%d" % (rescued, r0, r1))
+        rescued = _score_rows_c(net, ds, r0, r1, batch, out, code) if r1 > r0 else 0
     else:
         rescued = score_tiles(net, ds, r0 * W, r1 * W, batch, out, route=code)
     if info is not None:
-        info.update(rescued_batches=rescued, route=code, scales=list(net.ascale) if code == 0 else None)
+        info.update(rescued_batches=rescued, route=code, scales=list(net.ascale) if code in (0, 3) else None)
     out = out.view(H, W)
     return out.cpu().numpy() if to_numpy else out
 
@@ -659,20 +674,20 @@ def fcn_predict_flightline(cmf2d, model="COVID_QC", weights=None, scale=32, batc
     code = net._route_code(route)
     with torch.cuda.device(net.device):
         st = _ffi.stream_ptr()
-        if code == 0 and not net.half:
+        if code in (0, 3) and not net.half:
             # the split route's activation scales: calibrated on this plane's 256 x 256 windows (the same trunk, the same statistics)
             net.calibrate(FlightlineConvolve(plane, (mean, std) if (vmin, vmax) == (0.0, 4000.0) else
                                              Compose([ClampCH4(int(vmin), int(vmax)), Normalize([mean], [std])]), device=net.device))
         canvas = torch.empty((batch, Hc, Wc), dtype=torch.float32, device=net.device)
         starts = list(range(s0, s1, batch))
-        slots = net.overflow_slots(len(starts)) if (code == 0 and not net.half) else None
+        slots = net.overflow_slots(len(starts)) if (code in (0, 3) and not net.half) else None
 
         def run(i, rt):
             a = starts[i]
             n = min(batch, s1 - a)
             _ffi.check(L.sf_cnn_fcn_prepare(_ffi.ptr(plane), H, W, float(vmin), float(vmax), float(mean), float(std), scale,
                                             a, n, Hc, Wc, _ffi.ptr(canvas), st), "sf_cnn_fcn_prepare")
-            pred = net.forward_fcn(canvas[:n], route=rt, overflow=None if (slots is None or rt != 0) else slots[i:i + 1])
+            pred = net.forward_fcn(canvas[:n], route=rt, overflow=None if (slots is None or rt not in (0, 3)) else slots[i:i + 1])
             _ffi.check(L.sf_cnn_fcn_stitch(_ffi.ptr(pred), n, a, scale, pred.shape[1], pred.shape[2], _ffi.ptr(plane), H, W,
                                            NODATA, _ffi.ptr(out), st), "sf_cnn_fcn_stitch")
 

@@ -66,6 +66,8 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   return y;
 }
 
+#include "cmf_eigh_pre.h"   // the tridiagonal preconditioner of the Jacobi sweeps (round 6)
+
 // pair k of round-robin step s over p2 (even) players; m = p2 - 1
 __device__ __forceinline__ void rr_pair(int s, int k, int m, int &a, int &b) {
   int x = s + k;
@@ -86,8 +88,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // RMAX = ceil(p2/8) rows per lane; FULL = (p2 % 8 == 0): every lane owns exactly RMAX rows and all row
 // predicates fold away.  Loads are always unconditional (clamped row, value zeroed afterwards): predicated
 // LDS loads compile to one exec-masked branch + wait EACH and serialise the step (measured 2300 -> ~900 cycles).
-template <int EIG_RMAX, bool FULL, int LPP>
-__global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict__ nuse, int p, int p2, int LD,
+// PRE: 0, or p2 (72 / 84) -- the sweeps start from the preconditioned factor F of cmf_eigh_pre.h instead of L (a second p2 x LD
+// matrix and 8 p2 + 16 doubles of LDS behind nrm; 4 p2 threads).
+template <int EIG_RMAX, bool FULL, int LPP, int PRE = 0>
+__global__ __launch_bounds__(PRE > 0 ? 4 * PRE : 1024) void k_eigh(const double *__restrict__ cov, const int32_t *__restrict__ nuse, int p, int p2, int LD,
                        double *__restrict__ d_out, double *__restrict__ lam_out, double *__restrict__ evec_out,
                        int32_t *__restrict__ status, double2 *__restrict__ rot, size_t rot_stride, int unit) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -133,12 +137,21 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
       M[col * LD + row] = r;
     }
   };
-  load_R();
+  bool pre_ok = false, pre_done = false;
+  if constexpr (PRE > 0) {
+    __shared__ int preflag[2];
+    double *Bm = nrm + p2, *sml = Bm + (size_t)p2 * LD;
+    const int pr = eig_precondition<PRE>(M, Bm, sml, preflag, S, dv, p, LD, rot + (size_t)c * rot_stride);
+    pre_ok = pr != 0;
+    pre_done = pr == 2;        // F's columns already orthogonal to the sweeps' tolerance: no sweep would rotate anything
+    __syncthreads();
+  }
+  if (!pre_ok) load_R();
   __syncthreads();
 
   // ---------------- Cholesky R = L L^T in place (lower triangle of the column-major buffer)
   bool chol_ok = true;
-  for (int kk = 0; kk < p; ++kk) {
+  for (int kk = 0; kk < p && !pre_ok; ++kk) {
     const double dk = M[kk * LD + kk];  // final after the previous trailing update + barrier
     if (!(dk > 0.0) || !(dk <= 1.79769313486231570e+308)) { chol_ok = false; break; }  // uniform
     const double rk = rsqrt_nr(dk);
@@ -155,7 +168,9 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
     }
     __syncthreads();
   }
-  if (chol_ok) {
+  if (pre_ok) {
+    // M = F already (F F^T = R, columns orthogonal to ~1e-12: the first sweep below is the last)
+  } else if (chol_ok) {
     for (int i = tid; i < p2 * p2; i += nthr) {  // G = L: zero the strict upper triangle and the padding
       const int col = i / p2, row = i - col * p2;
       if (row < col || col >= p || row >= p) M[col * LD + row] = 0.0;
@@ -181,7 +196,7 @@ __global__ void k_eigh(const double *__restrict__ cov, const int32_t *__restrict
   const long long tstart = tprev;
 #endif
   // ---------------- phase 1: orthogonalise the columns of G (record the rotations in the fallback)
-  for (int sweep = 0; sweep < EIG_MAXSWEEP; ++sweep) {
+  for (int sweep = 0; sweep < (pre_done ? 0 : EIG_MAXSWEEP); ++sweep) {
     bool rotated = false, big = false;
     // exact squared norms once per sweep; inside the sweep they are carried through the rotations
     // (|a'|^2 = c^2 aa - 2cs ab + s^2 bb), so a step needs ONE dot product instead of three
@@ -409,7 +424,12 @@ static int launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, 
   if (lpp4) { while ((LD % 32) != 12 && (LD % 32) != 20) ++LD; }     // 4 consecutive columns x 4 rows: 64 distinct banks
   else if (lpp16) { while ((LD % 32) != 16) ++LD; }
   else { while ((LD % 32) != 8 && (LD % 32) != 24) ++LD; }
-  const size_t lds = ((size_t)p2 * LD + 2 * p2) * sizeof(double);
+  // The tridiagonal preconditioner (cmf_eigh_pre.h; the CH4 / CO2 window sizes, 8 lanes per pair) is built, correct and OFF by
+  // default: sf_debug_set(7, 2) turns it on.  Measured (profiles/r06_eigh_precond.md): one sweep instead of nine, but the
+  // preconditioner itself costs 1.34 M cycles of latency-bound float64 work on ONE workgroup (0.62 against 0.66 ms for a 72-band
+  // matrix alone) and its second LDS matrix leaves one workgroup per CU instead of three (598 columns: 1.90 against 1.14 ms).
+  const bool pre = !lpp4 && !lpp16 && (p2 == 72 || p2 == 84) && sf_tune().eigh_lpp == 2;
+  const size_t lds = ((size_t)p2 * LD + 2 * p2 + (pre ? (size_t)p2 * LD + 8 * p2 + 16 : 0)) * sizeof(double);
   if (lds > 160 * 1024 - 64 || g.p > SF_MAX_ACTIVE_FUSED) {
     sf_set_error("active window of %d bands exceeds the LDS-resident eigensolver (max %d)", g.p, SF_MAX_ACTIVE_FUSED);
     return -2;
@@ -417,6 +437,7 @@ static int launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, 
   int threads = (p2 / 2) * (lpp4 ? 4 : (lpp16 ? 16 : 8));
   threads = (threads + 63) / 64 * 64;
   if (threads < 64) threads = 64;
+  if (pre) threads = 4 * p2;                    // exactly four lanes per column (cmf_eigh_pre.h; __launch_bounds__ of the instantiation)
   const size_t rot_stride = (size_t)EIG_MAXSWEEP * (p2 - 1) * (p2 / 2);
   const int rmax = (p2 + 7) / 8;
   const bool full = (p2 % 8) == 0;
@@ -427,7 +448,9 @@ static int launch_eigh(const double *cov, const int32_t *nuse, const SfGeom &g, 
     return 0;
   };
   int rc = -2;
-  if (lpp4) {
+  if (pre) {
+    rc = (p2 == 72) ? go(k_eigh<9, true, 8, 72>) : go(k_eigh<11, false, 8, 84>);
+  } else if (lpp4) {
     rc = (p2 == 72) ? go(k_eigh<18, true, 4>) : go(k_eigh<21, true, 4>);
   } else if (lpp16) {
     rc = (p2 == 72) ? go(k_eigh<5, false, 16>) : go(k_eigh<6, false, 16>);

@@ -99,9 +99,51 @@ constexpr int NSCALE = 2 + 3 * 9;
 constexpr int NFLAG = 1024;              // overflow slots: one per batch, read back every NFLAG batches
 // behind the weights' split forms: the overflow slots of the batches in flight and the calibration maxima
 size_t tail_bytes() { return (size_t)NFLAG * sizeof(int) + 64 * sizeof(float); }
+size_t base_bytes(int batch);            // the workspace without the sharing buffers (below)
+
+// Trunk sharing (cnn_share.hip): the phase maps of conv2 / conv3 over a strip of image rows, and a batch's ring tensors
+constexpr int SHARE_ROWS = 2048;         // image rows a set of maps serves (a batch may reach `rows_batch` rows further)
+struct Share {
+  int rows, Hq, Wq, Hc, Wc;              // rows covered from the strip's first row; map / canvas geometry
+  size_t canvas, c1, p1, q2, c2ring, q3, p1ring, c3ring, total;   // float offsets; c2ring sits right behind q2 (one buffer descriptor)
+};
+Share share_layout(int batch, int H, int W) {
+  Share S{};
+  if (H < 1 || W < 1) return S;
+  const int rows_batch = (batch + W - 1) / W + 1;
+  const int Wq = ((W - 1) >> 2) + 64;
+  // the conv2 maps and the border tensor behind them are addressed through one < 2 GB buffer descriptor
+  long long strip = SHARE_ROWS;
+  const long long cap = ((long long)0x60000000 / 4 - (long long)(batch + 1) * 252 * 64) / ((long long)16 * Wq * 64);   // map rows that fit
+  if (cap * 4 - 4 * 66 - rows_batch < strip) strip = cap * 4 - 4 * 66 - rows_batch;
+  if (strip < 1) return S;                                        // (an image too wide to share: rows = 0)
+  if (strip > H) strip = H;
+  S.rows = (int)strip + rows_batch;
+  S.Hq = ((S.rows + 3) >> 2) + 1 + 64;
+  S.Wq = Wq;
+  S.Hc = 4 * S.Hq;
+  S.Wc = 4 * S.Wq;
+  size_t o = 0;
+  auto take = [&](size_t &slot, size_t n) { slot = o; o += (n + 63) / 64 * 64; };
+  take(S.canvas, (size_t)S.Hc * S.Wc);
+  take(S.c1, (size_t)(S.Hc / 2) * (S.Wc / 2) * 64);
+  take(S.p1, (size_t)S.Hq * S.Wq * 64);
+  take(S.q2, (size_t)16 * S.Hq * S.Wq * 64);
+  S.c2ring = S.q2 + (size_t)16 * S.Hq * S.Wq * 64;                 // (exactly behind the maps)
+  o = S.c2ring + ((size_t)(batch + 1) * 252 * 64 + 63) / 64 * 64;
+  take(S.q3, (size_t)16 * S.Hq * S.Wq * 192);
+  take(S.p1ring, (size_t)batch * 252 * 64);
+  take(S.c3ring, (size_t)batch * 496 * 192);
+  S.total = o;
+  return S;
+}
 
 struct Net {
   const float *blob;
+  Share SH;
+  float *share = nullptr;                // the sharing buffers (behind everything else); null: no sharing
+  int map_r0 = -1, map_r1 = -1, map_Rb = 0;   // image rows the maps in memory serve, their first canvas row
+  bool map_ok = false;
   Blob L; Wino WL; Splits SL; Acts A;
   float *pool1, *conv2, *conv3, *xa, *xb, *t2, *t3, *pooled, *wino, *sscale;
   _Float16 *shalf;
@@ -111,9 +153,10 @@ struct Net {
   hipStream_t st;
 };
 
-Net make_net(const float *blob, int batch, void *workspace, void *stream) {
+Net make_net(const float *blob, int batch, void *workspace, void *stream, int H = 0, int W = 0) {
   Net N{};
   N.blob = blob;
+  N.SH = share_layout(batch, H, W);
   N.L = blob_layout(); N.WL = wino_layout(); N.SL = split_layout(); N.A = acts((size_t)batch);
   float *ws = reinterpret_cast<float *>(workspace);
   N.pool1 = ws; N.conv2 = N.pool1 + N.A.pool1; N.conv3 = N.conv2 + N.A.conv2; N.xa = N.conv3 + N.A.conv3; N.xb = N.xa + N.A.x;
@@ -123,6 +166,7 @@ Net make_net(const float *blob, int batch, void *workspace, void *stream) {
   N.shalf = reinterpret_cast<_Float16 *>(N.sscale + N.SL.scales);
   N.flags = reinterpret_cast<int *>(N.shalf + N.SL.halves);
   N.amax = reinterpret_cast<float *>(N.flags + NFLAG);
+  if (N.SH.rows > 0) N.share = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + base_bytes(batch));
   N.st = (hipStream_t)stream;
   return N;
 }
@@ -168,7 +212,8 @@ int prepare_wino(Net &N) {
 int run_batch(Net &N, const float *padded, const float *plane, int H, int W, long long tile0, int n, int route, const float *as, int *flag,
               float *amax, float *out) {
   const int Hp = H + 255, Wp = W + 255;
-  const bool use_split = route == 0, use_wino = route == 4;
+  const bool share = route == 0;             // 0: operand splitting with the trunk up to conv3 shared; 3: every window on its own
+  const bool use_split = route == 0 || route == 3, use_wino = route == 4;
   void *stream = (void *)N.st;
   int rc = 0;
   auto conv3x3 = [&](const float *in, int hw, int cin, const Layer &l, size_t uoff, const SplitL &sl, int cout, float a_in, float *o, int ldo,
@@ -181,6 +226,22 @@ int run_batch(Net &N, const float *padded, const float *plane, int H, int W, lon
     return sf_cnn_conv(in, n, hw, hw, cin, cin, W_(l), B_(l), cout, 3, o, ldo, off, stream);
   };
   auto peak = [&](const float *x, size_t count, int slot) -> int { return amax ? sf_cnn_absmax(x, count, amax + slot, stream) : 0; };
+  int hw = pool_out(64, 3, 2, 0);
+  if (share) {
+    // conv1 .. maxpool2 with everything but each window's padding-dependent ring taken from the phase maps (cnn_share.hip)
+    const Share &S = N.SH;
+    float *p1ring = N.share + S.p1ring, *q2 = N.share + S.q2, *c2ring = N.share + S.c2ring, *q3 = N.share + S.q3,
+          *c3ring = N.share + S.c3ring;
+    if ((rc = sf_cnn_ring_pool1(padded, Hp, Wp, W, tile0, n, W_(N.L.conv1), B_(N.L.conv1), p1ring, stream))) return rc;
+    if ((rc = sf_cnn_conv_split(p1ring, 0, 1, 1, n * 252, 64, 64, N.shalf + N.SL.conv2.h, half_lo(N, N.SL.conv2, 64, 1, 64),
+                                N.sscale + N.SL.conv2.s, B_(N.L.conv2), 64, 1, as[0], c2ring, 1, as[1], 64, 0, flag, stream)))
+      return rc;
+    if ((rc = sf_cnn_conv3_ring(q2, tile0, n, W, N.map_Rb, S.Hq, S.Wq, S.c2ring - S.q2, N.shalf + N.SL.conv3.h,
+                                half_lo(N, N.SL.conv3, 192, 9, 64), N.sscale + N.SL.conv3.s, B_(N.L.conv3), 192, as[1], c3ring, flag,
+                                stream)))
+      return rc;
+    if ((rc = sf_cnn_pool2_shared(c3ring, q3, tile0, n, W, N.map_Rb, S.Hq, S.Wq, 192, N.xa, stream))) return rc;
+  } else {
   // conv1 + maxpool1 (googlenet1.py:60-61), conv2, conv3, maxpool2 (:62-64)
   if ((rc = sf_cnn_conv1_pool(padded, Hp, Wp, W, tile0, n, W_(N.L.conv1), B_(N.L.conv1), N.pool1, stream))) return rc;
   if ((rc = peak(N.pool1, (size_t)n * 64 * 64 * 64, 0))) return rc;
@@ -192,8 +253,8 @@ int run_batch(Net &N, const float *padded, const float *plane, int H, int W, lon
   if (rc) return rc;
   if ((rc = peak(N.conv2, (size_t)n * 64 * 64 * 64, 1))) return rc;
   if ((rc = conv3x3(N.conv2, 64, 64, N.L.conv3, N.WL.conv3, N.SL.conv3, 192, use_split ? as[1] : 1.0f, N.conv3, 192, 0))) return rc;
-  int hw = pool_out(64, 3, 2, 0);
   if ((rc = sf_cnn_maxpool(N.conv3, n, 64, 64, 192, 3, 2, 0, N.xa, hw, hw, stream))) return rc;
+  }
   float *x = N.xa, *y = N.xb;
   int cin = 192;
   for (int i = 0; i < 9; ++i) {
@@ -231,6 +292,41 @@ int run_batch(Net &N, const float *padded, const float *plane, int H, int W, lon
   }
   // global average pool, FC, softmax[:, 1], NODATA rule (:87-89; cnn_pred_pipeline.py:177-189)
   if (out) return sf_cnn_head(x, n, hw * hw, cin, W_(N.L.fc), B_(N.L.fc), plane, tile0, -9999.0f, out, stream);
+  return 0;
+}
+
+// The phase maps for the image rows [r0, r0 + SH.rows) (clipped to the plane): per phase (r & 3, c & 3) the plane shifted by the
+// phase through conv1 (fully convolutional kernel) -> maxpool1 -> conv2 -> conv3, the last two by operand splitting with the
+// batch kernels' scales.  Synchronises the stream (the maps' own overflow slot is read): once per SHARE_ROWS image rows.
+// map_ok = false when an activation left float16's range: the strip's batches then run unshared (route 3).
+int build_maps(Net &N, const float *padded, int H, int W, int r0, const float *as) {
+  const Share &S = N.SH;
+  const int Hp = H + 255, Wp = W + 255, Rb = r0 >> 2;
+  void *stream = (void *)N.st;
+  float *canvas = N.share + S.canvas, *c1 = N.share + S.c1, *p1 = N.share + S.p1, *q2 = N.share + S.q2, *q3 = N.share + S.q3;
+  int *mflag = reinterpret_cast<int *>(N.amax + 48);
+  SF_HIP(hipMemsetAsync(mflag, 0, sizeof(int), N.st));
+  int rc = 0;
+  for (int ph = 0; ph < 16; ++ph) {
+    const size_t plane = (size_t)S.Hq * S.Wq;
+    if ((rc = sf_cnn_phase_canvas(padded, Hp, Wp, 4 * Rb + (ph >> 2), ph & 3, S.Hc, S.Wc, canvas, stream))) return rc;
+    if ((rc = sf_cnn_conv1_image(canvas, 1, S.Hc, S.Wc, W_(N.L.conv1), B_(N.L.conv1), c1, 0, stream))) return rc;
+    if ((rc = sf_cnn_maxpool(c1, 1, S.Hc / 2, S.Wc / 2, 64, 3, 2, 0, p1, S.Hq, S.Wq, stream))) return rc;
+    if ((rc = sf_cnn_conv_split(p1, 0, 1, S.Hq, S.Wq, 64, 64, N.shalf + N.SL.conv2.h, half_lo(N, N.SL.conv2, 64, 1, 64),
+                                N.sscale + N.SL.conv2.s, B_(N.L.conv2), 64, 1, as[0], q2 + ph * plane * 64, 1, as[1], 64, 0, mflag, stream)))
+      return rc;
+    if ((rc = sf_cnn_conv_split(q2 + ph * plane * 64, 1, 1, S.Hq, S.Wq, 64, 64, N.shalf + N.SL.conv3.h, half_lo(N, N.SL.conv3, 192, 9, 64),
+                                N.sscale + N.SL.conv3.s, B_(N.L.conv3), 192, 3, as[1], q3 + ph * plane * 192, 0, 1.0f, 192, 0, mflag,
+                                stream)))
+      return rc;
+  }
+  int raised = 0;
+  SF_HIP(hipMemcpyAsync(&raised, mflag, sizeof(int), hipMemcpyDeviceToHost, N.st));
+  SF_HIP(hipStreamSynchronize(N.st));
+  N.map_r0 = r0;
+  N.map_r1 = (r0 + S.rows < H) ? r0 + S.rows : H;
+  N.map_Rb = Rb;
+  N.map_ok = raised == 0;
   return 0;
 }
 
@@ -272,22 +368,27 @@ int calibrate(Net &N, const float *padded, int H, int W, int batch, float *scale
   return 0;
 }
 
+size_t base_bytes(int batch) {
+  const Splits S = split_layout();
+  return sf_align((acts((size_t)batch).total + wino_layout().total + S.scales) * sizeof(float) + S.halves * 2 + tail_bytes());
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t sf_cnn_blob_floats(void) { return blob_layout().total; }
 int sf_cnn_num_scales(void) { return NSCALE; }
-size_t sf_cnn_score_workspace_bytes(int batch) {
-  const Splits S = split_layout();
-  return batch < 1 ? 0 : sf_align((acts((size_t)batch).total + wino_layout().total + S.scales) * sizeof(float) + S.halves * 2 + tail_bytes());
+size_t sf_cnn_score_workspace_bytes(int batch, int H, int W) {
+  if (batch < 1) return 0;
+  return base_bytes(batch) + sf_align(share_layout(batch, H, W).total * sizeof(float));
 }
 
 int sf_cnn_calibrate(const float *padded, int H, int W, const float *blob, int batch, void *workspace, size_t workspace_bytes,
                      float *scales, void *stream) {
   if (!padded || !blob || !workspace || !scales || H < 1 || W < 1 || batch < 1) { sf_set_error("sf_cnn_calibrate: bad argument"); return -1; }
-  if (workspace_bytes < sf_cnn_score_workspace_bytes(batch)) {
-    sf_set_error("sf_cnn_calibrate: workspace too small: need %zu bytes, got %zu", sf_cnn_score_workspace_bytes(batch), workspace_bytes);
+  if (workspace_bytes < sf_cnn_score_workspace_bytes(batch, 0, 0)) {
+    sf_set_error("sf_cnn_calibrate: workspace too small: need %zu bytes, got %zu", sf_cnn_score_workspace_bytes(batch, 0, 0), workspace_bytes);
     return -4;
   }
   Net N = make_net(blob, batch, workspace, stream);
@@ -297,20 +398,21 @@ int sf_cnn_calibrate(const float *padded, int H, int W, const float *blob, int b
 int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int r0, int r1, const float *blob, float *out,
                       int batch, int route, const float *scales, int *rescued, void *workspace, size_t workspace_bytes, void *stream) {
   if (!padded || !blob || !out || !workspace || H < 1 || W < 1 || r0 < 0 || r1 > H || r0 > r1 || batch < 1 ||
-      (route != 0 && route != 4 && route != 2 && route != 1)) {
+      (route != 0 && route != 3 && route != 4 && route != 2 && route != 1)) {
     sf_set_error("sf_cnn_score_rows: bad argument");
     return -1;
   }
-  if (workspace_bytes < sf_cnn_score_workspace_bytes(batch)) {
-    sf_set_error("sf_cnn_score_rows: workspace too small: need %zu bytes, got %zu", sf_cnn_score_workspace_bytes(batch), workspace_bytes);
+  const size_t need = sf_cnn_score_workspace_bytes(batch, route == 0 ? H : 0, route == 0 ? W : 0);
+  if (workspace_bytes < need) {
+    sf_set_error("sf_cnn_score_rows: workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     return -4;
   }
   if (rescued) *rescued = 0;
-  Net N = make_net(blob, batch, workspace, stream);
+  Net N = make_net(blob, batch, workspace, stream, route == 0 ? H : 0, route == 0 ? W : 0);
   const long long i0 = (long long)r0 * W, i1 = (long long)r1 * W;
   if (i0 >= i1) return 0;
   int rc = 0;
-  if (route != 0) {
+  if (route != 0 && route != 3) {
     if (route == 4 && (rc = prepare_wino(N))) return rc;
     for (long long tile0 = i0; tile0 < i1; tile0 += batch) {
       const int n = (int)((i1 - tile0 < batch) ? (i1 - tile0) : batch);
@@ -342,7 +444,14 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
     long long tile0 = group0;
     for (; tile0 < i1 && nb < NFLAG; tile0 += batch, ++nb) {
       const int n = (int)((i1 - tile0 < batch) ? (i1 - tile0) : batch);
-      if ((rc = run_batch(N, padded, plane, H, W, tile0, n, 0, as, N.flags + nb, nullptr, out))) return rc;
+      int rt = 3;
+      if (route == 0 && N.share) {             // the phase maps must cover the batch's image rows
+        const int rf = (int)(tile0 / W), rl = (int)((tile0 + n - 1) / W);
+        if (!(N.map_r0 >= 0 && N.map_r0 <= rf && rl < N.map_r1))
+          if ((rc = build_maps(N, padded, H, W, rf, as))) return rc;
+        if (N.map_ok) rt = 0;
+      }
+      if ((rc = run_batch(N, padded, plane, H, W, tile0, n, rt, as, N.flags + nb, nullptr, out))) return rc;
     }
     SF_HIP(hipMemcpyAsync(host_flags, N.flags, nb * sizeof(int), hipMemcpyDeviceToHost, N.st));
     SF_HIP(hipStreamSynchronize(N.st));

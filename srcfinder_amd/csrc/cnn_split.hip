@@ -44,6 +44,32 @@ struct ConvDstS {
 // halves ready for LDS: the split, a third of a chunk's time in the kernel below, is done once per value instead of once per
 // (value, tap, channel tile).
 
+// The RING form of the convolution (round 6, trunk sharing; cnn_share.hip has the geometry): the rows of the implicit GEMM are the
+// 496 border positions of conv3's 64 x 64 output per window (rows / columns 0, 1, 62, 63) instead of all 4096, and a tap of such a
+// row is fetched from one of two places -- the window's OWN border of conv2's output (252 positions: the rows / columns 0 and 63,
+// whose values depend on the window's zero padding) or the SHARED phase map of conv2 over the whole plane (every other position:
+// identical for all windows of the same phase) -- or is zero (outside the window).  Both live in one allocation behind `in`:
+// [16 phases][Hq][Wq][64] then [N][252][64], split format.
+struct RingArgs {
+  long long tile0;     // first window of the batch (window t = image pixel (t / W, t % W))
+  int W;               // image width
+  int Rb, Hq, Wq;      // the maps cover canvas rows Rb .. Rb + Hq - 1 (units of 4 image rows), Wq columns
+  unsigned ring_off;   // float offset of the batch's border tensor behind the maps
+};
+__device__ __forceinline__ int ring_border_index(int y, int x) {      // 0 .. 251: y, x in 0 .. 63 with y or x on the border
+  return (y == 0) ? x : ((y == 63) ? 64 + x : ((x == 0) ? 127 + y : 189 + y));
+}
+__device__ __forceinline__ void ring_position(int j, int &y, int &x) {   // 0 .. 495 -> (y, x): rows 0, 1, 62, 63, then columns 0, 1, 62, 63 of the rest
+  if (j < 256) {
+    y = (j >> 6) + ((j >= 128) ? 60 : 0);
+    x = j & 63;
+  } else {
+    const int k = j - 256;
+    y = 2 + (k >> 2);
+    x = (k & 3) + ((k & 2) ? 60 : 0);
+  }
+}
+
 // hi / lo halves of eight floats (scaled by s); big: the largest magnitude seen (float16 ends at 65504)
 __device__ __forceinline__ void sp_split8(const sp_f4 &x0, const sp_f4 &x1, float s, sp_h8 &hi, sp_h8 &lo, float &big) {
   const float v[8] = {x0.x * s, x0.y * s, x0.z * s, x0.w * s, x1.x * s, x1.y * s, x1.z * s, x1.w * s};
@@ -58,11 +84,11 @@ __device__ __forceinline__ void sp_split8(const sp_f4 &x0, const sp_f4 &x1, floa
 
 // (A form with two LDS sets and two register sets -- loads two chunks ahead, one barrier per chunk -- needed 306 registers, ran one
 //  workgroup per CU and was 1.7 x SLOWER: what hides the trips to L2 here is three workgroups per CU, not a deeper pipeline.)
-template <int BN, bool ASPLIT = false, int BMT = 128>      // ASPLIT: the input is in the split format; BMT: pixels per tile
+template <int BN, bool ASPLIT = false, int BMT = 128, bool RING = false>      // ASPLIT: the input is in the split format; BMT: pixels per tile
 __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 && BMT == 128) || (BN == 64 && BMT == 256)) ? 3 : 2)) void k_conv_split(const float *__restrict__ in, int M, int H, int W, int Cin, int ld_in,
                                                     const _Float16 *__restrict__ whi, const _Float16 *__restrict__ wlo,
                                                     const float *__restrict__ wscale, const float *__restrict__ bias, int Cout,
-                                                    int ks, float ascale, ConvDstS dst, int *__restrict__ overflow) {
+                                                    int ks, float ascale, ConvDstS dst, int *__restrict__ overflow, RingArgs ring) {
   constexpr int BM = BMT, BK = 32, NPA = BM / 64;
   constexpr int WN = (BN >= 128) ? 2 : 1;          // waves along N: 2 x 2 waves of 64 x BN/2, or 4 x 1 waves of 32 x 64
   constexpr int WM = 4 / WN;
@@ -88,9 +114,13 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
 
   constexpr unsigned OOB = 0x80000000u;
   unsigned rowoff[NPA], vmask[NPA], woff[NPB];
-  const size_t shift = ((size_t)pad * W + pad) * ld_in;          // taps are addressed from (y - pad, x - pad): offsets >= 0
+  const size_t shift = RING ? 0 : ((size_t)pad * W + pad) * ld_in;          // taps are addressed from (y - pad, x - pad): offsets >= 0
+  // (RING: `in` = the phase maps with the batch's border tensor behind them: M / 496 windows x 252 positions)
+  const size_t ring_floats = RING ? (size_t)ring.ring_off + (size_t)(M / 496 + 1) * 252 * ld_in : 0;
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in) - shift, 0,
-                                                                 (unsigned)(((size_t)M * ld_in + 2 * shift) * 4 + 64), 0x00020000);
+                                                                 RING ? (unsigned)(ring_floats * 4)
+                                                                      : (unsigned)(((size_t)M * ld_in + 2 * shift) * 4 + 64), 0x00020000);
+  unsigned rpos[NPA], rring[NPA];      // RING: (y << 8 | x) of the row's position, byte offset of its window's border tensor (+ 32 q)
   __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(whi), 0, (unsigned)((size_t)Cout * taps * Cin * 2), 0x00020000);
   __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(wlo), 0, (unsigned)((size_t)Cout * taps * Cin * 2), 0x00020000);
 #pragma unroll
@@ -98,6 +128,18 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
     const int m = m0 + ri + 64 * a;
     const bool ok = m < M;
     const int mm = ok ? m : 0;
+    if constexpr (RING) {
+      const int n = mm / 496, j = mm - n * 496;
+      int y3, x3;
+      ring_position(j, y3, x3);
+      const long long t = ring.tile0 + n;
+      const int r = (int)(t / ring.W), c = (int)(t - (long long)r * ring.W);
+      const int ph = (r & 3) * 4 + (c & 3);
+      rowoff[a] = (unsigned)((((size_t)(ph * ring.Hq + ((r >> 2) - ring.Rb)) * ring.Wq + (c >> 2)) * ld_in + 8 * q) * 4);   // the window's origin in its phase map
+      rring[a] = (unsigned)(((size_t)ring.ring_off + (size_t)n * 252 * ld_in + 8 * q) * 4);
+      rpos[a] = ok ? (unsigned)((y3 << 8) | x3) : 0xffffu;           // (a row past M: every tap outside)
+      vmask[a] = 0;
+    } else {
     const int py = ok ? (mm / W) % H : -100000, px = mm % W;
     rowoff[a] = (unsigned)(((size_t)mm * ld_in + 8 * q) * 4);
     unsigned vm = 0;
@@ -106,6 +148,7 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
       if (yy >= 0 && yy < H && xx >= 0 && xx < W) vm |= 1u << tp;
     }
     vmask[a] = vm;
+    }
   }
 #pragma unroll
   for (int b = 0; b < NPB; ++b) {
@@ -129,11 +172,21 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
   auto gload = [&](auto setc) {
     constexpr int S = decltype(setc)::value;
     const bool kin = g_c0 + 8 * q < Cin;          // Cin is a multiple of 8: whole 8-channel piece in or out
-    const unsigned sa = (unsigned)(((g_ty * W + g_tx) * ld_in + g_c0) * 4);
+    const unsigned sa = RING ? (unsigned)(g_c0 * 4) : (unsigned)(((g_ty * W + g_tx) * ld_in + g_c0) * 4);
     const unsigned sb = (unsigned)((g_tap * Cin + g_c0) * 2);
 #pragma unroll
     for (int a = 0; a < NPA; ++a) {
-      const unsigned off = (kin && ((vmask[a] >> g_tap) & 1u)) ? rowoff[a] : OOB;
+      unsigned off;
+      if constexpr (RING) {
+        const int ys = (int)(rpos[a] >> 8) + g_ty - 1, xs = (int)(rpos[a] & 255u) + g_tx - 1;
+        const bool inside = (unsigned)ys < 64u && (unsigned)xs < 64u;
+        const bool border = ys == 0 || ys == 63 || xs == 0 || xs == 63;
+        const unsigned o_ring = rring[a] + (unsigned)(ring_border_index(ys, xs) * ld_in * 4);
+        const unsigned o_map = rowoff[a] + (unsigned)((ys * ring.Wq + xs) * ld_in * 4);
+        off = (kin && inside) ? (border ? o_ring : o_map) : OOB;
+      } else {
+        off = (kin && ((vmask[a] >> g_tap) & 1u)) ? rowoff[a] : OOB;
+      }
       ra[S][a][0] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, off, sa, 0));
       ra[S][a][1] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rsA, off == OOB ? OOB : off + 16, sa, 0));
     }
@@ -469,9 +522,9 @@ int launch_split(const float *in, int in_split, int M, int H, int W, int Cin, in
                  hipStream_t st) {
   dim3 grid(8 * sf_cdiv(sf_cdiv(M, BM), 8) * sf_cdiv(Cout, BN));
   if (in_split)
-    hipLaunchKernelGGL((k_conv_split<BN, true, BM>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst, overflow);
+    hipLaunchKernelGGL((k_conv_split<BN, true, BM>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst, overflow, RingArgs{});
   else
-    hipLaunchKernelGGL((k_conv_split<BN, false, BM>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst, overflow);
+    hipLaunchKernelGGL((k_conv_split<BN, false, BM>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst, overflow, RingArgs{});
   SF_LAUNCH_CHECK("k_conv_split");
   return 0;
 }
@@ -574,6 +627,34 @@ int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int 
   d.fmt[0] = 0; d.fmt[1] = d.fmt[2] = out12_split ? 1 : 0;
   d.oscale[0] = 1.0f; d.oscale[1] = out12_split ? oscale1 : 1.0f; d.oscale[2] = out12_split ? oscale2 : 1.0f;
   return split_go(in, 0, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, c0 + c1 + c2, 1, ascale, d, overflow, (hipStream_t)stream);
+}
+
+// conv3 (3 x 3, 64 -> Cout) at the 496 border positions of every window of a batch (trunk sharing, cnn_share.hip): `maps` = the
+// conv2 phase maps [16][Hq][Wq][64] with the batch's own conv2 border [N][252][64] behind them at float offset ring_off (both in
+// the split format, scaled by ascale); out[N][496][Cout] float32.
+int sf_cnn_conv3_ring(const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, const void *whi,
+                      const void *wlo, const float *wscale, const float *bias, int Cout, float ascale, float *out, int *overflow,
+                      void *stream) {
+  const int Cin = 64;
+  const size_t total = (ring_off + (size_t)(N + 1) * 252 * Cin) * 4;
+  if (!maps || !whi || !wlo || !wscale || !bias || !out || !overflow || N < 1 || W < 1 || Hq < 64 || Wq < 64 || Cout < 1 || tile0 < 0 ||
+      !sp_pow2(ascale) || ring_off < (size_t)16 * Hq * Wq * Cin || total >= 0x7ff00000u) {
+    sf_set_error("sf_cnn_conv3_ring: bad argument (maps + border tensor below 2 GB)");
+    return -1;
+  }
+  ConvDstS d{};
+  d.p[0] = d.p[1] = d.p[2] = out;
+  d.ld[0] = d.ld[1] = d.ld[2] = Cout;
+  d.end[0] = d.end[1] = d.end[2] = Cout;
+  d.oscale[0] = d.oscale[1] = d.oscale[2] = 1.0f;
+  RingArgs ra{tile0, W, Rb, Hq, Wq, (unsigned)ring_off};
+  const int M = N * 496;
+  dim3 grid(8 * sf_cdiv(sf_cdiv(M, 256), 8) * sf_cdiv(Cout, 64));
+  hipLaunchKernelGGL((k_conv_split<64, true, 256, true>), grid, dim3(256), 0, (hipStream_t)stream, maps, M, 64, 64, Cin, Cin,
+                     reinterpret_cast<const _Float16 *>(whi), reinterpret_cast<const _Float16 *>(wlo), wscale, bias, Cout, 3, ascale, d,
+                     overflow, ra);
+  SF_LAUNCH_CHECK("k_conv_split<ring>");
+  return 0;
 }
 
 // 1 when sf_cnn_pool_conv_split takes this geometry (whole image rows per 128-pixel tile, operands below 2 GB); else sf_cnn_pool_conv

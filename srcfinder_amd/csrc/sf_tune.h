@@ -13,7 +13,7 @@ struct SfTune {
   int extract_variant = 0;    // key 6: 1 = never the flat (narrow-cube) kernel, 2 = the unpipelined blocked kernel, 3 / 5 = 3- / 2-line tiles in the pipelined kernel (default 4)
   int sweep_grid = 0;         // key 21: k_sweep4s workgroup order: 0 = the splits of a column adjacent (default), 1 = columns fastest (round 2's order)
   int extract_nt = 0;         // key 19: 1 = plain (not non-temporal) xt stores in the pipelined extract kernel
-  int eigh_lpp = 0;           // key 7: lanes per column pair of the Jacobi eigensolver
+  int eigh_lpp = 0;           // key 7: lanes per column pair of the Jacobi eigensolver (4 / 8 / 16); 2 = the sweeps behind the tridiagonal preconditioner of cmf_eigh_pre.h (8 lanes)
   int sweep4r_waves = 8;      // key 8: waves per workgroup of the rank-factored sweep (k_sweep4r, form 1)
   int sweep4_form = 0;        // key 20: rank-28 sweep kernel: 0 = k_sweep4s (round 3: one streamed ring), 1 = k_sweep4r (round 2, both ranks), 3 = k_sweep4r for the rank-36 columns only, 4 = k_sweep4s renormalising after every tile; 100 + bits = timing experiments (-DSF_SWEEP_EXPERIMENTS)
   int wide_eigh_variant = 0;  // key 10: 0 = blocked Jacobi behind the tridiagonal preconditioner (cmf_wtri.hip) for calls of 32 columns or more; 7 = the preconditioner for any number of columns; 6 = the sweeps from the Cholesky factor (round 4's first form: 11-12 sweeps); 1 = the single-workgroup eigensolver for every wide matrix, 8 = as 7 with every preconditioner refused afterwards (the fallback's test)

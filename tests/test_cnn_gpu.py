@@ -127,15 +127,23 @@ def test_c_driver_equals_the_python_sequenced_graph(gold):
     net = cnn.GoogLeNetHIP(synthetic_state_dict(seed=2024))
     plane = synthetic_plane(11, 7, seed=9)
     plane[2, 3] = -9999.0
-    a = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=13)            # C driver (default)
+    a = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=13, route="split_unshared")     # C driver
     net.c_driver = False
-    b = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=13)
+    b = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=13, route="split_unshared")
     net.c_driver = True
     assert torch.equal(a, b) and float(a[2, 3]) == -9999.0
-    c = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=64, rows=(3, 8))
+    c = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=64, rows=(3, 8), route="split_unshared")
     assert torch.equal(c[3:8], a[3:8]) and float(c[:3].abs().sum()) == 0.0
+    # the default route shares the trunk up to conv3 between the windows (C driver only): the same map inside float32 rounding,
+    # and row ranges / batch sizes still do not change a bit
+    d = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=13)
+    v = a != -9999.0
+    assert torch.equal(d == -9999.0, ~v) and float(((d[v] - a[v]).abs() / a[v].abs().clamp_min(1e-7)).max()) < 2e-5
+    e = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=64, rows=(3, 8))
+    assert torch.equal(e[3:8], d[3:8]) and float(e[:3].abs().sum()) == 0.0
     L = _ffi.lib()
-    assert net.packed_blob().numel() == L.sf_cnn_blob_floats() and L.sf_cnn_score_workspace_bytes(13) > 0
+    assert net.packed_blob().numel() == L.sf_cnn_blob_floats() and L.sf_cnn_score_workspace_bytes(13, 0, 0) > 0
+    assert L.sf_cnn_score_workspace_bytes(13, 11, 7) > L.sf_cnn_score_workspace_bytes(13, 0, 0)
     assert L.sf_cnn_score_rows(None, None, 4, 4, 0, 4, None, None, 8, 0, None, None, None, 0, None) == -1   # argument errors, no launch
 
 
@@ -186,7 +194,7 @@ def test_split_operand_and_winograd_convolutions_against_the_direct_kernel(gold)
     runs = {}
     for c_driver in (True, False):
         net.c_driver = c_driver
-        for knob, name in ((0, "split"), (4, "winograd"), (2, "direct")):
+        for knob, name in ((0, "split_unshared"), (4, "winograd"), (2, "direct")):
             runs[(c_driver, knob)] = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=32, route=name)
     net.c_driver = True
     # the tools' way in -- the calling thread's tuning knob 17 -- selects the same routes when no route is passed
@@ -208,6 +216,95 @@ def test_split_operand_and_winograd_convolutions_against_the_direct_kernel(gold)
         assert rel < 1e-4                                # ... the same numbers inside the parity bar (float32 rounding through 57 layers)
 
 
+def test_shared_trunk_against_every_window_on_its_own(net):
+    """Round 6 (csrc/cnn_share.hip; cnn_pred_pipeline.py:53-58, googlenet1.py:110-120): conv1 .. conv3 of a window equal the same
+    stack run fully convolutionally over the whole padded plane at the window's phase, except on the ring that sees the window's
+    zero padding.  (i) Kernel level, through the C ABI: maxpool2's output assembled from phase maps + ring tensors against the
+    per-window kernels (conv1+pool -> conv2 -> conv3 -> maxpool2) for windows of all 16 phases in the middle of a plane larger
+    than a window and for windows hanging over the plane's corners -- equal up to the order of conv1's 49-term sums.
+    (ii) Saliency of whole rows through sf_cnn_score_rows: route "split" (shared) against "split_unshared"."""
+    import ctypes as C
+    import torch
+    from srcfinder_amd import _ffi
+    L = _ffi.lib()
+    P, st = _ffi.ptr, _ffi.stream_ptr
+    dev = net.device
+    H, W = 300, 290
+    plane = synthetic_plane(H, W, seed=17)
+    ds = cnn.FlightlineConvolve(plane, (MEAN, STD), device=dev)
+    Hp, Wp = H + 255, W + 255
+    f32 = dict(dtype=torch.float32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    w1, b1 = net.w["conv1"]
+    h2, l2, s2 = net.split["conv2"]
+    h3, l3, s3 = net.split["conv3"]
+    b2, b3 = net.w["conv2"][1], net.w["conv3"][1]
+    for r0 in (148, 0, 296):                            # interior rows; rows whose windows hang over the top / bottom of the plane
+        Rb = r0 >> 2
+        rows = 4
+        Hq, Wq = ((rows + 3) >> 2) + 1 + 64, ((W - 1) >> 2) + 64
+        Hc, Wc = 4 * Hq, 4 * Wq
+        q2 = torch.zeros(16 * Hq * Wq * 64 + 64 * 252 * 64 + 4096, **f32)          # maps, then the border tensor of <= 63 windows
+        q3 = torch.empty((16, Hq, Wq, 192), **f32)
+        canvas = torch.empty((Hc, Wc), **f32)
+        c1 = torch.empty((Hc // 2, Wc // 2, 64), **f32)
+        p1 = torch.empty((Hq, Wq, 64), **f32)
+        for ph in range(16):
+            _ffi.check(L.sf_cnn_phase_canvas(P(ds.x), Hp, Wp, 4 * Rb + (ph >> 2), ph & 3, Hc, Wc, P(canvas), st()), "canvas")
+            _ffi.check(L.sf_cnn_conv1_image(P(canvas), 1, Hc, Wc, P(w1), P(b1), P(c1), 0, st()), "conv1_image")
+            _ffi.check(L.sf_cnn_maxpool(P(c1), 1, Hc // 2, Wc // 2, 64, 3, 2, 0, P(p1), Hq, Wq, st()), "pool1")
+            m2 = q2[ph * Hq * Wq * 64:(ph + 1) * Hq * Wq * 64]
+            _ffi.check(L.sf_cnn_conv_split(P(p1), 0, 1, Hq, Wq, 64, 64, P(h2), P(l2), P(s2), P(b2), 64, 1, C.c_float(1.0), P(m2), 1,
+                                           C.c_float(1.0), 64, 0, P(flag), st()), "conv2 map")
+            _ffi.check(L.sf_cnn_conv_split(P(m2), 1, 1, Hq, Wq, 64, 64, P(h3), P(l3), P(s3), P(b3), 192, 3, C.c_float(1.0), P(q3[ph]), 0,
+                                           C.c_float(1.0), 192, 0, P(flag), st()), "conv3 map")
+        for c0 in (0, 117, W - 20):                     # 20 consecutive windows: every column phase, the plane's left / right edges
+            n = 20
+            for rr in range(r0, min(H, r0 + rows)):
+                tile0 = rr * W + c0
+                # every window on its own
+                a1 = torch.empty((n, 64, 64, 64), **f32)
+                a2 = torch.empty((n, 64, 64, 64), **f32)
+                a3 = torch.empty((n, 64, 64, 192), **f32)
+                want = torch.empty((n, 32, 32, 192), **f32)
+                _ffi.check(L.sf_cnn_conv1_pool(P(ds.x), Hp, Wp, W, C.c_longlong(tile0), n, P(w1), P(b1), P(a1), st()), "conv1_pool")
+                _ffi.check(L.sf_cnn_conv_split(P(a1), 0, n, 64, 64, 64, 64, P(h2), P(l2), P(s2), P(b2), 64, 1, C.c_float(1.0), P(a2), 1,
+                                               C.c_float(1.0), 64, 0, P(flag), st()), "conv2")
+                _ffi.check(L.sf_cnn_conv_split(P(a2), 1, n, 64, 64, 64, 64, P(h3), P(l3), P(s3), P(b3), 192, 3, C.c_float(1.0), P(a3), 0,
+                                               C.c_float(1.0), 192, 0, P(flag), st()), "conv3")
+                _ffi.check(L.sf_cnn_maxpool(P(a3), n, 64, 64, 192, 3, 2, 0, P(want), 32, 32, st()), "pool2")
+                # shared
+                ring_off = 16 * Hq * Wq * 64
+                p1r = torch.empty((n, 252, 64), **f32)
+                c2r = q2[ring_off:ring_off + n * 252 * 64]
+                c3r = torch.empty((n, 496, 192), **f32)
+                got = torch.empty((n, 32, 32, 192), **f32)
+                _ffi.check(L.sf_cnn_ring_pool1(P(ds.x), Hp, Wp, W, C.c_longlong(tile0), n, P(w1), P(b1), P(p1r), st()), "ring_pool1")
+                _ffi.check(L.sf_cnn_conv_split(P(p1r), 0, 1, 1, n * 252, 64, 64, P(h2), P(l2), P(s2), P(b2), 64, 1, C.c_float(1.0), P(c2r),
+                                               1, C.c_float(1.0), 64, 0, P(flag), st()), "conv2 ring")
+                _ffi.check(L.sf_cnn_conv3_ring(P(q2), C.c_longlong(tile0), n, W, Rb, Hq, Wq, C.c_size_t(ring_off), P(h3), P(l3), P(s3),
+                                               P(b3), 192, C.c_float(1.0), P(c3r), P(flag), st()), "conv3 ring")
+                _ffi.check(L.sf_cnn_pool2_shared(P(c3r), P(q3), C.c_longlong(tile0), n, W, Rb, Hq, Wq, 192, P(got), st()), "pool2 shared")
+                torch.cuda.synchronize()
+                # the border of maxpool1 first (exactly the per-window kernel's values up to the order of conv1's sums)
+                border = torch.cat([a1[:, 0, :, :], a1[:, 63, :, :], a1[:, 1:63, 0, :], a1[:, 1:63, 63, :]], 1)
+                scale1 = float(border.abs().max())
+                assert float((p1r - border).abs().max()) <= 3e-6 * scale1, (r0, c0, rr)
+                scale = float(want.abs().max())
+                assert scale > 0 and float((got - want).abs().max()) <= 2e-5 * scale, (r0, c0, rr, float((got - want).abs().max()) / scale)
+    assert int(flag.item()) == 0
+    # (ii) whole rows through the C driver
+    for rows in ((148, 152), (0, 2), (298, 300)):
+        a = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=96, rows=rows, route="split")
+        b = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=96, rows=rows, route="split_unshared")
+        sa, sb = a[rows[0]:rows[1]], b[rows[0]:rows[1]]
+        v = sb != -9999.0
+        assert torch.equal(sa == -9999.0, ~v)
+        rel = float(((sa[v] - sb[v]).abs() / sb[v].abs().clamp_min(1e-7)).max())
+        print("rows %s: shared against unshared, max relative difference of the saliency %.2e" % (rows, rel))
+        assert rel < 2e-5
+
+
 def _scaled_family(sd, k):
     """The weight family with every activation of the trunk multiplied by s = 2^k and the same logits: conv1's folded weight and
     every folded bias times s (ReLU and max pooling are positively homogeneous), fc.weight divided by s.  In state_dict terms:
@@ -219,7 +316,7 @@ def _scaled_family(sd, k):
         v = np.array(v, copy=True)
         if name in ("conv1.bn.weight", "conv1.bn.bias"):
             v = v * s
-        elif name.endswith(".bn.bias") or name.endswith(".bn.running_mean"):
+        elif (name.endswith(".bn.bias") or name.endswith(".bn.running_mean")) and not name.startswith("conv1."):
             v = v * s
         elif name == "fc.weight":
             v = v / s

@@ -528,7 +528,7 @@ def cnn_section(res, ntiles, batch, with_cpu):
     plane = res.out[r0:r0 + rows, :, 3].to(torch.float32).contiguous()            # a strip of the flightline
     ds = cnn.FlightlineConvolve(plane, "COVID_QC", device=net.device)
     out = torch.zeros(rows * W, dtype=torch.float32, device=net.device)
-    ntiles = min(ntiles, rows * W)
+    ntiles = rows * W                                # whole image rows: the C-side driver sequences the graph (shared trunk)
 
     scales = net.calibrate(ds, batch)                # the split route's per-layer activation scales, from this plane
 
@@ -543,28 +543,37 @@ def cnn_section(res, ntiles, batch, with_cpu):
         torch.cuda.synchronize()
         return time.perf_counter() - t0, n
 
-    dt_w, _ = timed("winograd")                      # the other float32-tolerance route, kept on record beside the default
+    dt_w, _ = timed("winograd")                      # the other float32-tolerance routes, kept on record beside the default
+    dt_u, _ = timed("split_unshared")
     dt, rescued = timed("split")
     tf = ntiles * 3.706e9 / dt / 1e12
+    # Flops one window EXECUTES on the shared-trunk split route (srcfinder_amd/csrc/cnn_share.hip): conv1 .. conv3 of the reference
+    # (1.043 GFLOP of its 3.706) shrink to the per-window ring -- conv3 at 496 of 4096 positions (0.110 GFLOP), conv2 at 252
+    # (0.002) as fp16 operand-split products, conv1 + pool at the border on the fp32 vector units (0.008) -- the phase maps cost one
+    # window-equivalent per plane position (~1e-4 of a window); inception3a .. 5b + head (2.663 GFLOP) run as they are.  Every
+    # multiply of the split layers is three fp16 MFMA products.
+    split_gflop = 2.663 - 0.0001 + 0.110 + 0.002
+    exec_fp16_tf = ntiles / dt * 3.0 * split_gflop * 1e9 / 1e12
     sec = {"metric": "CNN tiles/s (GoogLeNet, one 256x256 window per pixel)", "value": round(ntiles / dt, 1), "unit": "tiles/s",
            "dtype": "f32 (split-operand: fp16 hi + lo halves, fp32 accumulate)", "data": "synthetic weights (seeded), CMF plane of this run", "tiles": ntiles, "batch": batch,
-           "route": "split (an argument of the call; per-layer activation scales calibrated on this plane: 2^%d .. 2^%d; one overflow "
-                    "slot per batch, %d of %d batches re-scored on the fp32 matrix cores)"
+           "route": "split, trunk up to conv3 shared between the overlapping windows (an argument of the call; per-layer activation scales "
+                    "calibrated on this plane: 2^%d .. 2^%d; one overflow slot per batch, %d of %d batches re-scored on the fp32 matrix cores)"
                     % (int(np.log2(min(scales))), int(np.log2(max(scales))), rescued, (ntiles + batch - 1) // batch),
            "fp32_mfma_route": {"value": round(ntiles / dt_w, 1), "unit": "tiles/s",
-                               "note": "route=\"winograd\": Winograd F(2x2, 3x3) + implicit GEMM on the fp32 matrix cores (the split "
-                                       "route's rescue path), same windows"},
-           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
-                        "frac": round(tf / 157.3, 4), "flop_per_tile": 3.706e9,
-                        "note": "all kernels of a forward pass; flop_per_tile is the direct-convolution count of the network (the "
-                                "reference's arithmetic) and peak the fp32 matrix-core peak, so frac is throughput in reference "
-                                "fp32 flops against what the fp32 instruction could deliver.  Every convolution of the trunk but "
-                                "conv1 (3.60 of the 3.71 GFLOP) runs by OPERAND SPLITTING on the fp16 matrix "
-                                "cores -- fp32 operands as fp16 hi + lo halves, three v_mfma_f32_32x32x16_f16 per product, fp32 "
-                                "accumulate: the fp32 tolerance class (errors against float64 equal to the fp32 kernel's; the "
-                                "reference goldens at 1e-4), not reduced precision -- so frac may exceed what the fp32 pipe allows; "
-                                "frac_of_fp16_peak_executed counts the three fp16 products per multiply against 2500 TFLOP/s",
-                        "frac_of_fp16_peak_executed": round(tf * (3.0 * 3.603 + 0.103) / 3.706 / 2500.0, 4)}}
+                               "note": "route=\"winograd\": Winograd F(2x2, 3x3) + implicit GEMM on the fp32 matrix cores, every window on "
+                                       "its own (the split route's rescue path), same windows"},
+           "unshared_split_route": {"value": round(ntiles / dt_u, 1), "unit": "tiles/s",
+                                    "note": "route=\"split_unshared\": round 5's form, every window evaluated on its own"},
+           "roofline": {"bound": "mfma", "achieved": round(exec_fp16_tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": round(exec_fp16_tf / 2500.0, 4), "executed_gflop_per_tile_fp16_products": round(3.0 * split_gflop, 3),
+                        "note": "EXECUTED flops against the pipe they run on: the split layers' multiplies as three "
+                                "v_mfma_f32_32x32x16_f16 products each (fp32 operands as fp16 hi + lo halves, fp32 accumulate: the fp32 "
+                                "tolerance class, every reference golden at its 1e-4) against the dense fp16 matrix peak; all kernels of "
+                                "a forward pass in the time (pools, pool-projections, ring kernels, head included)",
+                        "reference_flops": {"flop_per_tile": 3.706e9, "achieved": round(tf, 2), "unit": "TFLOP/s", "fp32_matrix_peak": 157.3,
+                                            "frac_of_fp32_matrix_peak": round(tf / 157.3, 4),
+                                            "note": "throughput in the REFERENCE's direct-convolution flops (3.706 GFLOP per window) over the "
+                                                    "fp32 matrix peak: above 1 because the restatement executes fewer and cheaper flops"}}}
     if with_cpu:
         from oracle import cnn_oracle as O
         cores = usable_cores()

@@ -407,8 +407,9 @@ int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, co
  * slots).  All launches are enqueued on `stream`.
  * route (an ARGUMENT of the call -- nothing process- or thread-wide selects the arithmetic):
  *   0  operand splitting on the fp16 matrix cores (sf_cnn_conv_split: the float32 tolerance class; the product's default) with the
- *      trunk up to conv3 SHARED between the overlapping windows (below: sf_cnn_ring_pool1 ...); 3 = the same with every window
- *      evaluated on its own (round 5's form; bit-identical to the kernels sequenced one batch at a time).  Both
+ *      trunk through inception3b SHARED between the overlapping windows (below: sf_cnn_ring_pool1 ...); 5 = shared through conv3
+ *      only (round 6's first form); 3 = every window evaluated on its own (round 5's form; bit-identical to the kernels sequenced
+ *      one batch at a time).  All three
  *      ends of float16's range are handled inside the call: `scales` = the sf_cnn_num_scales() per-layer activation scales (HOST
  *      floats, powers of two, e.g. from sf_cnn_calibrate) or NULL -- the call then calibrates itself on a fixed sample of the
  *      plane's windows (a function of the plane alone: every row range and batch size of a flightline gets the same scales, hence
@@ -426,28 +427,36 @@ int sf_cnn_calibrate(const float *padded, int H, int W, const float *blob, int b
 int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int r0, int r1, const float *blob, float *out,
                       int batch, int route, const float *scales, int *rescued, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Trunk sharing (csrc/cnn_share.hip): cnn_pred_pipeline.py:53-58 scores one 256 x 256 window per pixel, so neighbouring windows
- * overlap by 255/256.  Through conv3 (googlenet1.py:110-120) a window's activation at (y, x) of the 64 x 64 grid depends on the
- * window only through its zero padding: conv3 at y, x in 2..61 equals the same stack evaluated fully convolutionally on the whole
- * padded plane at the window's phase (r & 3, c & 3) -- 16 phase maps, built once per strip of image rows with the FCN kernels --
- * and only the ring is per window:
+/* Trunk sharing (csrc/cnn_share.hip, csrc/cnn_ring.h): cnn_pred_pipeline.py:53-58 scores one 256 x 256 window per pixel, so
+ * neighbouring windows overlap by 255/256.  A layer's activation for one window lives on a G x G grid and depends on the window only
+ * through its zero padding: with the layer's FRAME (lo, hi), rows / columns 0 .. lo - 1 and G - hi .. G - 1 -- the RING -- hold values
+ * only this window has, the interior equals the layer evaluated fully convolutionally on the whole padded plane at the window's
+ * phase (the phase MAPS, built once per strip of image rows with the FCN kernels).  Ring positions are enumerated: the lo top rows,
+ * the hi bottom rows (G positions each), then for the rows between them the lo left and the hi right columns
+ * (count = (lo + hi) G + (G - lo - hi)(lo + hi)).  Window t of a batch = image pixel ((tile0 + t) / W, (tile0 + t) % W); with P = 2^shift
+ * phases per axis its phase is (r & (P - 1)) P + (c & (P - 1)) and its origin in that map ((r >> shift) - Rb, c >> shift).
+ * Grid 64, shift 2 (googlenet1.py:60-64): maxpool1 / conv2 frame (1, 1), conv3 (2, 2).  Grid 32, shift 3 (:64-68): maxpool2 (1, 2),
+ * inception3a (2, 3), inception3b (3, 4); maxpool3 assembles inception4a's whole 16 x 16 input.
  *   sf_cnn_phase_canvas  canvas[Hc][Wc] = padded[y0 + u][x0 + v] (zero outside): the plane shifted by a phase
- *   sf_cnn_ring_pool1    maxpool1(conv1(window)) at the 252 border positions of the 64 x 64 grid (border index: row 0 -> x, row 63 ->
- *                        64 + x, column 0 -> 127 + y, column 63 -> 189 + y): out[ntiles][252][64]
- *   sf_cnn_conv3_ring    conv3 at the 496 ring positions (rows 0, 1, 62, 63: y' 64 + x with y' = 0..3, then 256 + 4 (y - 2) + {0, 1, 2, 3}
- *                        for x = 0, 1, 62, 63), taps from the window's own conv2 border [N][252][64] or the conv2 phase maps
- *                        [16][Hq][Wq][64] in front of it (one allocation, split format): out[N][496][Cout]
- *   sf_cnn_pool2_shared  maxpool2 (googlenet1.py:64) from that ring tensor + the conv3 phase maps [16][Hq][Wq][C]: out[N][32][32][C]
- * Window t of the batch = image pixel ((tile0 + t) / W, (tile0 + t) % W); its origin in phase map (r & 3) * 4 + (c & 3) is
- * ((r >> 2) - Rb, c >> 2).  sf_cnn_score_rows (route 0) sequences all of it. */
+ *   sf_cnn_ring_pool1    maxpool1(conv1(window)) at the 252 ring positions of frame (1, 1) on the 64 grid: out[ntiles][252][64]
+ *   sf_cnn_conv_ring     a 1 x 1 / 3 x 3 BasicConv2d (operand splitting) at the ring positions of the frame (olo, ohi), its input
+ *                        gathered from `maps` = the input's phase maps [P P][Hq][Wq][Cin] with the batch's ring tensor
+ *                        [N][count(G, ilo, ihi)][Cin] ring_off floats behind their start (both float32, or both in the split format):
+ *                        rows m = window * count(G, olo, ohi) + ring index; output segments as sf_cnn_conv_split3_split
+ *                        (c1 = c2 = 0: one)
+ *   sf_cnn_pool_gather   MaxPool2d(3, stride 1 pad 1 | stride 2 ceil_mode) of such a tensor, on the whole output grid (olo < 0:
+ *                        out[N][Go][Go][C]) or at the ring positions of (olo, ohi) on Go (out[N][count][C])
+ * sf_cnn_score_rows (routes 0 / 5) sequences all of it. */
 int sf_cnn_phase_canvas(const float *padded, int Hp, int Wp, int y0, int x0, int Hc, int Wc, float *canvas, void *stream);
 int sf_cnn_ring_pool1(const float *padded, int Hp, int Wp, int W, long long tile0, int ntiles, const float *w, const float *bias,
                       float *out, void *stream);
-int sf_cnn_conv3_ring(const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, const void *whi,
-                      const void *wlo, const float *wscale, const float *bias, int Cout, float ascale, float *out, int *overflow,
-                      void *stream);
-int sf_cnn_pool2_shared(const float *ring, const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, int C, float *out,
-                        void *stream);
+int sf_cnn_conv_ring(const float *maps, int in_split, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, int shift,
+                     int G, int ilo, int ihi, int olo, int ohi, int Cin, const void *whi, const void *wlo, const float *wscale,
+                     const float *bias, int c0, int c1, int c2, int ksize, float ascale, float *out0, int ld0, int off0, float *out1,
+                     int ld1, int off1, float *out2, int ld2, int off2, int out12_split, float oscale1, float oscale2, int *overflow,
+                     void *stream);
+int sf_cnn_pool_gather(const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, int shift, int G,
+                       int ilo, int ihi, int C, int stride, int Go, int olo, int ohi, float *out, void *stream);
 
 /* FCN shift-and-stitch, the reference's approximate fast mode (cnn/fcn_pred_pipeline.py).
  * sf_cnn_fcn_prepare: ClampCH4 + Normalize of the plane, embedded at (top, left) = divmod(shift, scale) in a zero canvas

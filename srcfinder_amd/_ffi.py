@@ -52,8 +52,9 @@ SIGNATURES = {
     "sf_cnn_num_scales": (i32, []),
     "sf_cnn_phase_canvas": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "sf_cnn_ring_pool1": (i32, [vp, i32, i32, i32, C.c_longlong, i32, vp, vp, vp, vp]),
-    "sf_cnn_conv3_ring": (i32, [vp, C.c_longlong, i32, i32, i32, i32, i32, sz, vp, vp, vp, vp, i32, C.c_float, vp, vp, vp]),
-    "sf_cnn_pool2_shared": (i32, [vp, vp, C.c_longlong, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "sf_cnn_conv_ring": (i32, [vp, i32, C.c_longlong, i32, i32, i32, i32, i32, sz, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32,
+                               i32, i32, C.c_float, vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, C.c_float, C.c_float, vp, vp]),
+    "sf_cnn_pool_gather": (i32, [vp, C.c_longlong, i32, i32, i32, i32, i32, sz, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "sf_cnn_calibrate": (i32, [vp, i32, i32, vp, i32, vp, sz, vp, vp]),
     "sf_cnn_conv_split3_split": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, C.c_float, vp, i32, i32, vp, i32, i32,
                                        vp, i32, i32, i32, C.c_float, C.c_float, vp, vp]),

@@ -32,7 +32,8 @@ NODATA = -9999.0
 # "split": operand splitting on the fp16 matrix cores; through the C driver (sf_cnn_score_rows) with the trunk up to conv3 SHARED
 # between the overlapping windows (csrc/cnn_share.hip), sequenced from Python one batch at a time (forward_tiles) every window on
 # its own -- "split_unshared" names that form on both drivers (bit-identical between them)
-ROUTES = {"split": 0, "split_unshared": 3, "winograd": 4, "direct": 2, "direct_pointer": 1}
+# ("split_conv3": the sharing stops behind conv3 -- round 6's first form; "split" carries it through inception3b)
+ROUTES = {"split": 0, "split_conv3": 5, "split_unshared": 3, "winograd": 4, "direct": 2, "direct_pointer": 1}
 
 
 def _torch():
@@ -266,8 +267,8 @@ class GoogLeNetHIP(object):
         if r is None:
             return 0 if self.half else _knob(17)
         r = ROUTES.get(r, r) if isinstance(r, str) else int(r)
-        if r not in (0, 1, 2, 3, 4):
-            raise ValueError("route must be one of %r or 0 / 3 / 4 / 2 / 1" % (sorted(ROUTES),))
+        if r not in (0, 1, 2, 3, 4, 5):
+            raise ValueError("route must be one of %r or 0 / 5 / 3 / 4 / 2 / 1" % (sorted(ROUTES),))
         return r
 
     def overflow_slots(self, n):
@@ -296,7 +297,7 @@ class GoogLeNetHIP(object):
         """Set the pass's route and overflow slot; returns True when this call owns the slot (and must check it itself)."""
         torch = _torch()
         self._route = self._route_code(route)
-        if self._route == 3:
+        if self._route in (3, 5):
             self._route = 0        # (the Python-sequenced graph always evaluates every window on its own)
         own = False
         if self._route == 0 and not self.half:
@@ -491,7 +492,7 @@ def _score_rows_c(net, ds, r0, r1, batch, out, code):
     L = _ffi.lib()
     H, W = ds.inshape[1], ds.inshape[2]
     with torch.cuda.device(net.device):
-        wsb = L.sf_cnn_score_workspace_bytes(int(batch), H if code == 0 else 0, W if code == 0 else 0)
+        wsb = L.sf_cnn_score_workspace_bytes(int(batch), H if code in (0, 5) else 0, W if code in (0, 5) else 0)
         ws = net._buf("c_driver_ws", ((wsb + 3) // 4,))
         nres = C.c_int(0)
         sc = (C.c_float * len(net.ascale))(*net.ascale)
@@ -512,7 +513,7 @@ def score_tiles(net, ds, t_first, t_last, batch, out, route=None):
     if not net.half and getattr(net, "c_driver", True) and t_first % W == 0 and t_last % W == 0 and t_last > t_first:
         return _score_rows_c(net, ds, t_first // W, t_last // W, batch, out, code)       # whole image rows: the C-side driver
     starts = list(range(int(t_first), int(t_last), int(batch)))
-    slots = net.overflow_slots(len(starts)) if (code in (0, 3) and not net.half) else None
+    slots = net.overflow_slots(len(starts)) if (code in (0, 3, 5) and not net.half) else None
     for i, t0 in enumerate(starts):
         net.forward_tiles(ds.x, W, t0, min(batch, t_last - t0), plane=ds.plane, out=out, route=code,
                           overflow=None if slots is None else slots[i:i + 1])
@@ -571,7 +572,7 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
     r0, r1 = (0, H) if rows is None else rows
     code = net._route_code(route)
     rescued = 0
-    if code in (0, 3) and not net.half:
+    if code in (0, 3, 5) and not net.half:
         # ONE set of scales for the call, whichever driver sequences the graph: the caller's, or sf_cnn_calibrate on this plane
         if scales is not None:
             if len(scales) != len(net.ascale):
@@ -586,7 +587,7 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
     else:
         rescued = score_tiles(net, ds, r0 * W, r1 * W, batch, out, route=code)
     if info is not None:
-        info.update(rescued_batches=rescued, route=code, scales=list(net.ascale) if code in (0, 3) else None)
+        info.update(rescued_batches=rescued, route=code, scales=list(net.ascale) if code in (0, 3, 5) else None)
     out = out.view(H, W)
     return out.cpu().numpy() if to_numpy else out
 
@@ -674,20 +675,20 @@ def fcn_predict_flightline(cmf2d, model="COVID_QC", weights=None, scale=32, batc
     code = net._route_code(route)
     with torch.cuda.device(net.device):
         st = _ffi.stream_ptr()
-        if code in (0, 3) and not net.half:
+        if code in (0, 3, 5) and not net.half:
             # the split route's activation scales: calibrated on this plane's 256 x 256 windows (the same trunk, the same statistics)
             net.calibrate(FlightlineConvolve(plane, (mean, std) if (vmin, vmax) == (0.0, 4000.0) else
                                              Compose([ClampCH4(int(vmin), int(vmax)), Normalize([mean], [std])]), device=net.device))
         canvas = torch.empty((batch, Hc, Wc), dtype=torch.float32, device=net.device)
         starts = list(range(s0, s1, batch))
-        slots = net.overflow_slots(len(starts)) if (code in (0, 3) and not net.half) else None
+        slots = net.overflow_slots(len(starts)) if (code in (0, 3, 5) and not net.half) else None
 
         def run(i, rt):
             a = starts[i]
             n = min(batch, s1 - a)
             _ffi.check(L.sf_cnn_fcn_prepare(_ffi.ptr(plane), H, W, float(vmin), float(vmax), float(mean), float(std), scale,
                                             a, n, Hc, Wc, _ffi.ptr(canvas), st), "sf_cnn_fcn_prepare")
-            pred = net.forward_fcn(canvas[:n], route=rt, overflow=None if (slots is None or rt not in (0, 3)) else slots[i:i + 1])
+            pred = net.forward_fcn(canvas[:n], route=rt, overflow=None if (slots is None or rt not in (0, 3, 5)) else slots[i:i + 1])
             _ffi.check(L.sf_cnn_fcn_stitch(_ffi.ptr(pred), n, a, scale, pred.shape[1], pred.shape[2], _ffi.ptr(plane), H, W,
                                            NODATA, _ffi.ptr(out), st), "sf_cnn_fcn_stitch")
 

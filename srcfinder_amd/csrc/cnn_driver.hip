@@ -5,6 +5,7 @@
 // Weights: ONE float32 blob of BatchNorm-folded convolutions in the order of sf_cnn_blob_layout() (conv weights
 // [Cout][k*k][Cin], then the bias [Cout]); GoogLeNetHIP.packed_blob() builds it from a state_dict.
 #include "cmf_common.h"
+#include "cnn_ring.h"
 
 namespace {
 
@@ -101,39 +102,70 @@ constexpr int NFLAG = 1024;              // overflow slots: one per batch, read 
 size_t tail_bytes() { return (size_t)NFLAG * sizeof(int) + 64 * sizeof(float); }
 size_t base_bytes(int batch);            // the workspace without the sharing buffers (below)
 
-// Trunk sharing (cnn_share.hip): the phase maps of conv2 / conv3 over a strip of image rows, and a batch's ring tensors
-constexpr int SHARE_ROWS = 2048;         // image rows a set of maps serves (a batch may reach `rows_batch` rows further)
+// Trunk sharing (cnn_share.hip): the phase maps over a strip of image rows and a batch's ring tensors.  depth 1: conv1 .. conv3 on
+// 16 phase maps of the 64 x 64 grid; depth 2: also maxpool2, inception3a, inception3b on 64 phase maps of the 32 x 32 grid (frames
+// (1, 2) -> (2, 3) -> (3, 4), cnn_ring.h) with maxpool3 assembling inception4a's input.  Every tensor a gather convolution reads has its
+// ring tensor RIGHT BEHIND its maps (one < 2 GB buffer descriptor).
+constexpr int SHARE_ROWS1 = 2048, SHARE_ROWS2 = 512;   // image rows a set of maps serves (a batch may reach `rows_batch` rows further)
+constexpr int F32_PL = 1, F32_PH = 2, F3A_L = 2, F3A_H = 3, F3B_L = 3, F3B_H = 4;      // frames on the 32 x 32 grid
+struct MapT { size_t map, ring; int C; };    // float offsets of a tensor's maps and of its ring tensor (ring - map = the maps' size)
 struct Share {
-  int rows, Hq, Wq, Hc, Wc;              // rows covered from the strip's first row; map / canvas geometry
-  size_t canvas, c1, p1, q2, c2ring, q3, p1ring, c3ring, total;   // float offsets; c2ring sits right behind q2 (one buffer descriptor)
+  int depth, rows, Hq, Wq, Hc, Wc, H8, W8;   // rows covered from the strip's first row; map / canvas geometry (H8 x W8: the 64-phase maps)
+  size_t canvas, c1, p1, p1ring, pooled, pring;
+  MapT q2, q3, x3a, t2a, t3a, y3a, t2b, t3b, y3b;
+  size_t total;
 };
-Share share_layout(int batch, int H, int W) {
+Share share_layout(int batch, int H, int W, int depth) {
   Share S{};
-  if (H < 1 || W < 1) return S;
+  if (H < 1 || W < 1 || depth < 1) return S;
   const int rows_batch = (batch + W - 1) / W + 1;
-  const int Wq = ((W - 1) >> 2) + 64;
-  // the conv2 maps and the border tensor behind them are addressed through one < 2 GB buffer descriptor
-  long long strip = SHARE_ROWS;
-  const long long cap = ((long long)0x60000000 / 4 - (long long)(batch + 1) * 252 * 64) / ((long long)16 * Wq * 64);   // map rows that fit
-  if (cap * 4 - 4 * 66 - rows_batch < strip) strip = cap * 4 - 4 * 66 - rows_batch;
-  if (strip < 1) return S;                                        // (an image too wide to share: rows = 0)
+  const int Wq = (((W - 1) >> 2) + 64 + 4 + 1) & ~1;
+  const int n3b = sf_frame_count(32, F3B_L, F3B_H), n3a = sf_frame_count(32, F3A_L, F3A_H), npl = sf_frame_count(32, F32_PL, F32_PH);
+  long long strip = depth >= 2 ? SHARE_ROWS2 : SHARE_ROWS1;
   if (strip > H) strip = H;
+  for (;; strip /= 2) {                      // the largest map + ring pair must stay below 2 GB
+    if (strip < 1) return S;                 // (an image too wide to share: rows = 0)
+    const long long rows = strip + rows_batch, Hq = ((((rows + 3) >> 2) + 1 + 64 + 4) + 1) & ~1ll;
+    const long long H8 = Hq / 2 - 1, W8 = Wq / 2 - 1;
+    const long long pair1 = ((long long)16 * Hq * Wq * 192 + (long long)(batch + 1) * 496 * 192) * 4;
+    const long long pair2 = ((long long)64 * H8 * W8 * 480 + (long long)(batch + 1) * n3b * 480) * 4;
+    if (pair1 < 0x7f000000ll && (depth < 2 || pair2 < 0x7f000000ll)) break;
+  }
+  S.depth = depth;
   S.rows = (int)strip + rows_batch;
-  S.Hq = ((S.rows + 3) >> 2) + 1 + 64;
+  S.Hq = ((((S.rows + 3) >> 2) + 1 + 64 + 4) + 1) & ~1;
   S.Wq = Wq;
   S.Hc = 4 * S.Hq;
   S.Wc = 4 * S.Wq;
+  S.H8 = S.Hq / 2 - 1;
+  S.W8 = S.Wq / 2 - 1;
   size_t o = 0;
   auto take = [&](size_t &slot, size_t n) { slot = o; o += (n + 63) / 64 * 64; };
-  take(S.canvas, (size_t)S.Hc * S.Wc);
+  auto pair = [&](MapT &t, size_t positions, int C, int ringpos) {
+    t.C = C;
+    t.map = o;
+    o += positions * C;                      // (the ring tensor exactly behind the maps)
+    t.ring = o;
+    o += ((size_t)(batch + 1) * ringpos * C + 63) / 64 * 64;
+  };
+  take(S.canvas, (size_t)S.Hc * S.Wc + 64);
   take(S.c1, (size_t)(S.Hc / 2) * (S.Wc / 2) * 64);
   take(S.p1, (size_t)S.Hq * S.Wq * 64);
-  take(S.q2, (size_t)16 * S.Hq * S.Wq * 64);
-  S.c2ring = S.q2 + (size_t)16 * S.Hq * S.Wq * 64;                 // (exactly behind the maps)
-  o = S.c2ring + ((size_t)(batch + 1) * 252 * 64 + 63) / 64 * 64;
-  take(S.q3, (size_t)16 * S.Hq * S.Wq * 192);
   take(S.p1ring, (size_t)batch * 252 * 64);
-  take(S.c3ring, (size_t)batch * 496 * 192);
+  const size_t P16 = (size_t)16 * S.Hq * S.Wq, P64 = (size_t)64 * S.H8 * S.W8;
+  pair(S.q2, P16, 64, 252);
+  pair(S.q3, P16 + (depth >= 2 ? (size_t)S.Wq + 2 : 0), 192, 496);     // (+ a row: the offset views of the maxpool2 maps)
+  if (depth >= 2) {
+    pair(S.x3a, P64, 192, npl);
+    pair(S.t2a, P64, 96, n3a);
+    pair(S.t3a, P64, 16, n3a);
+    pair(S.y3a, P64, 256, n3a);
+    pair(S.t2b, P64, 128, n3b);
+    pair(S.t3b, P64, 32, n3b);
+    pair(S.y3b, P64, 480, n3b);
+    take(S.pooled, P64 * 256);               // branch 4's pooled input while the maps are built
+    take(S.pring, (size_t)batch * n3b * 256);   // ... and at the ring positions of a batch
+  }
   S.total = o;
   return S;
 }
@@ -153,10 +185,10 @@ struct Net {
   hipStream_t st;
 };
 
-Net make_net(const float *blob, int batch, void *workspace, void *stream, int H = 0, int W = 0) {
+Net make_net(const float *blob, int batch, void *workspace, void *stream, int H = 0, int W = 0, int depth = 0) {
   Net N{};
   N.blob = blob;
-  N.SH = share_layout(batch, H, W);
+  N.SH = share_layout(batch, H, W, depth);
   N.L = blob_layout(); N.WL = wino_layout(); N.SL = split_layout(); N.A = acts((size_t)batch);
   float *ws = reinterpret_cast<float *>(workspace);
   N.pool1 = ws; N.conv2 = N.pool1 + N.A.pool1; N.conv3 = N.conv2 + N.A.conv2; N.xa = N.conv3 + N.A.conv3; N.xb = N.xa + N.A.x;
@@ -227,20 +259,67 @@ int run_batch(Net &N, const float *padded, const float *plane, int H, int W, lon
   };
   auto peak = [&](const float *x, size_t count, int slot) -> int { return amax ? sf_cnn_absmax(x, count, amax + slot, stream) : 0; };
   int hw = pool_out(64, 3, 2, 0);
+  int first_block = 0;
   if (share) {
-    // conv1 .. maxpool2 with everything but each window's padding-dependent ring taken from the phase maps (cnn_share.hip)
+    // conv1 .. maxpool2 (depth 2: .. maxpool3) with everything but each window's padding-dependent ring taken from the phase maps
     const Share &S = N.SH;
-    float *p1ring = N.share + S.p1ring, *q2 = N.share + S.q2, *c2ring = N.share + S.c2ring, *q3 = N.share + S.q3,
-          *c3ring = N.share + S.c3ring;
-    if ((rc = sf_cnn_ring_pool1(padded, Hp, Wp, W, tile0, n, W_(N.L.conv1), B_(N.L.conv1), p1ring, stream))) return rc;
-    if ((rc = sf_cnn_conv_split(p1ring, 0, 1, 1, n * 252, 64, 64, N.shalf + N.SL.conv2.h, half_lo(N, N.SL.conv2, 64, 1, 64),
-                                N.sscale + N.SL.conv2.s, B_(N.L.conv2), 64, 1, as[0], c2ring, 1, as[1], 64, 0, flag, stream)))
+    float *B = N.share;
+    const int Rb = N.map_Rb, Rb8 = Rb >> 1;
+    if ((rc = sf_cnn_ring_pool1(padded, Hp, Wp, W, tile0, n, W_(N.L.conv1), B_(N.L.conv1), B + S.p1ring, stream))) return rc;
+    if ((rc = sf_cnn_conv_split(B + S.p1ring, 0, 1, 1, n * 252, 64, 64, N.shalf + N.SL.conv2.h, half_lo(N, N.SL.conv2, 64, 1, 64),
+                                N.sscale + N.SL.conv2.s, B_(N.L.conv2), 64, 1, as[0], B + S.q2.ring, 1, as[1], 64, 0, flag, stream)))
       return rc;
-    if ((rc = sf_cnn_conv3_ring(q2, tile0, n, W, N.map_Rb, S.Hq, S.Wq, S.c2ring - S.q2, N.shalf + N.SL.conv3.h,
-                                half_lo(N, N.SL.conv3, 192, 9, 64), N.sscale + N.SL.conv3.s, B_(N.L.conv3), 192, as[1], c3ring, flag,
-                                stream)))
+    if ((rc = sf_cnn_conv_ring(B + S.q2.map, 1, tile0, n, W, Rb, S.Hq, S.Wq, S.q2.ring - S.q2.map, 2, 64, 1, 1, 2, 2, 64,
+                               N.shalf + N.SL.conv3.h, half_lo(N, N.SL.conv3, 192, 9, 64), N.sscale + N.SL.conv3.s, B_(N.L.conv3), 192, 0, 0, 3,
+                               as[1], B + S.q3.ring, 192, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 1.0f, 1.0f, flag, stream)))
       return rc;
-    if ((rc = sf_cnn_pool2_shared(c3ring, q3, tile0, n, W, N.map_Rb, S.Hq, S.Wq, 192, N.xa, stream))) return rc;
+    if (S.depth < 2) {
+      if ((rc = sf_cnn_pool_gather(B + S.q3.map, tile0, n, W, Rb, S.Hq, S.Wq, S.q3.ring - S.q3.map, 2, 64, 2, 2, 192, 2, 32, -1, 0, N.xa,
+                                   stream)))
+        return rc;
+    } else {
+      // maxpool2 at its ring, inception3a and 3b at theirs, maxpool3 assembling inception4a's input (googlenet1.py:64-68, :184-228)
+      if ((rc = sf_cnn_pool_gather(B + S.q3.map, tile0, n, W, Rb, S.Hq, S.Wq, S.q3.ring - S.q3.map, 2, 64, 2, 2, 192, 2, 32, F32_PL, F32_PH,
+                                   B + S.x3a.ring, stream)))
+        return rc;
+      const MapT *xin = &S.x3a;
+      int ilo = F32_PL, ihi = F32_PH;
+      for (int i = 0; i < 2; ++i) {
+        const Incep &s = INC[i];
+        const int cout = s.c1 + s.c3 + s.c5 + s.pp, olo = ilo + 1, ohi = ihi + 1, nout = sf_frame_count(32, olo, ohi);
+        const MapT &t2 = i == 0 ? S.t2a : S.t2b, &t3 = i == 0 ? S.t3a : S.t3b, &yo = i == 0 ? S.y3a : S.y3b;
+        const float ax = as[2 + 3 * i], a2 = as[3 + 3 * i], a3 = as[4 + 3 * i];
+        float *yr = B + yo.ring;
+        // branch1 | 3x3 reduce | "5x5" reduce at the OUTPUT frame's ring positions, the input gathered (ring tensor / maps)
+        if ((rc = sf_cnn_conv_ring(B + xin->map, 0, tile0, n, W, Rb8, S.H8, S.W8, xin->ring - xin->map, 3, 32, ilo, ihi, olo, ohi, s.cin,
+                                   N.shalf + N.SL.head3[i].h, half_lo(N, N.SL.head3[i], s.c1 + s.c3r + s.c5r, 1, s.cin),
+                                   N.sscale + N.SL.head3[i].s, B_(N.L.head3[i]), s.c1, s.c3r, s.c5r, 1, ax, yr, cout, 0, B + t2.ring,
+                                   s.c3r, 0, B + t3.ring, s.c5r, 0, 1, a2, a3, flag, stream)))
+          return rc;
+        if ((rc = sf_cnn_conv_ring(B + t2.map, 1, tile0, n, W, Rb8, S.H8, S.W8, t2.ring - t2.map, 3, 32, olo, ohi, olo, ohi, s.c3r,
+                                   N.shalf + N.SL.b2[i].h, half_lo(N, N.SL.b2[i], s.c3, 9, s.c3r), N.sscale + N.SL.b2[i].s, B_(N.L.b2[i]),
+                                   s.c3, 0, 0, 3, a2, yr, cout, s.c1, nullptr, 0, 0, nullptr, 0, 0, 0, 1.0f, 1.0f, flag, stream)))
+          return rc;
+        if ((rc = sf_cnn_conv_ring(B + t3.map, 1, tile0, n, W, Rb8, S.H8, S.W8, t3.ring - t3.map, 3, 32, olo, ohi, olo, ohi, s.c5r,
+                                   N.shalf + N.SL.b3[i].h, half_lo(N, N.SL.b3[i], s.c5, 9, s.c5r), N.sscale + N.SL.b3[i].s, B_(N.L.b3[i]),
+                                   s.c5, 0, 0, 3, a3, yr, cout, s.c1 + s.c3, nullptr, 0, 0, nullptr, 0, 0, 0, 1.0f, 1.0f, flag, stream)))
+          return rc;
+        if ((rc = sf_cnn_pool_gather(B + xin->map, tile0, n, W, Rb8, S.H8, S.W8, xin->ring - xin->map, 3, 32, ilo, ihi, s.cin, 1, 32, olo, ohi,
+                                     B + S.pring, stream)))
+          return rc;
+        if ((rc = sf_cnn_conv_split(B + S.pring, 0, 1, 1, n * nout, s.cin, s.cin, N.shalf + N.SL.b4[i].h, half_lo(N, N.SL.b4[i], s.pp, 1, s.cin),
+                                    N.sscale + N.SL.b4[i].s, B_(N.L.b4[i]), s.pp, 1, ax, yr, 0, 1.0f, cout, s.c1 + s.c3 + s.c5, flag, stream)))
+          return rc;
+        xin = &yo;
+        ilo = olo;
+        ihi = ohi;
+      }
+      if ((rc = sf_cnn_pool_gather(B + S.y3b.map, tile0, n, W, Rb8, S.H8, S.W8, S.y3b.ring - S.y3b.map, 3, 32, F3B_L, F3B_H, 480, 2, 16, -1,
+                                   0, N.xa, stream)))
+        return rc;
+      first_block = 2;
+      hw = 16;
+    }
   } else {
   // conv1 + maxpool1 (googlenet1.py:60-61), conv2, conv3, maxpool2 (:62-64)
   if ((rc = sf_cnn_conv1_pool(padded, Hp, Wp, W, tile0, n, W_(N.L.conv1), B_(N.L.conv1), N.pool1, stream))) return rc;
@@ -256,8 +335,8 @@ int run_batch(Net &N, const float *padded, const float *plane, int H, int W, lon
   if ((rc = sf_cnn_maxpool(N.conv3, n, 64, 64, 192, 3, 2, 0, N.xa, hw, hw, stream))) return rc;
   }
   float *x = N.xa, *y = N.xb;
-  int cin = 192;
-  for (int i = 0; i < 9; ++i) {
+  int cin = first_block == 2 ? 480 : 192;
+  for (int i = first_block; i < 9; ++i) {
     const Incep &s = INC[i];
     const int cout = s.c1 + s.c3 + s.c5 + s.pp;
     const float ax = use_split ? as[2 + 3 * i] : 1.0f, a2 = use_split ? as[3 + 3 * i] : 1.0f, a3 = use_split ? as[4 + 3 * i] : 1.0f;
@@ -301,14 +380,15 @@ int run_batch(Net &N, const float *padded, const float *plane, int H, int W, lon
 // map_ok = false when an activation left float16's range: the strip's batches then run unshared (route 3).
 int build_maps(Net &N, const float *padded, int H, int W, int r0, const float *as) {
   const Share &S = N.SH;
-  const int Hp = H + 255, Wp = W + 255, Rb = r0 >> 2;
+  const int Hp = H + 255, Wp = W + 255, Rb = (r0 >> 3) << 1;       // (an even canvas row: the 64-phase maps start on a multiple of 8)
   void *stream = (void *)N.st;
-  float *canvas = N.share + S.canvas, *c1 = N.share + S.c1, *p1 = N.share + S.p1, *q2 = N.share + S.q2, *q3 = N.share + S.q3;
+  float *B = N.share;
+  float *canvas = B + S.canvas, *c1 = B + S.c1, *p1 = B + S.p1, *q2 = B + S.q2.map, *q3 = B + S.q3.map;
   int *mflag = reinterpret_cast<int *>(N.amax + 48);
   SF_HIP(hipMemsetAsync(mflag, 0, sizeof(int), N.st));
   int rc = 0;
+  const size_t plane = (size_t)S.Hq * S.Wq;
   for (int ph = 0; ph < 16; ++ph) {
-    const size_t plane = (size_t)S.Hq * S.Wq;
     if ((rc = sf_cnn_phase_canvas(padded, Hp, Wp, 4 * Rb + (ph >> 2), ph & 3, S.Hc, S.Wc, canvas, stream))) return rc;
     if ((rc = sf_cnn_conv1_image(canvas, 1, S.Hc, S.Wc, W_(N.L.conv1), B_(N.L.conv1), c1, 0, stream))) return rc;
     if ((rc = sf_cnn_maxpool(c1, 1, S.Hc / 2, S.Wc / 2, 64, 3, 2, 0, p1, S.Hq, S.Wq, stream))) return rc;
@@ -320,11 +400,49 @@ int build_maps(Net &N, const float *padded, int H, int W, int r0, const float *a
                                 stream)))
       return rc;
   }
+  if (S.depth >= 2) {
+    // The 64 phase maps of the 32 x 32 grid.  Window (r, c): its conv3 rows 2 p .. 2 p + 2 sit at rows 2 ((r >> 3) - Rb / 2 + p) +
+    // ((r >> 2) & 1) + {0, 1, 2} of the conv3 map of phase (r & 3, c & 3): maxpool2's map of phase (r & 7, c & 7) is the 3 x 3 / 2
+    // pool of that conv3 map read from row (r >> 2) & 1, column (c >> 2) & 1 on.
+    const size_t p8 = (size_t)S.H8 * S.W8;
+    for (int a = 0; a < 8; ++a)
+      for (int b = 0; b < 8; ++b) {
+        const int ph4 = (a & 3) * 4 + (b & 3), oa = a >> 2, ob = b >> 2;
+        const float *src = q3 + (ph4 * plane + (size_t)oa * S.Wq + ob) * 192;
+        if ((rc = sf_cnn_maxpool(src, 1, S.Hq - oa, S.Wq, 192, 3, 2, 0, B + S.x3a.map + (size_t)(a * 8 + b) * p8 * 192, S.H8, S.W8, stream)))
+          return rc;
+      }
+    // inception3a, 3b fully convolutionally on the 64 maps (googlenet1.py:184-228): reducers' maps in the split format
+    const MapT *xin = &S.x3a;
+    for (int i = 0; i < 2; ++i) {
+      const Incep &s = INC[i];
+      const int cout = s.c1 + s.c3 + s.c5 + s.pp;
+      const MapT &t2 = i == 0 ? S.t2a : S.t2b, &t3 = i == 0 ? S.t3a : S.t3b, &yo = i == 0 ? S.y3a : S.y3b;
+      const float ax = as[2 + 3 * i], a2 = as[3 + 3 * i], a3 = as[4 + 3 * i];
+      if ((rc = sf_cnn_conv_split3_split(B + xin->map, 64, S.H8, S.W8, s.cin, s.cin, N.shalf + N.SL.head3[i].h,
+                                         half_lo(N, N.SL.head3[i], s.c1 + s.c3r + s.c5r, 1, s.cin), N.sscale + N.SL.head3[i].s,
+                                         B_(N.L.head3[i]), s.c1, s.c3r, s.c5r, ax, B + yo.map, cout, 0, B + t2.map, s.c3r, 0, B + t3.map,
+                                         s.c5r, 0, 1, a2, a3, mflag, stream)))
+        return rc;
+      if ((rc = sf_cnn_conv_split(B + t2.map, 1, 64, S.H8, S.W8, s.c3r, s.c3r, N.shalf + N.SL.b2[i].h, half_lo(N, N.SL.b2[i], s.c3, 9, s.c3r),
+                                  N.sscale + N.SL.b2[i].s, B_(N.L.b2[i]), s.c3, 3, a2, B + yo.map, 0, 1.0f, cout, s.c1, mflag, stream)))
+        return rc;
+      if ((rc = sf_cnn_conv_split(B + t3.map, 1, 64, S.H8, S.W8, s.c5r, s.c5r, N.shalf + N.SL.b3[i].h, half_lo(N, N.SL.b3[i], s.c5, 9, s.c5r),
+                                  N.sscale + N.SL.b3[i].s, B_(N.L.b3[i]), s.c5, 3, a3, B + yo.map, 0, 1.0f, cout, s.c1 + s.c3, mflag, stream)))
+        return rc;
+      if ((rc = sf_cnn_maxpool(B + xin->map, 64, S.H8, S.W8, s.cin, 3, 1, 1, B + S.pooled, S.H8, S.W8, stream))) return rc;
+      if ((rc = sf_cnn_conv_split(B + S.pooled, 0, 64, S.H8, S.W8, s.cin, s.cin, N.shalf + N.SL.b4[i].h, half_lo(N, N.SL.b4[i], s.pp, 1, s.cin),
+                                  N.sscale + N.SL.b4[i].s, B_(N.L.b4[i]), s.pp, 1, ax, B + yo.map, 0, 1.0f, cout, s.c1 + s.c3 + s.c5, mflag,
+                                  stream)))
+        return rc;
+      xin = &yo;
+    }
+  }
   int raised = 0;
   SF_HIP(hipMemcpyAsync(&raised, mflag, sizeof(int), hipMemcpyDeviceToHost, N.st));
   SF_HIP(hipStreamSynchronize(N.st));
   N.map_r0 = r0;
-  N.map_r1 = (r0 + S.rows < H) ? r0 + S.rows : H;
+  N.map_r1 = (r0 + S.rows - 8 < H) ? r0 + S.rows - 8 : H;          // (the even canvas row may sit up to 7 image rows above r0)
   N.map_Rb = Rb;
   N.map_ok = raised == 0;
   return 0;
@@ -381,7 +499,7 @@ size_t sf_cnn_blob_floats(void) { return blob_layout().total; }
 int sf_cnn_num_scales(void) { return NSCALE; }
 size_t sf_cnn_score_workspace_bytes(int batch, int H, int W) {
   if (batch < 1) return 0;
-  return base_bytes(batch) + sf_align(share_layout(batch, H, W).total * sizeof(float));
+  return base_bytes(batch) + sf_align(share_layout(batch, H, W, 2).total * sizeof(float));    // (the deeper form's: it is the larger)
 }
 
 int sf_cnn_calibrate(const float *padded, int H, int W, const float *blob, int batch, void *workspace, size_t workspace_bytes,
@@ -398,21 +516,22 @@ int sf_cnn_calibrate(const float *padded, int H, int W, const float *blob, int b
 int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int r0, int r1, const float *blob, float *out,
                       int batch, int route, const float *scales, int *rescued, void *workspace, size_t workspace_bytes, void *stream) {
   if (!padded || !blob || !out || !workspace || H < 1 || W < 1 || r0 < 0 || r1 > H || r0 > r1 || batch < 1 ||
-      (route != 0 && route != 3 && route != 4 && route != 2 && route != 1)) {
+      (route != 0 && route != 5 && route != 3 && route != 4 && route != 2 && route != 1)) {
     sf_set_error("sf_cnn_score_rows: bad argument");
     return -1;
   }
-  const size_t need = sf_cnn_score_workspace_bytes(batch, route == 0 ? H : 0, route == 0 ? W : 0);
+  const bool sharing = route == 0 || route == 5;       // 0: through inception3b (depth 2); 5: through conv3 (depth 1, round 6's first form)
+  const size_t need = sf_cnn_score_workspace_bytes(batch, sharing ? H : 0, sharing ? W : 0);
   if (workspace_bytes < need) {
     sf_set_error("sf_cnn_score_rows: workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     return -4;
   }
   if (rescued) *rescued = 0;
-  Net N = make_net(blob, batch, workspace, stream, route == 0 ? H : 0, route == 0 ? W : 0);
+  Net N = make_net(blob, batch, workspace, stream, sharing ? H : 0, sharing ? W : 0, route == 0 ? 2 : 1);
   const long long i0 = (long long)r0 * W, i1 = (long long)r1 * W;
   if (i0 >= i1) return 0;
   int rc = 0;
-  if (route != 0 && route != 3) {
+  if (!sharing && route != 3) {
     if (route == 4 && (rc = prepare_wino(N))) return rc;
     for (long long tile0 = i0; tile0 < i1; tile0 += batch) {
       const int n = (int)((i1 - tile0 < batch) ? (i1 - tile0) : batch);
@@ -445,7 +564,7 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
     for (; tile0 < i1 && nb < NFLAG; tile0 += batch, ++nb) {
       const int n = (int)((i1 - tile0 < batch) ? (i1 - tile0) : batch);
       int rt = 3;
-      if (route == 0 && N.share) {             // the phase maps must cover the batch's image rows
+      if (sharing && N.share) {                // the phase maps must cover the batch's image rows
         const int rf = (int)(tile0 / W), rl = (int)((tile0 + n - 1) / W);
         if (!(N.map_r0 >= 0 && N.map_r0 <= rf && rl < N.map_r1))
           if ((rc = build_maps(N, padded, H, W, rf, as))) return rc;

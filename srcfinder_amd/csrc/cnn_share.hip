@@ -10,12 +10,14 @@
 // computed ONCE per strip of image rows at a cost of one window-equivalent per plane position.  Per window only the ring remains:
 //     k_ring_pool1      conv1 + maxpool1 at the 252 border positions of the 64 x 64 grid        (fp32 vector units)
 //     sf_cnn_conv_split conv2 on those 252 positions                                             (a plain GEMM)
-//     sf_cnn_conv3_ring conv3 at the 496 ring positions, taps from the border tensor / the shared conv2 map (cnn_split.hip)
-//     k_pool2_shared    maxpool2 (3x3 s2 ceil) reading ring positions from the ring tensor, the others from the shared conv3 map
-// and inception3a takes over.  Exact: the same kernels and the same summation order produce a map position and a window position
+//     sf_cnn_conv_ring  conv3 at the 496 ring positions, taps from the border tensor / the shared conv2 map (cnn_split.hip)
+//     k_pool_gather     maxpool2 (3x3 s2 ceil) reading ring positions from the ring tensor, the others from the shared conv3 map
+// and inception3a takes over -- or (the deeper form) the same idea carried on through inception3a, 3b and maxpool3 on 64 phase
+// maps of the 32 x 32 grid: frames (1, 2) -> (2, 3) -> (3, 4) (cnn_ring.h), and inception4a takes over.  Exact: the same kernels and the same summation order produce a map position and a window position
 // (conv1's 49-term sum differs in ORDER between the fused per-window kernel and the FCN kernel: float32 rounding, inside the
 // parity bar and independent of batch size and row sharding).
 #include "cmf_common.h"
+#include "cnn_ring.h"
 
 namespace {
 
@@ -27,13 +29,6 @@ __global__ __launch_bounds__(256) void k_phase_canvas(const float *__restrict__ 
   const int u = (int)(i / Wc), v = (int)(i - (size_t)u * Wc);
   const int y = y0 + u, x = x0 + v;
   canvas[i] = (y >= 0 && y < Hp && x >= 0 && x < Wp) ? padded[(size_t)y * Wp + x] : 0.f;
-}
-
-__device__ __forceinline__ void border_position(int b, int &y, int &x) {   // inverse of ring_border_index (cnn_split.hip)
-  if (b < 64) { y = 0; x = b; }
-  else if (b < 128) { y = 63; x = b - 64; }
-  else if (b < 190) { y = b - 127; x = 0; }
-  else { y = b - 189; x = 63; }
 }
 
 // maxpool1(conv1(window)) at the 252 border positions of the 64 x 64 grid: one wave per (window, position) at a time, lane = output
@@ -54,7 +49,7 @@ __global__ __launch_bounds__(256) void k_ring_pool1(const float *__restrict__ pa
   for (long long item = (long long)blockIdx.x * 4 + wave; item < total; item += (long long)gridDim.x * 4) {
     const int n = (int)(item / 252), b = (int)(item - (long long)n * 252);
     int py, px;
-    border_position(b, py, px);
+    sf_frame_position(64, 1, 1, b, py, px);
     const long long t = tile0 + n;
     const int r = (int)(t / Wimg), c = (int)(t - (long long)r * Wimg);
     const float *win = padded + (size_t)r * Wp + c;               // window pixel (wy, wx) = win[wy * Wp + wx]
@@ -83,44 +78,44 @@ __global__ __launch_bounds__(256) void k_ring_pool1(const float *__restrict__ pa
   }
 }
 
-// conv3's output position (y, x) of a window: in the ring tensor (index) or in the shared map (-1)
-__device__ __forceinline__ int ring_index(int y, int x) {
-  if (y < 2) return y * 64 + x;
-  if (y > 61) return 128 + (y - 62) * 64 + x;
-  if (x < 2) return 256 + (y - 2) * 4 + x;
-  if (x > 61) return 256 + (y - 2) * 4 + (x - 60);
-  return -1;
-}
-
-// maxpool2 (3 x 3 stride 2 ceil: 64 x 64 -> 32 x 32, googlenet1.py:64) of a batch of windows whose conv3 activation exists only as
-// ring tensor [N][496][C] + shared phase maps [16][Hq][Wq][C]: out[N][32][32][C].  One workgroup per (window, output row).
-__global__ __launch_bounds__(256) void k_pool2_shared(const float *__restrict__ ringt, const float *__restrict__ maps, long long tile0,
-                                                       int Wimg, int Rb, int Hq, int Wq, int C, float *__restrict__ out) {
-  const int n = blockIdx.x >> 5, py = blockIdx.x & 31;
-  const long long t = tile0 + n;
-  const int r = (int)(t / Wimg), c = (int)(t - (long long)r * Wimg);
-  const int ph = (r & 3) * 4 + (c & 3);
-  const float *mp = maps + (((size_t)ph * Hq + ((r >> 2) - Rb)) * Wq + (c >> 2)) * C;    // the window's origin in its phase map
-  const float *rg = ringt + (size_t)n * 496 * C;
+// A 3 x 3 max pool (stride 1 pad 1, or stride 2 pad 0 in ceil mode: googlenet1.py:61-68, :213) of a tensor that exists only as per-window
+// ring tensor [N][count][C] + shared phase maps (SfGather), for a batch of windows: the output either on the WHOLE output grid
+// (out[N][Go][Go][C]: olo < 0) or at the ring positions of the frame (olo, ohi) on Go (out[N][count(Go, olo, ohi)][C]).
+// Activations are ReLU outputs: 0 is the identity of the max (a tap outside the grid contributes nothing).
+__global__ __launch_bounds__(256) void k_pool_gather(const float *__restrict__ maps, SfGather gi, int C, int stride, int pad, int Go, int olo,
+                                                      int ohi, int npos, int N, float *__restrict__ out) {
   const int c4n = C >> 2;
-  for (int i = threadIdx.x; i < 32 * c4n; i += 256) {
-    const int px = i / c4n, c4 = i - px * c4n;
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);                   // ReLU outputs
+  const size_t total = (size_t)N * npos * c4n;
+  const int nin = sf_frame_count(gi.G, gi.lo, gi.hi);
+  const int pm = (1 << gi.shift) - 1;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    const size_t rest = i / c4n;
+    const int j = (int)(rest % npos), n = (int)(rest / npos);
+    int oy, ox;
+    if (olo < 0) { oy = j / Go; ox = j - oy * Go; }
+    else sf_frame_position(Go, olo, ohi, j, oy, ox);
+    const long long t = gi.tile0 + n;
+    const int r = (int)(t / gi.W), c = (int)(t - (long long)r * gi.W);
+    const int ph = ((r & pm) << gi.shift) + (c & pm);
+    const float *mp = maps + (((size_t)ph * gi.Hq + ((r >> gi.shift) - gi.Rb)) * gi.Wq + (c >> gi.shift)) * C;   // the window's origin in its map
+    const float *rg = maps + gi.ring_off + (size_t)n * nin * C;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
-      const int y = 2 * py + dy;
-      if (y > 63) continue;
+      const int y = oy * stride - pad + dy;
+      if ((unsigned)y >= (unsigned)gi.G) continue;
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
-        const int x = 2 * px + dx;
-        if (x > 63) continue;
-        const int ri = ring_index(y, x);
-        const float *src = (ri >= 0) ? rg + (size_t)ri * C : mp + ((size_t)y * Wq + x) * C;
+        const int x = ox * stride - pad + dx;
+        if ((unsigned)x >= (unsigned)gi.G) continue;
+        const float *src = sf_frame_ring(gi.G, gi.lo, gi.hi, y, x) ? rg + (size_t)sf_frame_index(gi.G, gi.lo, gi.hi, y, x) * C
+                                                                   : mp + ((size_t)y * gi.Wq + x) * C;
         const float4 v = *reinterpret_cast<const float4 *>(src + 4 * c4);
         m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
       }
     }
-    *reinterpret_cast<float4 *>(out + (((size_t)n * 32 + py) * 32 + px) * C + 4 * c4) = m;
+    *reinterpret_cast<float4 *>(out + (rest * c4n + c4) * 4) = m;
   }
 }
 
@@ -150,14 +145,21 @@ int sf_cnn_ring_pool1(const float *padded, int Hp, int Wp, int W, long long tile
   return 0;
 }
 
-int sf_cnn_pool2_shared(const float *ring, const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, int C, float *out,
-                        void *stream) {
-  if (!ring || !maps || !out || N < 1 || W < 1 || Hq < 64 || Wq < 64 || C < 4 || (C & 3) || tile0 < 0) {
-    sf_set_error("sf_cnn_pool2_shared: bad argument");
+int sf_cnn_pool_gather(const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, int shift, int G,
+                       int ilo, int ihi, int C, int stride, int Go, int olo, int ohi, float *out, void *stream) {
+  if (!maps || !out || N < 1 || W < 1 || tile0 < 0 || G < 4 || G > 128 || shift < 1 || shift > 4 || ilo < 0 || ihi < 0 || ilo + ihi >= G ||
+      Hq < G || Wq < G || C < 4 || (C & 3) || (stride != 1 && stride != 2) || (ring_off & 3) ||
+      Go != (stride == 1 ? G : (G + 1) / 2) || (olo >= 0 && (ohi < 0 || olo + ohi >= Go))) {
+    sf_set_error("sf_cnn_pool_gather: bad argument");
     return -1;
   }
-  hipLaunchKernelGGL(k_pool2_shared, dim3((unsigned)N * 32), dim3(256), 0, (hipStream_t)stream, ring, maps, tile0, W, Rb, Hq, Wq, C, out);
-  SF_LAUNCH_CHECK("k_pool2_shared");
+  const SfGather gi{tile0, W, Rb, Hq, Wq, shift, G, ilo, ihi, (unsigned)ring_off};
+  const int npos = olo < 0 ? Go * Go : sf_frame_count(Go, olo, ohi);
+  const size_t total = (size_t)N * npos * (C >> 2);
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 65536 * 8 ? (total + 255) / 256 : 65536 * 8);
+  hipLaunchKernelGGL(k_pool_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, maps, gi, C, stride, stride == 1 ? 1 : 0, Go, olo, ohi,
+                     npos, N, out);
+  SF_LAUNCH_CHECK("k_pool_gather");
   return 0;
 }
 

@@ -19,6 +19,7 @@
 // tiles [row][k] with 80-byte rows -- here four of them (A hi / lo, B hi / lo); the activations are split on their way
 // from global memory into LDS.
 #include "cmf_common.h"
+#include "cnn_ring.h"
 #include <type_traits>
 
 typedef _Float16 sp_h8 __attribute__((ext_vector_type(8)));
@@ -44,31 +45,15 @@ struct ConvDstS {
 // halves ready for LDS: the split, a third of a chunk's time in the kernel below, is done once per value instead of once per
 // (value, tap, channel tile).
 
-// The RING form of the convolution (round 6, trunk sharing; cnn_share.hip has the geometry): the rows of the implicit GEMM are the
-// 496 border positions of conv3's 64 x 64 output per window (rows / columns 0, 1, 62, 63) instead of all 4096, and a tap of such a
-// row is fetched from one of two places -- the window's OWN border of conv2's output (252 positions: the rows / columns 0 and 63,
-// whose values depend on the window's zero padding) or the SHARED phase map of conv2 over the whole plane (every other position:
-// identical for all windows of the same phase) -- or is zero (outside the window).  Both live in one allocation behind `in`:
-// [16 phases][Hq][Wq][64] then [N][252][64], split format.
+// The RING form of the convolution (round 6, trunk sharing; cnn_ring.h has the geometry): the rows of the implicit GEMM are the ring
+// positions of the OUTPUT tensor's frame, per window (conv3: 496 of 4096), and a tap of such a row is fetched from one of two places
+// -- the window's own ring tensor of the INPUT (the positions that see the window's zero padding) or the SHARED phase map of the
+// input over the whole plane (every other position: identical for all windows of a phase) -- or is zero (outside the window's grid).
 struct RingArgs {
-  long long tile0;     // first window of the batch (window t = image pixel (t / W, t % W))
-  int W;               // image width
-  int Rb, Hq, Wq;      // the maps cover canvas rows Rb .. Rb + Hq - 1 (units of 4 image rows), Wq columns
-  unsigned ring_off;   // float offset of the batch's border tensor behind the maps
+  SfGather in;         // where the input lives
+  int olo, ohi, nout;  // the rows: ring positions of the frame (olo, ohi) on the same grid, nout of them per window
+  int nin;             // ring positions of the input frame
 };
-__device__ __forceinline__ int ring_border_index(int y, int x) {      // 0 .. 251: y, x in 0 .. 63 with y or x on the border
-  return (y == 0) ? x : ((y == 63) ? 64 + x : ((x == 0) ? 127 + y : 189 + y));
-}
-__device__ __forceinline__ void ring_position(int j, int &y, int &x) {   // 0 .. 495 -> (y, x): rows 0, 1, 62, 63, then columns 0, 1, 62, 63 of the rest
-  if (j < 256) {
-    y = (j >> 6) + ((j >= 128) ? 60 : 0);
-    x = j & 63;
-  } else {
-    const int k = j - 256;
-    y = 2 + (k >> 2);
-    x = (k & 3) + ((k & 2) ? 60 : 0);
-  }
-}
 
 // hi / lo halves of eight floats (scaled by s); big: the largest magnitude seen (float16 ends at 65504)
 __device__ __forceinline__ void sp_split8(const sp_f4 &x0, const sp_f4 &x1, float s, sp_h8 &hi, sp_h8 &lo, float &big) {
@@ -116,7 +101,7 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
   unsigned rowoff[NPA], vmask[NPA], woff[NPB];
   const size_t shift = RING ? 0 : ((size_t)pad * W + pad) * ld_in;          // taps are addressed from (y - pad, x - pad): offsets >= 0
   // (RING: `in` = the phase maps with the batch's border tensor behind them: M / 496 windows x 252 positions)
-  const size_t ring_floats = RING ? (size_t)ring.ring_off + (size_t)(M / 496 + 1) * 252 * ld_in : 0;
+  const size_t ring_floats = RING ? (size_t)ring.in.ring_off + (size_t)(M / (RING ? ring.nout : 1) + 1) * ring.nin * ld_in : 0;
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in) - shift, 0,
                                                                  RING ? (unsigned)(ring_floats * 4)
                                                                       : (unsigned)(((size_t)M * ld_in + 2 * shift) * 4 + 64), 0x00020000);
@@ -129,14 +114,16 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
     const bool ok = m < M;
     const int mm = ok ? m : 0;
     if constexpr (RING) {
-      const int n = mm / 496, j = mm - n * 496;
+      const SfGather &gi = ring.in;
+      const int n = mm / ring.nout, j = mm - n * ring.nout;
       int y3, x3;
-      ring_position(j, y3, x3);
-      const long long t = ring.tile0 + n;
-      const int r = (int)(t / ring.W), c = (int)(t - (long long)r * ring.W);
-      const int ph = (r & 3) * 4 + (c & 3);
-      rowoff[a] = (unsigned)((((size_t)(ph * ring.Hq + ((r >> 2) - ring.Rb)) * ring.Wq + (c >> 2)) * ld_in + 8 * q) * 4);   // the window's origin in its phase map
-      rring[a] = (unsigned)(((size_t)ring.ring_off + (size_t)n * 252 * ld_in + 8 * q) * 4);
+      sf_frame_position(gi.G, ring.olo, ring.ohi, j, y3, x3);
+      const long long t = gi.tile0 + n;
+      const int r = (int)(t / gi.W), c = (int)(t - (long long)r * gi.W);
+      const int pm = (1 << gi.shift) - 1;
+      const int ph = ((r & pm) << gi.shift) + (c & pm);
+      rowoff[a] = (unsigned)((((size_t)(ph * gi.Hq + ((r >> gi.shift) - gi.Rb)) * gi.Wq + (c >> gi.shift)) * ld_in + 8 * q) * 4);   // the window's origin in its phase map
+      rring[a] = (unsigned)(((size_t)gi.ring_off + (size_t)n * ring.nin * ld_in + 8 * q) * 4);
       rpos[a] = ok ? (unsigned)((y3 << 8) | x3) : 0xffffu;           // (a row past M: every tap outside)
       vmask[a] = 0;
     } else {
@@ -178,11 +165,12 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
     for (int a = 0; a < NPA; ++a) {
       unsigned off;
       if constexpr (RING) {
-        const int ys = (int)(rpos[a] >> 8) + g_ty - 1, xs = (int)(rpos[a] & 255u) + g_tx - 1;
-        const bool inside = (unsigned)ys < 64u && (unsigned)xs < 64u;
-        const bool border = ys == 0 || ys == 63 || xs == 0 || xs == 63;
-        const unsigned o_ring = rring[a] + (unsigned)(ring_border_index(ys, xs) * ld_in * 4);
-        const unsigned o_map = rowoff[a] + (unsigned)((ys * ring.Wq + xs) * ld_in * 4);
+        const SfGather &gi = ring.in;
+        const int ys = (int)(rpos[a] >> 8) + g_ty - pad, xs = (int)(rpos[a] & 255u) + g_tx - pad;
+        const bool inside = (unsigned)ys < (unsigned)gi.G && (unsigned)xs < (unsigned)gi.G;
+        const bool border = sf_frame_ring(gi.G, gi.lo, gi.hi, ys, xs);
+        const unsigned o_ring = rring[a] + (unsigned)(sf_frame_index(gi.G, gi.lo, gi.hi, ys, xs) * ld_in * 4);
+        const unsigned o_map = rowoff[a] + (unsigned)((ys * gi.Wq + xs) * ld_in * 4);
         off = (kin && inside) ? (border ? o_ring : o_map) : OOB;
       } else {
         off = (kin && ((vmask[a] >> g_tap) & 1u)) ? rowoff[a] : OOB;
@@ -629,30 +617,56 @@ int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int 
   return split_go(in, 0, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, c0 + c1 + c2, 1, ascale, d, overflow, (hipStream_t)stream);
 }
 
-// conv3 (3 x 3, 64 -> Cout) at the 496 border positions of every window of a batch (trunk sharing, cnn_share.hip): `maps` = the
-// conv2 phase maps [16][Hq][Wq][64] with the batch's own conv2 border [N][252][64] behind them at float offset ring_off (both in
-// the split format, scaled by ascale); out[N][496][Cout] float32.
-int sf_cnn_conv3_ring(const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, const void *whi,
-                      const void *wlo, const float *wscale, const float *bias, int Cout, float ascale, float *out, int *overflow,
-                      void *stream) {
-  const int Cin = 64;
-  const size_t total = (ring_off + (size_t)(N + 1) * 252 * Cin) * 4;
-  if (!maps || !whi || !wlo || !wscale || !bias || !out || !overflow || N < 1 || W < 1 || Hq < 64 || Wq < 64 || Cout < 1 || tile0 < 0 ||
-      !sp_pow2(ascale) || ring_off < (size_t)16 * Hq * Wq * Cin || total >= 0x7ff00000u) {
-    sf_set_error("sf_cnn_conv3_ring: bad argument (maps + border tensor below 2 GB)");
+// A convolution (1 x 1 or 3 x 3) at the ring positions of the frame (olo, ohi) of every window of a batch, its input gathered from the
+// window's own ring tensor or the shared phase maps (trunk sharing, cnn_share.hip / cnn_ring.h): `maps` = the input's phase maps
+// [P * P][Hq][Wq][Cin] with the batch's ring tensor [N][count(G, ilo, ihi)][Cin] `ring_off` floats behind their start (float32, or
+// both in the split format scaled by ascale when in_split); rows m = window * nout + ring index.  Output channels as
+// sf_cnn_conv_split3_split: [0, c0) -> out0 (float32), [c0, c0 + c1) -> out1, the rest -> out2 (c1 = c2 = 0: one segment).
+int sf_cnn_conv_ring(const float *maps, int in_split, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, int shift,
+                     int G, int ilo, int ihi, int olo, int ohi, int Cin, const void *whi, const void *wlo, const float *wscale,
+                     const float *bias, int c0, int c1, int c2, int ksize, float ascale, float *out0, int ld0, int off0, float *out1,
+                     int ld1, int off1, float *out2, int ld2, int off2, int out12_split, float oscale1, float oscale2, int *overflow,
+                     void *stream) {
+  const int nin = sf_frame_count(G, ilo, ihi), nout = sf_frame_count(G, olo, ohi), Cout = c0 + c1 + c2;
+  const size_t total = (ring_off + (size_t)(N + 1) * nin * Cin) * 4;
+  if (!maps || !whi || !wlo || !wscale || !bias || !out0 || !overflow || N < 1 || W < 1 || tile0 < 0 || (ksize != 1 && ksize != 3) ||
+      (Cin & 7) || c0 < 1 || c1 < 0 || c2 < 0 || (c2 > 0 && c1 < 1) || off0 + c0 > ld0 || (c1 > 0 && (!out1 || off1 + c1 > ld1)) ||
+      (c2 > 0 && (!out2 || off2 + c2 > ld2)) || G < 4 || G > 128 || shift < 1 || shift > 4 || ilo < 0 || ihi < 0 || olo < 0 || ohi < 0 ||
+      ilo + ihi >= G || olo + ohi >= G || nout < 1 || Hq < G || Wq < G || !sp_pow2(ascale) ||
+      ring_off < ((size_t)1 << (2 * shift)) * Hq * Wq * Cin || total >= 0x7ff00000u ||
+      (out12_split && ((c1 > 0 && (ld1 != c1 || off1 != 0 || (c1 & 7) || !sp_pow2(oscale1))) ||
+                       (c2 > 0 && (ld2 != c2 || off2 != 0 || (c2 & 7) || !sp_pow2(oscale2)))))) {
+    sf_set_error("sf_cnn_conv_ring: bad argument (maps + ring tensor below 2 GB; Cin a multiple of 8)");
     return -1;
   }
   ConvDstS d{};
-  d.p[0] = d.p[1] = d.p[2] = out;
-  d.ld[0] = d.ld[1] = d.ld[2] = Cout;
-  d.end[0] = d.end[1] = d.end[2] = Cout;
-  d.oscale[0] = d.oscale[1] = d.oscale[2] = 1.0f;
-  RingArgs ra{tile0, W, Rb, Hq, Wq, (unsigned)ring_off};
-  const int M = N * 496;
-  dim3 grid(8 * sf_cdiv(sf_cdiv(M, 256), 8) * sf_cdiv(Cout, 64));
-  hipLaunchKernelGGL((k_conv_split<64, true, 256, true>), grid, dim3(256), 0, (hipStream_t)stream, maps, M, 64, 64, Cin, Cin,
-                     reinterpret_cast<const _Float16 *>(whi), reinterpret_cast<const _Float16 *>(wlo), wscale, bias, Cout, 3, ascale, d,
-                     overflow, ra);
+  d.p[0] = out0; d.p[1] = c1 > 0 ? out1 : out0; d.p[2] = c2 > 0 ? out2 : out0;
+  d.ld[0] = ld0; d.ld[1] = c1 > 0 ? ld1 : ld0; d.ld[2] = c2 > 0 ? ld2 : ld0;
+  d.off[0] = off0; d.off[1] = c1 > 0 ? off1 : off0; d.off[2] = c2 > 0 ? off2 : off0;
+  d.end[0] = c0; d.end[1] = c0 + c1; d.end[2] = Cout;
+  d.fmt[0] = 0; d.fmt[1] = (out12_split && c1 > 0) ? 1 : 0; d.fmt[2] = (out12_split && c2 > 0) ? 1 : 0;
+  d.oscale[0] = 1.0f; d.oscale[1] = d.fmt[1] ? oscale1 : 1.0f; d.oscale[2] = d.fmt[2] ? oscale2 : 1.0f;
+  RingArgs ra{};
+  ra.in = SfGather{tile0, W, Rb, Hq, Wq, shift, G, ilo, ihi, (unsigned)ring_off};
+  ra.olo = olo; ra.ohi = ohi; ra.nout = nout; ra.nin = nin;
+  const long long Ml = (long long)N * nout;
+  if (Ml * (long long)(ld0 > Cout ? ld0 : Cout) * 4 >= (1ll << 40) || Ml >= 0x7fffffff) { sf_set_error("sf_cnn_conv_ring: batch too large"); return -2; }
+  const int M = (int)Ml;
+  const _Float16 *h = reinterpret_cast<const _Float16 *>(whi), *l = reinterpret_cast<const _Float16 *>(wlo);
+  hipStream_t st = (hipStream_t)stream;
+#define SF_RING_LAUNCH(BN, BM)                                                                                                          \
+  {                                                                                                                                     \
+    dim3 grid(8 * sf_cdiv(sf_cdiv(M, BM), 8) * sf_cdiv(Cout, BN));                                                                     \
+    if (in_split)                                                                                                                       \
+      hipLaunchKernelGGL((k_conv_split<BN, true, BM, true>), grid, dim3(256), 0, st, maps, M, G, G, Cin, Cin, h, l, wscale, bias, Cout, \
+                         ksize, ascale, d, overflow, ra);                                                                               \
+    else                                                                                                                                \
+      hipLaunchKernelGGL((k_conv_split<BN, false, BM, true>), grid, dim3(256), 0, st, maps, M, G, G, Cin, Cin, h, l, wscale, bias,     \
+                         Cout, ksize, ascale, d, overflow, ra);                                                                         \
+  }
+  if (Cout > 64 && sf_cdiv(Cout, 128) * 128 <= sf_cdiv(Cout, 64) * 64) SF_RING_LAUNCH(128, 128)
+  else SF_RING_LAUNCH(64, 256)
+#undef SF_RING_LAUNCH
   SF_LAUNCH_CHECK("k_conv_split<ring>");
   return 0;
 }

@@ -245,7 +245,8 @@ def test_shared_trunk_against_every_window_on_its_own(net):
         Hq, Wq = ((rows + 3) >> 2) + 1 + 64, ((W - 1) >> 2) + 64
         Hc, Wc = 4 * Hq, 4 * Wq
         q2 = torch.zeros(16 * Hq * Wq * 64 + 64 * 252 * 64 + 4096, **f32)          # maps, then the border tensor of <= 63 windows
-        q3 = torch.empty((16, Hq, Wq, 192), **f32)
+        q3all = torch.empty(16 * Hq * Wq * 192 + 20 * 496 * 192, **f32)            # conv3's maps with the ring tensor right behind them
+        q3 = q3all[:16 * Hq * Wq * 192].view(16, Hq, Wq, 192)
         canvas = torch.empty((Hc, Wc), **f32)
         c1 = torch.empty((Hc // 2, Wc // 2, 64), **f32)
         p1 = torch.empty((Hq, Wq, 64), **f32)
@@ -277,32 +278,35 @@ def test_shared_trunk_against_every_window_on_its_own(net):
                 ring_off = 16 * Hq * Wq * 64
                 p1r = torch.empty((n, 252, 64), **f32)
                 c2r = q2[ring_off:ring_off + n * 252 * 64]
-                c3r = torch.empty((n, 496, 192), **f32)
+                c3r = q3all[16 * Hq * Wq * 192:].view(n, 496, 192)
                 got = torch.empty((n, 32, 32, 192), **f32)
                 _ffi.check(L.sf_cnn_ring_pool1(P(ds.x), Hp, Wp, W, C.c_longlong(tile0), n, P(w1), P(b1), P(p1r), st()), "ring_pool1")
                 _ffi.check(L.sf_cnn_conv_split(P(p1r), 0, 1, 1, n * 252, 64, 64, P(h2), P(l2), P(s2), P(b2), 64, 1, C.c_float(1.0), P(c2r),
                                                1, C.c_float(1.0), 64, 0, P(flag), st()), "conv2 ring")
-                _ffi.check(L.sf_cnn_conv3_ring(P(q2), C.c_longlong(tile0), n, W, Rb, Hq, Wq, C.c_size_t(ring_off), P(h3), P(l3), P(s3),
-                                               P(b3), 192, C.c_float(1.0), P(c3r), P(flag), st()), "conv3 ring")
-                _ffi.check(L.sf_cnn_pool2_shared(P(c3r), P(q3), C.c_longlong(tile0), n, W, Rb, Hq, Wq, 192, P(got), st()), "pool2 shared")
+                _ffi.check(L.sf_cnn_conv_ring(P(q2), 1, C.c_longlong(tile0), n, W, Rb, Hq, Wq, C.c_size_t(ring_off), 2, 64, 1, 1, 2, 2, 64,
+                                              P(h3), P(l3), P(s3), P(b3), 192, 0, 0, 3, C.c_float(1.0), P(c3r), 192, 0, None, 0, 0, None, 0, 0,
+                                              0, C.c_float(1.0), C.c_float(1.0), P(flag), st()), "conv3 ring")
+                _ffi.check(L.sf_cnn_pool_gather(P(q3), C.c_longlong(tile0), n, W, Rb, Hq, Wq, C.c_size_t(q3.numel()), 2, 64, 2, 2, 192, 2,
+                                                32, -1, 0, P(got), st()), "pool2 from the maps + ring")
                 torch.cuda.synchronize()
                 # the border of maxpool1 first (exactly the per-window kernel's values up to the order of conv1's sums)
-                border = torch.cat([a1[:, 0, :, :], a1[:, 63, :, :], a1[:, 1:63, 0, :], a1[:, 1:63, 63, :]], 1)
+                border = torch.cat([a1[:, 0, :, :], a1[:, 63, :, :], a1[:, 1:63][:, :, [0, 63], :].reshape(n, 124, 64)], 1)
                 scale1 = float(border.abs().max())
                 assert float((p1r - border).abs().max()) <= 3e-6 * scale1, (r0, c0, rr)
                 scale = float(want.abs().max())
                 assert scale > 0 and float((got - want).abs().max()) <= 2e-5 * scale, (r0, c0, rr, float((got - want).abs().max()) / scale)
     assert int(flag.item()) == 0
-    # (ii) whole rows through the C driver
-    for rows in ((148, 152), (0, 2), (298, 300)):
-        a = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=96, rows=rows, route="split")
+    # (ii) whole rows through the C driver: shared through inception3b ("split", the default), through conv3 ("split_conv3"), not at all
+    for rows in ((144, 153), (0, 2), (298, 300)):
         b = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=96, rows=rows, route="split_unshared")
-        sa, sb = a[rows[0]:rows[1]], b[rows[0]:rows[1]]
-        v = sb != -9999.0
-        assert torch.equal(sa == -9999.0, ~v)
-        rel = float(((sa[v] - sb[v]).abs() / sb[v].abs().clamp_min(1e-7)).max())
-        print("rows %s: shared against unshared, max relative difference of the saliency %.2e" % (rows, rel))
-        assert rel < 2e-5
+        for name in ("split", "split_conv3"):
+            a = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=96, rows=rows, route=name)
+            sa, sb = a[rows[0]:rows[1]], b[rows[0]:rows[1]]
+            v = sb != -9999.0
+            assert torch.equal(sa == -9999.0, ~v)
+            rel = float(((sa[v] - sb[v]).abs() / sb[v].abs().clamp_min(1e-7)).max())
+            print("rows %s: %s against unshared, max relative difference of the saliency %.2e" % (rows, name, rel))
+            assert rel < 2e-5, (rows, name, rel)
 
 
 def _scaled_family(sd, k):

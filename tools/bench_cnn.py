@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="conv1 and maxpool1 as two kernels (A/B of the fused kernel)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"])
     ap.add_argument("--knob", action="append", default=[], help="key=value for sf_debug_set (repeatable)")
+    ap.add_argument("--route", default="split", help="split (shared trunk, C driver) | split_unshared | winograd | direct")
+    ap.add_argument("--width", type=int, default=598, help="image width (whole rows are scored)")
     args = ap.parse_args()
     import torch
     from srcfinder_amd import cnn
@@ -35,15 +37,17 @@ def main():
     sd = synthetic_state_dict(2024)
     net = cnn.GoogLeNetHIP(sd, precision=args.precision)
     net.fuse_conv1 = not args.no_fuse
-    w = 64
+    w = args.width
     h = (args.tiles + w - 1) // w
+    args.tiles = h * w                              # whole image rows: the C-side driver (sf_cnn_score_rows) sequences the graph
     plane = synthetic_plane(h, w, seed=5)
     ds = cnn.FlightlineConvolve(plane, "COVID_QC")
     out = torch.zeros(h * w, dtype=torch.float32, device="cuda")
+    if args.precision == "fp32":
+        net.calibrate(ds, args.batch)
 
     def run():
-        for t0 in range(0, args.tiles, args.batch):
-            net.forward_tiles(ds.x, w, t0, min(args.batch, args.tiles - t0), plane=ds.plane, out=out)
+        cnn.score_tiles(net, ds, 0, args.tiles, args.batch, out, route=args.route if args.precision == "fp32" else None)
 
     run()
     torch.cuda.synchronize()
@@ -53,7 +57,7 @@ def main():
     dt = time.perf_counter() - t0
     line = {"metric": "CNN tiles/s (GoogLeNet 256x256 window per pixel, %s)" % args.precision, "value": round(args.tiles / dt, 1),
             "unit": "tiles/s", "tflops": round(args.tiles * 3.706e9 / dt / 1e12, 2), "batch": args.batch,
-            "tiles": args.tiles, "dtype": "f32" if args.precision == "fp32" else "f16 (fp32 accumulate)",
+            "tiles": args.tiles, "route": args.route, "dtype": "f32" if args.precision == "fp32" else "f16 (fp32 accumulate)",
             "mfma_peak_tflops": 157.3 if args.precision == "fp32" else 2500.0}
     if args.cpu:
         from oracle import cnn_oracle as O

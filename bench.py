@@ -36,8 +36,8 @@ def main():
     ap.add_argument("--samples", type=int, default=SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cnn", action="store_true", help="skip the CNN tile-scorer section of the line (BASELINE configs 4/5)")
-    ap.add_argument("--cnn-tiles", type=int, default=8192)
-    ap.add_argument("--cnn-batch", type=int, default=512)
+    ap.add_argument("--cnn-tiles", type=int, default=16384)
+    ap.add_argument("--cnn-batch", type=int, default=1024)
     ap.add_argument("--no-wide", action="store_true", help="skip the full-band (p = 425) section of the line (SURVEY 8(d) config F425)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the CMF -> CNN end-to-end section (BASELINE config 4)")
     ap.add_argument("--no-ceiling", action="store_true",
@@ -463,7 +463,7 @@ def e2e_section(cube, lib, cmf_seconds, cnn, strip_lines=2500):
     plane = res.out[..., 3].to(torch.float32).contiguous()
     # ---- parity path on a strip in the middle of the flightline (the windows reach 128 lines up and down: real context)
     r0 = max(0, min(lines - strip_lines, lines // 2))
-    batch = 512
+    batch = 1024
     ds = C.FlightlineConvolve(plane, "COVID_QC", device=net.device)
     sal = torch.zeros(lines * ncols, dtype=torch.float32, device=net.device)
     t_first, n_strip = r0 * ncols, strip_lines * ncols
@@ -545,18 +545,19 @@ def cnn_section(res, ntiles, batch, with_cpu):
 
     dt_w, _ = timed("winograd")                      # the other float32-tolerance routes, kept on record beside the default
     dt_u, _ = timed("split_unshared")
+    dt_c, _ = timed("split_conv3")
     dt, rescued = timed("split")
     tf = ntiles * 3.706e9 / dt / 1e12
-    # Flops one window EXECUTES on the shared-trunk split route (srcfinder_amd/csrc/cnn_share.hip): conv1 .. conv3 of the reference
-    # (1.043 GFLOP of its 3.706) shrink to the per-window ring -- conv3 at 496 of 4096 positions (0.110 GFLOP), conv2 at 252
-    # (0.002) as fp16 operand-split products, conv1 + pool at the border on the fp32 vector units (0.008) -- the phase maps cost one
-    # window-equivalent per plane position (~1e-4 of a window); inception3a .. 5b + head (2.663 GFLOP) run as they are.  Every
-    # multiply of the split layers is three fp16 MFMA products.
-    split_gflop = 2.663 - 0.0001 + 0.110 + 0.002
+    # Flops one window EXECUTES on the shared-trunk split route (srcfinder_amd/csrc/cnn_share.hip; SURVEY Appendix C's MACs x 2): the
+    # layers through inception3b shrink to the per-window ring -- conv2 at 252 of 4096 positions (0.002 GFLOP), conv3 at 496 (0.110),
+    # inception3a at 295 of 1024 (0.091 of its 0.318), inception3b at 399 (0.271 of 0.694) as fp16 operand-split products, conv1 +
+    # maxpool1 at the border on the fp32 vector units (0.014) -- the phase maps cost ~1e-4 of a window per window; inception4a .. 5b +
+    # head (1.652 GFLOP) run as they are.  Every multiply of the split layers is three fp16 MFMA products.
+    split_gflop = 0.002 + 0.110 + 0.091 + 0.271 + 1.652
     exec_fp16_tf = ntiles / dt * 3.0 * split_gflop * 1e9 / 1e12
     sec = {"metric": "CNN tiles/s (GoogLeNet, one 256x256 window per pixel)", "value": round(ntiles / dt, 1), "unit": "tiles/s",
            "dtype": "f32 (split-operand: fp16 hi + lo halves, fp32 accumulate)", "data": "synthetic weights (seeded), CMF plane of this run", "tiles": ntiles, "batch": batch,
-           "route": "split, trunk up to conv3 shared between the overlapping windows (an argument of the call; per-layer activation scales "
+           "route": "split, trunk through inception3b shared between the overlapping windows (an argument of the call; per-layer activation scales "
                     "calibrated on this plane: 2^%d .. 2^%d; one overflow slot per batch, %d of %d batches re-scored on the fp32 matrix cores)"
                     % (int(np.log2(min(scales))), int(np.log2(max(scales))), rescued, (ntiles + batch - 1) // batch),
            "fp32_mfma_route": {"value": round(ntiles / dt_w, 1), "unit": "tiles/s",
@@ -564,6 +565,8 @@ def cnn_section(res, ntiles, batch, with_cpu):
                                        "its own (the split route's rescue path), same windows"},
            "unshared_split_route": {"value": round(ntiles / dt_u, 1), "unit": "tiles/s",
                                     "note": "route=\"split_unshared\": round 5's form, every window evaluated on its own"},
+           "shared_through_conv3_only": {"value": round(ntiles / dt_c, 1), "unit": "tiles/s",
+                                         "note": "route=\"split_conv3\": round 6's first form (16 phase maps of the 64 x 64 grid)"},
            "roofline": {"bound": "mfma", "achieved": round(exec_fp16_tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": round(exec_fp16_tf / 2500.0, 4), "executed_gflop_per_tile_fp16_products": round(3.0 * split_gflop, 3),
                         "note": "EXECUTED flops against the pipe they run on: the split layers' multiplies as three "

@@ -1168,6 +1168,12 @@ int sf_launch_wsyrk(const void *xt, int xt_f64, const uint8_t *mask_t, const int
   // store half of the loader inside the MFMA stream and the operands of the next MFMA step prefetched the kernel wants 216
   // registers (three workgroups per CU at 168 registers spilled: 435 ms a flightline against 332)
   if (xt_f64) return wsyrk_go<double, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
+  // Round 6 ("the tile size has to follow p"): the band tile that pads the upper triangle of tile pairs least.
+  // 64-band tiles are 28 pairs at p = 425 / 416 (114.7 k band pairs) against the 15 pairs of 96 (138.2 k): 17 % fewer MFMAs for a
+  // third more operand reads per MFMA -- measured 285 -> 275 ms a flightline at p = 425, the covariance bit-identical (every
+  // element is the same sum over the rows in the same order).  sf_debug_set(5, 3): 96-band tiles whatever p.
+  auto pairs = [&](int T) { const long long n = sf_cdiv(g.p, T); return n * (n + 1) / 2 * T * T; };
+  if (sf_tune().cov_variant != 3 && pairs(64) * 103 < pairs(96) * 100) return wsyrk_go<float, 2, 3>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
   return wsyrk_go<float, 3, 2>(xt, mask_t, nuse, mu, g, c0, nb, cov, st);
 }
 

@@ -414,7 +414,8 @@ int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, co
  *      floats, powers of two, e.g. from sf_cnn_calibrate) or NULL -- the call then calibrates itself on a fixed sample of the
  *      plane's windows (a function of the plane alone: every row range and batch size of a flightline gets the same scales, hence
  *      the same bits); every batch owns an overflow slot in the workspace, the slots are read back every 1024 batches and a batch
- *      that raised its slot is scored AGAIN on route 4 before the call returns (*rescued, if given, counts them).  The call
+ *      that raised its slot is scored AGAIN on route 4 before the call returns (info, if given: int[2] -- [0] the batches scored again,
+ *      [1] the batches that ran on the shared trunk; a strip whose phase maps leave float16's range runs unshared).  The call
  *      therefore synchronises `stream` before returning on this route;
  *   4  Winograd F(2 x 2, 3 x 3) + fp32 implicit GEMM on the fp32 matrix cores;   2 (1)  the direct fp32 kernel for everything.
  * sf_cnn_calibrate: the scales alone (host array of sf_cnn_num_scales() floats: [0] maxpool1's output, [1] conv2's output,
@@ -425,7 +426,7 @@ int sf_cnn_num_scales(void);
 int sf_cnn_calibrate(const float *padded, int H, int W, const float *blob, int batch, void *workspace, size_t workspace_bytes,
                      float *scales, void *stream);
 int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int r0, int r1, const float *blob, float *out,
-                      int batch, int route, const float *scales, int *rescued, void *workspace, size_t workspace_bytes, void *stream);
+                      int batch, int route, const float *scales, int *info, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Trunk sharing (csrc/cnn_share.hip, csrc/cnn_ring.h): cnn_pred_pipeline.py:53-58 scores one 256 x 256 window per pixel, so
  * neighbouring windows overlap by 255/256.  A layer's activation for one window lives on a G x G grid and depends on the window only

@@ -494,14 +494,15 @@ def _score_rows_c(net, ds, r0, r1, batch, out, code):
     with torch.cuda.device(net.device):
         wsb = L.sf_cnn_score_workspace_bytes(int(batch), H if code in (0, 5) else 0, W if code in (0, 5) else 0)
         ws = net._buf("c_driver_ws", ((wsb + 3) // 4,))
-        nres = C.c_int(0)
+        nres = (C.c_int * 2)(0, 0)
         sc = (C.c_float * len(net.ascale))(*net.ascale)
         _ffi.check(L.sf_cnn_score_rows(_ffi.ptr(ds.x), _ffi.ptr(ds.plane), H, W, int(r0), int(r1), _ffi.ptr(net.packed_blob()),
-                                       _ffi.ptr(out), int(batch), code, sc, C.byref(nres), _ffi.ptr(ws),
+                                       _ffi.ptr(out), int(batch), code, sc, nres, _ffi.ptr(ws),
                                        C.c_size_t(ws.numel() * 4), _ffi.stream_ptr()), "sf_cnn_score_rows")
-    if nres.value:
-        _overflow_warning("%d batch(es) of rows %d..%d" % (nres.value, r0, r1))
-    return nres.value
+    net.last_shared_batches = int(nres[1])       # (batches of the call that ran on the shared trunk)
+    if nres[0]:
+        _overflow_warning("%d batch(es) of rows %d..%d" % (nres[0], r0, r1))
+    return int(nres[0])
 
 
 def score_tiles(net, ds, t_first, t_last, batch, out, route=None):
@@ -587,7 +588,8 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
     else:
         rescued = score_tiles(net, ds, r0 * W, r1 * W, batch, out, route=code)
     if info is not None:
-        info.update(rescued_batches=rescued, route=code, scales=list(net.ascale) if code in (0, 3, 5) else None)
+        info.update(rescued_batches=rescued, route=code, scales=list(net.ascale) if code in (0, 3, 5) else None,
+                    shared_batches=getattr(net, "last_shared_batches", 0) if code in (0, 5) else 0)
     out = out.view(H, W)
     return out.cpu().numpy() if to_numpy else out
 

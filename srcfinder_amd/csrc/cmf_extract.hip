@@ -432,11 +432,10 @@ __global__ __launch_bounds__(512) void k_mean(const double *__restrict__ sum_par
 // with fully coalesced loads, one workgroup per line chunk, the next tile's loads in flight (registers) while
 // the current one is transposed out of LDS.  Same chunking and the same line order of the fused masked sums
 // as k_extract, so a column's mean is bit-identical whichever kernel (shard layout) produced it.
-constexpr int XF_NT = 1024;           // one 16-wave workgroup per line chunk: the grid is only ~250 workgroups, so the
-                                      // parallelism that hides LDS / HBM latency has to come from inside the workgroup
-constexpr int XF_MAXLD = 12;          // loads per thread per tile: tile <= 12 * 1024 floats = 48 KB
-constexpr int XF_MAXSUM = 6;          // (band, column) pairs per thread for the fused sums: p*C <= 6144
-
+// XF_NT = 1024: one 16-wave workgroup per CU (tiles of up to 12 * 1024 floats = 48 KB, 6 (band, column) pairs per thread for the fused
+// sums: p C <= 6144).  (Round 6 measured the other shape -- XF_NT = 512, two 8-wave workgroups per CU on one-line tiles, 11 pairs per
+// thread: 128 registers with 6 spilled, the 75-column shard step 1.53-1.54 ms against 1.48 -- and kept this one.)
+template <int XF_NT, int XF_MAXLD, int XF_MAXSUM>
 __global__ __launch_bounds__(XF_NT) void k_extract_flat(const float *__restrict__ cube, int L, int B, int C, int b0,
                                                        int p, int PS, int TL, float *__restrict__ xt,
                                                        uint8_t *__restrict__ mask_t, int lines_per_wg,
@@ -567,14 +566,19 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
   int lpw;
   const int nchunk = extract_chunks(lines, ncols, &lpw);
   // a compact narrow cube (a rank's shard): the flat kernel, if a tile of at least one line fits
-  if (s0 == 0 && ncols == samples && p <= XT_PBMAX && (size_t)p * ncols <= XF_NT * (size_t)XF_MAXSUM &&
-      ncols <= 256 && sf_tune().extract_variant != 1) {
-    int tl = (XF_NT * XF_MAXLD) / (p * ncols);
-    if (tl > 4) tl = 4;
-    const size_t ldsf = ((size_t)XF_NT * (((size_t)tl * p * ncols + XF_NT - 1) / XF_NT) + (size_t)tl * ncols) * sizeof(float);
-    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_flat), ldsf > 64 * 1024 ? ldsf : (size_t)64 * 1024)) return rc;
-    hipLaunchKernelGGL(k_extract_flat, dim3(nchunk), dim3(XF_NT), ldsf, st, cube, lines, bands, samples, b0, p, PS, tl, xt,
-                       mask_t, lpw, fuse ? sum_part : nullptr, fuse ? cnt_part : nullptr);
+  if (s0 == 0 && ncols == samples && p <= XT_PBMAX && (size_t)p * ncols <= 1024 * (size_t)6 && ncols <= 256 &&
+      sf_tune().extract_variant != 1) {
+    auto flat = [&](auto kern, int NT, int MAXLD) -> int {
+      int tl = (NT * MAXLD) / (p * ncols);
+      if (tl > 4) tl = 4;
+      const size_t ldsf = ((size_t)NT * (((size_t)tl * p * ncols + NT - 1) / NT) + (size_t)tl * ncols) * sizeof(float);
+      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(kern), ldsf > 64 * 1024 ? ldsf : (size_t)64 * 1024)) return rc;
+      hipLaunchKernelGGL(kern, dim3(nchunk), dim3(NT), ldsf, st, cube, lines, bands, samples, b0, p, PS, tl, xt, mask_t, lpw,
+                         fuse ? sum_part : nullptr, fuse ? cnt_part : nullptr);
+      return 0;
+    };
+    const int rc = flat(k_extract_flat<1024, 12, 6>, 1024, 12);
+    if (rc) return rc;
     SF_LAUNCH_CHECK("k_extract_flat");
     return 0;
   }

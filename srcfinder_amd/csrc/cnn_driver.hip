@@ -514,7 +514,7 @@ int sf_cnn_calibrate(const float *padded, int H, int W, const float *blob, int b
 }
 
 int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int r0, int r1, const float *blob, float *out,
-                      int batch, int route, const float *scales, int *rescued, void *workspace, size_t workspace_bytes, void *stream) {
+                      int batch, int route, const float *scales, int *info, void *workspace, size_t workspace_bytes, void *stream) {
   if (!padded || !blob || !out || !workspace || H < 1 || W < 1 || r0 < 0 || r1 > H || r0 > r1 || batch < 1 ||
       (route != 0 && route != 5 && route != 3 && route != 4 && route != 2 && route != 1)) {
     sf_set_error("sf_cnn_score_rows: bad argument");
@@ -526,7 +526,7 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
     sf_set_error("sf_cnn_score_rows: workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     return -4;
   }
-  if (rescued) *rescued = 0;
+  if (info) info[0] = info[1] = 0;          // [0] batches scored again on the fp32 matrix cores, [1] batches that ran on the shared trunk
   Net N = make_net(blob, batch, workspace, stream, sharing ? H : 0, sharing ? W : 0, route == 0 ? 2 : 1);
   const long long i0 = (long long)r0 * W, i1 = (long long)r1 * W;
   if (i0 >= i1) return 0;
@@ -569,6 +569,7 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
         if (!(N.map_r0 >= 0 && N.map_r0 <= rf && rl < N.map_r1))
           if ((rc = build_maps(N, padded, H, W, rf, as))) return rc;
         if (N.map_ok) rt = 0;
+        if (N.map_ok && info) ++info[1];
       }
       if ((rc = run_batch(N, padded, plane, H, W, tile0, n, rt, as, N.flags + nb, nullptr, out))) return rc;
     }
@@ -580,7 +581,7 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
       const int n = (int)((i1 - t0 < batch) ? (i1 - t0) : batch);
       if ((rc = prepare_wino(N))) return rc;
       if ((rc = run_batch(N, padded, plane, H, W, t0, n, 4, nullptr, nullptr, nullptr, out))) return rc;
-      if (rescued) ++*rescued;
+      if (info) ++info[0];
     }
     group0 = tile0;
   }

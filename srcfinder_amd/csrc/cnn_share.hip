@@ -13,9 +13,8 @@
 //     sf_cnn_conv_ring  conv3 at the 496 ring positions, taps from the border tensor / the shared conv2 map (cnn_split.hip)
 //     k_pool_gather     maxpool2 (3x3 s2 ceil) reading ring positions from the ring tensor, the others from the shared conv3 map
 // and inception3a takes over -- or (the deeper form) the same idea carried on through inception3a, 3b and maxpool3 on 64 phase
-// maps of the 32 x 32 grid: frames (1, 2) -> (2, 3) -> (3, 4) (cnn_ring.h), and inception4a takes over.  Exact: the same kernels and the same summation order produce a map position and a window position
-// (conv1's 49-term sum differs in ORDER between the fused per-window kernel and the FCN kernel: float32 rounding, inside the
-// parity bar and independent of batch size and row sharding).
+// maps of the 32 x 32 grid: frames (1, 2) -> (2, 3) -> (3, 4) (cnn_ring.h), and inception4a takes over.  Exact: a map position and a window position are produced by the same summation order
+// (the saliency maps are bit-identical to every window evaluated on its own: tests/test_cnn_gpu.py, tools/fuzz_cnn.py).
 #include "cmf_common.h"
 #include "cnn_ring.h"
 

@@ -45,5 +45,26 @@ for (H, W) in [(1, 1), (2, 7), (5, 3)]:
     ok = np.array_equal(got == -9999, want == -9999) and np.allclose(got[want != -9999], want[want != -9999], rtol=2e-4, atol=1e-7)
     print("tiles %d x %d: %s (%.0f s)" % (H, W, "ok" if ok else "MISMATCH", time.time() - t0), flush=True)
     bad += 0 if ok else 1
+# round 6: the shared trunk (route "split": phase maps + per-window rings, csrc/cnn_share.hip) against every window on its own, on
+# random plane shapes (narrower / wider / taller than a window, sides at and around multiples of 4 and 8: every phase, map edges on
+# both sides), batch sizes that straddle image rows, and row ranges -- the same bits as the unshared route, whatever batch and rows
+for it in range(14):
+    H, W = int(rng.integers(1, 420)), int(rng.integers(1, 330))
+    if it == 0: H, W = 300, 8
+    if it == 1: H, W = 9, 600
+    batch = int(rng.choice([7, 33, 96, 256, 700]))
+    r0 = int(rng.integers(0, H)); r1 = min(H, r0 + int(rng.integers(1, 4)))
+    plane = synthetic_plane(H, W, seed=int(rng.integers(1 << 30)))
+    plane[int(rng.integers(H)), int(rng.integers(W))] = -9999.0
+    a = cnn.predict_flightline(plane, "COVID_QC", net=net, batch=batch, rows=(r0, r1), route="split")
+    b = cnn.predict_flightline(plane, "COVID_QC", net=net, batch=batch, rows=(r0, r1), route="split_unshared")
+    c = cnn.predict_flightline(plane, "COVID_QC", net=net, batch=max(1, batch // 2 + 1), rows=(r0, min(H, r1 + 1)), route="split")
+    sa, sb = a[r0:r1], b[r0:r1]
+    v = sb != -9999
+    rel = float(((sa[v] - sb[v]).abs() / sb[v].abs().clamp_min(1e-7)).max()) if bool(v.any()) else 0.0
+    ok = bool(torch.equal(sa, sb)) and bool(torch.equal(c[r0:r1], sa))      # bit-identical to every window on its own, and to itself
+    print("shared trunk %3d x %3d batch %3d rows %d..%d: %s (max rel %.1e; %.0f s)" % (H, W, batch, r0, r1, "ok" if ok else "MISMATCH", rel,
+                                                                                     time.time() - t0), flush=True)
+    bad += 0 if ok else 1
 print("fuzz cnn: %d mismatches" % bad)
 sys.exit(1 if bad else 0)

@@ -311,6 +311,21 @@ def test_shared_trunk_against_every_window_on_its_own(net):
             assert torch.equal(sa, sb), (rows, name, float(((sa[v] - sb[v]).abs() / sb[v].abs().clamp_min(1e-7)).max()))
 
 
+def test_shared_trunk_rebuilds_its_maps_across_strips_at_flightline_width(net):
+    """One call over more image rows than a set of phase maps serves (512 at flightline width): the driver rebuilds the maps when a
+    batch leaves the strip -- 540 rows x 598 columns = 323 k windows, batches that straddle image rows and the strip boundary.  The map
+    equals the unshared route's bit for bit, and every batch ran on the shared trunk."""
+    import torch
+    H, W, r0, r1, batch = 1100, 598, 500, 1040, 1000
+    plane = synthetic_plane(H, W, seed=23)
+    info = {}
+    a = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=batch, rows=(r0, r1), route="split", info=info)
+    b = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=batch, rows=(r0, r1), route="split_unshared")
+    assert info["shared_batches"] == -(-(r1 - r0) * W // batch) and info["rescued_batches"] == 0
+    assert torch.equal(a, b)
+    assert float(a[:r0].abs().sum()) == 0.0 and float(a[r1:].abs().sum()) == 0.0
+
+
 def _scaled_family(sd, k):
     """The weight family with every activation of the trunk multiplied by s = 2^k and the same logits: conv1's folded weight and
     every folded bias times s (ReLU and max pooling are positively homogeneous), fc.weight divided by s.  In state_dict terms:

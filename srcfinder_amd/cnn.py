@@ -28,11 +28,11 @@ MODEL_NORM = {
 }
 BN_EPS = 0.001          # googlenet1.py:270
 NODATA = -9999.0
-# the convolutions' arithmetic routes (all float32 in / float32 accumulate; include/srcfinder_amd.h: sf_cnn_score_rows)
-# "split": operand splitting on the fp16 matrix cores; through the C driver (sf_cnn_score_rows) with the trunk up to conv3 SHARED
-# between the overlapping windows (csrc/cnn_share.hip), sequenced from Python one batch at a time (forward_tiles) every window on
-# its own -- "split_unshared" names that form on both drivers (bit-identical between them)
-# ("split_conv3": the sharing stops behind conv3 -- round 6's first form; "split" carries it through inception3b)
+# The convolutions' arithmetic routes (all float32 in / float32 accumulate; include/srcfinder_amd.h: sf_cnn_score_rows).
+# "split": operand splitting on the fp16 matrix cores; through the C driver (sf_cnn_score_rows: whole image rows) with the trunk through
+# inception3b SHARED between the overlapping windows (csrc/cnn_share.hip); sequenced from Python one batch at a time (forward_tiles)
+# every window on its own -- "split_unshared" names that form on both drivers; "split_conv3": the sharing stops behind conv3 (round
+# 6's first form).  The three give the same bits.  "winograd" / "direct": the fp32 matrix cores (the split route's rescue path).
 ROUTES = {"split": 0, "split_conv3": 5, "split_unshared": 3, "winograd": 4, "direct": 2, "direct_pointer": 1}
 
 
@@ -540,13 +540,15 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
               of the 69 MB padded plane and scores a contiguous block of image rows from its own host thread; the
               blocks are copied to the first device once.  A negative index (the reference's CPU run) is refused.
     route   : the convolutions' arithmetic -- ``"split"`` (default: fp32 operands as fp16 hi + lo halves on the fp16 matrix cores,
-              the float32 tolerance class), ``"winograd"`` (fp32 matrix cores), ``"direct"``.  On the split route the per-layer
+              the float32 tolerance class; through the C driver the trunk through inception3b is shared between the overlapping
+              windows -- ``"split_conv3"`` / ``"split_unshared"``: less / none of that, the same bits), ``"winograd"`` (fp32
+              matrix cores), ``"direct"``.  On the split routes the per-layer
               activation scales are calibrated on this plane and a batch whose activations leave float16's range is scored again
               on the fp32 matrix cores inside the call (with a warning): route and overflow handling are per call, so concurrent
               threads / streams / GPUs cannot disturb each other.
     scales  : split route only: the per-layer activation scales (``sf_cnn_num_scales()`` powers of two) instead of the
               calibration on this plane (a campaign that wants ONE set of scales for all its flightlines; the tests)
-    info    : optional dict; receives ``rescued_batches``, ``route`` and the ``scales`` used
+    info    : optional dict; receives ``rescued_batches``, ``shared_batches``, ``route`` and the ``scales`` used
     """
     torch = _torch()
     if gpus is not None and len(gpus) > 0:

@@ -50,6 +50,10 @@ def main():
     ap.add_argument("--active", type=str, default="", help="a0,a1 (1-based inclusive) override of the active window, e.g. 1,425")
     ap.add_argument("--no-placement", action="store_true", help="skip the product-buffer placement pick of the setup phase")
     ap.add_argument("--knob", action="append", default=[], help="key=value for sf_debug_set (tuning / A-B runs; repeatable)")
+    ap.add_argument("--replicas", action="store_true",
+                    help="BASELINE config 5 instead of the sharded headline: every rank runs a WHOLE flightline (its own synthetic cube) "
+                         "through CMF + CNN end to end; no collective on the data path; per-GPU and aggregate throughput")
+    ap.add_argument("--strip-lines", type=int, default=2500, help="lines of the CMF plane the tile scorer measures (e2e / --replicas)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="flightlines in flight per GPU (srcfinder_amd.inflight); 0 = the default, 3 for every N")
     args = ap.parse_args()
@@ -95,6 +99,8 @@ def main():
 
     lib = np.load(os.path.join(ROOT, "tests", "golden", "ch4_library.npz"))["library"]
     lines, samples = args.lines, args.samples
+    if args.replicas:
+        return replicas_main(args, lib, rank, world, dev, backend, share_gpu, force_dist)
     s0, s1 = sd.shard_columns(samples, world, rank)
     ncols = s1 - s0
     a0, a1 = cmf.active_window("ch4", False)
@@ -306,6 +312,65 @@ def main():
         print(json.dumps(line), flush=True)      # the last line of the job's output
 
 
+def replicas_main(args, lib, rank, world, dev, backend, share_gpu, force_dist):
+    """BASELINE config 5: a batch of flightlines, one per GPU -- every rank takes a whole flightline (its own synthetic cube) through
+    the CMF (K steps, three in flight, as the headline) and the tile scorer (a measured strip of --strip-lines full-width lines of
+    its CMF plane, scaled to the flightline) and reports cube -> saliency map seconds.  Replicas only: no collective on the data
+    path; the ranks' figures meet in one all_gather AFTER the timed regions.  value = the aggregate Mpixel/s of the
+    flightlines in flight on the node; scaling "weak" (per-GPU work is fixed as N grows)."""
+    import torch
+    import torch.distributed as dist
+    from srcfinder_amd import cmf
+    from srcfinder_amd.inflight import FlightlinePipeline
+    from srcfinder_amd.synth import make_cube_torch
+    lines, samples = args.lines, args.samples
+    cube = make_cube_torch(lines, samples, seed=1234 + rank, abscf_full=lib[:, 2], device=dev, nodata_column=samples // 3)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    depth = args.in_flight if args.in_flight > 0 else 3
+    outs = [torch.empty((lines, samples, 4), dtype=torch.float64, device=dev) for _ in range(depth)]
+    with FlightlinePipeline(depth, dev) as pipe:
+        for i in range(depth + args.warmup):
+            pipe.submit(cube, lib, out=outs[i % depth], out_column0=0)
+        pipe.synchronize()
+        if world > 1 or force_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            pipe.submit(cube, lib, out=outs[i % depth], out_column0=0)
+        pipe.synchronize()
+        cmf_s = (time.perf_counter() - t0) / args.steps
+    del outs
+    sec = e2e_section(cube, lib, cmf_s, None, strip_lines=min(args.strip_lines, lines), with_fcn=False)
+    mine = torch.tensor([sec["seconds"], cmf_s, sec["strip"]["windows_per_s"]], dtype=torch.float64,
+                        device=dev if backend == "nccl" else "cpu")
+    every = [torch.empty_like(mine) for _ in range(world)]
+    if world > 1 or force_dist:
+        dist.all_gather(every, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        every = [mine]
+    flush_c_stdio()
+    if rank == 0:
+        per = [{"rank": r, "seconds_per_flightline": round(float(e[0]), 2), "cmf_ms": round(float(e[1]) * 1e3, 3),
+                "cnn_windows_per_s": round(float(e[2]), 1), "value": round(lines * samples / float(e[0]) / 1e6, 4)} for r, e in enumerate(every)]
+        slow = max(p["seconds_per_flightline"] for p in per)
+        line = {"metric": "CMF + CNN saliency map end to end, one flightline per GPU (BASELINE config 5)",
+                "value": round(sum(p["value"] for p in per), 4), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(slow * 1e3, 1), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64 (CMF) + f32 (CNN, split-operand route)", "data": "synthetic",
+                "config": {"workload": "%d flightline(s) of %d samples x %d lines x %d bands, one per GPU: CMF (CH4 window, 201-point "
+                                       "sweep) -> per-pixel 256 x 256 GoogLeNet tile scorer" % (world, samples, lines, BANDS),
+                           "parallelism": ("replicas only: no collective on the data path" if not share_gpu else
+                                           "FUNCTIONAL RUN: %d replicas sharing ONE GPU -- not a scaling measurement" % world),
+                           "cnn_measured_on": "%d full-width lines of each rank's CMF plane, scaled to the flightline" % min(args.strip_lines, lines),
+                           "ms_per_step_is": "seconds per flightline of the slowest replica, in ms"},
+                "per_gpu": per}
+        print(json.dumps(line), flush=True)
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` (N > 1) with no launcher around it: run `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` as a child process and relay
@@ -445,7 +510,7 @@ def wide_section(cube, lib, steps=2, with_cpu=True):
     return sec
 
 
-def e2e_section(cube, lib, cmf_seconds, cnn, strip_lines=2500):
+def e2e_section(cube, lib, cmf_seconds, cnn, strip_lines=2500, with_fcn=True):
     """BASELINE config 4 (cube -> CMF -> CNN saliency map) on the benchmark flightline.  `value` is the PARITY path
     (cnn/cnn_pred_pipeline.py:159-181: one 256 x 256 window per pixel), measured: the CMF step as timed above plus the tile
     scorer over a strip of `strip_lines` full-width lines of this flightline's CMF plane -- 2500 lines = 1 495 000 windows,
@@ -474,7 +539,7 @@ def e2e_section(cube, lib, cmf_seconds, cnn, strip_lines=2500):
         # one overflow slot per batch, read once at the end; raised batches are scored again on the fp32 matrix cores
         return C.score_tiles(net, ds, t_first, t_first + n_strip, batch, sal, route="split")
 
-    C.score_tiles(net, ds, t_first, t_first + 4 * batch, batch, sal, route="split")   # buffers, code objects (not the strip: ~50 s)
+    C.score_tiles(net, ds, t_first, t_first + min(strip_lines, 8) * ncols, batch, sal, route="split")   # buffers, code objects, maps (not the strip)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rescued = run_strip()
@@ -484,14 +549,17 @@ def e2e_section(cube, lib, cmf_seconds, cnn, strip_lines=2500):
     t_tiles = lines * ncols / tiles_per_s
     del ds, sal
     # ---- the approximate fast mode over the whole plane
-    C.fcn_predict_flightline(plane[:512].contiguous(), net=net)                  # buffers, code objects
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    fsal = C.fcn_predict_flightline(plane, net=net)
-    torch.cuda.synchronize()
-    t_fcn = time.perf_counter() - t0
-    valid = float((fsal != -9999).float().mean().item())
-    del fsal, plane, res, net
+    t_fcn, valid = 0.0, 0.0
+    if with_fcn:
+        C.fcn_predict_flightline(plane[:512].contiguous(), net=net)              # buffers, code objects
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fsal = C.fcn_predict_flightline(plane, net=net)
+        torch.cuda.synchronize()
+        t_fcn = time.perf_counter() - t0
+        valid = float((fsal != -9999).float().mean().item())
+        del fsal
+    del plane, res, net
     cmf._Workspace._bufs.clear()
     torch.cuda.empty_cache()
     tot = cmf_seconds + t_tiles

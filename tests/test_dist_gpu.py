@@ -94,3 +94,19 @@ def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
     line = json.loads(last)
     assert line["n_gpus"] == 2 and line["config"]["gather_verified"] is True
     assert line["value"] > 0 and line["scaling"] == "strong"
+
+
+def test_bench_replicas_mode_one_flightline_per_rank():
+    """BASELINE config 5 (`bench.py --gpus 2 --replicas`): every rank takes a whole flightline through CMF + CNN, no collective on the
+    data path; rank 0 prints per-GPU and aggregate figures.  Two replicas share the one GPU here (functional run)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SF_BENCH_SHARE_GPU="1", SF_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--replicas", "--steps", "2", "--warmup", "1", "--lines", "600",
+           "--samples", "40", "--strip-lines", "6"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and len(line["per_gpu"]) == 2
+    assert abs(line["value"] - sum(p["value"] for p in line["per_gpu"])) < 1e-3 and all(p["cnn_windows_per_s"] > 0 for p in line["per_gpu"])

@@ -152,16 +152,16 @@ __device__ __forceinline__ void xt_lds_barrier() { asm volatile("s_waitcnt lgkmc
 
 // (152 VGPRs: three workgroups per CU; forcing four -- 128 VGPRs -- spills and is slower: 1.96 against 1.43 ms)
 // (at least two waves per SIMD for the kernel below: left alone the CO2 instantiation took 270 registers and one workgroup per CU)
-template <int TL, int P, bool NTS>
+template <int TL, int P, bool NTS, int NW = 4>      // NW: waves per workgroup (rows of the tile are dealt wave, wave + NW, ...)
 __device__ __forceinline__ void extract_pipe_body(const float *__restrict__ cube, int L, int B, int C, int s0,
                                                   int Cs, int b0, int PS, float *__restrict__ xt,
                                                   uint8_t *__restrict__ mask_t, int lines_per_wg, int cs, int ncb,
                                                   int nchunk, double *__restrict__ sum_part, int *__restrict__ cnt_part) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
-  __shared__ uint8_t vf[64][4];
-  constexpr int NSUM = (P + 3) / 4;
-  constexpr int NLD = (TL * P + 3) / 4;                    // rows per wave per tile: row = wave + 4 u (the last u may be short)
-  constexpr bool EVEN = (TL * P) % 4 == 0;
+  __shared__ uint8_t vf[64][NW > TL ? NW : TL];
+  constexpr int NSUM = (P + NW - 1) / NW;
+  constexpr int NLD = (TL * P + NW - 1) / NW;              // rows per wave per tile: row = wave + NW u (the last u may be short)
+  constexpr bool EVEN = (TL * P) % NW == 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int cbi, chunk;
   if (!sf_xcd_map(blockIdx.x, ncb, nchunk, cbi, chunk)) return;
@@ -185,16 +185,16 @@ __device__ __forceinline__ void extract_pipe_body(const float *__restrict__ cube
       const float *pp = cbase + ((size_t)min(l0, lend - 1) * B + wave) * C + lanec;
 #pragma unroll
       for (int u = 0; u < NLD; ++u) {
-        if (!EVEN && u == NLD - 1) pp -= (size_t)max(wave + 4 * u - (P - 1), 0) * C;   // (a short last round re-reads the last row)
+        if (!EVEN && u == NLD - 1) pp -= (size_t)max(wave + NW * u - (P - 1), 0) * C;   // (a short last round re-reads the last row)
         v[u] = *pp;
-        pp += 4 * (size_t)C;
+        pp += NW * (size_t)C;
         asm volatile("" : "+v"(pp));
       }
       return;
     }
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-      const int rr = EVEN ? wave + 4 * u : min(wave + 4 * u, TL * P - 1);   // (a short last round re-reads the last row)
+      const int rr = EVEN ? wave + NW * u : min(wave + NW * u, TL * P - 1);   // (a short last round re-reads the last row)
       const int l = rr / P, b = rr - l * P;                // wave-uniform
       const int line = min(l0 + l, lend - 1);
       v[u] = (cbase + ((size_t)line * B + b) * C)[lanec];
@@ -206,7 +206,7 @@ __device__ __forceinline__ void extract_pipe_body(const float *__restrict__ cube
     const int nl = FULL ? TL : min(TL, lend - l0);
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-      const int rr = wave + 4 * u;
+      const int rr = wave + NW * u;
       if ((FULL && (EVEN || rr < TL * P)) || rr < nl * P) tile[lane * cs + rr] = v[u];
     }
     xt_lds_barrier();
@@ -218,12 +218,14 @@ __device__ __forceinline__ void extract_pipe_body(const float *__restrict__ cube
       const float *tp = tile + lane * cs;
 #pragma unroll 8
       for (int i = 0; i < NSUM; ++i) {
-        const int b = wave + 4 * i;
+        const int b = wave + NW * i;
         if (b < P) ok = ok & sf_valid(tp[b]);
       }
       vf[lane][wave] = ok ? 1 : 0;
       xt_lds_barrier();
-      const bool all = vf[lane][0] & vf[lane][1] & vf[lane][2] & vf[lane][3];
+      bool all = true;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) all = all & (vf[lane][w] != 0);
       xt_lds_barrier();                                   // everybody has read the partial verdicts
       if (wave == 0) vf[lane][0] = all ? 1 : 0;
     } else if (FULL || wave < nl) {
@@ -239,7 +241,7 @@ __device__ __forceinline__ void extract_pipe_body(const float *__restrict__ cube
     if (P == PS) {
       const int nel = nl * P;
       constexpr int NST = (TL * P + 63) / 64;
-      for (int c = wave; c < ncol; c += 4) {
+      for (int c = wave; c < ncol; c += NW) {
         float *dst = xt + ((size_t)(colbase + c) * L + l0) * PS;
         const float *src = tile + c * cs;
         float r[NST];
@@ -258,7 +260,7 @@ __device__ __forceinline__ void extract_pipe_body(const float *__restrict__ cube
       constexpr int PSC = (P + 3) / 4 * 4;
       const int nel = nl * PSC;
       constexpr int NST = (TL * PSC + 63) / 64;
-      for (int c = wave; c < ncol; c += 4) {
+      for (int c = wave; c < ncol; c += NW) {
         float *dst = xt + ((size_t)(colbase + c) * L + l0) * PSC;
         const float *src = tile + c * cs;
         float r[NST];
@@ -286,7 +288,7 @@ __device__ __forceinline__ void extract_pipe_body(const float *__restrict__ cube
       const float *tp = tile + lane * cs;
 #pragma unroll
       for (int i = 0; i < NSUM; ++i) {
-        const int b = wave + 4 * i;
+        const int b = wave + NW * i;
         if (b < P) {
 #pragma unroll
           for (int l = 0; l < TL; ++l)
@@ -312,7 +314,7 @@ __device__ __forceinline__ void extract_pipe_body(const float *__restrict__ cube
     double *o = sum_part + ((size_t)chunk * Cs + colbase + lane) * PS;
 #pragma unroll
     for (int i = 0; i < NSUM; ++i) {
-      const int b = wave + 4 * i;
+      const int b = wave + NW * i;
       if (b < P) o[b] = sums[i];
     }
     if (wave == 0) {
@@ -337,6 +339,15 @@ void k_extract_wide(const float *__restrict__ cube, int L, int B, int C, int s0,
                     uint8_t *__restrict__ mask_t, int lines_per_wg, int cs, int ncb, int nchunk, double *__restrict__ sum_part,
                     int *__restrict__ cnt_part) {
   extract_pipe_body<1, P, true>(cube, L, B, C, s0, Cs, b0, PS, xt, mask_t, lines_per_wg, cs, ncb, nchunk, sum_part, cnt_part);
+}
+
+// the same with EIGHT waves (two per SIMD, half the rows and half the sums each: round 6; the default)
+template <int P>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_extract_wide8(const float *__restrict__ cube, int L, int B, int C, int s0, int Cs, int b0, int PS, float *__restrict__ xt,
+                     uint8_t *__restrict__ mask_t, int lines_per_wg, int cs, int ncb, int nchunk, double *__restrict__ sum_part,
+                     int *__restrict__ cnt_part) {
+  extract_pipe_body<1, P, true, 8>(cube, L, B, C, s0, Cs, b0, PS, xt, mask_t, lines_per_wg, cs, ncb, nchunk, sum_part, cnt_part);
 }
 
 // Masked column sums over a chunk of lines.  One workgroup = (column, line chunk); thread (sub, q4)
@@ -602,22 +613,28 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
       hipLaunchKernelGGL((k_extract_pipe<4, 72>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), ldsx, st, cube, lines, bands, samples,
                          s0, ncols, b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);
     }
-  } else if (fuse && sf_tune().extract_variant == 0 && (p == 425 || p == 416)) {
+  } else if (fuse && (sf_tune().extract_variant == 0 || sf_tune().extract_variant == 9) && (p == 425 || p == 416)) {
     // the full-band window of the benchmark (1..425) and the reference's -R window (5..420: robust_mf.py:186-187): ONE line per
     // tile (64 columns x p bands = 109 KB of LDS, one workgroup per CU with the whole register file: 107 row loads in flight
     // and 107 float64 column sums per lane), the column sums fused as on the narrow windows -- round 4 ran the blocked kernel
     // (2.7 TB/s) and re-read the 20.5 GB of xt for the sums (k_colsum)
     const int csx = p | 1;
     const size_t ldsx = (size_t)64 * csx * sizeof(float);
+    // round 6: EIGHT waves (two per SIMD, half the rows and half the float64 sums each: 196 registers) -- 14.6 -> ~10 ms a
+    // flightline at p = 425 (the full-band step 274.4 -> 270.1 ms), the same bits; sf_debug_set(6, 9): the four-wave form
+    const bool w4 = sf_tune().extract_variant == 9;
+#define SF_WIDE_GO(K)                                                                                                             \
+  {                                                                                                                               \
+    if (int rc = sf_lds_attr(reinterpret_cast<const void *>(K), ldsx)) return rc;                                                 \
+    hipLaunchKernelGGL((K), dim3(sf_xcd_grid(ncb, nchunk)), dim3(w4 ? 256 : 512), ldsx, st, cube, lines, bands, samples, s0, ncols, \
+                       b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);                                            \
+  }
     if (p == 425) {
-      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_wide<425>), ldsx)) return rc;
-      hipLaunchKernelGGL((k_extract_wide<425>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), ldsx, st, cube, lines, bands,
-                         samples, s0, ncols, b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);
+      if (w4) SF_WIDE_GO(k_extract_wide<425>) else SF_WIDE_GO(k_extract_wide8<425>)
     } else {
-      if (int rc = sf_lds_attr(reinterpret_cast<const void *>(k_extract_wide<416>), ldsx)) return rc;
-      hipLaunchKernelGGL((k_extract_wide<416>), dim3(sf_xcd_grid(ncb, nchunk)), dim3(256), ldsx, st, cube, lines, bands,
-                         samples, s0, ncols, b0, PS, xt, mask_t, lpw, csx, ncb, nchunk, sum_part, cnt_part);
+      if (w4) SF_WIDE_GO(k_extract_wide<416>) else SF_WIDE_GO(k_extract_wide8<416>)
     }
+#undef SF_WIDE_GO
   } else if (fuse && sf_tune().extract_variant == 0 && p == 83) {
     // the CO2 window (robust_mf.py:190-191): the same kernel, three lines per tile (64 KB of LDS: two workgroups per CU;
     // four lines would be 85 KB and one), rows padded to 84 floats, non-temporal stores
@@ -646,7 +663,9 @@ size_t sf_extract_sum_bytes(const SfGeom &g) {
   const int nchunk = extract_chunks(g.lines, g.ncols, &lpw);
   return sf_align((size_t)nchunk * g.ncols * g.ps * sizeof(double)) + sf_align((size_t)nchunk * g.ncols * sizeof(int));
 }
-bool sf_extract_fuses_sum(int p) { return p <= XT_PBMAX || ((p == 425 || p == 416) && sf_tune().extract_variant == 0); }
+bool sf_extract_fuses_sum(int p) {
+  return p <= XT_PBMAX || ((p == 425 || p == 416) && (sf_tune().extract_variant == 0 || sf_tune().extract_variant == 9));
+}
 
 int sf_launch_extract_fused(const float *cube, int lines, int bands, int samples, int s0, int b0, const SfGeom &g,
                             float *xt, uint8_t *mask_t, void *scratch, hipStream_t st) {

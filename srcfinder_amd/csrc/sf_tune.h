@@ -10,7 +10,7 @@ struct SfTune {
   int score_xcd = 1;          // key 3: XCD-aware block map of the column-block score kernel
   int sweep_variant = 0;      // key 4: 1 = force the 16x16x4 sweep, 2 = full-rank 4x4x4 sweep only
   int cov_variant = 0;        // key 5: 1 = force the 16x16x4 covariance, 3 = two waves per SIMD
-  int extract_variant = 0;    // key 6: 1 = never the flat (narrow-cube) kernel, 2 = the unpipelined blocked kernel, 3 / 5 = 3- / 2-line tiles in the pipelined kernel (default 4)
+  int extract_variant = 0;    // key 6: 1 = never the flat (narrow-cube) kernel, 2 = the unpipelined blocked kernel, 3 / 5 = 3- / 2-line tiles in the pipelined kernel (default 4), 9 = the four-wave form of the wide-window kernel (default: eight waves)
   int sweep_grid = 0;         // key 21: k_sweep4s workgroup order: 0 = the splits of a column adjacent (default), 1 = columns fastest (round 2's order)
   int extract_nt = 0;         // key 19: 1 = plain (not non-temporal) xt stores in the pipelined extract kernel
   int eigh_lpp = 0;           // key 7: lanes per column pair of the Jacobi eigensolver (4 / 8 / 16); 2 = the sweeps behind the tridiagonal preconditioner of cmf_eigh_pre.h (8 lanes)

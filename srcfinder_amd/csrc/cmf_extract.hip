@@ -152,7 +152,10 @@ __device__ __forceinline__ void xt_lds_barrier() { asm volatile("s_waitcnt lgkmc
 
 // (152 VGPRs: three workgroups per CU; forcing four -- 128 VGPRs -- spills and is slower: 1.96 against 1.43 ms)
 // (at least two waves per SIMD for the kernel below: left alone the CO2 instantiation took 270 registers and one workgroup per CU)
-template <int TL, int P, bool NTS, int NW = 4>      // NW: waves per workgroup (rows of the tile are dealt wave, wave + NW, ...)
+// NW: waves per workgroup (rows of the tile are dealt wave, wave + NW, ...).  Eight waves pay on the wide windows' one-line tile (one
+// workgroup per CU: 14.6 -> 9.5 ms); on the CH4 window's four-line tile (two workgroups of four waves per CU already) two workgroups
+// of eight measured the same step (9.00-9.11 against 9.03-9.05 ms) and were not kept.
+template <int TL, int P, bool NTS, int NW = 4>
 __device__ __forceinline__ void extract_pipe_body(const float *__restrict__ cube, int L, int B, int C, int s0,
                                                   int Cs, int b0, int PS, float *__restrict__ xt,
                                                   uint8_t *__restrict__ mask_t, int lines_per_wg, int cs, int ncb,

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restri
   constexpr int WN = (BN >= 128) ? 2 : 1, WM = 4 / WN, TM = BM / (32 * WM), TN = BN / (32 * WN), NPB = BN / 64;
   constexpr int RMAX = BM + 2 * 32;                         // raw pixels at W = 32
   constexpr int NRAW = (RMAX * KQ + 255) / 256, NPOOL = BM * KQ / 256;
-  __shared__ __attribute__((aligned(16))) float raw[RMAX * BK];
+  __shared__ __attribute__((aligned(16))) float raw[RMAX * BK + BK];      // (+ a pixel of zeros: where a masked tap reads)
   __shared__ __attribute__((aligned(16))) _Float16 sm[(2 * BM + 2 * BN) * SP_LD];
   _Float16 *Ah = sm, *Al = Ah + BM * SP_LD, *Bh = Al + BM * SP_LD, *Bl = Bh + BN * SP_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -371,7 +371,9 @@ __global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restri
   }
   const int pq = tid % KQ, pblk = tid / KQ;                 // pooled items: quad pq of pixel 32 a + permuted block (k_poolconv's bank order)
   int ppx[NPOOL];
-  unsigned pmask[NPOOL];
+  int ptap[NPOOL][9];          // quad index of every tap of every pooled item in `raw` (the zero pixel for a tap outside the image):
+                               // unconditional LDS reads -- a predicated read compiles to a branch and a wait per tap (193 branches
+                               // and 87 full LDS waits per chunk loop: 3.7 us per chunk; round 6)
 #pragma unroll
   for (int a = 0; a < NPOOL; ++a) {
     const int b8 = pblk & 7;
@@ -382,13 +384,14 @@ __global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restri
     const bool ok = m < M;
     const int mm = ok ? m : 0;
     const int x = mm % W, y = (mm / W) % H;
-    unsigned vm = 0;
+#pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
       const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-      if (ok && yy >= 0 && yy < H && xx >= 0 && xx < W) vm |= 1u << tp;
+      const bool in = ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      ptap[a][tp] = in ? (px + W + (tp / 3 - 1) * W + (tp % 3 - 1)) * KQ + pq : RMAX * KQ + pq;      // (in 16-byte quads)
     }
-    pmask[a] = vm;
   }
+  if (tid < BK / 4) *reinterpret_cast<sp_f4 *>(raw + RMAX * BK + 4 * tid) = sp_f4{0.f, 0.f, 0.f, 0.f};
   sp_f16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -423,15 +426,11 @@ __global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restri
   auto pool = [&]() {             // A tiles = hi / lo halves of the max over the 3 x 3 neighbourhood
 #pragma unroll
     for (int a = 0; a < NPOOL; ++a) {
-      const float *c = raw + ((ppx[a] + W) * KQ + pq) * 4;
-      sp_f4 mx = {0.f, 0.f, 0.f, 0.f};
+      sp_f4 mx = {0.f, 0.f, 0.f, 0.f};      // (0 is the identity: the activations are ReLU outputs)
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp) {
-        const int d = ((tp / 3 - 1) * W + (tp % 3 - 1)) * KQ * 4;
-        if ((pmask[a] >> tp) & 1u) {     // (a masked tap is never read; 0 is the identity: the activations are ReLU outputs)
-          const sp_f4 v = *reinterpret_cast<const sp_f4 *>(c + d);
-          mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
-        }
+        const sp_f4 v = reinterpret_cast<const sp_f4 *>(raw)[ptap[a][tp]];
+        mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
       }
       const float v4[4] = {mx.x * ascale, mx.y * ascale, mx.z * ascale, mx.w * ascale};
       _Float16 h4[4], l4[4];

@@ -84,11 +84,12 @@ __global__ __launch_bounds__(256) void k_ring_pool1(const float *__restrict__ pa
 // (One thread per (position, four channels), every thread classifying its own taps.  The other shape -- one WAVE per position with
 //  scalar tap classification, lanes over the channels -- was measured: 0.79 ms of pools per batch against 0.61; loads in flight win.)
 __global__ __launch_bounds__(256) void k_pool_gather(const float *__restrict__ maps, SfGather gi, int C, int stride, int pad, int Go, int olo,
-                                                      int ohi, int npos, int N, float *__restrict__ out) {
+                                                      int ohi, int npos, int N, unsigned bytes, float *__restrict__ out) {
   const int c4n = C >> 2;
   const size_t total = (size_t)N * npos * c4n;
   const int nin = sf_frame_count(gi.G, gi.lo, gi.hi);
   const int pm = (1 << gi.shift) - 1;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(maps), 0, bytes, 0x00020000);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c4 = (int)(i % c4n);
     const size_t rest = i / c4n;
@@ -99,22 +100,30 @@ __global__ __launch_bounds__(256) void k_pool_gather(const float *__restrict__ m
     const long long t = gi.tile0 + n;
     const int r = (int)(t / gi.W), c = (int)(t - (long long)r * gi.W);
     const int ph = ((r & pm) << gi.shift) + (c & pm);
-    const float *mp = maps + (((size_t)ph * gi.Hq + ((r >> gi.shift) - gi.Rb)) * gi.Wq + (c >> gi.shift)) * C;   // the window's origin in its map
-    const float *rg = maps + gi.ring_off + (size_t)n * nin * C;
-    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    // nine unconditional 16-byte buffer loads (a tap outside the grid reads out of range -> 0): a load inside a branch is waited for
+    // before the next tap is classified, nine round trips in a row (round 6: 0.60 -> 0.4x ms of pools per batch)
+    const unsigned mp = (unsigned)(((((size_t)ph * gi.Hq + ((r >> gi.shift) - gi.Rb)) * gi.Wq + (c >> gi.shift)) * C + 4 * c4) * 4);   // the window's origin in its map
+    const unsigned rg = (unsigned)(((size_t)gi.ring_off + (size_t)n * nin * C + 4 * c4) * 4);
+    typedef float pg_f4 __attribute__((ext_vector_type(4)));
+    typedef unsigned pg_u4 __attribute__((ext_vector_type(4)));
+    pg_u4 v[9];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int y = oy * stride - pad + dy;
-      if ((unsigned)y >= (unsigned)gi.G) continue;
+    for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
-        const int x = ox * stride - pad + dx;
-        if ((unsigned)x >= (unsigned)gi.G) continue;
-        const float *src = sf_frame_ring(gi.G, gi.lo, gi.hi, y, x) ? rg + (size_t)sf_frame_index(gi.G, gi.lo, gi.hi, y, x) * C
-                                                                   : mp + ((size_t)y * gi.Wq + x) * C;
-        const float4 v = *reinterpret_cast<const float4 *>(src + 4 * c4);
-        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        const int y = oy * stride - pad + dy, x = ox * stride - pad + dx;
+        const bool in = (unsigned)y < (unsigned)gi.G && (unsigned)x < (unsigned)gi.G;
+        const unsigned o_ring = rg + (unsigned)(sf_frame_index(gi.G, gi.lo, gi.hi, y, x) * C * 4);
+        const unsigned o_map = mp + (unsigned)((y * gi.Wq + x) * C * 4);
+        const unsigned off = in ? (sf_frame_ring(gi.G, gi.lo, gi.hi, y, x) ? o_ring : o_map) : 0x80000000u;
+        v[3 * dy + dx] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
       }
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      union { pg_u4 u; pg_f4 f; } cv;
+      cv.u = v[k];
+      m.x = fmaxf(m.x, cv.f.x); m.y = fmaxf(m.y, cv.f.y); m.z = fmaxf(m.z, cv.f.z); m.w = fmaxf(m.w, cv.f.w);
     }
     *reinterpret_cast<float4 *>(out + (rest * c4n + c4) * 4) = m;
   }
@@ -154,12 +163,14 @@ int sf_cnn_pool_gather(const float *maps, long long tile0, int N, int W, int Rb,
     sf_set_error("sf_cnn_pool_gather: bad argument");
     return -1;
   }
+  const size_t bytes = (ring_off + (size_t)(N + 1) * sf_frame_count(G, ilo, ihi) * C) * 4;      // maps + the batch's ring tensor: one descriptor
+  if (bytes >= 0x7ff00000u) { sf_set_error("sf_cnn_pool_gather: maps + ring tensor of 2 GB or more"); return -2; }
   const SfGather gi{tile0, W, Rb, Hq, Wq, shift, G, ilo, ihi, (unsigned)ring_off};
   const int npos = olo < 0 ? Go * Go : sf_frame_count(Go, olo, ohi);
   const size_t total = (size_t)N * npos * (C >> 2);
   const unsigned blocks = (unsigned)((total + 255) / 256 < 65536 * 8 ? (total + 255) / 256 : 65536 * 8);
   hipLaunchKernelGGL(k_pool_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, maps, gi, C, stride, stride == 1 ? 1 : 0, Go, olo, ohi,
-                     npos, N, out);
+                     npos, N, (unsigned)bytes, out);
   SF_LAUNCH_CHECK("k_pool_gather");
   return 0;
 }

@@ -772,7 +772,16 @@ __global__ __launch_bounds__(256) void k_head(const float *__restrict__ in, int 
   const float inv = 1.0f / (float)HW;
   for (int c = tid; c < C; c += 256) {
     float s = 0.f;
-    for (int p = 0; p < HW; ++p) s += in[((size_t)t * HW + p) * C + c];
+    const float *col = in + (size_t)t * HW * C + c;
+    int p = 0;
+    for (; p + 16 <= HW; p += 16) {       // sixteen loads in flight, summed in position order (the order of the plain loop)
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = col[(size_t)(p + k) * C];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += v[k];
+    }
+    for (; p < HW; ++p) s += col[(size_t)p * C];
     const float a = s * inv;
     d0 = fmaf(a, fcw[c], d0);
     d1 = fmaf(a, fcw[C + c], d1);

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_phase_canvas(const float *__restrict__ 
 __global__ __launch_bounds__(256) void k_ring_pool1(const float *__restrict__ padded, int Wp, int Wimg, long long tile0, int ntiles,
                                                      const float *__restrict__ w /*[64][49]*/, const float *__restrict__ bias,
                                                      float *__restrict__ out /*[ntiles][252][64]*/) {
-  __shared__ float patch[4][11 * 11 + 7];
+  __shared__ __attribute__((aligned(16))) float patch[4][11 * 12];      // rows of 12: whole rows leave LDS as three 16-byte reads
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float wr[49];
 #pragma unroll
@@ -53,12 +53,21 @@ __global__ __launch_bounds__(256) void k_ring_pool1(const float *__restrict__ pa
     const int r = (int)(t / Wimg), c = (int)(t - (long long)r * Wimg);
     const float *win = padded + (size_t)r * Wp + c;               // window pixel (wy, wx) = win[wy * Wp + wx]
     const int wy0 = 4 * py - 3, wx0 = 4 * px - 3;                 // the patch's origin in the window
-    for (int i = lane; i < 121; i += 64) {
-      const int wy = wy0 + i / 11, wx = wx0 + i % 11;
-      pw[i] = ((unsigned)wy < 256u && (unsigned)wx < 256u) ? win[(size_t)wy * Wp + wx] : 0.f;
+    for (int i = lane; i < 132; i += 64) {
+      const int wy = wy0 + i / 12, wx = wx0 + i % 12;
+      pw[i] = ((unsigned)wy < 256u && (unsigned)wx < 256u && i % 12 < 11) ? win[(size_t)wy * Wp + wx] : 0.f;
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the whole patch into registers (33 broadcast reads of 16 bytes) instead of one 4-byte LDS read per multiply: 185 -> 1xx us
+    float pr[11][12];
+#pragma unroll
+    for (int y = 0; y < 11; ++y)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(pw + 12 * y + 4 * q);
+        pr[y][4 * q] = v.x; pr[y][4 * q + 1] = v.y; pr[y][4 * q + 2] = v.z; pr[y][4 * q + 3] = v.w;
+      }
     float best = 0.f;                                             // ReLU outputs: 0 is the identity of the max
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(256) void k_ring_pool1(const float *__restrict__ pa
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
-          for (int kx = 0; kx < 7; ++kx) acc = fmaf(pw[(2 * dy + ky) * 11 + 2 * dx + kx], wr[ky * 7 + kx], acc);
+          for (int kx = 0; kx < 7; ++kx) acc = fmaf(pr[2 * dy + ky][2 * dx + kx], wr[ky * 7 + kx], acc);
         best = fmaxf(best, fmaxf(acc + bb, 0.f));
       }
     out[(size_t)item * 64 + lane] = best;

@@ -75,11 +75,11 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
                                                     const float *__restrict__ wscale, const float *__restrict__ bias, int Cout,
                                                     int ks, float ascale, ConvDstS dst, int *__restrict__ overflow, RingArgs ring) {
   constexpr int BM = BMT, BK = 32, NPA = BM / 64;
-  constexpr int WN = (BN >= 128) ? 2 : 1;          // waves along N: 2 x 2 waves of 64 x BN/2, or 4 x 1 waves of 32 x 64
+  constexpr int WN = (BN >= 128 && BN != 160) ? 2 : 1;   // waves along N: 2 x 2 waves of 64 x BN/2, or 4 x 1 waves of 32 x 64 (32 x 160 at BN = 160)
   constexpr int WM = 4 / WN;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int NPB = (BN + 63) / 64;            // weight-tile passes of 64 rows (the last one partly used at BN = 96)
-  static_assert(BN == 64 || BN == 96 || BN == 128 || BN == 192 || BN == 256, "channel tile");
+  static_assert(BN == 64 || BN == 96 || BN == 128 || BN == 160 || BN == 192 || BN == 256, "channel tile");
   constexpr int NSET = 1;
   constexpr int SETH = (2 * BM + 2 * BN) * SP_LD;     // halves per set: A hi | A lo | B hi | B lo
   __shared__ __attribute__((aligned(16))) _Float16 sm[NSET * SETH];
@@ -567,6 +567,19 @@ static int split_go(const float *in, int in_split, int N, int H, int W, int Cin,
   // windows/s against 43.2-43.7 k in alternating runs; 192 / 256-channel tiles need 228 / 270 registers, run two / one workgroup
   // per CU instead of three and were slower still: what hides this kernel's trips to L2 is occupancy; 96-channel tiles of 256
   // pixels for 96 / 192 / 288 channels -- 236 registers, two workgroups per CU -- were the same within the noise.)
+  // 160-channel tiles of 128 pixels (round 6; 4 x 1 waves of 32 x 160): at equal padding they run at the speed of the others when the
+  // launch fills many rounds of the 256 CUs (A/B on inception4a-4e: 181 vs 181 us for the stacked 1 x 1, the 3 x 3 layers 5 % slower),
+  // so they are taken only where they balance the launch better -- the per-CU load ceil(workgroups / 256) x tile area:
+  // inception5a's 3 x 3 124 -> 107 us, 5b's stacked 1 x 1 142 -> 137 (profiles/r06_conv_bound.md)
+  {
+    const bool wide = Cout > 64 && sf_cdiv(Cout, 128) * 128 <= sf_cdiv(Cout, 64) * 64;
+    const long long bm = wide ? 128 : 256, bn = wide ? 128 : 64;
+    auto cd = [](long long a, long long b) { return (a + b - 1) / b; };
+    const long long load_now = cd(cd(Ml, bm) * cd(Cout, bn), 256) * bm * bn;
+    const long long load_160 = cd(cd(Ml, 128) * cd(Cout, 160), 256) * 128 * 160;
+    if (Cout > 128 && load_160 * 20 < load_now * 19 && sf_tune().cnn_variant != 2)
+      return launch_split<160>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, overflow, st);
+  }
   if (Cout > 64 && sf_cdiv(Cout, 128) * 128 <= sf_cdiv(Cout, 64) * 64)
     return launch_split<128>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, overflow, st);
   // 64-channel tiles take 256 pixels: wave tiles of 64 x 64 as in the 128 x 128 form -- 8 fragment reads per 12 matrix instructions

@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void k_ring_pool1(const float *__restrict__ pa
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // the whole patch into registers (33 broadcast reads of 16 bytes) instead of one 4-byte LDS read per multiply: 185 -> 1xx us
+    // the whole patch into registers (33 broadcast reads of 16 bytes) instead of one 4-byte LDS read per multiply.  The time did not
+    // move (185 us per 512 windows): the kernel is bound by the issue of its 441 multiply-adds per position and lane; two positions per
+    // wave on v_pk_fma_f32 (half the instructions) measured SLOWER, 235 us -- packed float32 is not a faster pipe here.
     float pr[11][12];
 #pragma unroll
     for (int y = 0; y < 11; ++y)

@@ -6,6 +6,7 @@
 // [Cout][k*k][Cin], then the bias [Cout]); GoogLeNetHIP.packed_blob() builds it from a state_dict.
 #include "cmf_common.h"
 #include "cnn_ring.h"
+#include "cnn_internal.h"
 
 namespace {
 
@@ -107,12 +108,17 @@ size_t base_bytes(int batch);            // the workspace without the sharing bu
 // (1, 2) -> (2, 3) -> (3, 4), cnn_ring.h) with maxpool3 assembling inception4a's input.  Every tensor a gather convolution reads has its
 // ring tensor RIGHT BEHIND its maps (one < 2 GB buffer descriptor).
 constexpr int SHARE_ROWS1 = 2048, SHARE_ROWS2 = 512;   // image rows a set of maps serves (a batch may reach `rows_batch` rows further)
+constexpr int STRIP_ROWS = 16;                         // image rows a set of strip maps serves (band sharing): one build per ~19 batches of 512 at 598 columns
 constexpr int F32_PL = 1, F32_PH = 2, F3A_L = 2, F3A_H = 3, F3B_L = 3, F3B_H = 4;      // frames on the 32 x 32 grid
 struct MapT { size_t map, ring; int C; };    // float offsets of a tensor's maps and of its ring tensor (ring - map = the maps' size)
 struct Share {
   int depth, rows, Hq, Wq, Hc, Wc, H8, W8;   // rows covered from the strip's first row; map / canvas geometry (H8 x W8: the 64-phase maps)
   size_t canvas, c1, p1, p1ring, pooled, pring;
   MapT q2, q3, x3a, t2a, t3a, y3a, t2b, t3b, y3b;
+  // band sharing (depth 2; cnn_ring.h): the strip maps of the image rows a batch touches -- every layer run on the top and the bottom
+  // 64 pixel rows of those rows' windows (per column phase: 8 nrows images of 16 rows at the 64 x 64 grid, 16 nrows of 8 rows at 32 x 32)
+  int band, nrows;
+  size_t s_canvas, s_c1, s_p1, s_q2, s_q3, s_x3, s_t2[2], s_t3[2], s_y[2], s_pool;
   size_t total;
 };
 Share share_layout(int batch, int H, int W, int depth) {
@@ -165,6 +171,21 @@ Share share_layout(int batch, int H, int W, int depth) {
     pair(S.y3b, P64, 480, n3b);
     take(S.pooled, P64 * 256);               // branch 4's pooled input while the maps are built
     take(S.pring, (size_t)batch * n3b * 256);   // ... and at the ring positions of a batch
+    S.band = 1;
+    S.nrows = rows_batch > STRIP_ROWS ? rows_batch : STRIP_ROWS;
+    const size_t n4 = (size_t)S.nrows * 8, n8 = (size_t)S.nrows * 16, p4 = n4 * 16 * S.Wq, p8 = n8 * 8 * S.W8;
+    take(S.s_canvas, n4 * 64 * S.Wc);
+    take(S.s_c1, n4 * 32 * (S.Wc / 2) * 64);
+    take(S.s_p1, p4 * 64);
+    take(S.s_q2, p4 * 64);
+    take(S.s_q3, (p4 + 2) * 192);            // (+ the column a shifted pool view may name)
+    take(S.s_x3, p8 * 192);
+    for (int i = 0; i < 2; ++i) {
+      take(S.s_t2[i], p8 * INC[i].c3r);
+      take(S.s_t3[i], p8 * INC[i].c5r);
+      take(S.s_y[i], p8 * (INC[i].c1 + INC[i].c3 + INC[i].c5 + INC[i].pp));
+    }
+    take(S.s_pool, p8 * 256);
   }
   S.total = o;
   return S;
@@ -176,6 +197,8 @@ struct Net {
   float *share = nullptr;                // the sharing buffers (behind everything else); null: no sharing
   int map_r0 = -1, map_r1 = -1, map_Rb = 0;   // image rows the maps in memory serve, their first canvas row
   bool map_ok = false;
+  int strip_r0 = -1, strip_nr = 0;              // image rows the strip maps in memory serve
+  bool strip_ok = false;
   Blob L; Wino WL; Splits SL; Acts A;
   float *pool1, *conv2, *conv3, *xa, *xb, *t2, *t3, *pooled, *wino, *sscale;
   _Float16 *shalf;
@@ -236,6 +259,8 @@ int prepare_wino(Net &N) {
   return 0;
 }
 
+int build_strips(Net &N, const float *padded, int H, int W, int ra, const float *as);
+
 // One batch of windows through the eval graph (googlenet1.py:110-163) on the given route:
 //   0 operand splitting on the fp16 matrix cores (cnn_split.hip; `as`: the NSCALE activation scales, `flag`: this batch's overflow slot)
 //   4 Winograd F(2 x 2, 3 x 3) for the 3 x 3 layers where the geometry allows + the fp32 implicit GEMM (cnn_wino.hip / cnn_kernels.hip)
@@ -265,6 +290,68 @@ int run_batch(Net &N, const float *padded, const float *plane, int H, int W, lon
     const Share &S = N.SH;
     float *B = N.share;
     const int Rb = N.map_Rb, Rb8 = Rb >> 1;
+    const int ra = (int)(tile0 / W), rb = (int)((tile0 + n - 1) / W);
+    const bool band = S.band && S.depth >= 2 && N.strip_ok && N.strip_r0 >= 0 && N.strip_r0 <= ra && rb < N.strip_r0 + N.strip_nr;
+    if (band) {
+      // BAND SHARING (round 6; cnn_ring.h): per window only the SIDE positions of every ring are computed; the band interiors -- the
+      // rows that see the window's top / bottom padding only -- are copied from strip maps built once for the batch's image rows
+      auto copy = [&](size_t strips, int shift, int Hs, int Wm, int G, int lo, int hi, int C, float *ring) {
+        return sfi_cnn_band_copy(B + strips, tile0, n, W, N.strip_r0, N.strip_nr, shift, Hs, Wm, G, lo, hi, C, ring, stream);
+      };
+      if ((rc = sfi_cnn_ring_pool1_side(padded, Hp, Wp, W, tile0, n, W_(N.L.conv1), B_(N.L.conv1), B + S.p1ring, stream))) return rc;
+      if ((rc = copy(S.s_p1, 2, 16, S.Wq, 64, 1, 1, 64, B + S.p1ring))) return rc;
+      if ((rc = sf_cnn_conv_split(B + S.p1ring, 0, 1, 1, n * 252, 64, 64, N.shalf + N.SL.conv2.h, half_lo(N, N.SL.conv2, 64, 1, 64),
+                                  N.sscale + N.SL.conv2.s, B_(N.L.conv2), 64, 1, as[0], B + S.q2.ring, 1, as[1], 64, 0, flag, stream)))
+        return rc;
+      if ((rc = sfi_cnn_conv_side(B + S.q2.map, 1, tile0, n, W, Rb, S.Hq, S.Wq, S.q2.ring - S.q2.map, 2, 64, 1, 1, 2, 2, 64,
+                                  N.shalf + N.SL.conv3.h, half_lo(N, N.SL.conv3, 192, 9, 64), N.sscale + N.SL.conv3.s, B_(N.L.conv3), 192, 0, 0,
+                                  3, as[1], B + S.q3.ring, 192, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 1.0f, 1.0f, flag, stream)))
+        return rc;
+      if ((rc = copy(S.s_q3, 2, 16, S.Wq, 64, 2, 2, 192, B + S.q3.ring))) return rc;
+      if ((rc = sfi_cnn_pool_gather_side(B + S.q3.map, tile0, n, W, Rb, S.Hq, S.Wq, S.q3.ring - S.q3.map, 2, 64, 2, 2, 192, 2, 32, F32_PL,
+                                         F32_PH, B + S.x3a.ring, 1, stream)))
+        return rc;
+      if ((rc = copy(S.s_x3, 3, 8, S.W8, 32, F32_PL, F32_PH, 192, B + S.x3a.ring))) return rc;
+      const MapT *xin = &S.x3a;
+      int ilo = F32_PL, ihi = F32_PH;
+      for (int i = 0; i < 2; ++i) {
+        const Incep &s = INC[i];
+        const int cout = s.c1 + s.c3 + s.c5 + s.pp, olo = ilo + 1, ohi = ihi + 1;
+        const MapT &t2 = i == 0 ? S.t2a : S.t2b, &t3 = i == 0 ? S.t3a : S.t3b, &yo = i == 0 ? S.y3a : S.y3b;
+        const float ax = as[2 + 3 * i], a2 = as[3 + 3 * i], a3 = as[4 + 3 * i];
+        float *yr = B + yo.ring;
+        if ((rc = sfi_cnn_conv_side(B + xin->map, 0, tile0, n, W, Rb8, S.H8, S.W8, xin->ring - xin->map, 3, 32, ilo, ihi, olo, ohi, s.cin,
+                                    N.shalf + N.SL.head3[i].h, half_lo(N, N.SL.head3[i], s.c1 + s.c3r + s.c5r, 1, s.cin),
+                                    N.sscale + N.SL.head3[i].s, B_(N.L.head3[i]), s.c1, s.c3r, s.c5r, 1, ax, yr, cout, 0, B + t2.ring,
+                                    s.c3r, 0, B + t3.ring, s.c5r, 0, 1, a2, a3, flag, stream)))
+          return rc;
+        if ((rc = copy(S.s_t2[i], 3, 8, S.W8, 32, olo, ohi, s.c3r, B + t2.ring))) return rc;
+        if ((rc = copy(S.s_t3[i], 3, 8, S.W8, 32, olo, ohi, s.c5r, B + t3.ring))) return rc;
+        if ((rc = sfi_cnn_conv_side(B + t2.map, 1, tile0, n, W, Rb8, S.H8, S.W8, t2.ring - t2.map, 3, 32, olo, ohi, olo, ohi, s.c3r,
+                                    N.shalf + N.SL.b2[i].h, half_lo(N, N.SL.b2[i], s.c3, 9, s.c3r), N.sscale + N.SL.b2[i].s, B_(N.L.b2[i]),
+                                    s.c3, 0, 0, 3, a2, yr, cout, s.c1, nullptr, 0, 0, nullptr, 0, 0, 0, 1.0f, 1.0f, flag, stream)))
+          return rc;
+        if ((rc = sfi_cnn_conv_side(B + t3.map, 1, tile0, n, W, Rb8, S.H8, S.W8, t3.ring - t3.map, 3, 32, olo, ohi, olo, ohi, s.c5r,
+                                    N.shalf + N.SL.b3[i].h, half_lo(N, N.SL.b3[i], s.c5, 9, s.c5r), N.sscale + N.SL.b3[i].s, B_(N.L.b3[i]),
+                                    s.c5, 0, 0, 3, a3, yr, cout, s.c1 + s.c3, nullptr, 0, 0, nullptr, 0, 0, 0, 1.0f, 1.0f, flag, stream)))
+          return rc;
+        if ((rc = sfi_cnn_pool_gather_side(B + xin->map, tile0, n, W, Rb8, S.H8, S.W8, xin->ring - xin->map, 3, 32, ilo, ihi, s.cin, 1, 32, olo,
+                                           ohi, B + S.pring, 2, stream)))
+          return rc;
+        if ((rc = sfi_cnn_conv_rows_side(B + S.pring, n, 32, olo, ohi, s.cin, N.shalf + N.SL.b4[i].h, half_lo(N, N.SL.b4[i], s.pp, 1, s.cin),
+                                         N.sscale + N.SL.b4[i].s, B_(N.L.b4[i]), s.pp, ax, yr, cout, s.c1 + s.c3 + s.c5, flag, stream)))
+          return rc;
+        if ((rc = copy(S.s_y[i], 3, 8, S.W8, 32, olo, ohi, cout, yr))) return rc;
+        xin = &yo;
+        ilo = olo;
+        ihi = ohi;
+      }
+      if ((rc = sf_cnn_pool_gather(B + S.y3b.map, tile0, n, W, Rb8, S.H8, S.W8, S.y3b.ring - S.y3b.map, 3, 32, F3B_L, F3B_H, 480, 2, 16, -1,
+                                   0, N.xa, stream)))
+        return rc;
+      first_block = 2;
+      hw = 16;
+    } else {
     if ((rc = sf_cnn_ring_pool1(padded, Hp, Wp, W, tile0, n, W_(N.L.conv1), B_(N.L.conv1), B + S.p1ring, stream))) return rc;
     if ((rc = sf_cnn_conv_split(B + S.p1ring, 0, 1, 1, n * 252, 64, 64, N.shalf + N.SL.conv2.h, half_lo(N, N.SL.conv2, 64, 1, 64),
                                 N.sscale + N.SL.conv2.s, B_(N.L.conv2), 64, 1, as[0], B + S.q2.ring, 1, as[1], 64, 0, flag, stream)))
@@ -319,6 +406,7 @@ int run_batch(Net &N, const float *padded, const float *plane, int H, int W, lon
         return rc;
       first_block = 2;
       hw = 16;
+    }
     }
   } else {
   // conv1 + maxpool1 (googlenet1.py:60-61), conv2, conv3, maxpool2 (:62-64)
@@ -448,6 +536,66 @@ int build_maps(Net &N, const float *padded, int H, int W, int r0, const float *a
   return 0;
 }
 
+// Band sharing: the strip maps of the image rows [ra, ra + nr) -- conv1 .. inception3b as in build_maps, on the top and the bottom 64
+// pixel rows of those rows' windows instead of the whole plane: a strip's first (last) row IS the windows' top (bottom) edge, so the
+// dense kernels' own zero padding reproduces what a window sees there; what the strip's far edge contaminates (<= 3 rows of 8 at
+// the 32 x 32 grid) lies outside every band.  Images in (row, top | bottom, column phase) order; at the 32 x 32 grid the eight column
+// phases come from two pool launches over the four-phase conv3 strips (column offset (phase >> 2): build_maps' views), phases 4 .. 7
+// behind 0 .. 3.  One build serves STRIP_ROWS image rows (the launches are small: built per batch they cost as much as they saved) and
+// synchronises the stream to read the strips' own overflow slot; strip_ok = false: those rows' batches compute their whole rings.
+int build_strips(Net &N, const float *padded, int H, int W, int ra, const float *as) {
+  const Share &S = N.SH;
+  const int nr = (H - ra < S.nrows) ? H - ra : S.nrows;
+  const int Hp = H + 255, Wp = W + 255, n4 = nr * 8, n8 = nr * 16;
+  void *stream = (void *)N.st;
+  float *B = N.share;
+  int *flag = reinterpret_cast<int *>(N.amax + 49);
+  SF_HIP(hipMemsetAsync(flag, 0, sizeof(int), N.st));
+  int rc = 0;
+  if ((rc = sfi_cnn_strip_canvas(padded, Hp, Wp, ra, nr, S.Wc, B + S.s_canvas, stream))) return rc;
+  if ((rc = sf_cnn_conv1_image(B + S.s_canvas, n4, 64, S.Wc, W_(N.L.conv1), B_(N.L.conv1), B + S.s_c1, 0, stream))) return rc;
+  if ((rc = sf_cnn_maxpool(B + S.s_c1, n4, 32, S.Wc / 2, 64, 3, 2, 0, B + S.s_p1, 16, S.Wq, stream))) return rc;
+  if ((rc = sf_cnn_conv_split(B + S.s_p1, 0, n4, 16, S.Wq, 64, 64, N.shalf + N.SL.conv2.h, half_lo(N, N.SL.conv2, 64, 1, 64),
+                              N.sscale + N.SL.conv2.s, B_(N.L.conv2), 64, 1, as[0], B + S.s_q2, 1, as[1], 64, 0, flag, stream)))
+    return rc;
+  if ((rc = sf_cnn_conv_split(B + S.s_q2, 1, n4, 16, S.Wq, 64, 64, N.shalf + N.SL.conv3.h, half_lo(N, N.SL.conv3, 192, 9, 64),
+                              N.sscale + N.SL.conv3.s, B_(N.L.conv3), 192, 3, as[1], B + S.s_q3, 0, 1.0f, 192, 0, flag, stream)))
+    return rc;
+  const size_t p8 = (size_t)8 * S.W8;
+  for (int ob = 0; ob < 2; ++ob)
+    if ((rc = sf_cnn_maxpool(B + S.s_q3 + (size_t)ob * 192, n4, 16, S.Wq, 192, 3, 2, 0, B + S.s_x3 + (size_t)ob * n4 * p8 * 192, 8, S.W8, stream)))
+      return rc;
+  size_t xin = S.s_x3;
+  for (int i = 0; i < 2; ++i) {
+    const Incep &s = INC[i];
+    const int cout = s.c1 + s.c3 + s.c5 + s.pp;
+    const float ax = as[2 + 3 * i], a2 = as[3 + 3 * i], a3 = as[4 + 3 * i];
+    float *y = B + S.s_y[i], *t2 = B + S.s_t2[i], *t3 = B + S.s_t3[i];
+    if ((rc = sf_cnn_conv_split3_split(B + xin, n8, 8, S.W8, s.cin, s.cin, N.shalf + N.SL.head3[i].h,
+                                       half_lo(N, N.SL.head3[i], s.c1 + s.c3r + s.c5r, 1, s.cin), N.sscale + N.SL.head3[i].s,
+                                       B_(N.L.head3[i]), s.c1, s.c3r, s.c5r, ax, y, cout, 0, t2, s.c3r, 0, t3, s.c5r, 0, 1, a2, a3, flag, stream)))
+      return rc;
+    if ((rc = sf_cnn_conv_split(t2, 1, n8, 8, S.W8, s.c3r, s.c3r, N.shalf + N.SL.b2[i].h, half_lo(N, N.SL.b2[i], s.c3, 9, s.c3r),
+                                N.sscale + N.SL.b2[i].s, B_(N.L.b2[i]), s.c3, 3, a2, y, 0, 1.0f, cout, s.c1, flag, stream)))
+      return rc;
+    if ((rc = sf_cnn_conv_split(t3, 1, n8, 8, S.W8, s.c5r, s.c5r, N.shalf + N.SL.b3[i].h, half_lo(N, N.SL.b3[i], s.c5, 9, s.c5r),
+                                N.sscale + N.SL.b3[i].s, B_(N.L.b3[i]), s.c5, 3, a3, y, 0, 1.0f, cout, s.c1 + s.c3, flag, stream)))
+      return rc;
+    if ((rc = sf_cnn_maxpool(B + xin, n8, 8, S.W8, s.cin, 3, 1, 1, B + S.s_pool, 8, S.W8, stream))) return rc;
+    if ((rc = sf_cnn_conv_split(B + S.s_pool, 0, n8, 8, S.W8, s.cin, s.cin, N.shalf + N.SL.b4[i].h, half_lo(N, N.SL.b4[i], s.pp, 1, s.cin),
+                                N.sscale + N.SL.b4[i].s, B_(N.L.b4[i]), s.pp, 1, ax, y, 0, 1.0f, cout, s.c1 + s.c3 + s.c5, flag, stream)))
+      return rc;
+    xin = S.s_y[i];
+  }
+  int raised = 0;
+  SF_HIP(hipMemcpyAsync(&raised, flag, sizeof(int), hipMemcpyDeviceToHost, N.st));
+  SF_HIP(hipStreamSynchronize(N.st));
+  N.strip_r0 = ra;
+  N.strip_nr = nr;
+  N.strip_ok = raised == 0;
+  return 0;
+}
+
 // The activation scales from a FIXED sample of the plane's windows (eight groups of up to eight consecutive windows, evenly spaced
 // over all H W of them -- a function of the plane alone, not of `batch`, so every row shard and batch size of a flightline works with the same
 // scales and produces the same bits): one pass on the fp32 matrix cores, the largest magnitude of every tensor a split convolution
@@ -570,6 +718,8 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
           if ((rc = build_maps(N, padded, H, W, rf, as))) return rc;
         if (N.map_ok) rt = 0;
         if (N.map_ok && info) ++info[1];
+        if (N.map_ok && N.SH.band && route == 0 && sf_tune().cnn_variant != 3 && !(N.strip_r0 >= 0 && N.strip_r0 <= rf && rl < N.strip_r0 + N.strip_nr))
+          if ((rc = build_strips(N, padded, H, W, rf, as))) return rc;
       }
       if ((rc = run_batch(N, padded, plane, H, W, tile0, n, rt, as, N.flags + nb, nullptr, out))) return rc;
     }

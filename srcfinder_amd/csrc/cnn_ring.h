@@ -36,6 +36,25 @@ __host__ __device__ inline void sf_frame_position(int G, int lo, int hi, int j, 
   }
 }
 
+// Round 6, band sharing: the ring splits into its SIDE part -- the columns x < lo and x >= G - hi of EVERY row (G (lo + hi) positions:
+// they see the window's left / right padding) -- and the BAND interior -- rows y < lo and y >= G - hi at lo <= x < G - hi: those see
+// only the window's top / bottom padding, i.e. they are the same for every window of an image row at the same column phase, and come
+// from STRIP maps (the layer run on 64 canvas rows starting at the window's top edge / ending at its bottom edge: cnn_driver.hip).
+// Side positions are enumerated row by row: j = y (lo + hi) + (x < lo ? x : lo + x - (G - hi)).
+__host__ __device__ inline int sf_side_count(int G, int lo, int hi) { return G * (lo + hi); }
+__host__ __device__ inline void sf_side_position(int G, int lo, int hi, int j, int &y, int &x) {
+  const int w = lo + hi;
+  y = j / w;
+  const int t = j - y * w;
+  x = t < lo ? t : G - hi + (t - lo);
+}
+__host__ __device__ inline int sf_band_count(int G, int lo, int hi) { return (lo + hi) * (G - lo - hi); }
+__host__ __device__ inline void sf_band_position(int G, int lo, int hi, int j, int &y, int &x) {     // band interior, row by row
+  const int w = G - lo - hi, row = j / w;
+  x = lo + (j - row * w);
+  y = row < lo ? row : G - hi + (row - lo);
+}
+
 // What a gather kernel needs to find (window, position) of a layer's INPUT: the per-window ring tensor [N][count][C] or the phase maps
 // [P * P][Hq][Wq][C].  Both live in ONE allocation (maps first, the ring tensor `ring_off` floats behind their start) so that a single
 // < 2 GB buffer descriptor serves a tap wherever it lands.

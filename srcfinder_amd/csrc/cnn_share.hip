@@ -17,6 +17,7 @@
 // (the saliency maps are bit-identical to every window evaluated on its own: tests/test_cnn_gpu.py, tools/fuzz_cnn.py).
 #include "cmf_common.h"
 #include "cnn_ring.h"
+#include "cnn_internal.h"
 
 namespace {
 
@@ -36,19 +37,21 @@ __global__ __launch_bounds__(256) void k_phase_canvas(const float *__restrict__ 
 // conv rows 2 y .. 2 y + 2 that exist (ceil mode: row 128 does not), googlenet1.py:61.  Summation order ky, kx ascending (k_conv1_img's).
 __global__ __launch_bounds__(256) void k_ring_pool1(const float *__restrict__ padded, int Wp, int Wimg, long long tile0, int ntiles,
                                                      const float *__restrict__ w /*[64][49]*/, const float *__restrict__ bias,
-                                                     float *__restrict__ out /*[ntiles][252][64]*/) {
+                                                     float *__restrict__ out /*[ntiles][252][64]*/, int side) {
   __shared__ __attribute__((aligned(16))) float patch[4][11 * 12];      // rows of 12: whole rows leave LDS as three 16-byte reads
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float wr[49];
 #pragma unroll
   for (int t = 0; t < 49; ++t) wr[t] = w[lane * 49 + t];
   const float bb = bias[lane];
-  const long long total = (long long)ntiles * 252;
+  const int per = side ? 128 : 252;                               // side: the positions px = 0 / 63 only (band sharing, cnn_ring.h)
+  const long long total = (long long)ntiles * per;
   float *pw = patch[wave];
   for (long long item = (long long)blockIdx.x * 4 + wave; item < total; item += (long long)gridDim.x * 4) {
-    const int n = (int)(item / 252), b = (int)(item - (long long)n * 252);
+    const int n = (int)(item / per), b = (int)(item - (long long)n * per);
     int py, px;
-    sf_frame_position(64, 1, 1, b, py, px);
+    if (side) sf_side_position(64, 1, 1, b, py, px);
+    else sf_frame_position(64, 1, 1, b, py, px);
     const long long t = tile0 + n;
     const int r = (int)(t / Wimg), c = (int)(t - (long long)r * Wimg);
     const float *win = padded + (size_t)r * Wp + c;               // window pixel (wy, wx) = win[wy * Wp + wx]
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void k_ring_pool1(const float *__restrict__ pa
           for (int kx = 0; kx < 7; ++kx) acc = fmaf(pr[2 * dy + ky][2 * dx + kx], wr[ky * 7 + kx], acc);
         best = fmaxf(best, fmaxf(acc + bb, 0.f));
       }
-    out[(size_t)item * 64 + lane] = best;
+    out[((size_t)n * 252 + (side ? sf_frame_index(64, 1, 1, py, px) : b)) * 64 + lane] = best;
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void k_ring_pool1(const float *__restrict__ pa
 // (One thread per (position, four channels), every thread classifying its own taps.  The other shape -- one WAVE per position with
 //  scalar tap classification, lanes over the channels -- was measured: 0.79 ms of pools per batch against 0.61; loads in flight win.)
 __global__ __launch_bounds__(256) void k_pool_gather(const float *__restrict__ maps, SfGather gi, int C, int stride, int pad, int Go, int olo,
-                                                      int ohi, int npos, int N, unsigned bytes, float *__restrict__ out) {
+                                                      int ohi, int npos, int N, unsigned bytes, float *__restrict__ out, int side) {
   const int c4n = C >> 2;
   const size_t total = (size_t)N * npos * c4n;
   const int nin = sf_frame_count(gi.G, gi.lo, gi.hi);
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(256) void k_pool_gather(const float *__restrict__ m
     const int j = (int)(rest % npos), n = (int)(rest / npos);
     int oy, ox;
     if (olo < 0) { oy = j / Go; ox = j - oy * Go; }
+    else if (side) sf_side_position(Go, olo, ohi, j, oy, ox);
     else sf_frame_position(Go, olo, ohi, j, oy, ox);
     const long long t = gi.tile0 + n;
     const int r = (int)(t / gi.W), c = (int)(t - (long long)r * gi.W);
@@ -136,10 +140,47 @@ __global__ __launch_bounds__(256) void k_pool_gather(const float *__restrict__ m
       cv.u = v[k];
       m.x = fmaxf(m.x, cv.f.x); m.y = fmaxf(m.y, cv.f.y); m.z = fmaxf(m.z, cv.f.z); m.w = fmaxf(m.w, cv.f.w);
     }
-    *reinterpret_cast<float4 *>(out + (rest * c4n + c4) * 4) = m;
+    const size_t orow = (side == 1) ? (size_t)n * sf_frame_count(Go, olo, ohi) + sf_frame_index(Go, olo, ohi, oy, ox) : rest;
+    *reinterpret_cast<float4 *>(out + (orow * c4n + c4) * 4) = m;
   }
 }
 
+
+// strip canvases of the band sharing (cnn_driver.hip): image ((ri * 2 + bottom) * 4 + phase)[u][v] = padded[row0 + ri + 192 bottom + u][phase + v],
+// 64 rows each: the top 64 / the bottom 64 pixel rows of the windows of image row row0 + ri, shifted by the column phase
+__global__ __launch_bounds__(256) void k_strip_canvas(const float *__restrict__ padded, int Hp, int Wp, int row0, int nrows, int Wc,
+                                                       float *__restrict__ canvas) {
+  const size_t per = (size_t)64 * Wc, total = (size_t)nrows * 8 * per;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int img = (int)(i / per);
+    const size_t rest = i - (size_t)img * per;
+    const int u = (int)(rest / Wc), v = (int)(rest - (size_t)u * Wc);
+    const int ph = img & 3, bottom = (img >> 2) & 1, ri = img >> 3;
+    const int y = row0 + ri + 192 * bottom + u, x = ph + v;
+    canvas[i] = (y >= 0 && y < Hp && x >= 0 && x < Wp) ? padded[(size_t)y * Wp + x] : 0.f;
+  }
+}
+
+// band interior of a ring tensor <- strip maps (cnn_internal.h: sfi_cnn_band_copy)
+__global__ __launch_bounds__(256) void k_band_copy(const float *__restrict__ strips, long long tile0, int N, int W, int row0, int shift, int Hs,
+                                                    int Wq, int G, int lo, int hi, int C, int nrb, float *__restrict__ ring) {
+  const int c4n = C >> 2, nb = sf_band_count(G, lo, hi), nfull = sf_frame_count(G, lo, hi), P = 1 << shift;
+  const size_t total = (size_t)N * nb * c4n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    const size_t rest = i / c4n;
+    const int j = (int)(rest % nb), n = (int)(rest / nb);
+    int y, x;
+    sf_band_position(G, lo, hi, j, y, x);
+    const long long t = tile0 + n;
+    const int r = (int)(t / W), c = (int)(t - (long long)r * W);
+    const int bottom = y >= G - hi, ys = bottom ? Hs - (G - y) : y;
+    const int ph = c & (P - 1);
+    const size_t strip = (size_t)(ph >> 2) * (nrb * 4) + (size_t)((r - row0) * 2 + bottom) * 4 + (ph & 3);      // (cnn_internal.h)
+    const float4 v = *reinterpret_cast<const float4 *>(strips + ((strip * Hs + ys) * Wq + (c >> shift) + x) * C + 4 * c4);
+    *reinterpret_cast<float4 *>(ring + ((size_t)n * nfull + sf_frame_index(G, lo, hi, y, x)) * C + 4 * c4) = v;
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -153,21 +194,25 @@ int sf_cnn_phase_canvas(const float *padded, int Hp, int Wp, int y0, int x0, int
   return 0;
 }
 
-int sf_cnn_ring_pool1(const float *padded, int Hp, int Wp, int W, long long tile0, int ntiles, const float *w, const float *bias,
-                      float *out, void *stream) {
+static int ring_pool1_go(const float *padded, int Hp, int Wp, int W, long long tile0, int ntiles, const float *w, const float *bias,
+                         float *out, void *stream, int side) {
   if (!padded || !w || !bias || !out || ntiles < 1 || W < 1 || Wp != W + 255 || Hp < 256 || tile0 < 0) {
     sf_set_error("sf_cnn_ring_pool1: bad argument");
     return -1;
   }
-  const long long items = (long long)ntiles * 252;
+  const long long items = (long long)ntiles * (side ? 128 : 252);
   const int blocks = (int)((items + 3) / 4 < 8192 ? (items + 3) / 4 : 8192);
-  hipLaunchKernelGGL(k_ring_pool1, dim3(blocks), dim3(256), 0, (hipStream_t)stream, padded, Wp, W, tile0, ntiles, w, bias, out);
+  hipLaunchKernelGGL(k_ring_pool1, dim3(blocks), dim3(256), 0, (hipStream_t)stream, padded, Wp, W, tile0, ntiles, w, bias, out, side);
   SF_LAUNCH_CHECK("k_ring_pool1");
   return 0;
 }
+int sf_cnn_ring_pool1(const float *padded, int Hp, int Wp, int W, long long tile0, int ntiles, const float *w, const float *bias,
+                      float *out, void *stream) {
+  return ring_pool1_go(padded, Hp, Wp, W, tile0, ntiles, w, bias, out, stream, 0);
+}
 
-int sf_cnn_pool_gather(const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, int shift, int G,
-                       int ilo, int ihi, int C, int stride, int Go, int olo, int ohi, float *out, void *stream) {
+static int pool_gather_go(const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, int shift, int G,
+                          int ilo, int ihi, int C, int stride, int Go, int olo, int ohi, float *out, void *stream, int side) {
   if (!maps || !out || N < 1 || W < 1 || tile0 < 0 || G < 4 || G > 128 || shift < 1 || shift > 4 || ilo < 0 || ihi < 0 || ilo + ihi >= G ||
       Hq < G || Wq < G || C < 4 || (C & 3) || (stride != 1 && stride != 2) || (ring_off & 3) ||
       Go != (stride == 1 ? G : (G + 1) / 2) || (olo >= 0 && (ohi < 0 || olo + ohi >= Go))) {
@@ -177,13 +222,50 @@ int sf_cnn_pool_gather(const float *maps, long long tile0, int N, int W, int Rb,
   const size_t bytes = (ring_off + (size_t)(N + 1) * sf_frame_count(G, ilo, ihi) * C) * 4;      // maps + the batch's ring tensor: one descriptor
   if (bytes >= 0x7ff00000u) { sf_set_error("sf_cnn_pool_gather: maps + ring tensor of 2 GB or more"); return -2; }
   const SfGather gi{tile0, W, Rb, Hq, Wq, shift, G, ilo, ihi, (unsigned)ring_off};
-  const int npos = olo < 0 ? Go * Go : sf_frame_count(Go, olo, ohi);
+  if (side && (olo < 0 || olo + ohi < 1)) { sf_set_error("sf_cnn_pool_gather: side rows need a frame"); return -1; }
+  const int npos = olo < 0 ? Go * Go : (side ? sf_side_count(Go, olo, ohi) : sf_frame_count(Go, olo, ohi));
   const size_t total = (size_t)N * npos * (C >> 2);
   const unsigned blocks = (unsigned)((total + 255) / 256 < 65536 * 8 ? (total + 255) / 256 : 65536 * 8);
   hipLaunchKernelGGL(k_pool_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, maps, gi, C, stride, stride == 1 ? 1 : 0, Go, olo, ohi,
-                     npos, N, (unsigned)bytes, out);
+                     npos, N, (unsigned)bytes, out, side);
   SF_LAUNCH_CHECK("k_pool_gather");
   return 0;
 }
+int sf_cnn_pool_gather(const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, int shift, int G,
+                       int ilo, int ihi, int C, int stride, int Go, int olo, int ohi, float *out, void *stream) {
+  return pool_gather_go(maps, tile0, N, W, Rb, Hq, Wq, ring_off, shift, G, ilo, ihi, C, stride, Go, olo, ohi, out, stream, 0);
+}
 
 }  // extern "C"
+
+// ---- internal entry points (cnn_internal.h)
+int sfi_cnn_pool_gather_side(const float *maps, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, int shift, int G, int ilo,
+                             int ihi, int C, int stride, int Go, int olo, int ohi, float *out, int side, void *stream) {
+  return pool_gather_go(maps, tile0, N, W, Rb, Hq, Wq, ring_off, shift, G, ilo, ihi, C, stride, Go, olo, ohi, out, stream, side);
+}
+int sfi_cnn_ring_pool1_side(const float *padded, int Hp, int Wp, int W, long long tile0, int ntiles, const float *w, const float *bias,
+                            float *out, void *stream) {
+  return ring_pool1_go(padded, Hp, Wp, W, tile0, ntiles, w, bias, out, stream, 1);
+}
+int sfi_cnn_band_copy(const float *strips, long long tile0, int N, int W, int row0, int nrows, int shift, int Hs, int Wq, int G, int lo, int hi,
+                      int C, float *ring, void *stream) {
+  if (!strips || !ring || N < 1 || W < 1 || tile0 < 0 || shift < 1 || shift > 4 || Hs < lo || Hs < hi || lo < 0 || hi < 0 || lo + hi < 1 ||
+      lo + hi >= G || (C & 3) || tile0 / W < row0 || (tile0 + N - 1) / W >= row0 + nrows || (shift != 2 && shift != 3)) {
+    sf_set_error("sfi_cnn_band_copy: bad argument");
+    return -1;
+  }
+  const size_t total = (size_t)N * sf_band_count(G, lo, hi) * (C >> 2);
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 65536 * 8 ? (total + 255) / 256 : 65536 * 8);
+  hipLaunchKernelGGL(k_band_copy, dim3(blocks), dim3(256), 0, (hipStream_t)stream, strips, tile0, N, W, row0, shift, Hs, Wq, G, lo, hi, C, 2 * nrows, ring);
+  SF_LAUNCH_CHECK("k_band_copy");
+  return 0;
+}
+int sfi_cnn_strip_canvas(const float *padded, int Hp, int Wp, int row0, int nrows, int Wc, float *canvas, void *stream) {
+  if (!padded || !canvas || Hp < 1 || Wp < 1 || nrows < 1 || Wc < 1 || row0 < 0) { sf_set_error("sfi_cnn_strip_canvas: bad argument"); return -1; }
+  const size_t total = (size_t)nrows * 8 * 64 * Wc;
+  hipLaunchKernelGGL(k_strip_canvas, dim3((unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536)), dim3(256), 0, (hipStream_t)stream,
+                     padded, Hp, Wp, row0, nrows, Wc, canvas);
+  SF_LAUNCH_CHECK("k_strip_canvas");
+  return 0;
+}
+

@@ -20,6 +20,7 @@
 // from global memory into LDS.
 #include "cmf_common.h"
 #include "cnn_ring.h"
+#include "cnn_internal.h"
 #include <type_traits>
 
 typedef _Float16 sp_h8 __attribute__((ext_vector_type(8)));
@@ -53,6 +54,8 @@ struct RingArgs {
   SfGather in;         // where the input lives
   int olo, ohi, nout;  // the rows: ring positions of the frame (olo, ohi) on the same grid, nout of them per window
   int nin;             // ring positions of the input frame
+  int side, nfull;     // side = 1 (band sharing, cnn_ring.h): the rows are the frame's SIDE positions (nout = G (olo + ohi)) and row
+                       // (window, j) is written to row window * nfull + its ring index of the output tensors (nfull = the whole ring)
 };
 
 // hi / lo halves of eight floats (scaled by s); big: the largest magnitude seen (float16 ends at 65504)
@@ -117,7 +120,8 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
       const SfGather &gi = ring.in;
       const int n = mm / ring.nout, j = mm - n * ring.nout;
       int y3, x3;
-      sf_frame_position(gi.G, ring.olo, ring.ohi, j, y3, x3);
+      if (ring.side) sf_side_position(gi.G, ring.olo, ring.ohi, j, y3, x3);
+      else sf_frame_position(gi.G, ring.olo, ring.ohi, j, y3, x3);
       const long long t = gi.tile0 + n;
       const int r = (int)(t / gi.W), c = (int)(t - (long long)r * gi.W);
       const int pm = (1 << gi.shift) - 1;
@@ -255,6 +259,21 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
     }
   }
   // epilogue: acc[r] = D[row = (r&3) + 8(r>>2) + 4(lane>>5)][col = lane&31]; unscale (powers of two), bias, ReLU
+  int *orow = reinterpret_cast<int *>(sm);           // side rows: where each of the tile's rows goes (the operand tiles are done with)
+  if (ring.side) {
+    for (int i = tid; i < BM; i += 256) {
+      const int m = m0 + i;
+      int o = 0;
+      if (m < M) {
+        const int n = m / ring.nout, j = m - n * ring.nout;
+        int y, x;
+        sf_side_position(ring.in.G, ring.olo, ring.ohi, j, y, x);
+        o = n * ring.nfull + sf_frame_index(ring.in.G, ring.olo, ring.ohi, y, x);
+      }
+      orow[i] = o;
+    }
+    __syncthreads();
+  }
   const float ia = 1.0f / ascale;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -278,8 +297,9 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
             const _Float16 h = (_Float16)v;
             big = fmaxf(big, v);
             if (m < M) {
-              hp[(size_t)m * 2 * ld] = h;
-              hp[(size_t)m * 2 * ld + 8] = (_Float16)(v - (float)h);
+              const size_t om = ring.side ? (size_t)orow[m - m0] : (size_t)m;
+              hp[om * 2 * ld] = h;
+              hp[om * 2 * ld + 8] = (_Float16)(v - (float)h);
             }
           }
       } else {
@@ -288,7 +308,7 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < M) op[(size_t)m * ld] = fmaxf(__builtin_fmaf(acc[i][j][r], sc, bb), 0.f);
+            if (m < M) op[(ring.side ? (size_t)orow[m - m0] : (size_t)m) * ld] = fmaxf(__builtin_fmaf(acc[i][j][r], sc, bb), 0.f);
           }
       }
     }
@@ -506,12 +526,12 @@ __global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restri
 template <int BN, int BM = 128>
 int launch_split(const float *in, int in_split, int M, int H, int W, int Cin, int ld_in, const _Float16 *whi, const _Float16 *wlo,
                  const float *wscale, const float *bias, int Cout, int ks, float ascale, const ConvDstS &dst, int *overflow,
-                 hipStream_t st) {
+                 hipStream_t st, const RingArgs &rows = RingArgs{}) {
   dim3 grid(8 * sf_cdiv(sf_cdiv(M, BM), 8) * sf_cdiv(Cout, BN));
   if (in_split)
-    hipLaunchKernelGGL((k_conv_split<BN, true, BM>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst, overflow, RingArgs{});
+    hipLaunchKernelGGL((k_conv_split<BN, true, BM>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst, overflow, rows);
   else
-    hipLaunchKernelGGL((k_conv_split<BN, false, BM>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst, overflow, RingArgs{});
+    hipLaunchKernelGGL((k_conv_split<BN, false, BM>), grid, dim3(256), 0, st, in, M, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ks, ascale, dst, overflow, rows);
   SF_LAUNCH_CHECK("k_conv_split");
   return 0;
 }
@@ -544,13 +564,15 @@ int sf_cnn_split_weights(const float *w, int Cout, int K, void *hi, void *lo, fl
 }
 
 static int split_go(const float *in, int in_split, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo, const float *wscale,
-                    const float *bias, int Cout, int ksize, float ascale, const ConvDstS &d, int *overflow, hipStream_t st) {
+                    const float *bias, int Cout, int ksize, float ascale, const ConvDstS &d, int *overflow, hipStream_t st,
+                    const RingArgs &rows = RingArgs{}) {
   const long long Ml = (long long)N * H * W;
   const size_t halo = 2 * ((size_t)(ksize >> 1) * W + (ksize >> 1)) * ld_in * 4 + 64, img = (size_t)H * W * ld_in * 4;
   if ((size_t)Cout * ksize * ksize * Cin * 2 >= 0x7ff00000u || img + halo >= 0x7ff00000u) {
     sf_set_error("sf_cnn_conv_split: weights or one image of 2 GB or more (use sf_cnn_conv)");
     return -2;
   }
+  if ((size_t)N * img + halo >= 0x7ff00000u && rows.side) { sf_set_error("sf_cnn_conv_split: scattered rows of 2 GB or more"); return -2; }
   if ((size_t)N * img + halo >= 0x7ff00000u) {   // the buffer descriptors address < 2 GB: images are independent, run them in pieces
     const int per = (int)((0x7ff00000u - 1 - halo) / img);
     for (int n0 = 0; n0 < N; n0 += per) {
@@ -578,13 +600,13 @@ static int split_go(const float *in, int in_split, int N, int H, int W, int Cin,
     const long long load_now = cd(cd(Ml, bm) * cd(Cout, bn), 256) * bm * bn;
     const long long load_160 = cd(cd(Ml, 128) * cd(Cout, 160), 256) * 128 * 160;
     if (Cout > 128 && load_160 * 20 < load_now * 19 && sf_tune().cnn_variant != 2)
-      return launch_split<160>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, overflow, st);
+      return launch_split<160>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, overflow, st, rows);
   }
   if (Cout > 64 && sf_cdiv(Cout, 128) * 128 <= sf_cdiv(Cout, 64) * 64)
-    return launch_split<128>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, overflow, st);
+    return launch_split<128>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, overflow, st, rows);
   // 64-channel tiles take 256 pixels: wave tiles of 64 x 64 as in the 128 x 128 form -- 8 fragment reads per 12 matrix instructions
   // instead of 6 per 6 (the kernel sits at the LDS's bandwidth): 48.9 k -> 49.9 k windows/s
-  return launch_split<64, 256>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, overflow, st);
+  return launch_split<64, 256>(in, in_split, (int)Ml, H, W, Cin, ld_in, h, l, wscale, bias, Cout, ksize, ascale, d, overflow, st, rows);
 }
 
 static bool sp_pow2(float v) { int e; return v > 0.f && v < 3.0e38f && frexpf(v, &e) == 0.5f; }
@@ -634,12 +656,13 @@ int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int 
 // [P * P][Hq][Wq][Cin] with the batch's ring tensor [N][count(G, ilo, ihi)][Cin] `ring_off` floats behind their start (float32, or
 // both in the split format scaled by ascale when in_split); rows m = window * nout + ring index.  Output channels as
 // sf_cnn_conv_split3_split: [0, c0) -> out0 (float32), [c0, c0 + c1) -> out1, the rest -> out2 (c1 = c2 = 0: one segment).
-int sf_cnn_conv_ring(const float *maps, int in_split, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, int shift,
+static int conv_ring_go(const float *maps, int in_split, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, int shift,
                      int G, int ilo, int ihi, int olo, int ohi, int Cin, const void *whi, const void *wlo, const float *wscale,
                      const float *bias, int c0, int c1, int c2, int ksize, float ascale, float *out0, int ld0, int off0, float *out1,
                      int ld1, int off1, float *out2, int ld2, int off2, int out12_split, float oscale1, float oscale2, int *overflow,
-                     void *stream) {
-  const int nin = sf_frame_count(G, ilo, ihi), nout = sf_frame_count(G, olo, ohi), Cout = c0 + c1 + c2;
+                     void *stream, int side) {
+  const int nin = sf_frame_count(G, ilo, ihi), nfull = sf_frame_count(G, olo, ohi), nout = side ? sf_side_count(G, olo, ohi) : nfull;
+  const int Cout = c0 + c1 + c2;
   const size_t total = (ring_off + (size_t)(N + 1) * nin * Cin) * 4;
   if (!maps || !whi || !wlo || !wscale || !bias || !out0 || !overflow || N < 1 || W < 1 || tile0 < 0 || (ksize != 1 && ksize != 3) ||
       (Cin & 7) || c0 < 1 || c1 < 0 || c2 < 0 || (c2 > 0 && c1 < 1) || off0 + c0 > ld0 || (c1 > 0 && (!out1 || off1 + c1 > ld1)) ||
@@ -660,7 +683,7 @@ int sf_cnn_conv_ring(const float *maps, int in_split, long long tile0, int N, in
   d.oscale[0] = 1.0f; d.oscale[1] = d.fmt[1] ? oscale1 : 1.0f; d.oscale[2] = d.fmt[2] ? oscale2 : 1.0f;
   RingArgs ra{};
   ra.in = SfGather{tile0, W, Rb, Hq, Wq, shift, G, ilo, ihi, (unsigned)ring_off};
-  ra.olo = olo; ra.ohi = ohi; ra.nout = nout; ra.nin = nin;
+  ra.olo = olo; ra.ohi = ohi; ra.nout = nout; ra.nin = nin; ra.side = side; ra.nfull = nfull;
   const long long Ml = (long long)N * nout;
   if (Ml * (long long)(ld0 > Cout ? ld0 : Cout) * 4 >= (1ll << 40) || Ml >= 0x7fffffff) { sf_set_error("sf_cnn_conv_ring: batch too large"); return -2; }
   const int M = (int)Ml;
@@ -681,6 +704,15 @@ int sf_cnn_conv_ring(const float *maps, int in_split, long long tile0, int N, in
 #undef SF_RING_LAUNCH
   SF_LAUNCH_CHECK("k_conv_split<ring>");
   return 0;
+}
+
+int sf_cnn_conv_ring(const float *maps, int in_split, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, int shift,
+                     int G, int ilo, int ihi, int olo, int ohi, int Cin, const void *whi, const void *wlo, const float *wscale,
+                     const float *bias, int c0, int c1, int c2, int ksize, float ascale, float *out0, int ld0, int off0, float *out1,
+                     int ld1, int off1, float *out2, int ld2, int off2, int out12_split, float oscale1, float oscale2, int *overflow,
+                     void *stream) {
+  return conv_ring_go(maps, in_split, tile0, N, W, Rb, Hq, Wq, ring_off, shift, G, ilo, ihi, olo, ohi, Cin, whi, wlo, wscale, bias, c0, c1, c2,
+                      ksize, ascale, out0, ld0, off0, out1, ld1, off1, out2, ld2, off2, out12_split, oscale1, oscale2, overflow, stream, 0);
 }
 
 // 1 when sf_cnn_pool_conv_split takes this geometry (whole image rows per 128-pixel tile, operands below 2 GB); else sf_cnn_pool_conv
@@ -716,3 +748,32 @@ int sf_cnn_absmax(const float *x, size_t n, float *amax, void *stream) {
 }
 
 }  // extern "C"
+
+// ---- internal entry points (cnn_internal.h): the side-row forms for the band-sharing driver
+int sfi_cnn_conv_side(const float *maps, int in_split, long long tile0, int N, int W, int Rb, int Hq, int Wq, size_t ring_off, int shift, int G,
+                      int ilo, int ihi, int olo, int ohi, int Cin, const void *whi, const void *wlo, const float *wscale, const float *bias,
+                      int c0, int c1, int c2, int ksize, float ascale, float *out0, int ld0, int off0, float *out1, int ld1, int off1,
+                      float *out2, int ld2, int off2, int out12_split, float oscale1, float oscale2, int *overflow, void *stream) {
+  if (olo + ohi < 1) { sf_set_error("sfi_cnn_conv_side: the frame has no side"); return -1; }
+  return conv_ring_go(maps, in_split, tile0, N, W, Rb, Hq, Wq, ring_off, shift, G, ilo, ihi, olo, ohi, Cin, whi, wlo, wscale, bias, c0, c1, c2,
+                      ksize, ascale, out0, ld0, off0, out1, ld1, off1, out2, ld2, off2, out12_split, oscale1, oscale2, overflow, stream, 1);
+}
+
+int sfi_cnn_conv_rows_side(const float *in, int N, int G, int olo, int ohi, int Cin, const void *whi, const void *wlo, const float *wscale,
+                           const float *bias, int Cout, float ascale, float *out, int ld_out, int ch_off, int *overflow, void *stream) {
+  if (!in || !whi || !wlo || !wscale || !bias || !out || !overflow || N < 1 || G < 4 || olo < 0 || ohi < 0 || olo + ohi < 1 || olo + ohi >= G ||
+      (Cin & 7) || ch_off < 0 || ch_off + Cout > ld_out || !sp_pow2(ascale)) {
+    sf_set_error("sfi_cnn_conv_rows_side: bad argument");
+    return -1;
+  }
+  ConvDstS d{};
+  d.p[0] = d.p[1] = d.p[2] = out;
+  d.ld[0] = d.ld[1] = d.ld[2] = ld_out;
+  d.off[0] = d.off[1] = d.off[2] = ch_off;
+  d.end[0] = d.end[1] = d.end[2] = Cout;
+  d.oscale[0] = d.oscale[1] = d.oscale[2] = 1.0f;
+  RingArgs rows{};
+  rows.in.G = G; rows.olo = olo; rows.ohi = ohi; rows.nout = sf_side_count(G, olo, ohi); rows.nfull = sf_frame_count(G, olo, ohi); rows.side = 1;
+  return split_go(in, 0, 1, 1, N * rows.nout, Cin, Cin, whi, wlo, wscale, bias, Cout, 1, ascale, d, overflow, (hipStream_t)stream, rows);
+}
+

@@ -616,16 +616,18 @@ def cnn_section(res, ntiles, batch, with_cpu):
     dt_c, _ = timed("split_conv3")
     dt, rescued = timed("split")
     tf = ntiles * 3.706e9 / dt / 1e12
-    # Flops one window EXECUTES on the shared-trunk split route (srcfinder_amd/csrc/cnn_share.hip; SURVEY Appendix C's MACs x 2): the
-    # layers through inception3b shrink to the per-window ring -- conv2 at 252 of 4096 positions (0.002 GFLOP), conv3 at 496 (0.110),
-    # inception3a at 295 of 1024 (0.091 of its 0.318), inception3b at 399 (0.271 of 0.694) as fp16 operand-split products, conv1 +
-    # maxpool1 at the border on the fp32 vector units (0.014) -- the phase maps cost ~1e-4 of a window per window; inception4a .. 5b +
-    # head (1.652 GFLOP) run as they are.  Every multiply of the split layers is three fp16 MFMA products.
-    split_gflop = 0.002 + 0.110 + 0.091 + 0.271 + 1.652
+    # Flops one window EXECUTES on the shared-trunk split route (srcfinder_amd/csrc/cnn_share.hip, cnn_ring.h; SURVEY Appendix C's MACs x 2):
+    # the layers through inception3b shrink to the SIDE columns of the per-window ring (band sharing: the top / bottom rows come from
+    # strip maps) -- conv2 at the 252 border positions (0.002 GFLOP), conv3 at 256 of 4096 (0.057), inception3a at 160 of 1024 (0.050 of
+    # its 0.318), inception3b at 224 (0.152 of 0.694) as fp16 operand-split products, the strip maps 0.033 per window at 598 columns
+    # (conv3 on 8 x 16 x 218 positions, inception3a / 3b on 16 x 8 x 108 per image row), conv1 + maxpool1 at the side of the border on the
+    # fp32 vector units (0.007) -- the phase maps cost ~1e-4 of a window per window; inception4a .. 5b + head (1.652 GFLOP) run as they are.
+    # Every multiply of the split layers is three fp16 MFMA products.
+    split_gflop = 0.002 + 0.057 + 0.050 + 0.152 + 0.033 + 1.652
     exec_fp16_tf = ntiles / dt * 3.0 * split_gflop * 1e9 / 1e12
     sec = {"metric": "CNN tiles/s (GoogLeNet, one 256x256 window per pixel)", "value": round(ntiles / dt, 1), "unit": "tiles/s",
            "dtype": "f32 (split-operand: fp16 hi + lo halves, fp32 accumulate)", "data": "synthetic weights (seeded), CMF plane of this run", "tiles": ntiles, "batch": batch,
-           "route": "split, trunk through inception3b shared between the overlapping windows (an argument of the call; per-layer activation scales "
+           "route": "split, trunk through inception3b shared between the overlapping windows -- phase maps + strip maps of the band rows, per window the rings' side columns (an argument of the call; per-layer activation scales "
                     "calibrated on this plane: 2^%d .. 2^%d; one overflow slot per batch, %d of %d batches re-scored on the fp32 matrix cores)"
                     % (int(np.log2(min(scales))), int(np.log2(max(scales))), rescued, (ntiles + batch - 1) // batch),
            "fp32_mfma_route": {"value": round(ntiles / dt_w, 1), "unit": "tiles/s",

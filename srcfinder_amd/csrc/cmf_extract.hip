@@ -449,7 +449,7 @@ __global__ __launch_bounds__(512) void k_mean(const double *__restrict__ sum_par
 // XF_NT = 1024: one 16-wave workgroup per CU (tiles of up to 12 * 1024 floats = 48 KB, 6 (band, column) pairs per thread for the fused
 // sums: p C <= 6144).  (Round 6 measured the other shape -- XF_NT = 512, two 8-wave workgroups per CU on one-line tiles, 11 pairs per
 // thread: 128 registers with 6 spilled, the 75-column shard step 1.53-1.54 ms against 1.48 -- and kept this one.)
-template <int XF_NT, int XF_MAXLD, int XF_MAXSUM>
+template <int XF_NT, int XF_MAXLD, int XF_MAXSUM, bool V4 = false>      // V4: the lines fetched as 16-byte pieces (rows of a multiple of four floats)
 __global__ __launch_bounds__(XF_NT) void k_extract_flat(const float *__restrict__ cube, int L, int B, int C, int b0,
                                                        int p, int PS, int TL, float *__restrict__ xt,
                                                        uint8_t *__restrict__ mask_t, int lines_per_wg,
@@ -458,7 +458,8 @@ __global__ __launch_bounds__(XF_NT) void k_extract_flat(const float *__restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int chunk = blockIdx.x;
   const int rowlen = p * C;
-  int *vf = reinterpret_cast<int *>(tile + (size_t)XF_NT * ((TL * rowlen + XF_NT - 1) / XF_NT));
+  constexpr int XF_ROW = V4 ? 4 * XF_NT : XF_NT;              // floats a whole row of stores covers
+  int *vf = reinterpret_cast<int *>(tile + (size_t)XF_ROW * ((TL * rowlen + XF_ROW - 1) / XF_ROW));
   const int lbeg = chunk * lines_per_wg, lend = min(L, lbeg + lines_per_wg);
   const bool fuse = sum_part != nullptr;
   double sums[XF_MAXSUM];
@@ -467,15 +468,32 @@ __global__ __launch_bounds__(XF_NT) void k_extract_flat(const float *__restrict_
   for (int k = 0; k < XF_MAXSUM; ++k) { sums[k] = 0.0; ccol[k] = (tid + XF_NT * k) % C; }
   int nvalid = 0;
 
-  float v[XF_MAXLD];
+  // V4 (round 6): XF_MAXLD pieces of 16 bytes per thread instead of XF_MAXLD floats -- four times the bytes in flight per load
+  // instruction and four-line tiles (86 KB in flight per CU against 43).  A window row starts on any float, so the pieces are only
+  // 4-byte aligned in global memory (the unaligned-capable global path); in the LDS tile they sit on 16-byte boundaries.
+  typedef float xf_f4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef float xf_f4 __attribute__((ext_vector_type(4)));
+  constexpr int NV = V4 ? 4 : 1;
+  float v[XF_MAXLD * NV];
   auto fetch = [&](int l0) {
     const int nl = min(TL, lend - l0);
+    if constexpr (V4) {
+      const int r4 = rowlen >> 2, n4 = nl * r4;
+#pragma unroll
+      for (int k = 0; k < XF_MAXLD; ++k) {
+        const int idx = min(tid + XF_NT * k, n4 - 1);
+        const int l = (idx >= r4) + (idx >= 2 * r4) + (idx >= 3 * r4);
+        const xf_f4 t = *reinterpret_cast<const xf_f4u *>(cube + ((size_t)(l0 + l) * B + b0) * C + 4 * (idx - l * r4));
+        v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+      }
+    } else {
     const int n = nl * rowlen;
 #pragma unroll
     for (int k = 0; k < XF_MAXLD; ++k) {
       const int idx = min(tid + XF_NT * k, n - 1);            // clamped duplicates are loaded but not stored
       const int l = (idx >= rowlen) + (idx >= 2 * rowlen) + (idx >= 3 * rowlen);
       v[k] = cube[((size_t)(l0 + l) * B + b0) * C + (idx - l * rowlen)];
+    }
     }
   };
   if (lbeg < lend) fetch(lbeg);
@@ -484,10 +502,13 @@ __global__ __launch_bounds__(XF_NT) void k_extract_flat(const float *__restrict_
     const int n = nl * rowlen;
     // whole rows of XF_NT floats (a uniform trip count: per-lane predicates would put every store in its own
     // exec-masked block with a vmcnt(0) wait); the clamped duplicates of the last row land in the slack before vf
-    const int kmax = (n + XF_NT - 1) / XF_NT;
+    const int kmax = ((V4 ? n >> 2 : n) + XF_NT - 1) / XF_NT;
 #pragma unroll
     for (int k = 0; k < XF_MAXLD; ++k)
-      if (k < kmax) tile[tid + XF_NT * k] = v[k];
+      if (k < kmax) {
+        if constexpr (V4) reinterpret_cast<xf_f4 *>(tile)[tid + XF_NT * k] = xf_f4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+        else tile[tid + XF_NT * k] = v[k];
+      }
     for (int i = tid; i < nl * C; i += XF_NT) vf[i] = 1;
     // LDS-only barriers from here on: __syncthreads() would wait for the tile requested next (vmcnt(0))
     xt_lds_barrier();
@@ -582,16 +603,18 @@ int sf_launch_extract(const float *cube, int lines, int bands, int samples, int 
   // a compact narrow cube (a rank's shard): the flat kernel, if a tile of at least one line fits
   if (s0 == 0 && ncols == samples && p <= XT_PBMAX && (size_t)p * ncols <= 1024 * (size_t)6 && ncols <= 256 &&
       sf_tune().extract_variant != 1) {
-    auto flat = [&](auto kern, int NT, int MAXLD) -> int {
+    auto flat = [&](auto kern, int NT, int MAXLD, int threads) -> int {     // (NT: floats a row of stores covers, MAXLD rows per thread)
       int tl = (NT * MAXLD) / (p * ncols);
       if (tl > 4) tl = 4;
       const size_t ldsf = ((size_t)NT * (((size_t)tl * p * ncols + NT - 1) / NT) + (size_t)tl * ncols) * sizeof(float);
       if (int rc = sf_lds_attr(reinterpret_cast<const void *>(kern), ldsf > 64 * 1024 ? ldsf : (size_t)64 * 1024)) return rc;
-      hipLaunchKernelGGL(kern, dim3(nchunk), dim3(NT), ldsf, st, cube, lines, bands, samples, b0, p, PS, tl, xt, mask_t, lpw,
+      hipLaunchKernelGGL(kern, dim3(nchunk), dim3(threads), ldsf, st, cube, lines, bands, samples, b0, p, PS, tl, xt, mask_t, lpw,
                          fuse ? sum_part : nullptr, fuse ? cnt_part : nullptr);
       return 0;
     };
-    const int rc = flat(k_extract_flat<1024, 12, 6>, 1024, 12);
+    // 16-byte pieces where a window row is a whole number of them (p = 72: 5400 floats at 75 columns); knob 6 = 7 keeps the 4-byte form
+    const bool v4 = ((p * ncols) & 3) == 0 && sf_tune().extract_variant != 7;
+    const int rc = v4 ? flat(k_extract_flat<1024, 6, 6, true>, 4096, 6, 1024) : flat(k_extract_flat<1024, 12, 6>, 1024, 12, 1024);
     if (rc) return rc;
     SF_LAUNCH_CHECK("k_extract_flat");
     return 0;

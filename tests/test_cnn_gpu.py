@@ -326,6 +326,27 @@ def test_shared_trunk_rebuilds_its_maps_across_strips_at_flightline_width(net):
     assert float(a[:r0].abs().sum()) == 0.0 and float(a[r1:].abs().sum()) == 0.0
 
 
+def test_band_sharing_equals_the_whole_rings_and_the_unshared_route(net):
+    """Round 6, band sharing: the ring rows that see only a window's top / bottom padding come from strip maps built once per 16 image
+    rows, per window only the side columns are computed (csrc/cnn_ring.h, cnn_driver.hip::build_strips).  Same bits as the rings
+    computed whole (sf_debug_set(16, 3)) and as every window on its own -- across a strip-map boundary (rows 12 .. 20), with batches
+    that straddle image rows, and at a width where one batch spans more image rows than a strip group (21 columns, batch 700)."""
+    import torch
+    from srcfinder_amd import _ffi
+    for (H, W, rows, batch) in ((40, 70, (12, 21), 96), (60, 21, (3, 58), 700)):
+        plane = synthetic_plane(H, W, seed=31 + W)
+        info = {}
+        a = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=batch, rows=rows, route="split", info=info)
+        assert info["shared_batches"] == -(-(rows[1] - rows[0]) * W // batch) and info["rescued_batches"] == 0
+        try:
+            assert _ffi.lib().sf_debug_set(16, 3) == 0
+            whole = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=batch, rows=rows, route="split")
+        finally:
+            _ffi.lib().sf_debug_set(16, 0)
+        own = cnn.predict_flightline(plane, (MEAN, STD), net=net, batch=batch, rows=rows, route="split_unshared")
+        assert torch.equal(a, whole) and torch.equal(a, own), (H, W)
+
+
 def _scaled_family(sd, k):
     """The weight family with every activation of the trunk multiplied by s = 2^k and the same logits: conv1's folded weight and
     every folded bias times s (ReLU and max pooling are positively homogeneous), fc.weight divided by s.  In state_dict terms:

@@ -23,6 +23,10 @@ int main() {
     for (int j = 0; j < n; ++j) { int y, x; sf_frame_position(G, lo, hi, j, y, x); std::printf("P %d %d %d\n", j, y, x); }
     for (int y = 0; y < G; ++y)
       for (int x = 0; x < G; ++x) std::printf("Q %d %d %d\n", y, x, sf_frame_ring(G, lo, hi, y, x) ? sf_frame_index(G, lo, hi, y, x) : -1);
+    // band sharing: the side and the band-interior enumerations
+    for (int j = 0; j < sf_side_count(G, lo, hi); ++j) { int y, x; sf_side_position(G, lo, hi, j, y, x); std::printf("S %d %d %d\n", j, y, x); }
+    for (int j = 0; j < sf_band_count(G, lo, hi); ++j) { int y, x; sf_band_position(G, lo, hi, j, y, x); std::printf("B %d %d %d\n", j, y, x); }
+    std::printf("E\n");
   }
   return 0;
 }
@@ -62,6 +66,18 @@ def test_ring_enumeration_is_a_bijection_onto_the_frame():
         assert sorted(grid[ring].tolist()) == list(range(n))        # every index exactly once
         for j, (y, x) in pos.items():
             assert grid[y, x] == j                                  # position(index(y, x)) == (y, x)
+        # band sharing (round 6): side columns + band interior partition the ring; the side is every row's columns x < lo, x >= G - hi
+        side, band = [], []
+        while lines[i] != "E":
+            tag, j, y, x = lines[i].split()
+            (side if tag == "S" else band).append((int(y), int(x)))
+            i += 1
+        i += 1
+        assert len(side) == G * (lo + hi) and len(band) == (lo + hi) * (G - lo - hi) and len(side) + len(band) == n
+        assert len(set(side)) == len(side) and len(set(band)) == len(band) and not set(side) & set(band)
+        assert all(x < lo or x >= G - hi for _y, x in side)
+        assert all(lo <= x < G - hi and (y < lo or y >= G - hi) for y, x in band)
+        assert all(ring[y, x] for y, x in side + band) if n else True
 
 
 def test_frames_follow_from_the_receptive_fields():

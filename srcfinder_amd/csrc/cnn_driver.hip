@@ -121,7 +121,7 @@ struct Share {
   size_t s_canvas, s_c1, s_p1, s_q2, s_q3, s_x3, s_t2[2], s_t3[2], s_y[2], s_pool;
   size_t total;
 };
-Share share_layout(int batch, int H, int W, int depth) {
+Share share_layout(int batch, int H, int W, int depth, int rows_call = 0) {
   Share S{};
   if (H < 1 || W < 1 || depth < 1) return S;
   const int rows_batch = (batch + W - 1) / W + 1;
@@ -188,6 +188,14 @@ Share share_layout(int batch, int H, int W, int depth) {
     take(S.s_pool, p8 * 256);
   }
   S.total = o;
+  // a call over fewer image rows than a strip serves builds its maps over those rows only (the buffers keep the full strip's offsets:
+  // sf_cnn_score_workspace_bytes does not know the rows)
+  if (rows_call > 0 && rows_call + 8 < strip) {
+    S.rows = rows_call + rows_batch + 8;      // (+ 8: the maps start on an even canvas row, up to 7 image rows above the first)
+    S.Hq = ((((S.rows + 3) >> 2) + 1 + 64 + 4) + 1) & ~1;
+    S.Hc = 4 * S.Hq;
+    S.H8 = S.Hq / 2 - 1;
+  }
   return S;
 }
 
@@ -198,6 +206,7 @@ struct Net {
   int map_r0 = -1, map_r1 = -1, map_Rb = 0;   // image rows the maps in memory serve, their first canvas row
   bool map_ok = false;
   int strip_r0 = -1, strip_nr = 0;              // image rows the strip maps in memory serve
+  int row_end = 0;                              // the call's last image row + 1 (maps and strips are not built past it)
   bool strip_ok = false;
   Blob L; Wino WL; Splits SL; Acts A;
   float *pool1, *conv2, *conv3, *xa, *xb, *t2, *t3, *pooled, *wino, *sscale;
@@ -208,10 +217,11 @@ struct Net {
   hipStream_t st;
 };
 
-Net make_net(const float *blob, int batch, void *workspace, void *stream, int H = 0, int W = 0, int depth = 0) {
+Net make_net(const float *blob, int batch, void *workspace, void *stream, int H = 0, int W = 0, int depth = 0, int r0 = 0, int r1 = 0) {
   Net N{};
   N.blob = blob;
-  N.SH = share_layout(batch, H, W, depth);
+  N.SH = share_layout(batch, H, W, depth, r1 - r0);
+  N.row_end = r1;
   N.L = blob_layout(); N.WL = wino_layout(); N.SL = split_layout(); N.A = acts((size_t)batch);
   float *ws = reinterpret_cast<float *>(workspace);
   N.pool1 = ws; N.conv2 = N.pool1 + N.A.pool1; N.conv3 = N.conv2 + N.A.conv2; N.xa = N.conv3 + N.A.conv3; N.xb = N.xa + N.A.x;
@@ -545,7 +555,8 @@ int build_maps(Net &N, const float *padded, int H, int W, int r0, const float *a
 // synchronises the stream to read the strips' own overflow slot; strip_ok = false: those rows' batches compute their whole rings.
 int build_strips(Net &N, const float *padded, int H, int W, int ra, const float *as) {
   const Share &S = N.SH;
-  const int nr = (H - ra < S.nrows) ? H - ra : S.nrows;
+  const int last = (N.row_end > 0 && N.row_end < H) ? N.row_end : H;
+  const int nr = (last - ra < S.nrows) ? last - ra : S.nrows;
   const int Hp = H + 255, Wp = W + 255, n4 = nr * 8, n8 = nr * 16;
   void *stream = (void *)N.st;
   float *B = N.share;
@@ -675,7 +686,7 @@ int sf_cnn_score_rows(const float *padded, const float *plane, int H, int W, int
     return -4;
   }
   if (info) info[0] = info[1] = 0;          // [0] batches scored again on the fp32 matrix cores, [1] batches that ran on the shared trunk
-  Net N = make_net(blob, batch, workspace, stream, sharing ? H : 0, sharing ? W : 0, route == 0 ? 2 : 1);
+  Net N = make_net(blob, batch, workspace, stream, sharing ? H : 0, sharing ? W : 0, route == 0 ? 2 : 1, r0, r1);
   const long long i0 = (long long)r0 * W, i1 = (long long)r1 * W;
   if (i0 >= i1) return 0;
   int rc = 0;

@@ -407,7 +407,9 @@ int sf_cnn_head(const float *in, int ntiles, int HW, int C, const float *fcw, co
  * slots).  All launches are enqueued on `stream`.
  * route (an ARGUMENT of the call -- nothing process- or thread-wide selects the arithmetic):
  *   0  operand splitting on the fp16 matrix cores (sf_cnn_conv_split: the float32 tolerance class; the product's default) with the
- *      trunk through inception3b SHARED between the overlapping windows (below: sf_cnn_ring_pool1 ...); 5 = shared through conv3
+ *      trunk through inception3b SHARED between the overlapping windows (below: sf_cnn_ring_pool1 ...; since the second half of round 6
+ *      also the ring rows that see only a window's top / bottom padding, from strip maps the call builds per 16 image rows -- the
+ *      side-row forms of the ring kernels are internal, csrc/cnn_internal.h); 5 = shared through conv3
  *      only (round 6's first form); 3 = every window evaluated on its own (round 5's form; bit-identical to the kernels sequenced
  *      one batch at a time).  All three
  *      ends of float16's range are handled inside the call: `scales` = the sf_cnn_num_scales() per-layer activation scales (HOST

@@ -301,56 +301,85 @@ int run_batch(Net &N, const float *padded, const float *plane, int H, int W, lon
     float *B = N.share;
     const int Rb = N.map_Rb, Rb8 = Rb >> 1;
     const int ra = (int)(tile0 / W), rb = (int)((tile0 + n - 1) / W);
+    // BAND SHARING (round 6; cnn_ring.h): with strip maps over the batch's image rows only the SIDE positions of every ring are computed
+    // per window; the band interiors -- the rows that see the window's top / bottom padding only -- are copied from the strips
     const bool band = S.band && S.depth >= 2 && N.strip_ok && N.strip_r0 >= 0 && N.strip_r0 <= ra && rb < N.strip_r0 + N.strip_nr;
-    if (band) {
-      // BAND SHARING (round 6; cnn_ring.h): per window only the SIDE positions of every ring are computed; the band interiors -- the
-      // rows that see the window's top / bottom padding only -- are copied from strip maps built once for the batch's image rows
-      auto copy = [&](size_t strips, int shift, int Hs, int Wm, int G, int lo, int hi, int C, float *ring) {
-        return sfi_cnn_band_copy(B + strips, tile0, n, W, N.strip_r0, N.strip_nr, shift, Hs, Wm, G, lo, hi, C, ring, stream);
-      };
-      if ((rc = sfi_cnn_ring_pool1_side(padded, Hp, Wp, W, tile0, n, W_(N.L.conv1), B_(N.L.conv1), B + S.p1ring, stream))) return rc;
-      if ((rc = copy(S.s_p1, 2, 16, S.Wq, 64, 1, 1, 64, B + S.p1ring))) return rc;
-      if ((rc = sf_cnn_conv_split(B + S.p1ring, 0, 1, 1, n * 252, 64, 64, N.shalf + N.SL.conv2.h, half_lo(N, N.SL.conv2, 64, 1, 64),
-                                  N.sscale + N.SL.conv2.s, B_(N.L.conv2), 64, 1, as[0], B + S.q2.ring, 1, as[1], 64, 0, flag, stream)))
+    auto copy = [&](size_t strips, int shift, int Hs, int Wm, int G, int lo, int hi, int C, float *ring) -> int {
+      return band ? sfi_cnn_band_copy(B + strips, tile0, n, W, N.strip_r0, N.strip_nr, shift, Hs, Wm, G, lo, hi, C, ring, stream) : 0;
+    };
+    // a convolution at the ring (or its side) of the frame (olo, ohi), input gathered from `in`'s maps + ring tensor
+    auto ring_conv = [&](const MapT &in, int in_split, int rb_, int Hm, int Wm, int shift, int G, int ilo, int ihi, int olo, int ohi, int cin,
+                         const Layer &l, const SplitL &sl, int c0, int c1, int c2, int ks, float a_in, float *o0, int ld0, int off0, float *o1,
+                         float *o2, int o12_split, float s1, float s2) -> int {
+      const int cout = c0 + c1 + c2;
+      auto fn = band ? sfi_cnn_conv_side : sf_cnn_conv_ring;
+      return fn(B + in.map, in_split, tile0, n, W, rb_, Hm, Wm, in.ring - in.map, shift, G, ilo, ihi, olo, ohi, cin, N.shalf + sl.h,
+                half_lo(N, sl, cout, ks * ks, cin), N.sscale + sl.s, B_(l), c0, c1, c2, ks, a_in, o0, ld0, off0, o1, c1, 0, o2, c2, 0, o12_split, s1,
+                s2, flag, stream);
+    };
+    // a 3 x 3 pool at the ring (side) positions of (olo, ohi) on Go into the ring tensor `out`
+    auto ring_pool = [&](const MapT &in, int rb_, int Hm, int Wm, int shift, int G, int ilo, int ihi, int C, int stride, int Go, int olo, int ohi,
+                         float *out) -> int {
+      return band ? sfi_cnn_pool_gather_side(B + in.map, tile0, n, W, rb_, Hm, Wm, in.ring - in.map, shift, G, ilo, ihi, C, stride, Go, olo, ohi, out, 1,
+                                             stream)
+                  : sf_cnn_pool_gather(B + in.map, tile0, n, W, rb_, Hm, Wm, in.ring - in.map, shift, G, ilo, ihi, C, stride, Go, olo, ohi, out, stream);
+    };
+    // conv1 + maxpool1 at the border of the 64 x 64 grid, conv2 on it (a plain GEMM over the 252 rows), conv3 at its ring
+    if ((rc = band ? sfi_cnn_ring_pool1_side(padded, Hp, Wp, W, tile0, n, W_(N.L.conv1), B_(N.L.conv1), B + S.p1ring, stream)
+                   : sf_cnn_ring_pool1(padded, Hp, Wp, W, tile0, n, W_(N.L.conv1), B_(N.L.conv1), B + S.p1ring, stream)))
+      return rc;
+    if ((rc = copy(S.s_p1, 2, 16, S.Wq, 64, 1, 1, 64, B + S.p1ring))) return rc;
+    if ((rc = sf_cnn_conv_split(B + S.p1ring, 0, 1, 1, n * 252, 64, 64, N.shalf + N.SL.conv2.h, half_lo(N, N.SL.conv2, 64, 1, 64),
+                                N.sscale + N.SL.conv2.s, B_(N.L.conv2), 64, 1, as[0], B + S.q2.ring, 1, as[1], 64, 0, flag, stream)))
+      return rc;
+    if ((rc = ring_conv(S.q2, 1, Rb, S.Hq, S.Wq, 2, 64, 1, 1, 2, 2, 64, N.L.conv3, N.SL.conv3, 192, 0, 0, 3, as[1], B + S.q3.ring, 192, 0, nullptr,
+                        nullptr, 0, 1.0f, 1.0f)))
+      return rc;
+    if ((rc = copy(S.s_q3, 2, 16, S.Wq, 64, 2, 2, 192, B + S.q3.ring))) return rc;
+    if (S.depth < 2) {
+      if ((rc = sf_cnn_pool_gather(B + S.q3.map, tile0, n, W, Rb, S.Hq, S.Wq, S.q3.ring - S.q3.map, 2, 64, 2, 2, 192, 2, 32, -1, 0, N.xa,
+                                   stream)))
         return rc;
-      if ((rc = sfi_cnn_conv_side(B + S.q2.map, 1, tile0, n, W, Rb, S.Hq, S.Wq, S.q2.ring - S.q2.map, 2, 64, 1, 1, 2, 2, 64,
-                                  N.shalf + N.SL.conv3.h, half_lo(N, N.SL.conv3, 192, 9, 64), N.sscale + N.SL.conv3.s, B_(N.L.conv3), 192, 0, 0,
-                                  3, as[1], B + S.q3.ring, 192, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 1.0f, 1.0f, flag, stream)))
-        return rc;
-      if ((rc = copy(S.s_q3, 2, 16, S.Wq, 64, 2, 2, 192, B + S.q3.ring))) return rc;
-      if ((rc = sfi_cnn_pool_gather_side(B + S.q3.map, tile0, n, W, Rb, S.Hq, S.Wq, S.q3.ring - S.q3.map, 2, 64, 2, 2, 192, 2, 32, F32_PL,
-                                         F32_PH, B + S.x3a.ring, 1, stream)))
-        return rc;
+    } else {
+      // maxpool2 at its ring, inception3a and 3b at theirs, maxpool3 assembling inception4a's input (googlenet1.py:64-68, :184-228)
+      if ((rc = ring_pool(S.q3, Rb, S.Hq, S.Wq, 2, 64, 2, 2, 192, 2, 32, F32_PL, F32_PH, B + S.x3a.ring))) return rc;
       if ((rc = copy(S.s_x3, 3, 8, S.W8, 32, F32_PL, F32_PH, 192, B + S.x3a.ring))) return rc;
       const MapT *xin = &S.x3a;
       int ilo = F32_PL, ihi = F32_PH;
       for (int i = 0; i < 2; ++i) {
         const Incep &s = INC[i];
-        const int cout = s.c1 + s.c3 + s.c5 + s.pp, olo = ilo + 1, ohi = ihi + 1;
+        const int cout = s.c1 + s.c3 + s.c5 + s.pp, olo = ilo + 1, ohi = ihi + 1, nout = sf_frame_count(32, olo, ohi);
         const MapT &t2 = i == 0 ? S.t2a : S.t2b, &t3 = i == 0 ? S.t3a : S.t3b, &yo = i == 0 ? S.y3a : S.y3b;
         const float ax = as[2 + 3 * i], a2 = as[3 + 3 * i], a3 = as[4 + 3 * i];
         float *yr = B + yo.ring;
-        if ((rc = sfi_cnn_conv_side(B + xin->map, 0, tile0, n, W, Rb8, S.H8, S.W8, xin->ring - xin->map, 3, 32, ilo, ihi, olo, ohi, s.cin,
-                                    N.shalf + N.SL.head3[i].h, half_lo(N, N.SL.head3[i], s.c1 + s.c3r + s.c5r, 1, s.cin),
-                                    N.sscale + N.SL.head3[i].s, B_(N.L.head3[i]), s.c1, s.c3r, s.c5r, 1, ax, yr, cout, 0, B + t2.ring,
-                                    s.c3r, 0, B + t3.ring, s.c5r, 0, 1, a2, a3, flag, stream)))
+        // branch1 | 3x3 reduce | "5x5" reduce at the OUTPUT frame's ring positions, the input gathered (ring tensor / maps)
+        if ((rc = ring_conv(*xin, 0, Rb8, S.H8, S.W8, 3, 32, ilo, ihi, olo, ohi, s.cin, N.L.head3[i], N.SL.head3[i], s.c1, s.c3r, s.c5r, 1, ax, yr,
+                            cout, 0, B + t2.ring, B + t3.ring, 1, a2, a3)))
           return rc;
         if ((rc = copy(S.s_t2[i], 3, 8, S.W8, 32, olo, ohi, s.c3r, B + t2.ring))) return rc;
         if ((rc = copy(S.s_t3[i], 3, 8, S.W8, 32, olo, ohi, s.c5r, B + t3.ring))) return rc;
-        if ((rc = sfi_cnn_conv_side(B + t2.map, 1, tile0, n, W, Rb8, S.H8, S.W8, t2.ring - t2.map, 3, 32, olo, ohi, olo, ohi, s.c3r,
-                                    N.shalf + N.SL.b2[i].h, half_lo(N, N.SL.b2[i], s.c3, 9, s.c3r), N.sscale + N.SL.b2[i].s, B_(N.L.b2[i]),
-                                    s.c3, 0, 0, 3, a2, yr, cout, s.c1, nullptr, 0, 0, nullptr, 0, 0, 0, 1.0f, 1.0f, flag, stream)))
+        if ((rc = ring_conv(t2, 1, Rb8, S.H8, S.W8, 3, 32, olo, ohi, olo, ohi, s.c3r, N.L.b2[i], N.SL.b2[i], s.c3, 0, 0, 3, a2, yr, cout, s.c1,
+                            nullptr, nullptr, 0, 1.0f, 1.0f)))
           return rc;
-        if ((rc = sfi_cnn_conv_side(B + t3.map, 1, tile0, n, W, Rb8, S.H8, S.W8, t3.ring - t3.map, 3, 32, olo, ohi, olo, ohi, s.c5r,
-                                    N.shalf + N.SL.b3[i].h, half_lo(N, N.SL.b3[i], s.c5, 9, s.c5r), N.sscale + N.SL.b3[i].s, B_(N.L.b3[i]),
-                                    s.c5, 0, 0, 3, a3, yr, cout, s.c1 + s.c3, nullptr, 0, 0, nullptr, 0, 0, 0, 1.0f, 1.0f, flag, stream)))
+        if ((rc = ring_conv(t3, 1, Rb8, S.H8, S.W8, 3, 32, olo, ohi, olo, ohi, s.c5r, N.L.b3[i], N.SL.b3[i], s.c5, 0, 0, 3, a3, yr, cout,
+                            s.c1 + s.c3, nullptr, nullptr, 0, 1.0f, 1.0f)))
           return rc;
-        if ((rc = sfi_cnn_pool_gather_side(B + xin->map, tile0, n, W, Rb8, S.H8, S.W8, xin->ring - xin->map, 3, 32, ilo, ihi, s.cin, 1, 32, olo,
-                                           ohi, B + S.pring, 2, stream)))
-          return rc;
-        if ((rc = sfi_cnn_conv_rows_side(B + S.pring, n, 32, olo, ohi, s.cin, N.shalf + N.SL.b4[i].h, half_lo(N, N.SL.b4[i], s.pp, 1, s.cin),
-                                         N.sscale + N.SL.b4[i].s, B_(N.L.b4[i]), s.pp, ax, yr, cout, s.c1 + s.c3 + s.c5, flag, stream)))
-          return rc;
+        // branch 4: the 3 x 3 / 1 pool at the ring (side) positions, then its 1 x 1 convolution over those rows
+        if (band) {
+          if ((rc = sfi_cnn_pool_gather_side(B + xin->map, tile0, n, W, Rb8, S.H8, S.W8, xin->ring - xin->map, 3, 32, ilo, ihi, s.cin, 1, 32, olo,
+                                             ohi, B + S.pring, 2, stream)))
+            return rc;
+          if ((rc = sfi_cnn_conv_rows_side(B + S.pring, n, 32, olo, ohi, s.cin, N.shalf + N.SL.b4[i].h, half_lo(N, N.SL.b4[i], s.pp, 1, s.cin),
+                                           N.sscale + N.SL.b4[i].s, B_(N.L.b4[i]), s.pp, ax, yr, cout, s.c1 + s.c3 + s.c5, flag, stream)))
+            return rc;
+        } else {
+          if ((rc = sf_cnn_pool_gather(B + xin->map, tile0, n, W, Rb8, S.H8, S.W8, xin->ring - xin->map, 3, 32, ilo, ihi, s.cin, 1, 32, olo, ohi,
+                                       B + S.pring, stream)))
+            return rc;
+          if ((rc = sf_cnn_conv_split(B + S.pring, 0, 1, 1, n * nout, s.cin, s.cin, N.shalf + N.SL.b4[i].h, half_lo(N, N.SL.b4[i], s.pp, 1, s.cin),
+                                      N.sscale + N.SL.b4[i].s, B_(N.L.b4[i]), s.pp, 1, ax, yr, 0, 1.0f, cout, s.c1 + s.c3 + s.c5, flag, stream)))
+            return rc;
+        }
         if ((rc = copy(S.s_y[i], 3, 8, S.W8, 32, olo, ohi, cout, yr))) return rc;
         xin = &yo;
         ilo = olo;
@@ -361,62 +390,6 @@ int run_batch(Net &N, const float *padded, const float *plane, int H, int W, lon
         return rc;
       first_block = 2;
       hw = 16;
-    } else {
-    if ((rc = sf_cnn_ring_pool1(padded, Hp, Wp, W, tile0, n, W_(N.L.conv1), B_(N.L.conv1), B + S.p1ring, stream))) return rc;
-    if ((rc = sf_cnn_conv_split(B + S.p1ring, 0, 1, 1, n * 252, 64, 64, N.shalf + N.SL.conv2.h, half_lo(N, N.SL.conv2, 64, 1, 64),
-                                N.sscale + N.SL.conv2.s, B_(N.L.conv2), 64, 1, as[0], B + S.q2.ring, 1, as[1], 64, 0, flag, stream)))
-      return rc;
-    if ((rc = sf_cnn_conv_ring(B + S.q2.map, 1, tile0, n, W, Rb, S.Hq, S.Wq, S.q2.ring - S.q2.map, 2, 64, 1, 1, 2, 2, 64,
-                               N.shalf + N.SL.conv3.h, half_lo(N, N.SL.conv3, 192, 9, 64), N.sscale + N.SL.conv3.s, B_(N.L.conv3), 192, 0, 0, 3,
-                               as[1], B + S.q3.ring, 192, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 1.0f, 1.0f, flag, stream)))
-      return rc;
-    if (S.depth < 2) {
-      if ((rc = sf_cnn_pool_gather(B + S.q3.map, tile0, n, W, Rb, S.Hq, S.Wq, S.q3.ring - S.q3.map, 2, 64, 2, 2, 192, 2, 32, -1, 0, N.xa,
-                                   stream)))
-        return rc;
-    } else {
-      // maxpool2 at its ring, inception3a and 3b at theirs, maxpool3 assembling inception4a's input (googlenet1.py:64-68, :184-228)
-      if ((rc = sf_cnn_pool_gather(B + S.q3.map, tile0, n, W, Rb, S.Hq, S.Wq, S.q3.ring - S.q3.map, 2, 64, 2, 2, 192, 2, 32, F32_PL, F32_PH,
-                                   B + S.x3a.ring, stream)))
-        return rc;
-      const MapT *xin = &S.x3a;
-      int ilo = F32_PL, ihi = F32_PH;
-      for (int i = 0; i < 2; ++i) {
-        const Incep &s = INC[i];
-        const int cout = s.c1 + s.c3 + s.c5 + s.pp, olo = ilo + 1, ohi = ihi + 1, nout = sf_frame_count(32, olo, ohi);
-        const MapT &t2 = i == 0 ? S.t2a : S.t2b, &t3 = i == 0 ? S.t3a : S.t3b, &yo = i == 0 ? S.y3a : S.y3b;
-        const float ax = as[2 + 3 * i], a2 = as[3 + 3 * i], a3 = as[4 + 3 * i];
-        float *yr = B + yo.ring;
-        // branch1 | 3x3 reduce | "5x5" reduce at the OUTPUT frame's ring positions, the input gathered (ring tensor / maps)
-        if ((rc = sf_cnn_conv_ring(B + xin->map, 0, tile0, n, W, Rb8, S.H8, S.W8, xin->ring - xin->map, 3, 32, ilo, ihi, olo, ohi, s.cin,
-                                   N.shalf + N.SL.head3[i].h, half_lo(N, N.SL.head3[i], s.c1 + s.c3r + s.c5r, 1, s.cin),
-                                   N.sscale + N.SL.head3[i].s, B_(N.L.head3[i]), s.c1, s.c3r, s.c5r, 1, ax, yr, cout, 0, B + t2.ring,
-                                   s.c3r, 0, B + t3.ring, s.c5r, 0, 1, a2, a3, flag, stream)))
-          return rc;
-        if ((rc = sf_cnn_conv_ring(B + t2.map, 1, tile0, n, W, Rb8, S.H8, S.W8, t2.ring - t2.map, 3, 32, olo, ohi, olo, ohi, s.c3r,
-                                   N.shalf + N.SL.b2[i].h, half_lo(N, N.SL.b2[i], s.c3, 9, s.c3r), N.sscale + N.SL.b2[i].s, B_(N.L.b2[i]),
-                                   s.c3, 0, 0, 3, a2, yr, cout, s.c1, nullptr, 0, 0, nullptr, 0, 0, 0, 1.0f, 1.0f, flag, stream)))
-          return rc;
-        if ((rc = sf_cnn_conv_ring(B + t3.map, 1, tile0, n, W, Rb8, S.H8, S.W8, t3.ring - t3.map, 3, 32, olo, ohi, olo, ohi, s.c5r,
-                                   N.shalf + N.SL.b3[i].h, half_lo(N, N.SL.b3[i], s.c5, 9, s.c5r), N.sscale + N.SL.b3[i].s, B_(N.L.b3[i]),
-                                   s.c5, 0, 0, 3, a3, yr, cout, s.c1 + s.c3, nullptr, 0, 0, nullptr, 0, 0, 0, 1.0f, 1.0f, flag, stream)))
-          return rc;
-        if ((rc = sf_cnn_pool_gather(B + xin->map, tile0, n, W, Rb8, S.H8, S.W8, xin->ring - xin->map, 3, 32, ilo, ihi, s.cin, 1, 32, olo, ohi,
-                                     B + S.pring, stream)))
-          return rc;
-        if ((rc = sf_cnn_conv_split(B + S.pring, 0, 1, 1, n * nout, s.cin, s.cin, N.shalf + N.SL.b4[i].h, half_lo(N, N.SL.b4[i], s.pp, 1, s.cin),
-                                    N.sscale + N.SL.b4[i].s, B_(N.L.b4[i]), s.pp, 1, ax, yr, 0, 1.0f, cout, s.c1 + s.c3 + s.c5, flag, stream)))
-          return rc;
-        xin = &yo;
-        ilo = olo;
-        ihi = ohi;
-      }
-      if ((rc = sf_cnn_pool_gather(B + S.y3b.map, tile0, n, W, Rb8, S.H8, S.W8, S.y3b.ring - S.y3b.map, 3, 32, F3B_L, F3B_H, 480, 2, 16, -1,
-                                   0, N.xa, stream)))
-        return rc;
-      first_block = 2;
-      hw = 16;
-    }
     }
   } else {
   // conv1 + maxpool1 (googlenet1.py:60-61), conv2, conv3, maxpool2 (:62-64)

@@ -413,7 +413,13 @@ int run_batch(Net &N, const float *padded, const float *plane, int H, int W, lon
     const float ax = use_split ? as[2 + 3 * i] : 1.0f, a2 = use_split ? as[3 + 3 * i] : 1.0f, a3 = use_split ? as[4 + 3 * i] : 1.0f;
     if ((rc = peak(x, (size_t)n * hw * hw * cin, 2 + 3 * i))) return rc;
     // branch1 | 3x3 reduce | "5x5" reduce in one GEMM, then the two 3x3 convolutions, the pool branch (:184-228)
-    if (use_split)
+    // inception4e on the split route: maxpool4 (2 x 2 / 2 on 16 x 16, :75) is taken in the four producers' epilogues (round 6: the pool
+    // kernel read 436 MB to write 109) -- the block's output lands as [n][8][8][cout]; sf_debug_set(16, 4) keeps the pool kernel
+    const bool pool4 = use_split && i == 6 && hw == 16 && sf_cnn_pool_conv_split_ok(n, hw, hw, cin, s.pp) && sf_tune().cnn_variant != 4;
+    if (pool4)
+      rc = sfi_cnn_conv_split3_pool2(x, n, cin, cin, N.shalf + N.SL.head3[i].h, half_lo(N, N.SL.head3[i], s.c1 + s.c3r + s.c5r, 1, cin),
+                                     N.sscale + N.SL.head3[i].s, B_(N.L.head3[i]), s.c1, s.c3r, s.c5r, ax, y, cout, 0, N.t2, N.t3, a2, a3, flag, stream);
+    else if (use_split)
       rc = sf_cnn_conv_split3_split(x, n, hw, hw, cin, cin, N.shalf + N.SL.head3[i].h, half_lo(N, N.SL.head3[i], s.c1 + s.c3r + s.c5r, 1, cin),
                                     N.sscale + N.SL.head3[i].s, B_(N.L.head3[i]), s.c1, s.c3r, s.c5r, ax, y, cout, 0, N.t2, s.c3r, 0, N.t3,
                                     s.c5r, 0, 1, a2, a3, flag, stream);
@@ -423,6 +429,21 @@ int run_batch(Net &N, const float *padded, const float *plane, int H, int W, lon
     if (rc) return rc;
     if ((rc = peak(N.t2, (size_t)n * hw * hw * s.c3r, 3 + 3 * i))) return rc;
     if ((rc = peak(N.t3, (size_t)n * hw * hw * s.c5r, 4 + 3 * i))) return rc;
+    if (pool4) {
+      if ((rc = sfi_cnn_conv_split_pool2(N.t2, 1, n, s.c3r, s.c3r, N.shalf + N.SL.b2[i].h, half_lo(N, N.SL.b2[i], s.c3, 9, s.c3r),
+                                         N.sscale + N.SL.b2[i].s, B_(N.L.b2[i]), s.c3, 3, a2, y, cout, s.c1, flag, stream)))
+        return rc;
+      if ((rc = sfi_cnn_conv_split_pool2(N.t3, 1, n, s.c5r, s.c5r, N.shalf + N.SL.b3[i].h, half_lo(N, N.SL.b3[i], s.c5, 9, s.c5r),
+                                         N.sscale + N.SL.b3[i].s, B_(N.L.b3[i]), s.c5, 3, a3, y, cout, s.c1 + s.c3, flag, stream)))
+        return rc;
+      if ((rc = sfi_cnn_pool_conv_split_pool2(x, n, cin, N.shalf + N.SL.b4[i].h, half_lo(N, N.SL.b4[i], s.pp, 1, cin), N.sscale + N.SL.b4[i].s,
+                                              B_(N.L.b4[i]), s.pp, ax, y, cout, s.c1 + s.c3 + s.c5, flag, stream)))
+        return rc;
+      float *t = x; x = y; y = t;
+      cin = cout;
+      hw = pool_out(hw, 2, 2, 0);
+      continue;
+    }
     if ((rc = conv3x3(N.t2, hw, s.c3r, N.L.b2[i], N.WL.b2[i], N.SL.b2[i], s.c3, a2, y, cout, s.c1))) return rc;
     if ((rc = conv3x3(N.t3, hw, s.c5r, N.L.b3[i], N.WL.b3[i], N.SL.b3[i], s.c5, a3, y, cout, s.c1 + s.c3))) return rc;
     if (use_split && sf_cnn_pool_conv_split_ok(n, hw, hw, cin, s.pp))

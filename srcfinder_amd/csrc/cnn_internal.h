@@ -30,3 +30,14 @@ int sfi_cnn_band_copy(const float *strips, long long tile0, int N, int W, int ro
                       int C, float *ring, void *stream);
 // canvas[(ri * 2 + bottom) * 4 + phase][64][Wc] = the top / bottom 64 pixel rows of the windows of image row row0 + ri, from column `phase` on
 int sfi_cnn_strip_canvas(const float *padded, int Hp, int Wp, int row0, int nrows, int Wc, float *canvas, void *stream);
+
+// inception4e with maxpool4 (googlenet1.py:75: 2 x 2 stride 2 on the 16 x 16 grid) taken in the convolutions' epilogues: the float32
+// outputs land pooled, [window][8][8][ld] -- sf_cnn_conv_split / sf_cnn_conv_split3_split (its first segment; the reducers' split-format
+// outputs stay on the 16 x 16 grid) / sf_cnn_pool_conv_split with H = W = 16.  Same bits as pooling afterwards (monotone epilogue).
+int sfi_cnn_conv_split_pool2(const float *in, int in_split, int N, int Cin, int ld_in, const void *whi, const void *wlo, const float *wscale,
+                             const float *bias, int Cout, int ksize, float ascale, float *out, int ld_out, int ch_off, int *overflow, void *stream);
+int sfi_cnn_conv_split3_pool2(const float *in, int N, int Cin, int ld_in, const void *whi, const void *wlo, const float *wscale, const float *bias,
+                              int c0, int c1, int c2, float ascale, float *out0, int ld0, int off0, float *out1, float *out2, float oscale1,
+                              float oscale2, int *overflow, void *stream);
+int sfi_cnn_pool_conv_split_pool2(const float *in, int N, int Cin, const void *whi, const void *wlo, const float *wscale, const float *bias, int Cout,
+                                  float ascale, float *out, int ld_out, int ch_off, int *overflow, void *stream);

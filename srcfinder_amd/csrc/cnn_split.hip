@@ -36,7 +36,8 @@ constexpr int SP_LD = 40;   // halves per LDS row (32 + 8 pad = 80 bytes)
 struct ConvDstS {
   float *p[3];
   int ld[3], off[3], end[3];
-  int fmt[3];      // 0: float32 [pixel][channel]; 1: the split format below (dense tensors: ld == the segment's channels, off == 0)
+  int fmt[3];      // 0: float32 [pixel][channel]; 1: the split format below (dense tensors: ld == the segment's channels, off == 0);
+                   // 2: float32, the 2 x 2 / 2 max pool of the 16 x 16 grid taken in the epilogue -- [window][8][8][channel] (maxpool4)
   float oscale[3]; // split-format segments: the power of two their CONSUMER expects (its ascale), applied before the split
 };
 // The SPLIT FORMAT of an activation tensor [M][C], C a multiple of 8: per pixel and 8-channel group 16 halves -- the eight high halves,
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
       const int cbase = (sg == 0) ? 0 : dst.end[sg - 1];
       float *op = dst.p[sg] + dst.off[sg] + (co - cbase);
       const int ld = dst.ld[sg];
-      if (dst.fmt[sg]) {      // split format: halves (m 2 ld + 16 (c / 8) + c % 8) and + 8
+      if (dst.fmt[sg] == 1) {      // split format: halves (m 2 ld + 16 (c / 8) + c % 8) and + 8
         const int cl = co - cbase;
         _Float16 *hp = reinterpret_cast<_Float16 *>(dst.p[sg]) + 16 * (cl >> 3) + (cl & 7);
         const float os = dst.oscale[sg];
@@ -302,6 +303,25 @@ __global__ __launch_bounds__(256, (BN == 64 && BMT == 128) ? 4 : (((BN == 128 &&
               hp[om * 2 * ld + 8] = (_Float16)(v - (float)h);
             }
           }
+      } else if (dst.fmt[sg] == 2) {
+        // maxpool4 (googlenet1.py:75: 2 x 2 stride 2 on 16 x 16) in registers: a 32-row block of the tile is two rows of one window's grid
+        // (row = x + 16 dy) and a lane holds, for px = a + 4 b + 2 (lane >> 5), all four of r = (2 a + e) + 4 (b + 2 dy).  Bias, scale (> 0)
+        // and ReLU are monotone: applied to the largest accumulator they give the largest output -- the bits of pooling afterwards.
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mb = m0 + 32 * (TM * wm + i);
+          if (mb < M) {
+            const size_t prow = (size_t)(mb >> 8) * 64 + (size_t)((mb >> 5) & 7) * 8 + 2 * (lane >> 5);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) {
+                const float v = fmaxf(fmaxf(acc[i][j][2 * a + 4 * b], acc[i][j][2 * a + 1 + 4 * b]),
+                                      fmaxf(acc[i][j][2 * a + 4 * (b + 2)], acc[i][j][2 * a + 1 + 4 * (b + 2)]));
+                op[(prow + a + 4 * b) * ld] = fmaxf(__builtin_fmaf(v, sc, bb), 0.f);
+              }
+          }
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -357,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restri
                                                            const _Float16 *__restrict__ whi, const _Float16 *__restrict__ wlo,
                                                            const float *__restrict__ wscale, const float *__restrict__ bias, int Cout,
                                                            float ascale, float *__restrict__ out, int ld_out, int ch_off,
-                                                           int *__restrict__ overflow) {
+                                                           int *__restrict__ overflow, int pool2) {
   constexpr int BM = 128, BK = 32, KQ = BK / 4;
   constexpr int WN = (BN >= 128) ? 2 : 1, WM = 4 / WN, TM = BM / (32 * WM), TN = BN / (32 * WN), NPB = BN / 64;
   constexpr int RMAX = BM + 2 * 32;                         // raw pixels at W = 32
@@ -510,6 +530,23 @@ __global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restri
     if (co < Cout) {
       const float bb = bias[co], sc = wscale[co] * (1.0f / ascale);
       float *op = out + ch_off + co;
+      if (pool2) {      // maxpool4 in registers (k_conv_split's fmt 2: 16 x 16 grids)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mb = m0 + 32 * (TM * wm + i);
+          if (mb < M) {
+            const size_t prow = (size_t)(mb >> 8) * 64 + (size_t)((mb >> 5) & 7) * 8 + 2 * (lane >> 5);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) {
+                const float v = fmaxf(fmaxf(acc[i][j][2 * a + 4 * b], acc[i][j][2 * a + 1 + 4 * b]),
+                                      fmaxf(acc[i][j][2 * a + 4 * (b + 2)], acc[i][j][2 * a + 1 + 4 * (b + 2)]));
+                op[(prow + a + 4 * b) * ld_out] = fmaxf(__builtin_fmaf(v, sc, bb), 0.f);
+              }
+          }
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -517,6 +554,7 @@ __global__ __launch_bounds__(256, 2) void k_poolconv_split(const float *__restri
           const int m = m0 + 32 * (TM * wm + i) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (m < M) op[(size_t)m * ld_out] = fmaxf(__builtin_fmaf(acc[i][j][r], sc, bb), 0.f);
         }
+      }
     }
   }
   if (!(big < 65504.f)) *overflow = 1;
@@ -611,9 +649,10 @@ static int split_go(const float *in, int in_split, int N, int H, int W, int Cin,
 
 static bool sp_pow2(float v) { int e; return v > 0.f && v < 3.0e38f && frexpf(v, &e) == 0.5f; }
 
-int sf_cnn_conv_split(const float *in, int in_split, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
+static int conv_split_go(const float *in, int in_split, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
                       const float *wscale, const float *bias, int Cout, int ksize, float ascale, float *out, int out_split, float oscale,
-                      int ld_out, int ch_off, int *overflow, void *stream) {
+                      int ld_out, int ch_off, int *overflow, void *stream, int pool2) {
+  if (pool2 && (out_split || H != 16 || W != 16)) { sf_set_error("sf_cnn_conv_split: the pooled epilogue takes float32 16 x 16 grids"); return -1; }
   if (!in || !whi || !wlo || !wscale || !bias || !out || !overflow || N < 1 || (ksize != 1 && ksize != 3) || (Cin & 7) || (ld_in & 3) ||
       Cin > ld_in || ch_off < 0 || ch_off + Cout > ld_out || !sp_pow2(ascale) || (in_split && ld_in != Cin) ||
       (out_split && (ld_out != Cout || ch_off != 0 || (Cout & 7) || !sp_pow2(oscale)))) {
@@ -626,15 +665,22 @@ int sf_cnn_conv_split(const float *in, int in_split, int N, int H, int W, int Ci
   d.ld[0] = d.ld[1] = d.ld[2] = ld_out;
   d.off[0] = d.off[1] = d.off[2] = ch_off;
   d.end[0] = d.end[1] = d.end[2] = Cout;
-  d.fmt[0] = d.fmt[1] = d.fmt[2] = out_split ? 1 : 0;
+  d.fmt[0] = d.fmt[1] = d.fmt[2] = out_split ? 1 : (pool2 ? 2 : 0);
   d.oscale[0] = d.oscale[1] = d.oscale[2] = out_split ? oscale : 1.0f;
   return split_go(in, in_split, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, d, overflow, (hipStream_t)stream);
 }
+int sf_cnn_conv_split(const float *in, int in_split, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
+                      const float *wscale, const float *bias, int Cout, int ksize, float ascale, float *out, int out_split, float oscale,
+                      int ld_out, int ch_off, int *overflow, void *stream) {
+  return conv_split_go(in, in_split, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, out, out_split, oscale, ld_out, ch_off,
+                       overflow, stream, 0);
+}
 
-int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
+static int conv_split3_go(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
                              const float *wscale, const float *bias, int c0, int c1, int c2, float ascale, float *out0, int ld0,
                              int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, int out12_split, float oscale1,
-                             float oscale2, int *overflow, void *stream) {
+                             float oscale2, int *overflow, void *stream, int pool2) {
+  if (pool2 && (H != 16 || W != 16)) { sf_set_error("sf_cnn_conv_split3_split: the pooled epilogue takes 16 x 16 grids"); return -1; }
   if (!in || !whi || !wlo || !wscale || !bias || !out0 || !out1 || !out2 || !overflow || N < 1 || (Cin & 7) || (ld_in & 3) || Cin > ld_in ||
       c0 < 1 || c1 < 1 || c2 < 1 || off0 + c0 > ld0 || off1 + c1 > ld1 || off2 + c2 > ld2 || !sp_pow2(ascale) ||
       (out12_split && (ld1 != c1 || off1 != 0 || (c1 & 7) || ld2 != c2 || off2 != 0 || (c2 & 7) || !sp_pow2(oscale1) || !sp_pow2(oscale2)))) {
@@ -646,9 +692,16 @@ int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int 
   d.ld[0] = ld0; d.ld[1] = ld1; d.ld[2] = ld2;
   d.off[0] = off0; d.off[1] = off1; d.off[2] = off2;
   d.end[0] = c0; d.end[1] = c0 + c1; d.end[2] = c0 + c1 + c2;
-  d.fmt[0] = 0; d.fmt[1] = d.fmt[2] = out12_split ? 1 : 0;
+  d.fmt[0] = pool2 ? 2 : 0; d.fmt[1] = d.fmt[2] = out12_split ? 1 : 0;
   d.oscale[0] = 1.0f; d.oscale[1] = out12_split ? oscale1 : 1.0f; d.oscale[2] = out12_split ? oscale2 : 1.0f;
   return split_go(in, 0, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, c0 + c1 + c2, 1, ascale, d, overflow, (hipStream_t)stream);
+}
+int sf_cnn_conv_split3_split(const float *in, int N, int H, int W, int Cin, int ld_in, const void *whi, const void *wlo,
+                             const float *wscale, const float *bias, int c0, int c1, int c2, float ascale, float *out0, int ld0,
+                             int off0, float *out1, int ld1, int off1, float *out2, int ld2, int off2, int out12_split, float oscale1,
+                             float oscale2, int *overflow, void *stream) {
+  return conv_split3_go(in, N, H, W, Cin, ld_in, whi, wlo, wscale, bias, c0, c1, c2, ascale, out0, ld0, off0, out1, ld1, off1, out2, ld2, off2,
+                        out12_split, oscale1, oscale2, overflow, stream, 0);
 }
 
 // A convolution (1 x 1 or 3 x 3) at the ring positions of the frame (olo, ohi) of every window of a batch, its input gathered from the
@@ -720,8 +773,9 @@ int sf_cnn_pool_conv_split_ok(int N, int H, int W, int Cin, int Cout) {
   return (W >= 1 && W <= 32 && 128 % W == 0 && (Cin & 7) == 0 && (size_t)N * H * W * Cin * 4 < 0x7ff00000u &&
           (size_t)Cout * Cin * 2 < 0x7ff00000u) ? 1 : 0;
 }
-int sf_cnn_pool_conv_split(const float *in, int N, int H, int W, int Cin, const void *whi, const void *wlo, const float *wscale,
-                           const float *bias, int Cout, float ascale, float *out, int ld_out, int ch_off, int *overflow, void *stream) {
+static int pool_conv_go(const float *in, int N, int H, int W, int Cin, const void *whi, const void *wlo, const float *wscale,
+                           const float *bias, int Cout, float ascale, float *out, int ld_out, int ch_off, int *overflow, void *stream, int pool2) {
+  if (pool2 && (H != 16 || W != 16)) { sf_set_error("sf_cnn_pool_conv_split: the pooled epilogue takes 16 x 16 grids"); return -1; }
   if (!in || !whi || !wlo || !wscale || !bias || !out || !overflow || N < 1 || ch_off < 0 || ch_off + Cout > ld_out || !sp_pow2(ascale) ||
       !sf_cnn_pool_conv_split_ok(N, H, W, Cin, Cout)) {
     sf_set_error("sf_cnn_pool_conv_split: bad argument (dense input, W dividing 128, Cin multiple of 8, operands < 2 GB, ascale a power of two)");
@@ -731,12 +785,16 @@ int sf_cnn_pool_conv_split(const float *in, int N, int H, int W, int Cin, const 
   const _Float16 *h = reinterpret_cast<const _Float16 *>(whi), *l = reinterpret_cast<const _Float16 *>(wlo);
   if (Cout > 64)
     hipLaunchKernelGGL((k_poolconv_split<128>), dim3(sf_cdiv(M, 128), sf_cdiv(Cout, 128)), dim3(256), 0, (hipStream_t)stream, in, M, H, W,
-                       Cin, h, l, wscale, bias, Cout, ascale, out, ld_out, ch_off, overflow);
+                       Cin, h, l, wscale, bias, Cout, ascale, out, ld_out, ch_off, overflow, pool2);
   else
     hipLaunchKernelGGL((k_poolconv_split<64>), dim3(sf_cdiv(M, 128), sf_cdiv(Cout, 64)), dim3(256), 0, (hipStream_t)stream, in, M, H, W,
-                       Cin, h, l, wscale, bias, Cout, ascale, out, ld_out, ch_off, overflow);
+                       Cin, h, l, wscale, bias, Cout, ascale, out, ld_out, ch_off, overflow, pool2);
   SF_LAUNCH_CHECK("k_poolconv_split");
   return 0;
+}
+int sf_cnn_pool_conv_split(const float *in, int N, int H, int W, int Cin, const void *whi, const void *wlo, const float *wscale,
+                           const float *bias, int Cout, float ascale, float *out, int ld_out, int ch_off, int *overflow, void *stream) {
+  return pool_conv_go(in, N, H, W, Cin, whi, wlo, wscale, bias, Cout, ascale, out, ld_out, ch_off, overflow, stream, 0);
 }
 
 int sf_cnn_absmax(const float *x, size_t n, float *amax, void *stream) {
@@ -775,5 +833,22 @@ int sfi_cnn_conv_rows_side(const float *in, int N, int G, int olo, int ohi, int 
   RingArgs rows{};
   rows.in.G = G; rows.olo = olo; rows.ohi = ohi; rows.nout = sf_side_count(G, olo, ohi); rows.nfull = sf_frame_count(G, olo, ohi); rows.side = 1;
   return split_go(in, 0, 1, 1, N * rows.nout, Cin, Cin, whi, wlo, wscale, bias, Cout, 1, ascale, d, overflow, (hipStream_t)stream, rows);
+}
+
+// the block in front of maxpool4 (inception4e) with the pool taken in the epilogues: the float32 outputs land as [window][8][8][ld]
+int sfi_cnn_conv_split_pool2(const float *in, int in_split, int N, int Cin, int ld_in, const void *whi, const void *wlo, const float *wscale,
+                             const float *bias, int Cout, int ksize, float ascale, float *out, int ld_out, int ch_off, int *overflow, void *stream) {
+  return conv_split_go(in, in_split, N, 16, 16, Cin, ld_in, whi, wlo, wscale, bias, Cout, ksize, ascale, out, 0, 1.0f, ld_out, ch_off, overflow,
+                       stream, 1);
+}
+int sfi_cnn_conv_split3_pool2(const float *in, int N, int Cin, int ld_in, const void *whi, const void *wlo, const float *wscale, const float *bias,
+                              int c0, int c1, int c2, float ascale, float *out0, int ld0, int off0, float *out1, float *out2, float oscale1,
+                              float oscale2, int *overflow, void *stream) {
+  return conv_split3_go(in, N, 16, 16, Cin, ld_in, whi, wlo, wscale, bias, c0, c1, c2, ascale, out0, ld0, off0, out1, c1, 0, out2, c2, 0, 1, oscale1,
+                        oscale2, overflow, stream, 1);
+}
+int sfi_cnn_pool_conv_split_pool2(const float *in, int N, int Cin, const void *whi, const void *wlo, const float *wscale, const float *bias, int Cout,
+                                  float ascale, float *out, int ld_out, int ch_off, int *overflow, void *stream) {
+  return pool_conv_go(in, N, 16, 16, Cin, whi, wlo, wscale, bias, Cout, ascale, out, ld_out, ch_off, overflow, stream, 1);
 }
 

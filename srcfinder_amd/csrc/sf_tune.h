@@ -21,7 +21,7 @@ struct SfTune {
   int wsweep_variant = 0;     // key 24: the fused wide sweep: 0 = k_wsweep8 (eight waves, wave-private operand slices) where it applies; 1 = 32-row tiles, two workgroups per CU; 2 = eight waves on shared chunks; 4 = four waves on shared chunks (round 4's first form)
   int cnn_pool_variant = 0;   // key 18: inception branch 4: 0 = pool taken from the tile staged in LDS (k_poolconv), 3 = pool kernel then convolution, 2 = the same with the general pool kernel, 1 = pool inside the 1x1 convolution's tile fetch (nine reads; slower)
   int cnn_conv_variant = 0;   // key 17: the DEFAULT route of srcfinder_amd.cnn when a call passes none (tools' A/B runs; the product passes its route as an argument -- sf_cnn_score_rows(route), forward_tiles(route=) -- and the overflow rescue never touches this knob): 0 = operand splitting on the fp16 matrix cores (cnn_split.hip; default), 4 = Winograd F(2x2, 3x3) for the 3 x 3 layers + the fp32 implicit GEMM (cnn_wino.hip / cnn_kernels.hip), 2 = the direct fp32 implicit GEMM for everything, 1 = its pointer-form tile loads (the form operands of 2 GB or more take)
-  int cnn_variant = 0;        // key 16: 1 = the 8 x 8 conv1+pool kernel (cnn_kernels.hip); 2 = k_conv_split never takes 160-channel tiles (round 5's choice); 3 = no band sharing in sf_cnn_score_rows (the rings computed whole per window: round 6's first form)
+  int cnn_variant = 0;        // key 16: 1 = the 8 x 8 conv1+pool kernel (cnn_kernels.hip); 4 = maxpool4 as its own kernel (default on the split route: in inception4e's epilogues); 2 = k_conv_split never takes 160-channel tiles (round 5's choice); 3 = no band sharing in sf_cnn_score_rows (the rings computed whole per window: round 6's first form)
   int det_variant = 0;        // key 15: 1 = the plain window rule of the exact-determinant pass in one round, 2 = no pass in sf_cmf_run's narrow branch
   int det_slots = 0;          // key 26: workgroups (work matrices) of a launch of the exact-determinant pass; 0 = as many as fit (512)
   int lu_variant = 0;         // key 14: 1 = the unblocked LU in the determinant passes (linalg.hip)

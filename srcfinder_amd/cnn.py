@@ -486,23 +486,84 @@ def _overflow_warning(what):
                   "the fp32 matrix cores" % what)
 
 
-def _score_rows_c(net, ds, r0, r1, batch, out, code):
-    """sf_cnn_score_rows on image rows [r0, r1) with the network's current activation scales; returns the batches re-scored."""
+def _score_rows_one(net, ds, r0, r1, batch, out, code, ws_key="c_driver_ws"):
+    """ONE sf_cnn_score_rows call on image rows [r0, r1) on the calling thread's current stream; returns (re-scored, shared) batches."""
     torch = _torch()
     L = _ffi.lib()
     H, W = ds.inshape[1], ds.inshape[2]
     with torch.cuda.device(net.device):
         wsb = L.sf_cnn_score_workspace_bytes(int(batch), H if code in (0, 5) else 0, W if code in (0, 5) else 0)
-        ws = net._buf("c_driver_ws", ((wsb + 3) // 4,))
+        ws = net._buf(ws_key, ((wsb + 3) // 4,))
         nres = (C.c_int * 2)(0, 0)
         sc = (C.c_float * len(net.ascale))(*net.ascale)
         _ffi.check(L.sf_cnn_score_rows(_ffi.ptr(ds.x), _ffi.ptr(ds.plane), H, W, int(r0), int(r1), _ffi.ptr(net.packed_blob()),
                                        _ffi.ptr(out), int(batch), code, sc, nres, _ffi.ptr(ws),
                                        C.c_size_t(ws.numel() * 4), _ffi.stream_ptr()), "sf_cnn_score_rows")
-    net.last_shared_batches = int(nres[1])       # (batches of the call that ran on the shared trunk)
+    return int(nres[0]), int(nres[1])
+
+
+# Two halves of a row range in flight on two HIP streams of the device (round 6): a batch is ~60 launches, many of them far smaller than
+# the chip (the 8 x 8 layers, the ring kernels' side rows, the copies) -- a second batch fills their tails: 102 -> 108 k windows/s at
+# batch 1024, 97 -> 105 k at 512.  Row ranges are independent (own workspace, own phase / strip maps, own overflow slots): the same bits.
+LANES = 2
+
+
+def _score_rows_c(net, ds, r0, r1, batch, out, code, lanes=None):
+    """sf_cnn_score_rows on image rows [r0, r1) with the network's current activation scales; returns the batches re-scored.
+    ``lanes`` (default LANES): contiguous parts of the range scored concurrently from host threads, one HIP stream and one workspace
+    each, when every part has at least four batches."""
+    torch = _torch()
+    W = ds.inshape[2]
+    lanes = LANES if lanes is None else int(lanes)
+    lanes = max(1, min(lanes, ((r1 - r0) * W) // (4 * int(batch))))
+    net.last_batches = -(-(r1 - r0) * W // int(batch))         # batches the call launches (every lane's last one may be short)
+    if lanes == 1 or code not in (0, 3, 5):
+        nres = _score_rows_one(net, ds, r0, r1, batch, out, code)
+    else:
+        import threading
+        L = _ffi.lib()
+        knobs = {}
+        for key in (16, 17, 18):                                # the library's tuning knobs are per calling thread
+            v = C.c_int(0)
+            _ffi.check(L.sf_debug_get(key, C.byref(v)), "sf_debug_get")
+            knobs[key] = v.value
+        with torch.cuda.device(net.device):
+            cur = torch.cuda.current_stream()
+            if getattr(net, "_lane_streams", None) is None or len(net._lane_streams) < lanes:
+                net._lane_streams = [torch.cuda.Stream(device=net.device) for _ in range(lanes)]
+            net.packed_blob()                                    # (built once, here, not by two threads at a time)
+        cuts = [r0 + (r1 - r0) * i // lanes for i in range(lanes + 1)]
+        net.last_batches = sum(-(-(cuts[i + 1] - cuts[i]) * W // int(batch)) for i in range(lanes))
+        res, errs = [None] * lanes, [None] * lanes
+
+        def work(i):
+            try:
+                for key, v in knobs.items():
+                    L.sf_debug_set(key, v)
+                with torch.cuda.device(net.device):
+                    s = net._lane_streams[i]
+                    s.wait_stream(cur)                           # the plane and the weights were produced on the caller's stream
+                    with torch.cuda.stream(s):
+                        res[i] = _score_rows_one(net, ds, cuts[i], cuts[i + 1], batch, out, code, ws_key="c_driver_ws_lane%d" % i)
+            except Exception as e:                               # surfaced in the caller's thread
+                errs[i] = e
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(lanes)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+        with torch.cuda.device(net.device):
+            for s in net._lane_streams[:lanes]:
+                cur.wait_stream(s)
+        nres = (sum(r[0] for r in res), sum(r[1] for r in res))
+    net.last_shared_batches = nres[1]            # (batches of the call that ran on the shared trunk)
     if nres[0]:
         _overflow_warning("%d batch(es) of rows %d..%d" % (nres[0], r0, r1))
-    return int(nres[0])
+    return nres[0]
 
 
 def score_tiles(net, ds, t_first, t_last, batch, out, route=None):
@@ -528,7 +589,7 @@ def score_tiles(net, ds, t_first, t_last, batch, out, route=None):
 
 
 def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=None, rows=None, net=None, to_numpy=False,
-                       precision="fp32", route=None, info=None, scales=None):
+                       precision="fp32", route=None, info=None, scales=None, lanes=None):
     """saliency[H, W] float32 = softmax(GoogLeNet(window))[:, 1] for the 256x256 window centred on every pixel,
     -9999 where ``cmf2d`` is -9999 (cnn_pred_pipeline.py:159-189).
 
@@ -551,7 +612,11 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
               threads / streams / GPUs cannot disturb each other.
     scales  : split route only: the per-layer activation scales (``sf_cnn_num_scales()`` powers of two) instead of the
               calibration on this plane (a campaign that wants ONE set of scales for all its flightlines; the tests)
-    info    : optional dict; receives ``rescued_batches``, ``shared_batches``, ``route`` and the ``scales`` used
+    lanes   : concurrent parts of the row range on one device (default 2: two host threads, two HIP streams, two workspaces -- a
+              second batch in flight fills the tails of the first one's small launches, +5-7 %; 1: one stream).  The map does not depend
+              on it unless a batch overflows float16: the re-scored batches are then cut at other windows
+    info    : optional dict; receives ``rescued_batches``, ``shared_batches``, ``batches`` (launched by the C driver: the row range is
+              scored as two concurrent halves on two streams when it is long enough), ``route`` and the ``scales`` used
     """
     torch = _torch()
     if gpus is not None and len(gpus) > 0:
@@ -563,7 +628,7 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
         if len(gpus) > 1:
             if net is not None or rows is not None:
                 raise ValueError("gpus=[...] builds one network per device: do not pass net= or rows=")
-            return _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision, route, info, scales)
+            return _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision, route, info, scales, lanes)
         if net is None:
             if weights is None:
                 raise ValueError("weights (a GoogLeNet state_dict) are required")
@@ -589,17 +654,18 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
     if not net.half and getattr(net, "c_driver", True):
         # the C-side driver sequences the whole graph for the row range: one library call (shared trunk, per-batch overflow slots
         # and the fp32 re-scoring of raised batches included)
-        rescued = _score_rows_c(net, ds, r0, r1, batch, out, code) if r1 > r0 else 0
+        rescued = _score_rows_c(net, ds, r0, r1, batch, out, code, lanes) if r1 > r0 else 0
     else:
         rescued = score_tiles(net, ds, r0 * W, r1 * W, batch, out, route=code)
     if info is not None:
         info.update(rescued_batches=rescued, route=code, scales=list(net.ascale) if code in (0, 3, 5) else None,
-                    shared_batches=getattr(net, "last_shared_batches", 0) if code in (0, 5) else 0)
+                    shared_batches=getattr(net, "last_shared_batches", 0) if code in (0, 5) else 0,
+                    batches=getattr(net, "last_batches", None))
     out = out.view(H, W)
     return out.cpu().numpy() if to_numpy else out
 
 
-def _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision, route=None, info=None, scales=None):
+def _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision, route=None, info=None, scales=None, lanes=None):
     """Row blocks of the saliency map on several GPUs of one process (one host thread per device)."""
     import threading
     torch = _torch()
@@ -628,7 +694,8 @@ def _predict_multi_gpu(cmf2d, model, weights, batch, gpus, to_numpy, precision, 
             with torch.cuda.device(dev):
                 net = GoogLeNetHIP(weights, device=dev, precision=precision)
                 r0, r1 = i * H // n, (i + 1) * H // n
-                sal = predict_flightline(plane, model, net=net, batch=batch, rows=(r0, r1), route=route, info=infos[i], scales=scales)
+                sal = predict_flightline(plane, model, net=net, batch=batch, rows=(r0, r1), route=route, info=infos[i], scales=scales,
+                                         lanes=lanes)
                 parts[i] = sal[r0:r1].to(torch.device("cuda", gpus[0]), non_blocking=False)
         except Exception as e:                                  # surfaced in the caller's thread
             errs[i] = e

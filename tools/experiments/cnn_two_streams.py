@@ -8,7 +8,7 @@ import torch
 from srcfinder_amd import cnn
 from srcfinder_amd.cnn_weights import synthetic_plane, synthetic_state_dict
 
-W, rows, batch = 598, 112, int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+W, rows, batch = 598, 224, int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 sd = synthetic_state_dict(2024)
 plane = synthetic_plane(rows, W, seed=5)
 nets = [cnn.GoogLeNetHIP(sd) for _ in range(2)]

@@ -627,7 +627,7 @@ def cnn_section(res, ntiles, batch, with_cpu):
     exec_fp16_tf = ntiles / dt * 3.0 * split_gflop * 1e9 / 1e12
     sec = {"metric": "CNN tiles/s (GoogLeNet, one 256x256 window per pixel)", "value": round(ntiles / dt, 1), "unit": "tiles/s",
            "dtype": "f32 (split-operand: fp16 hi + lo halves, fp32 accumulate)", "data": "synthetic weights (seeded), CMF plane of this run", "tiles": ntiles, "batch": batch,
-           "route": "split, trunk through inception3b shared between the overlapping windows -- phase maps + strip maps of the band rows, per window the rings' side columns (an argument of the call; per-layer activation scales "
+           "route": "split, trunk through inception3b shared between the overlapping windows -- phase maps + strip maps of the band rows, per window the rings' side columns; two halves of the rows in flight on two streams (cnn.LANES) (an argument of the call; per-layer activation scales "
                     "calibrated on this plane: 2^%d .. 2^%d; one overflow slot per batch, %d of %d batches re-scored on the fp32 matrix cores)"
                     % (int(np.log2(min(scales))), int(np.log2(max(scales))), rescued, (ntiles + batch - 1) // batch),
            "fp32_mfma_route": {"value": round(ntiles / dt_w, 1), "unit": "tiles/s",

@@ -566,14 +566,14 @@ def _score_rows_c(net, ds, r0, r1, batch, out, code, lanes=None):
     return nres[0]
 
 
-def score_tiles(net, ds, t_first, t_last, batch, out, route=None):
+def score_tiles(net, ds, t_first, t_last, batch, out, route=None, lanes=None):
     """``net.forward_tiles`` over the windows [t_first, t_last) of the FlightlineConvolve ``ds`` in batches, asynchronously: on the
     split-operand route every batch raises its own overflow slot, the slots are read ONCE after the last batch and only the raised
     batches are scored again on the fp32 matrix cores (cnn_pred_pipeline.py:173-181).  Returns the number of batches re-scored."""
     W = ds.inshape[2]
     code = net._route_code(route)
     if not net.half and getattr(net, "c_driver", True) and t_first % W == 0 and t_last % W == 0 and t_last > t_first:
-        return _score_rows_c(net, ds, t_first // W, t_last // W, batch, out, code)       # whole image rows: the C-side driver
+        return _score_rows_c(net, ds, t_first // W, t_last // W, batch, out, code, lanes)       # whole image rows: the C-side driver
     starts = list(range(int(t_first), int(t_last), int(batch)))
     slots = net.overflow_slots(len(starts)) if (code in (0, 3, 5) and not net.half) else None
     for i, t0 in enumerate(starts):

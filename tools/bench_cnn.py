@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="conv1 and maxpool1 as two kernels (A/B of the fused kernel)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"])
     ap.add_argument("--knob", action="append", default=[], help="key=value for sf_debug_set (repeatable)")
+    ap.add_argument("--lanes", type=int, default=None, help="concurrent row parts (default: cnn.LANES = 2; 1 for a per-launch profile)")
     ap.add_argument("--route", default="split", help="split (shared trunk, C driver) | split_unshared | winograd | direct")
     ap.add_argument("--width", type=int, default=598, help="image width (whole rows are scored)")
     args = ap.parse_args()
@@ -47,7 +48,7 @@ def main():
         net.calibrate(ds, args.batch)
 
     def run():
-        cnn.score_tiles(net, ds, 0, args.tiles, args.batch, out, route=args.route if args.precision == "fp32" else None)
+        cnn.score_tiles(net, ds, 0, args.tiles, args.batch, out, route=args.route if args.precision == "fp32" else None, lanes=args.lanes)
 
     run()
     torch.cuda.synchronize()

@@ -3,7 +3,7 @@ root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for k in 0 1; do
   if [ $k = 1 ]; then export SF_ABL_SPLIT=1; fi
-  rocprofv3 --kernel-trace --output-format csv -d $root/$out/prof$k -o p -- python3 $root/tools/bench_cnn.py --tiles 2048 --width 512 --batch 512 --route split > $root/$out/prof$k.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d $root/$out/prof$k -o p -- python3 $root/tools/bench_cnn.py --tiles 2048 --width 512 --batch 512 --lanes 1 --route split > $root/$out/prof$k.log 2>&1
 done
 python3 - <<'PY'
 import csv,collections,os

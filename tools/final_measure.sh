@@ -37,7 +37,7 @@ tools/prof_bench.sh ${tag}fs75 --samples 75 --steps 10 --warmup 2 $B --in-flight
 cp gpurun_out/${tag}fs75_kstats.txt $out/kstats_shard75.txt
 rm -rf gpurun_out/prof_${tag}fs75
 root=$(pwd); mkdir -p $out/cnnprof; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $root/$out/cnnprof -o p -- python3 $root/tools/bench_cnn.py --tiles 4096 --width 512 --batch 512 > $root/$out/cnnprof.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $root/$out/cnnprof -o p -- python3 $root/tools/bench_cnn.py --tiles 4096 --width 512 --batch 512 --lanes 1 > $root/$out/cnnprof.log 2>&1
 cd $root; t=$(find $out/cnnprof -name "*kernel_trace.csv" | head -1); python3 tools/cnn_layers.py $t > $out/cnn_layers.txt; rm -rf $out/cnnprof
 # every step succeeded: the judged copies
 cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json

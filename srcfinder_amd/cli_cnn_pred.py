@@ -58,8 +58,8 @@ def main(argv=None):
     # the batch by the GPU count for DataParallel to split again, cnn_pred_pipeline.py:170)
     # --batch keeps the reference's flag and default (32 windows per device: a DataLoader batch, cnn_pred_pipeline.py:76, :165).  The
     # saliency map does not depend on the batch size (bit-identical: tests/test_cnn_gpu.py), only the speed does -- 19.6 k windows/s
-    # at 32, 88 k at 1024 on an MI355X (the per-window rings of the shared trunk are small GEMMs) -- so at least 1024 windows are
-    # scored per launch set (17 GB of workspace per device)
+    # at 32, 103-108 k at 1024 on an MI355X (the per-window rings of the shared trunk are small GEMMs) -- so at least 1024 windows are
+    # scored per launch set (two concurrent row halves with 19 GB of workspace each per device)
     exec_batch = max(int(args.batch), 1024)
     sal = cnn.predict_flightline(plane, args.model, weights=sd, batch=exec_batch, gpus=list(args.gpus), to_numpy=True)
     print("[STEP] RESULT EXPORT")

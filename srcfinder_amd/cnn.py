@@ -596,7 +596,7 @@ def predict_flightline(cmf2d, model="COVID_QC", weights=None, batch=32, gpus=Non
     model   : a name of MODEL_NORM or a (mean, std) pair
     weights : a GoogLeNet ``state_dict`` (name -> tensor/ndarray)
     batch   : windows per launch set.  The map does not depend on it (bit-identical for any batch size and row range); the speed
-              does: 20 k windows/s at the reference's default of 32, 84 k at 512, 88 k at 1024 on an MI355X (the CLI scores at
+              does: 20 k windows/s at the reference's default of 32, 100 k at 512, 103-108 k at 1024 on an MI355X (the CLI scores at
               least 1024 at a time)
     rows    : optional (r0, r1) image rows to score (multi-GPU row sharding); other rows are left at 0
     gpus    : device indices (the script's ``-g 0 1 2 3``, which wraps the model in ``DataParallel`` and re-scatters

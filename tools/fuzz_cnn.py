@@ -66,5 +66,19 @@ for it in range(14):
     print("shared trunk %3d x %3d batch %3d rows %d..%d: %s (max rel %.1e; %.0f s)" % (H, W, batch, r0, r1, "ok" if ok else "MISMATCH", rel,
                                                                                      time.time() - t0), flush=True)
     bad += 0 if ok else 1
+# round 6, second half: longer row ranges -- strip-map groups of 16 image rows are rebuilt inside the call, batches straddle the group
+# boundaries, and the range is scored as two concurrent halves (cnn.LANES) -- against one stream and against the unshared route
+for it in range(6):
+    H, W = int(rng.integers(40, 200)), int(rng.integers(20, 160))
+    batch = int(rng.choice([33, 96, 256, 700]))
+    r0 = int(rng.integers(0, H - 20)); r1 = min(H, r0 + int(rng.integers(17, 70)))
+    plane = synthetic_plane(H, W, seed=int(rng.integers(1 << 30)))
+    plane[int(rng.integers(H)), int(rng.integers(W))] = -9999.0
+    a = cnn.predict_flightline(plane, "COVID_QC", net=net, batch=batch, rows=(r0, r1), route="split")
+    b = cnn.predict_flightline(plane, "COVID_QC", net=net, batch=batch, rows=(r0, r1), route="split_unshared", lanes=1)
+    c = cnn.predict_flightline(plane, "COVID_QC", net=net, batch=batch, rows=(r0, r1), route="split", lanes=1)
+    ok = bool(torch.equal(a, b)) and bool(torch.equal(a, c))
+    print("band sharing %3d x %3d batch %3d rows %d..%d: %s (%.0f s)" % (H, W, batch, r0, r1, "ok" if ok else "MISMATCH", time.time() - t0), flush=True)
+    bad += 0 if ok else 1
 print("fuzz cnn: %d mismatches" % bad)
 sys.exit(1 if bad else 0)
